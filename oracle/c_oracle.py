@@ -1,0 +1,123 @@
+"""ctypes front-end of oracle/libgg_oracle.so (the C restatement).  TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg - as the
+checker, never by the product path (gymgo_amd/).  All arrays are NumPy uint8 / int32 on the host.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, 'libgg_oracle.so')
+_lib = None
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, 'gg_oracle.c')
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, '-s', '-B'])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        L.gg_oracle_next_state.restype = ctypes.c_int32
+        L.gg_oracle_next_state.argtypes = [_u8p, ctypes.c_int32, _u8p, ctypes.c_int32, ctypes.c_int32]
+        L.gg_oracle_batch_next_states.restype = None
+        L.gg_oracle_batch_next_states.argtypes = [_u8p, _i32p, _u8p, _i32p, ctypes.c_int64, ctypes.c_int32,
+                                                  ctypes.c_int32]
+        L.gg_oracle_compute_invalid_moves.restype = None
+        L.gg_oracle_compute_invalid_moves.argtypes = [_u8p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _u8p]
+        L.gg_oracle_batch_areas.restype = None
+        L.gg_oracle_batch_areas.argtypes = [_u8p, _i32p, _i32p, ctypes.c_int64, ctypes.c_int32]
+        L.gg_oracle_batch_children.restype = None
+        L.gg_oracle_batch_children.argtypes = [_u8p, _u8p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
+        L.gg_oracle_canonical_form.restype = None
+        L.gg_oracle_canonical_form.argtypes = [_u8p, ctypes.c_int32]
+        L.gg_oracle_rng_seed.restype = ctypes.c_uint64
+        L.gg_oracle_rng_seed.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
+        L.gg_oracle_batch_rollout.restype = None
+        L.gg_oracle_batch_rollout.argtypes = [_u8p, _u64p, _i32p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                              ctypes.c_int32]
+        _lib = L
+    return _lib
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(_u8p)
+
+
+def batch_next_states(states, actions, canonical=False):
+    """states [B,6,N,N] uint8, actions [B] -> (next [B,6,N,N] uint8, status [B] int32)."""
+    states, sp = _u8(states)
+    B, _, N, _ = states.shape
+    actions = np.ascontiguousarray(actions, dtype=np.int32)
+    out = np.empty_like(states)
+    status = np.zeros(B, dtype=np.int32)
+    lib().gg_oracle_batch_next_states(sp, actions.ctypes.data_as(_i32p), out.ctypes.data_as(_u8p),
+                                      status.ctypes.data_as(_i32p), B, N, int(bool(canonical)))
+    return out, status
+
+
+def next_state(state, action, canonical=False):
+    out, status = batch_next_states(np.asarray(state)[None], np.array([action]), canonical)
+    if status[0]:
+        raise AssertionError(('Invalid move', int(action)))
+    return out[0]
+
+
+def compute_invalid_moves(state, player, ko=-1):
+    state, sp = _u8(state)
+    N = state.shape[-1]
+    mask = np.empty((N, N), dtype=np.uint8)
+    lib().gg_oracle_compute_invalid_moves(sp, N, int(player), int(ko), mask.ctypes.data_as(_u8p))
+    return mask
+
+
+def batch_areas(states):
+    states, sp = _u8(states)
+    B, _, N, _ = states.shape
+    black = np.empty(B, dtype=np.int32)
+    white = np.empty(B, dtype=np.int32)
+    lib().gg_oracle_batch_areas(sp, black.ctypes.data_as(_i32p), white.ctypes.data_as(_i32p), B, N)
+    return black, white
+
+
+def batch_children(states, canonical=False):
+    states, sp = _u8(states)
+    B, _, N, _ = states.shape
+    out = np.empty((B, N * N + 1, 6, N, N), dtype=np.uint8)
+    lib().gg_oracle_batch_children(sp, out.ctypes.data_as(_u8p), B, N, int(bool(canonical)))
+    return out
+
+
+def canonical_form(state):
+    state = np.array(state, dtype=np.uint8, copy=True, order='C')
+    lib().gg_oracle_canonical_form(state.ctypes.data_as(_u8p), state.shape[-1])
+    return state
+
+
+def rng_seed(base_seed, B):
+    L = lib()
+    return np.array([L.gg_oracle_rng_seed(int(base_seed), b) for b in range(B)], dtype=np.uint64)
+
+
+def batch_rollout(states, rng, plies, auto_reset=True):
+    """In place on copies; returns (states, rng, last_actions)."""
+    states = np.array(states, dtype=np.uint8, copy=True, order='C')
+    rng = np.array(rng, dtype=np.uint64, copy=True)
+    B, _, N, _ = states.shape
+    last = np.full(B, -1, dtype=np.int32)
+    lib().gg_oracle_batch_rollout(states.ctypes.data_as(_u8p), rng.ctypes.data_as(_u64p),
+                                  last.ctypes.data_as(_i32p), B, N, int(plies), int(bool(auto_reset)))
+    return states, rng, last

@@ -1,0 +1,238 @@
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Run only in the build container (needs /root/reference):   python tests/golden/make_golden.py
+Outputs (committed; data only - inputs and expected outputs, no reference source):
+  scripted.npz   per-step uint8 states / rewards / done / info for every case of scripted_cases.json,
+                 driven through the reference's own GoEnv (gym.make('gym_go:go-v0', ...)).
+  random_games.npz   seeded uniform-random full games (3..19): actions, 64-bit state hashes per ply,
+                 sampled full states with areas, canonical forms and ko-sensitive invalid vectors.
+  children.npz   gogame.children(state, canonical in {F,T}, padded=True) at several plies.
+  batch_passes.npz   mixed pass / move batches answered by STACKED gogame.next_state.
+  rollout.npz    actions drawn by the build's counter-based sampler (oracle/gg_oracle.c), replayed
+                 through the reference's next_state: final states after K plies.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'oracle', 'ref_harness'))
+
+import refimport  # noqa: E402
+from oracle import c_oracle  # noqa: E402
+
+
+def u8(x):
+    return np.asarray(x).astype(np.uint8)
+
+
+def h64(state_u8):
+    return np.frombuffer(hashlib.blake2b(np.ascontiguousarray(state_u8).tobytes(), digest_size=8).digest(),
+                         dtype=np.uint64)[0]
+
+
+def as_action(m, size):
+    if m is None:
+        return size * size
+    if isinstance(m, (list, tuple)):
+        return m[0] * size + m[1]
+    return int(m)
+
+
+def scripted(gym, gogame):
+    cases = json.load(open(os.path.join(HERE, 'scripted_cases.json')))['cases']
+    out = {}
+    for c in cases:
+        size = c['size']
+        env = gym.make('gym_go:go-v0', size=size, komi=c.get('komi', 0), reward_method=c.get('reward_method', 'real'))
+        env.reset()
+        states, rewards, dones, turns, invds, passed, libs = [], [], [], [], [], [], []
+        moves = list(c['moves'])
+        n_main = len(moves)
+        moves += c.get('continue', [])
+        raises_ok = []
+        for i, m in enumerate(moves):
+            if i == n_main:
+                for bad in c.get('then_raises', []):
+                    try:
+                        env.step(tuple(bad) if isinstance(bad, list) else bad)
+                        raises_ok.append(0)
+                    except Exception:
+                        raises_ok.append(1)
+            s, r, d, info = env.step(tuple(m) if isinstance(m, list) else m)
+            states.append(u8(s)); rewards.append(float(r)); dones.append(int(d))
+            turns.append(int(info['turn'])); invds.append(u8(info['invalid_moves']))
+            passed.append(int(info['prev_player_passed']))
+            libs.append(gogame.num_liberties(s))
+        if len(moves) == n_main:
+            for bad in c.get('then_raises', []):
+                try:
+                    env.step(tuple(bad) if isinstance(bad, list) else bad)
+                    raises_ok.append(0)
+                except Exception:
+                    raises_ok.append(1)
+        assert all(raises_ok), c['name']
+        # the reference's own pins hold on the reference (sanity of the lifted scripts)
+        final = states[n_main - 1]
+        pins = c.get('pins', {})
+        if 'invd_count' in pins:
+            assert int(final[3].sum()) == pins['invd_count'], c['name']
+        for r_, c_, v in pins.get('invd_at', []):
+            assert final[3, r_, c_] == v, c['name']
+        if 'black' in pins:
+            assert int(final[0].sum()) == pins['black'], c['name']
+        if 'white' in pins:
+            assert int(final[1].sum()) == pins['white'], c['name']
+        if 'nonzero_total' in pins:
+            assert int(np.count_nonzero(final)) == pins['nonzero_total'], c['name']
+        if 'reward' in pins:
+            assert rewards[n_main - 1] == pins['reward'], c['name']
+        if 'done' in pins:
+            assert dones[n_main - 1] == pins['done'], c['name']
+        if 'rewards' in c:
+            assert rewards[:n_main] == [float(x) for x in c['rewards']], c['name']
+        if 'num_liberties' in c:
+            assert [list(map(int, x)) for x in libs[:n_main]] == c['num_liberties'], c['name']
+        n = c['name']
+        out[n + '/actions'] = np.array([as_action(m, size) for m in moves], dtype=np.int32)
+        out[n + '/states'] = np.stack(states)
+        out[n + '/rewards'] = np.array(rewards)
+        out[n + '/dones'] = np.array(dones, dtype=np.int32)
+        out[n + '/turns'] = np.array(turns, dtype=np.int32)
+        out[n + '/invalid_moves'] = np.stack(invds)
+        out[n + '/prev_passed'] = np.array(passed, dtype=np.int32)
+        out[n + '/num_liberties'] = np.array(libs, dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, 'scripted.npz'), **out)
+    print('scripted: %d cases' % len(cases))
+
+
+def random_games(gogame, govars):
+    rng = np.random.default_rng(7)
+    out = {}
+    plan = {3: 4, 5: 4, 7: 4, 9: 4, 13: 2, 19: 3}
+    for size, games in plan.items():
+        for g in range(games):
+            s = gogame.init_state(size)
+            actions, hashes, samp_idx, samp_states, samp_areas, samp_canon, samp_invalid = [], [], [], [], [], [], []
+            for ply in range(6 * size * size):
+                if gogame.game_ended(s):
+                    break
+                valid = np.flatnonzero(np.append(s[govars.INVD_CHNL].ravel(), 0) == 0)
+                a = int(rng.choice(valid))
+                s = gogame.next_state(s, a)
+                actions.append(a)
+                hashes.append(h64(u8(s)))
+                if ply % (16 if size > 9 else 5) == 0 or gogame.game_ended(s):
+                    samp_idx.append(ply)
+                    samp_states.append(u8(s))
+                    samp_areas.append([int(x) for x in gogame.areas(s)])
+                    samp_canon.append(u8(gogame.canonical_form(s)))
+                    samp_invalid.append(u8(gogame.invalid_moves(s)))
+            k = 'n%d_g%d/' % (size, g)
+            out[k + 'actions'] = np.array(actions, dtype=np.int32)
+            out[k + 'hashes'] = np.array(hashes, dtype=np.uint64)
+            out[k + 'sample_ply'] = np.array(samp_idx, dtype=np.int32)
+            out[k + 'sample_states'] = np.stack(samp_states)
+            out[k + 'sample_areas'] = np.array(samp_areas, dtype=np.int32)
+            out[k + 'sample_canonical'] = np.stack(samp_canon)
+            out[k + 'sample_invalid_moves'] = np.stack(samp_invalid)
+            out[k + 'winning_komi0'] = np.array(gogame.winning(s, 0))
+            out[k + 'winning_komi6p5'] = np.array(gogame.winning(s, 6.5))
+    np.savez_compressed(os.path.join(HERE, 'random_games.npz'), **out)
+    print('random_games: %d arrays' % len(out))
+
+
+def children(gogame, govars):
+    rng = np.random.default_rng(11)
+    out = {}
+    for size, plies_list in {3: (0, 3, 6), 5: (0, 9, 20), 7: (5, 30), 9: (12, 60), 19: (150,)}.items():
+        s = gogame.init_state(size)
+        done = 0
+        for target in plies_list:
+            while done < target and not gogame.game_ended(s):
+                valid = np.flatnonzero(np.append(s[govars.INVD_CHNL].ravel(), 0) == 0)[:-1]
+                if len(valid) == 0:
+                    break
+                s = gogame.next_state(s, int(rng.choice(valid)))
+                done += 1
+            k = 'n%d_p%d/' % (size, target)
+            out[k + 'state'] = u8(s)
+            out[k + 'children'] = u8(gogame.children(s, False, True))
+            out[k + 'children_canonical'] = u8(gogame.children(s, True, True))
+    np.savez_compressed(os.path.join(HERE, 'children.npz'), **out)
+    print('children: %d arrays' % len(out))
+
+
+def batch_passes(gogame, govars):
+    rng = np.random.default_rng(13)
+    out = {}
+    for size, B in ((5, 24), (9, 32), (19, 12)):
+        states, actions = [], []
+        for b in range(B):
+            s = gogame.init_state(size)
+            for _ in range(int(rng.integers(0, 3 * size * size))):
+                if gogame.game_ended(s):
+                    break
+                valid = np.flatnonzero(np.append(s[govars.INVD_CHNL].ravel(), 0) == 0)
+                s = gogame.next_state(s, int(rng.choice(valid)))
+            if gogame.game_ended(s) and b % 2:
+                s = gogame.init_state(size)
+            valid = np.flatnonzero(np.append(s[govars.INVD_CHNL].ravel(), 0) == 0)
+            a = size * size if (b % 3 == 0 or gogame.game_ended(s)) else int(rng.choice(valid))
+            states.append(s)
+            actions.append(a)
+        for canon in (False, True):
+            nxt = np.stack([u8(gogame.next_state(s, a, canon)) for s, a in zip(states, actions)])
+            out['n%d/next%s' % (size, '_canonical' if canon else '')] = nxt
+        out['n%d/states' % size] = np.stack([u8(s) for s in states])
+        out['n%d/actions' % size] = np.array(actions, dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, 'batch_passes.npz'), **out)
+    print('batch_passes: %d arrays' % len(out))
+
+
+def rollout(gogame, govars):
+    out = {}
+    for size, B, plies in ((5, 16, 80), (9, 16, 200), (19, 6, 700)):
+        seed = 20260927
+        rng0 = c_oracle.rng_seed(seed, B)
+        states = np.zeros((B, 6, size, size), dtype=np.uint8)
+        rng = rng0.copy()
+        ref = [gogame.init_state(size) for _ in range(B)]
+        n_resets = 0
+        for t in range(plies):
+            states, rng, last = c_oracle.batch_rollout(states, rng, 1, True)
+            for b in range(B):
+                if gogame.game_ended(ref[b]):
+                    ref[b] = gogame.init_state(size)   # build-side auto-reset policy
+                    n_resets += 1
+                # the sampled action must be valid in the reference's eyes, then replay it there
+                assert gogame.valid_moves(ref[b])[last[b]] == 1
+                ref[b] = gogame.next_state(ref[b], int(last[b]))
+                assert np.array_equal(u8(ref[b]), states[b]), (size, t, b)
+        k = 'n%d/' % size
+        out[k + 'seed'] = np.array(seed, dtype=np.uint64)
+        out[k + 'plies'] = np.array(plies, dtype=np.int32)
+        out[k + 'rng0'] = rng0
+        out[k + 'rng_final'] = rng
+        out[k + 'final_states'] = np.stack([u8(s) for s in ref])
+        out[k + 'last_actions'] = last
+        print('rollout n=%d: %d resets over %d plies x %d games' % (size, n_resets, plies, B))
+    np.savez_compressed(os.path.join(HERE, 'rollout.npz'), **out)
+
+
+def main():
+    gym, gogame, govars, _ = refimport.load()
+    scripted(gym, gogame)
+    random_games(gogame, govars)
+    children(gogame, govars)
+    batch_passes(gogame, govars)
+    rollout(gogame, govars)
+
+
+if __name__ == '__main__':
+    main()
