@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""bench.py - env steps/sec across batched games, 19x19 uniform-random rollouts (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = ONE PLY FOR EVERY GAME of the batch (B env transitions): sample a uniform valid action per
+game on the device, apply it (capture resolution, ko, new invalid-move mask, turn flip), auto-reset
+finished games.  Steps are issued as launches of gg_batch_rollout with `--fuse F` plies per launch
+(F = 1: the state makes a full HBM round trip every ply, the per-ply vector-env path; F > 1: the
+board stays on-chip for F plies).  K is rounded up to a multiple of F.  Inputs are resident in HBM
+before the timed region; nothing but the kernel launches sits inside it.
+
+Multi-GPU: the game batch is sharded across ranks, no data-path collective (games never interact);
+only the barrier and the max-over-ranks timing use RCCL.  scaling = "weak" (fixed games per GPU).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_STEP = {19: 4336, 13: 2032, 9: 976, 7: 592}  # read 6N^2 + write 6N^2 + 4 B action
+HBM_PEAK_GBS = 8000.0                                        # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def _cpu_worker(args):
+    size, seconds, seed = args
+    sys.path.insert(0, ROOT)
+    from oracle import np_oracle
+    return np_oracle.random_rollout_steps(size, seconds, seed)
+
+
+def cpu_baseline(size, cpu_seconds_total=20.0):
+    """The NumPy/SciPy port of the reference's next_state (oracle/np_oracle.py, same SciPy calls per step,
+    pinned bit-exact and speed-calibrated against the real reference) on this box's host cores:
+    one worker per core, each plays uniform-random games with auto-reset for a fixed wall time."""
+    import multiprocessing as mp
+    cores = min(os.cpu_count() or 1, 32)
+    seconds = max(1.0, cpu_seconds_total / cores)
+    ctx = mp.get_context('spawn')
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        steps = pool.map(_cpu_worker, [(size, seconds, 1000 + i) for i in range(cores)])
+    wall = time.perf_counter() - t0
+    return {
+        'value': round(sum(steps) / seconds, 1), 'unit': 'env steps/s', 'cores': cores, 'kind': 'port',
+        'per_core': round(sum(steps) / seconds / cores, 1),
+        'sample': '%d workers x %.1f s of %dx%d uniform-random self-play with auto-reset (oracle/np_oracle.py, '
+                  'same scipy.ndimage calls per step as the reference); %d steps total, pool wall %.1f s'
+                  % (cores, seconds, size, size, sum(steps), wall),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=512)
+    ap.add_argument('--warmup', type=int, default=64)
+    ap.add_argument('--size', type=int, default=19)
+    ap.add_argument('--games-per-gpu', type=int, default=0, help='0 = 65536 at 1 GPU, 131072 per GPU otherwise')
+    ap.add_argument('--fuse', type=int, default=int(os.environ.get('GG_BENCH_FUSE', '16')),
+                    help='plies per kernel launch')
+    ap.add_argument('--burn-in', type=int, default=256, help='untimed plies before warmup (stationary board mix)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        args.gpus = world
+
+    cpu = None
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.size, args.cpu_seconds)   # before the GPU context exists (spawned workers)
+
+    import torch
+    import torch.distributed as dist
+    from gymgo_amd import gogame
+    from gymgo_amd.envs.vec_env import shard
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    per_gpu = args.games_per_gpu or (65536 if world == 1 else 131072)
+    total_games = per_gpu * world
+    first, count = shard(total_games, rank, world)
+    N, F = args.size, max(1, args.fuse)
+    K = (args.steps + F - 1) // F * F
+    W = (args.warmup + F - 1) // F * F
+
+    states = gogame.batch_init_state(count, N, device=dev)
+    rng = gogame.rng_seed(count, 20260927, first, dev)
+    steps_done = torch.zeros(count, dtype=torch.int64, device=dev)
+    if args.burn_in:
+        gogame.batch_rollout(states, rng, args.burn_in, True, None, steps_done)
+    for _ in range(W // F):
+        gogame.batch_rollout(states, rng, F, True, None, steps_done)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    before = int(steps_done.sum())
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fence()
+    t0 = time.perf_counter()
+    ev0.record()            # launches go to torch's current stream (gymgo_amd/_lib.py: stream_ptr)
+    for _ in range(K // F):
+        gogame.batch_rollout(states, rng, F, True, None, steps_done)
+    ev1.record()
+    fence()
+    wall = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1)
+    played = int(steps_done.sum()) - before
+    assert played == K * count, 'work was skipped inside the timed region (%d != %d)' % (played, K * count)
+
+    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max = float(t[0])
+    if rank == 0:
+        value = K * total_games / wall_max
+        launches = K // F
+        algo = ALGO_BYTES_PER_STEP.get(N, 12 * N * N + 4)
+        launch_ms = kernel_ms / launches
+        achieved = algo * count * F / (launch_ms * 1e-3) / 1e9
+        traffic = None
+        tj = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+        if os.path.exists(tj):
+            try:
+                rec = json.load(open(tj))
+                if rec.get('size') == N and rec.get('fuse') == F and rec.get('games') == count:
+                    traffic = rec.get('bytes_per_launch')
+            except Exception:
+                traffic = None
+        line = {
+            'metric': 'env steps/sec across batched games, 19x19 uniform-random rollouts',
+            'value': round(value, 1), 'unit': 'env steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': round(wall_max * 1e3 / K, 6), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+            'config': {
+                'workload': '%dx%d, %d parallel games%s, uniform-random rollouts with auto-reset, %d plies per launch'
+                            % (N, N, total_games, '' if world == 1 else ' (%d per GPU)' % per_gpu, F),
+                'board': N, 'games': total_games, 'games_per_gpu': per_gpu, 'plies_per_launch': F,
+                'burn_in_plies': args.burn_in, 'sharding': 'batch split across ranks, no collective',
+            },
+            'roofline': {
+                'bound': 'hbm', 'kernel': 'k_rollout<%d>' % (9 if N <= 9 else 13 if N <= 13 else 19),
+                'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+                'algorithmic_bytes_per_step': algo, 'steps_per_launch': count * F,
+                'launch_ms': round(launch_ms, 5),
+            },
+        }
+        if cpu is not None:
+            line['cpu_baseline'] = cpu
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

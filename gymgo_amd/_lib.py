@@ -1,0 +1,87 @@
+"""ctypes loader of the in-tree HIP library (gymgo_amd/libgymgo_amd.so) + tensor plumbing.
+
+There is NO CPU fallback: if the shared library is missing, or a tensor is not a contiguous
+uint8/int32 ROCm device tensor, the call raises.  PyTorch is used only for device memory and the
+current HIP stream; every entry point of include/gymgo_amd.h is bound here with plain pointers.
+"""
+import ctypes
+import os
+
+import torch  # must be imported before the library so both share ONE HIP runtime (libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgymgo_amd.so')
+
+EXPORTS = (
+    'gg_version', 'gg_device_cus', 'gg_batch_next_states', 'gg_batch_invalid_mask', 'gg_batch_areas',
+    'gg_batch_children', 'gg_batch_rollout', 'gg_batch_sample_actions', 'gg_rng_seed',
+)
+
+_vp, _i64, _i32, _u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64
+_SIGNATURES = {
+    'gg_version': ([], _i32),
+    'gg_device_cus': ([], _i32),
+    'gg_batch_next_states': ([_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
+    'gg_batch_invalid_mask': ([_vp, _vp, _vp, _i64, _i32, _vp], _i32),
+    'gg_batch_areas': ([_vp, _vp, _vp, _i64, _i32, _vp], _i32),
+    'gg_batch_children': ([_vp, _vp, _i64, _i32, _i32, _vp], _i32),
+    'gg_batch_rollout': ([_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
+    'gg_batch_sample_actions': ([_vp, _vp, _vp, _i64, _i32, _vp], _i32),
+    'gg_rng_seed': ([_vp, _u64, _i64, _i64, _vp], _i32),
+}
+
+_lib = None
+
+
+class GymGoNativeError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    src = os.path.join(_HERE, 'csrc', 'gg_kernels.hip')
+    hdr = os.path.join(os.path.dirname(_HERE), 'include', 'gymgo_amd.h')
+    stale = (not os.path.exists(LIB_PATH) or
+             os.path.getmtime(LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    if force or stale:
+        subprocess.check_call(['make', '-C', os.path.join(_HERE, 'csrc'), '-s', '-B'])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GymGoNativeError(
+                'HIP library %s not built (run `make -C gymgo_amd/csrc` or __graft_entry__.build()); '
+                'gymgo_amd has no CPU fallback' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export what the header declares
+            fn.argtypes, fn.restype = argtypes, restype
+        _lib = L
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise GymGoNativeError('%s failed with code %d (%s)' % (
+            what, code, 'bad argument' if code < 0 else 'hipError_t'))
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dev_ptr(t, dtype, name):
+    """Pointer of a contiguous device tensor of `dtype`; raises instead of silently copying."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise GymGoNativeError('%s must be a ROCm device tensor (got %r); gymgo_amd has no CPU path'
+                               % (name, type(t) if not isinstance(t, torch.Tensor) else t.device))
+    if t.dtype != dtype or not t.is_contiguous():
+        raise GymGoNativeError('%s must be contiguous %s (got %s, contiguous=%s)'
+                               % (name, dtype, t.dtype, t.is_contiguous()))
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,852 @@
+// gg_kernels.hip - MI355X (gfx950 / CDNA4) kernels of the batched Go step path + the C-ABI.
+//
+// Design: ONE WAVEFRONT PER BOARD, 64-thread workgroups (so the workgroup barrier is a
+// wave-local LDS fence and every wave runs its own data-dependent loops), persistent waves that
+// grid-stride over the batch.  Integer / bit work only - no MFMA.
+//
+// A board lives in two register layouts:
+//   L1 "row per lane":   lane r (< N) holds row r of a plane as a 32-bit mask (bit c = column c).
+//                        Point-wise rules are 1 VALU op for the whole board; vertical neighbours are
+//                        one cross-lane move.
+//   L2 "flood per lane": every lane holds ALL rows of one colour (R registers) plus its own fill.
+//                        Each lane runs a DIFFERENT flood fill of the same board at the same time:
+//                        lanes 0-19 next mover's groups, lanes 32-51 mover's groups, one lane per
+//                        liberty class (bit k of the row / column index == v, k < 5, v in {0,1}).
+//                        A flood = Gauss-Seidel row sweeps (down, up) with a carry-propagate
+//                        horizontal run fill, so a sweep crosses the whole board.
+// From the 40 floods: a group reached from both classes (k,0) and (k,1) for some k has >= 2 distinct
+// liberties; a group reached by neither class of k = 0 has none (captured); everything else has
+// exactly one.  That is all the reference's invalid-move rule needs (state_utils.py:24-83 restated
+// point-wise): an empty point is playable iff a neighbour is empty, or a next-mover
+// stone with >= 2 liberties, or a mover stone with exactly 1.
+//
+// Reference citations are path:line relative to the reference root (huangeddie/GymGo).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gymgo_amd.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kClassBits = 5;                 // row / column indices < 32
+constexpr int kClasses = 4 * kClassBits;      // (row|col bit k) x (value v) = 20 floods per colour
+
+#define WAVE_SYNC() __syncthreads()  // 64-thread workgroups: a wave-local LDS fence
+
+template <int R>
+struct Cfg {
+  static constexpr int kMaxP = R * R;
+  static constexpr int kRowStride = (R + 3) & ~3;               // flood scratch words per lane (16-B multiple)
+  static constexpr int kIoBytes = ((6 * R * R + 15 + 15) + 15) & ~15;  // staged board + both misalignments
+  static constexpr int kCellsPerLane = (R * R + kWave - 1) / kWave;
+  static constexpr int kRowsPerBallotMin = kWave / R;
+  static constexpr int kMaxBallots = (R + kRowsPerBallotMin - 1) / kRowsPerBallotMin;
+};
+
+struct LaneClass {
+  uint32_t rowsel;   // bit r set: row r belongs to this lane's liberty class
+  uint32_t colmask;  // columns of this lane's liberty class
+  bool second;       // lanes 32..63 flood the second colour
+};
+
+__device__ __forceinline__ LaneClass make_lane_class(int lane) {
+  const uint32_t pat[kClassBits] = {0xAAAAAAAAu, 0xCCCCCCCCu, 0xF0F0F0F0u, 0xFF00FF00u, 0xFFFF0000u};
+  LaneClass lc;
+  int cls = lane & 31, k = cls >> 1, v = cls & 1;
+  lc.second = lane >= 32;
+  lc.rowsel = 0;
+  lc.colmask = 0;
+  if (cls < kClasses) {
+    uint32_t p = 0;
+#pragma unroll
+    for (int i = 0; i < kClassBits; ++i)
+      if ((k % kClassBits) == i) p = pat[i];
+    p = v ? p : ~p;
+    if (k < kClassBits) { lc.rowsel = p; lc.colmask = 0xFFFFFFFFu; }
+    else { lc.rowsel = 0xFFFFFFFFu; lc.colmask = p; }
+  }
+  return lc;
+}
+
+// Fill every maximal run of `m` that contains a bit of `s` (s subset of m), both directions.
+// Up-fill: t = m + s carries from each seed to the end of its run; (t&s)|(~t&m) keeps exactly the
+// bits from the lowest seed of a run upwards.  Down-fill = the same in the bit-reversed domain.
+__device__ __forceinline__ uint32_t run_fill(uint32_t m, uint32_t mrev, uint32_t s) {
+  uint32_t t = m + s;
+  uint32_t u = (t & s) | (~t & m);
+  uint32_t rs = __brev(u);
+  uint32_t t2 = mrev + rs;
+  uint32_t rr = (t2 & rs) | (~t2 & mrev);
+  return __brev(rr);
+}
+
+// Per-lane flood fill of `f` (seeds) through mask `m` to the fixed point.  All 64 lanes run their own
+// flood in lock-step; the loop ends when no lane changed during a full down+up sweep.
+template <int R>
+__device__ __forceinline__ void flood(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R]) {
+  uint32_t prev = 0xFFFFFFFFu;
+#pragma unroll 1
+  for (int it = 0; it < R * R + 2; ++it) {
+    f[0] = run_fill(m[0], mrev[0], f[0]);
+#pragma unroll
+    for (int r = 1; r < R; ++r) f[r] = run_fill(m[r], mrev[r], f[r] | (f[r - 1] & m[r]));
+#pragma unroll
+    for (int r = R - 2; r >= 0; --r) f[r] = run_fill(m[r], mrev[r], f[r] | (f[r + 1] & m[r]));
+    uint32_t tot = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) tot += __popc(f[r]);
+    bool changed = tot != prev;
+    prev = tot;
+    if (__ballot(changed) == 0) break;
+  }
+}
+
+// Liberty analysis of the whole board (L1 in, L1 out).  c0 / c1 = stones of the two colours
+// (lane r = row r), e = empty points.  Returns for lane r < R:
+//   multi0 / multi1: stones of c0 / c1 whose group has >= 2 distinct liberties
+//   alive0:          stones of c0 whose group has >= 1 liberty
+template <int R>
+__device__ __forceinline__ void analyze(uint32_t c0, uint32_t c1, uint32_t e, const LaneClass lc, uint32_t *sc,
+                                        int lane, uint32_t &multi0, uint32_t &alive0, uint32_t &multi1) {
+  constexpr int RS = Cfg<R>::kRowStride;
+  uint32_t m[R], mrev[R], f[R], ec[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    uint32_t s0 = __builtin_amdgcn_readlane(c0, r);
+    uint32_t s1 = __builtin_amdgcn_readlane(c1, r);
+    uint32_t se = __builtin_amdgcn_readlane(e, r);
+    m[r] = lc.second ? s1 : s0;
+    mrev[r] = __brev(m[r]);
+    uint32_t rowon = 0u - ((lc.rowsel >> r) & 1u);
+    ec[r] = se & rowon & lc.colmask;  // empties of this lane's liberty class
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    uint32_t nb = (ec[r] << 1) | (ec[r] >> 1);
+    if (r > 0) nb |= ec[r - 1];
+    if (r < R - 1) nb |= ec[r + 1];
+    f[r] = m[r] & nb;  // stones touching a liberty of the class
+  }
+  flood<R>(m, mrev, f);
+  WAVE_SYNC();  // earlier readers of the scratch are done
+#pragma unroll
+  for (int r = 0; r < R; ++r) sc[lane * RS + r] = f[r];
+  WAVE_SYNC();
+  multi0 = 0; multi1 = 0; alive0 = 0;
+  if (lane < R) {
+#pragma unroll
+    for (int k = 0; k < kClasses / 2; ++k) {
+      uint32_t a = sc[(2 * k) * RS + lane], b = sc[(2 * k + 1) * RS + lane];
+      multi0 |= a & b;
+      if (k == 0) alive0 = a | b;
+      uint32_t a1 = sc[(32 + 2 * k) * RS + lane], b1 = sc[(32 + 2 * k + 1) * RS + lane];
+      multi1 |= a1 & b1;
+    }
+  }
+}
+
+struct Geo {
+  int N, P;
+  uint32_t full_l1;  // lane < N ? (1<<N)-1 : 0
+};
+
+// compute_invalid_moves (gym_go/state_utils.py:24-83) in closed form for the side `nx` that moves next:
+// invalid = occupied or (no neighbour is: empty | nx stone with >=2 liberties | other stone with ==1).
+__device__ __forceinline__ uint32_t invalid_from(uint32_t nx, uint32_t pl, uint32_t multi_nx, uint32_t multi_pl,
+                                                 const Geo &g, int lane) {
+  uint32_t e = g.full_l1 & ~(nx | pl);
+  uint32_t x = e | (nx & multi_nx) | (pl & ~multi_pl);
+  uint32_t up = __shfl_up(x, 1), dn = __shfl_down(x, 1);
+  if (lane == 0) up = 0;
+  if (lane >= g.N - 1) dn = 0;
+  uint32_t nb = (x << 1) | (x >> 1) | up | dn;
+  return g.full_l1 & ~(e & nb);
+}
+
+// One transition on L1 bitboards (gym_go/gogame.py:34-87 without the plane bookkeeping).
+// mine = mover's stones, opp = next mover's stones; both updated.  Returns the invalid mask for the
+// next mover (incl. ko).  `a` must be a legal point or P (pass).
+template <int R>
+__device__ __forceinline__ uint32_t step_core(uint32_t &mine, uint32_t &opp, int a, const Geo &g, const LaneClass lc,
+                                              uint32_t *sc, int lane) {
+  const bool is_pass = a == g.P;
+  int ko_r = -1, ko_c = 0;
+  bool boxed = false;
+  if (!is_pass) {
+    int ra = a / g.N, ca = a - ra * g.N;
+    uint32_t bit = 1u << ca;
+    if (lane == ra) mine |= bit;                       // gogame.py:62
+    // state_utils.adj_data :214-223 - every on-board neighbour holds an opponent stone
+    uint32_t nbm = 0;
+    if (lane == ra) nbm = (bit << 1) | (bit >> 1);
+    if (lane == ra - 1 || lane == ra + 1) nbm = bit;
+    nbm &= g.full_l1;
+    boxed = __ballot((nbm & ~opp) != 0) == 0;
+  }
+  uint32_t multi_opp, alive_opp, multi_mine;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    uint32_t e = g.full_l1 & ~(mine | opp);
+    analyze<R>(opp, mine, e, lc, sc, lane, multi_opp, alive_opp, multi_mine);
+    if (pass == 0 && !is_pass) {
+      // state_utils.update_pieces :159-180 - opponent groups left without a liberty die.  Only groups
+      // touching the new stone can be in that state (every group had a liberty before the move).
+      uint32_t dead = opp & ~alive_opp;
+      uint64_t dm = __ballot(dead != 0);
+      if (dm) {
+        // gogame.py:72-75 - ko iff exactly one stone died and the new stone is boxed in
+        uint64_t multi_rows = __ballot(__popc(dead) > 1);
+        if (boxed && multi_rows == 0 && (dm & (dm - 1)) == 0) {
+          ko_r = __ffsll((unsigned long long)dm) - 1;
+          uint32_t drow = __builtin_amdgcn_readlane(dead, ko_r);
+          ko_c = __ffs(drow) - 1;
+        }
+        opp &= ~dead;
+        continue;  // liberties changed: analyse the board again
+      }
+    }
+    break;
+  }
+  uint32_t invalid = invalid_from(opp, mine, multi_opp, multi_mine, g, lane);
+  if (lane == ko_r) invalid |= 1u << ko_c;  // state_utils.py:81-82
+  return invalid;
+}
+
+// ---------------------------------------------------------------- staging: HBM <-> LDS <-> bitboards
+
+// Stage `nbytes` bytes starting at g into LDS so that lds[mis + j] = g[j], using 16-byte loads for
+// every 16-byte-aligned vector that lies inside [lo, hi); returns mis = g & 15.
+__device__ __forceinline__ uint32_t stage_in(const uint8_t *g, int nbytes, const uint8_t *lo, const uint8_t *hi,
+                                             uint8_t *lds, int lane) {
+  uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
+  const uint8_t *ga = g - mis;
+  int nv = (int)(mis + nbytes + 15) >> 4;
+  for (int v = lane; v < nv; v += kWave) {
+    const uint8_t *p = ga + 16 * v;
+    uint4 val;
+    if (p >= lo && p + 16 <= hi) {
+      val = *reinterpret_cast<const uint4 *>(p);
+    } else {
+      uint32_t w[4] = {0, 0, 0, 0};
+      for (int i = 0; i < 16; ++i)
+        if (p + i >= lo && p + i < hi) w[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
+      val = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    *reinterpret_cast<uint4 *>(lds + 16 * v) = val;
+  }
+  return mis;
+}
+
+// Write `nbytes` staged as lds[mis + j] to g[j]: 16-byte stores for the vectors fully inside the
+// board, byte stores for the (at most two) partial ones - neighbours belong to other waves.
+__device__ __forceinline__ void stage_out(uint8_t *g, int nbytes, const uint8_t *lds, int lane) {
+  uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
+  uint8_t *ga = g - mis;
+  int nv = (int)(mis + nbytes + 15) >> 4;
+  for (int v = lane; v < nv; v += kWave) {
+    int lo = 16 * v - (int)mis;
+    uint8_t *p = ga + 16 * v;
+    if (lo >= 0 && lo + 16 <= nbytes) {
+      *reinterpret_cast<uint4 *>(p) = *reinterpret_cast<const uint4 *>(lds + 16 * v);
+    } else {
+      for (int i = 0; i < 16; ++i) {
+        int j = lo + i;
+        if (j >= 0 && j < nbytes) p[i] = lds[16 * v + i];
+      }
+    }
+  }
+}
+
+// Two byte planes (0/1 per cell, P bytes each, plane 1 right after plane 0) -> L1 row masks.
+// A ballot over `rpb` whole rows at a time; lane r then cuts its row out of the ballot it belongs to.
+template <int R>
+__device__ __forceinline__ void planes_to_rows(const uint8_t *p0, const uint8_t *p1, const Geo &g, int lane,
+                                               uint32_t &r0, uint32_t &r1) {
+  const int rpb = kWave / g.N;
+  const int span = rpb * g.N;
+  const int myj = lane / rpb, sh = (lane - myj * rpb) * g.N;
+  const uint32_t full = (1u << g.N) - 1u;
+  r0 = 0; r1 = 0;
+#pragma unroll
+  for (int j = 0; j < Cfg<R>::kMaxBallots; ++j) {
+    int cell = j * span + lane;
+    bool ok = lane < span && cell < g.P;
+    uint8_t v0 = ok ? p0[cell] : (uint8_t)0;
+    uint8_t v1 = ok ? p1[cell] : (uint8_t)0;
+    uint64_t b0 = __ballot(v0 != 0), b1 = __ballot(v1 != 0);
+    if (lane < g.N && myj == j) {
+      r0 = (uint32_t)(b0 >> sh) & full;
+      r1 = (uint32_t)(b1 >> sh) & full;
+    }
+  }
+}
+
+struct CellMap {  // board cells handled by this lane when expanding rows to bytes
+  uint16_t rc[8]; // (row << 8) | col, for cell = lane + 64 j
+};
+
+template <int R>
+__device__ __forceinline__ CellMap make_cell_map(int lane, int N) {
+  CellMap cm;
+#pragma unroll
+  for (int j = 0; j < Cfg<R>::kCellsPerLane; ++j) {
+    int cell = lane + kWave * j;
+    int r = cell / N, c = cell - r * N;
+    cm.rc[j] = (uint16_t)((r << 8) | c);
+  }
+  return cm;
+}
+
+// ---------------------------------------------------------------- kernels
+
+struct PlaneBytes { uint8_t turn, passed, done; };
+
+// Emit a whole 6-plane board into the LDS staging buffer (ob[j] = board byte j) from L1 rows.
+template <int R>
+__device__ __forceinline__ void emit_board(uint8_t *ob, uint32_t *rowsw, uint32_t black, uint32_t white,
+                                           uint32_t invalid, PlaneBytes pb, const Geo &g, const CellMap &cm, int lane) {
+  WAVE_SYNC();
+  if (lane < 32) {
+    rowsw[lane] = black;
+    rowsw[32 + lane] = white;
+    rowsw[64 + lane] = invalid;
+  }
+  WAVE_SYNC();
+#pragma unroll
+  for (int j = 0; j < Cfg<R>::kCellsPerLane; ++j) {
+    int cell = lane + kWave * j;
+    if (cell < g.P) {
+      int r = cm.rc[j] >> 8, c = cm.rc[j] & 0xFF;
+      ob[cell] = (uint8_t)((rowsw[r] >> c) & 1u);
+      ob[g.P + cell] = (uint8_t)((rowsw[32 + r] >> c) & 1u);
+      ob[2 * g.P + cell] = pb.turn;
+      ob[3 * g.P + cell] = (uint8_t)((rowsw[64 + r] >> c) & 1u);
+      ob[4 * g.P + cell] = pb.passed;
+      ob[5 * g.P + cell] = pb.done;
+    }
+  }
+  WAVE_SYNC();
+}
+
+// Read the uniform-plane flags + the INVD byte of point `pt` of a board in HBM:
+// bit0 turn, bit1 INVD[pt], bit2 previous move was a pass, bit3 game over.
+__device__ __forceinline__ uint32_t load_flags(const uint8_t *g, int P, int pt, int lane) {
+  uint8_t fb = 0;
+  if (lane < 4) {
+    int off = lane == 0 ? 2 * P : lane == 1 ? 3 * P + pt : lane == 2 ? 4 * P : 5 * P;
+    fb = g[off];
+  }
+  return (uint32_t)__ballot(fb != 0) & 0xFu;
+}
+
+template <int R>
+__global__ __launch_bounds__(kWave) void k_next_states(const uint8_t *__restrict__ in,
+                                                       const int32_t *__restrict__ actions,
+                                                       uint8_t *__restrict__ out, int32_t *__restrict__ status,
+                                                       int64_t B, int N, int canonical) {
+  __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
+  __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
+  __shared__ uint32_t rowsw[96];
+  const int lane = threadIdx.x;
+  Geo g;
+  g.N = N; g.P = N * N;
+  g.full_l1 = lane < N ? (1u << N) - 1u : 0u;
+  const int S = 6 * g.P;
+  const LaneClass lc = make_lane_class(lane);
+  const CellMap cm = make_cell_map<R>(lane, N);
+  const uint8_t *in_end = in + B * (int64_t)S;
+
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const uint8_t *gi = in + b * (int64_t)S;
+    uint8_t *go = out + b * (int64_t)S;
+    int a = __builtin_amdgcn_readfirstlane(actions[b]);
+    const bool in_range = a >= 0 && a <= g.P;
+    const bool is_pass = a == g.P;
+    uint32_t flags = load_flags(gi, g.P, (in_range && !is_pass) ? a : 0, lane);
+    if (!in_range || (!is_pass && (flags & 2u))) {
+      // gogame.py:59 / :117 would raise: row passes through unchanged, status flags it
+      for (int i = lane; i < S; i += kWave) go[i] = gi[i];
+      if (status && lane == 0) status[b] = GG_STATUS_ILLEGAL;
+      continue;
+    }
+    WAVE_SYNC();
+    uint32_t mis = stage_in(gi, 2 * g.P, in, in_end, iobuf, lane);
+    WAVE_SYNC();
+    uint32_t black, white;
+    planes_to_rows<R>(iobuf + mis, iobuf + mis + g.P, g, lane, black, white);
+    const int pl = flags & 1u;                       // gogame.py:44 turn
+    uint32_t mine = pl ? white : black, opp = pl ? black : white;
+    uint32_t invalid = step_core<R>(mine, opp, a, g, lc, sc, lane);
+    black = pl ? opp : mine;
+    white = pl ? mine : opp;
+    PlaneBytes pb;
+    pb.passed = is_pass ? 1 : 0;                                            // gogame.py:50 / :56
+    pb.done = ((flags & 8u) || (is_pass && (flags & 4u))) ? 1 : 0;          // gogame.py:51-53 (sticky)
+    int nturn = 1 - pl;                                                     // state_utils.py:235-241
+    if (canonical && nturn == 1) {                                          // gogame.py:313-321
+      uint32_t t = black; black = white; white = t;
+      nturn = 0;
+    }
+    pb.turn = (uint8_t)nturn;
+    uint32_t mo = (uint32_t)((uintptr_t)go & 15u);
+    emit_board<R>(iobuf + mo, rowsw, black, white, invalid, pb, g, cm, lane);
+    stage_out(go, S, iobuf, lane);
+    if (status && lane == 0) status[b] = GG_STATUS_OK;
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(kWave) void k_invalid_mask(const uint8_t *__restrict__ states,
+                                                        const int32_t *__restrict__ ko, uint8_t *__restrict__ mask,
+                                                        int64_t B, int N) {
+  __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
+  __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
+  __shared__ uint32_t rowsw[32];
+  const int lane = threadIdx.x;
+  Geo g;
+  g.N = N; g.P = N * N;
+  g.full_l1 = lane < N ? (1u << N) - 1u : 0u;
+  const int S = 6 * g.P;
+  const LaneClass lc = make_lane_class(lane);
+  const CellMap cm = make_cell_map<R>(lane, N);
+  const uint8_t *in_end = states + B * (int64_t)S;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const uint8_t *gi = states + b * (int64_t)S;
+    uint32_t flags = load_flags(gi, g.P, 0, lane);
+    WAVE_SYNC();
+    uint32_t mis = stage_in(gi, 2 * g.P, states, in_end, iobuf, lane);
+    WAVE_SYNC();
+    uint32_t black, white;
+    planes_to_rows<R>(iobuf + mis, iobuf + mis + g.P, g, lane, black, white);
+    const int nx = flags & 1u;  // side to move
+    uint32_t nxs = nx ? white : black, pls = nx ? black : white;
+    uint32_t e = g.full_l1 & ~(black | white);
+    uint32_t multi_nx, alive_nx, multi_pl;
+    analyze<R>(nxs, pls, e, lc, sc, lane, multi_nx, alive_nx, multi_pl);
+    uint32_t invalid = invalid_from(nxs, pls, multi_nx, multi_pl, g, lane);
+    if (ko) {
+      int k = __builtin_amdgcn_readfirstlane(ko[b]);
+      if (k >= 0 && k < g.P) {
+        int kr = k / N, kc = k - kr * N;
+        if (lane == kr) invalid |= 1u << kc;
+      }
+    }
+    WAVE_SYNC();
+    if (lane < 32) rowsw[lane] = invalid;
+    WAVE_SYNC();
+    uint8_t *go = mask + b * (int64_t)g.P;
+    uint32_t mo = (uint32_t)((uintptr_t)go & 15u);
+#pragma unroll
+    for (int j = 0; j < Cfg<R>::kCellsPerLane; ++j) {
+      int cell = lane + kWave * j;
+      if (cell < g.P) iobuf[mo + cell] = (uint8_t)((rowsw[cm.rc[j] >> 8] >> (cm.rc[j] & 0xFF)) & 1u);
+    }
+    WAVE_SYNC();
+    stage_out(go, g.P, iobuf, lane);
+  }
+}
+
+// gogame.areas (gym_go/gogame.py:275-300): flood the empty points from those touching black (lane 0)
+// and those touching white (lane 1); a region reached by exactly one colour belongs to it.
+template <int R>
+__global__ __launch_bounds__(kWave) void k_areas(const uint8_t *__restrict__ states, int32_t *__restrict__ black_area,
+                                                 int32_t *__restrict__ white_area, int64_t B, int N) {
+  __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
+  const int lane = threadIdx.x;
+  Geo g;
+  g.N = N; g.P = N * N;
+  g.full_l1 = lane < N ? (1u << N) - 1u : 0u;
+  const int S = 6 * g.P;
+  const uint8_t *in_end = states + B * (int64_t)S;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const uint8_t *gi = states + b * (int64_t)S;
+    WAVE_SYNC();
+    uint32_t mis = stage_in(gi, 2 * g.P, states, in_end, iobuf, lane);
+    WAVE_SYNC();
+    uint32_t black, white;
+    planes_to_rows<R>(iobuf + mis, iobuf + mis + g.P, g, lane, black, white);
+    uint32_t e = g.full_l1 & ~(black | white);
+    uint32_t m[R], mrev[R], f[R], src[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      m[r] = __builtin_amdgcn_readlane(e, r);
+      mrev[r] = __brev(m[r]);
+      uint32_t sb = __builtin_amdgcn_readlane(black, r), sw = __builtin_amdgcn_readlane(white, r);
+      src[r] = lane == 0 ? sb : lane == 1 ? sw : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      uint32_t nb = (src[r] << 1) | (src[r] >> 1);
+      if (r > 0) nb |= src[r - 1];
+      if (r < R - 1) nb |= src[r + 1];
+      f[r] = m[r] & nb;
+    }
+    flood<R>(m, mrev, f);
+    int ba = 0, wa = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      uint32_t fb = __builtin_amdgcn_readlane(f[r], 0), fw = __builtin_amdgcn_readlane(f[r], 1);
+      ba += __popc(fb & ~fw);
+      wa += __popc(fw & ~fb);
+    }
+    // stone counts: sum of per-row popcounts over lanes
+    int sb = __popc(black), sw = __popc(white);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+      sb += __shfl_xor(sb, off);
+      sw += __shfl_xor(sw, off);
+    }
+    if (lane == 0) {
+      black_area[b] = ba + sb;
+      white_area[b] = wa + sw;
+    }
+  }
+}
+
+// gogame.children (gym_go/gogame.py:175-186), padded: work item = (parent, chunk of actions); the parent
+// is staged and converted once, each action of the chunk is one step_core on a copy of the bitboards.
+template <int R>
+__global__ __launch_bounds__(kWave) void k_children(const uint8_t *__restrict__ states, uint8_t *__restrict__ children,
+                                                    int64_t B, int N, int canonical, int chunks) {
+  __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
+  __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
+  __shared__ uint32_t rowsw[96];
+  const int lane = threadIdx.x;
+  Geo g;
+  g.N = N; g.P = N * N;
+  g.full_l1 = lane < N ? (1u << N) - 1u : 0u;
+  const int S = 6 * g.P;
+  const int A = g.P + 1;
+  const LaneClass lc = make_lane_class(lane);
+  const CellMap cm = make_cell_map<R>(lane, N);
+  const uint8_t *in_end = states + B * (int64_t)S;
+  const int per = (A + chunks - 1) / chunks;
+  for (int64_t w = blockIdx.x; w < B * chunks; w += gridDim.x) {
+    const int64_t b = w / chunks;
+    const int ch = (int)(w - b * chunks);
+    const uint8_t *gi = states + b * (int64_t)S;
+    uint32_t flags = load_flags(gi, g.P, 0, lane);
+    WAVE_SYNC();
+    // planes 0,1 for the stones and plane 3 for slot validity (planes 0..3 are contiguous)
+    uint32_t mis = stage_in(gi, 4 * g.P, states, in_end, iobuf, lane);
+    WAVE_SYNC();
+    uint32_t black, white, dummy, invd;
+    planes_to_rows<R>(iobuf + mis, iobuf + mis + g.P, g, lane, black, white);
+    planes_to_rows<R>(iobuf + mis + 2 * g.P, iobuf + mis + 3 * g.P, g, lane, dummy, invd);
+    const int pl = flags & 1u;
+    const int a0 = ch * per, a1 = min(A, a0 + per);
+#pragma unroll 1
+    for (int a = a0; a < a1; ++a) {
+      uint8_t *go = children + (b * A + a) * (int64_t)S;
+      bool valid = true;
+      if (a < g.P) {
+        int ra = a / N, ca = a - ra * N;
+        uint32_t row = __builtin_amdgcn_readlane(invd, ra);
+        valid = ((row >> ca) & 1u) == 0;
+      }
+      uint32_t mo = (uint32_t)((uintptr_t)go & 15u);
+      if (!valid) {
+        WAVE_SYNC();
+        for (int i = lane; i < Cfg<R>::kIoBytes / 16; i += kWave)
+          reinterpret_cast<uint4 *>(iobuf)[i] = make_uint4(0, 0, 0, 0);
+        WAVE_SYNC();
+        stage_out(go, S, iobuf, lane);
+        continue;
+      }
+      const bool is_pass = a == g.P;
+      uint32_t mine = pl ? white : black, opp = pl ? black : white;
+      uint32_t invalid = step_core<R>(mine, opp, a, g, lc, sc, lane);
+      uint32_t nb = pl ? opp : mine, nw = pl ? mine : opp;
+      PlaneBytes pb;
+      pb.passed = is_pass ? 1 : 0;
+      pb.done = ((flags & 8u) || (is_pass && (flags & 4u))) ? 1 : 0;
+      int nturn = 1 - pl;
+      if (canonical && nturn == 1) {
+        uint32_t t = nb; nb = nw; nw = t;
+        nturn = 0;
+      }
+      pb.turn = (uint8_t)nturn;
+      emit_board<R>(iobuf + mo, rowsw, nb, nw, invalid, pb, g, cm, lane);
+      stage_out(go, S, iobuf, lane);
+    }
+  }
+}
+
+// wave-uniform copy of a 64-bit value (readfirstlane returns a SIGNED int: cast before widening)
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
+
+// ---- sampler shared by the rollout kernels (mirrors oracle/gg_oracle.c splitmix_next / rollout_ply)
+__device__ __forceinline__ uint64_t splitmix_next(uint64_t &x) {
+  uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// k-th (0-based) valid action in ascending index order; valid = L1 rows of playable points; k == count -> pass
+__device__ __forceinline__ int pick_action(uint32_t valid, uint32_t k, const Geo &g, int lane) {
+  int cnt = __popc(valid);
+  int incl = cnt;  // inclusive prefix over lanes 0..31 (rows live in lanes < 32)
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    int t = __shfl_up(incl, off);
+    if ((lane & 31) >= off) incl += t;
+  }
+  uint64_t hit = __ballot(lane < 32 && (uint32_t)incl > k);
+  if (hit == 0) return g.P;  // pass
+  int r = __ffsll((unsigned long long)hit) - 1;
+  uint32_t row = __builtin_amdgcn_readlane(valid, r);
+  uint32_t before = (uint32_t)__builtin_amdgcn_readlane(incl, r) - (uint32_t)__popc(row);
+  uint32_t t = k - before;
+  for (uint32_t i = 0; i < t; ++i) row &= row - 1;
+  return r * g.N + (__ffs(row) - 1);
+}
+
+template <int R>
+__global__ __launch_bounds__(kWave) void k_rollout(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+                                                   int32_t *__restrict__ last_actions, int64_t *__restrict__ steps_done,
+                                                   int64_t B, int N, int plies, int auto_reset) {
+  __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
+  __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
+  __shared__ uint32_t rowsw[96];
+  const int lane = threadIdx.x;
+  Geo g;
+  g.N = N; g.P = N * N;
+  g.full_l1 = lane < N ? (1u << N) - 1u : 0u;
+  const int S = 6 * g.P;
+  const LaneClass lc = make_lane_class(lane);
+  const CellMap cm = make_cell_map<R>(lane, N);
+  const uint8_t *in_end = states + B * (int64_t)S;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    uint8_t *gs = states + b * (int64_t)S;
+    uint32_t flags = load_flags(gs, g.P, 0, lane);
+    WAVE_SYNC();
+    uint32_t mis = stage_in(gs, 4 * g.P, states, in_end, iobuf, lane);
+    WAVE_SYNC();
+    uint32_t black, white, dummy, invalid;
+    planes_to_rows<R>(iobuf + mis, iobuf + mis + g.P, g, lane, black, white);
+    planes_to_rows<R>(iobuf + mis + 2 * g.P, iobuf + mis + 3 * g.P, g, lane, dummy, invalid);
+    int turn = flags & 1u, passed = (flags >> 2) & 1u, done = (flags >> 3) & 1u;
+    uint64_t x = uniform64(rng[b]);
+    int last = -1, played = 0;
+#pragma unroll 1
+    for (int t = 0; t < plies; ++t) {
+      if (done) {
+        if (!auto_reset) break;
+        black = white = invalid = 0;
+        turn = passed = done = 0;
+      }
+      uint32_t valid = g.full_l1 & ~invalid;
+      int cnt = __popc(valid);
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+      cnt = __builtin_amdgcn_readfirstlane(cnt);
+      uint64_t u = splitmix_next(x);
+      uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(cnt + 1)) >> 32);
+      int a = pick_action(valid, k, g, lane);
+      uint32_t mine = turn ? white : black, opp = turn ? black : white;
+      invalid = step_core<R>(mine, opp, a, g, lc, sc, lane);
+      black = turn ? opp : mine;
+      white = turn ? mine : opp;
+      if (a == g.P) { if (passed) done = 1; passed = 1; } else passed = 0;
+      turn ^= 1;
+      last = a;
+      ++played;
+    }
+    PlaneBytes pb;
+    pb.turn = (uint8_t)turn; pb.passed = (uint8_t)passed; pb.done = (uint8_t)done;
+    if (played) {
+      uint32_t mo = (uint32_t)((uintptr_t)gs & 15u);
+      emit_board<R>(iobuf + mo, rowsw, black, white, invalid, pb, g, cm, lane);
+      stage_out(gs, S, iobuf, lane);
+    }
+    if (lane == 0) {
+      rng[b] = x;
+      if (last_actions) last_actions[b] = last;
+      if (steps_done) steps_done[b] += played;
+    }
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(kWave) void k_sample(const uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+                                                  int32_t *__restrict__ actions, int64_t B, int N) {
+  __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
+  const int lane = threadIdx.x;
+  Geo g;
+  g.N = N; g.P = N * N;
+  g.full_l1 = lane < N ? (1u << N) - 1u : 0u;
+  const int S = 6 * g.P;
+  const uint8_t *in_end = states + B * (int64_t)S;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const uint8_t *gs = states + b * (int64_t)S;
+    uint32_t flags = load_flags(gs, g.P, 0, lane);
+    WAVE_SYNC();
+    uint32_t mis = stage_in(gs + 2 * g.P, 2 * g.P, states, in_end, iobuf, lane);
+    WAVE_SYNC();
+    uint32_t dummy, invalid;
+    planes_to_rows<R>(iobuf + mis, iobuf + mis + g.P, g, lane, dummy, invalid);
+    if (flags & 8u) invalid = 0;  // gogame.invalid_moves: zeros once the game ended (gogame.py:155-156)
+    uint32_t valid = g.full_l1 & ~invalid;
+    int cnt = __popc(valid);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    cnt = __builtin_amdgcn_readfirstlane(cnt);
+    uint64_t x = uniform64(rng[b]);
+    uint64_t u = splitmix_next(x);
+    uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(cnt + 1)) >> 32);
+    int a = pick_action(valid, k, g, lane);
+    if (lane == 0) {
+      rng[b] = x;
+      actions[b] = a;
+    }
+  }
+}
+
+__global__ void k_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  uint64_t x = base_seed ^ ((uint64_t)(first_game + i) * 0xD1342543DE82EF95ull);
+  splitmix_next(x);
+  rng[i] = x;
+}
+
+// ---------------------------------------------------------------- host side
+
+int g_cus = -1;
+
+int device_cus() {
+  if (g_cus < 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    g_cus = cus;
+  }
+  return g_cus;
+}
+
+// persistent grid: enough single-wave workgroups to fill every SIMD several times over
+int grid_for(int64_t work) {
+  int cus = device_cus();
+  if (cus <= 0) cus = 256;
+  int64_t cap = (int64_t)cus * 32;
+  return (int)(work < cap ? (work > 0 ? work : 1) : cap);
+}
+
+int32_t check(int64_t B, int32_t N) { return (N < 2 || N > GG_MAX_BOARD || B < 0) ? GG_E_BADSIZE : 0; }
+
+#define GG_DISPATCH(N, CALL9, CALL13, CALL19) \
+  do {                                        \
+    if ((N) <= 9) { CALL9; }                  \
+    else if ((N) <= 13) { CALL13; }           \
+    else { CALL19; }                          \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int32_t gg_version(void) { return GG_ABI_VERSION; }
+
+int32_t gg_device_cus(void) { return device_cus(); }
+
+int32_t gg_batch_next_states(const uint8_t *in, const int32_t *actions, uint8_t *out, int32_t *status, int64_t B,
+                             int32_t N, int32_t canonical, void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (B == 0) return 0;
+  if (!in || !actions || !out) return GG_E_NULLPTR;
+  hipStream_t s = (hipStream_t)hip_stream;
+  int grid = grid_for(B);
+  GG_DISPATCH(N, (k_next_states<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, canonical)),
+              (k_next_states<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, canonical)),
+              (k_next_states<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, canonical)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_invalid_mask(const uint8_t *states, const int32_t *ko, uint8_t *mask, int64_t B, int32_t N,
+                              void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (B == 0) return 0;
+  if (!states || !mask) return GG_E_NULLPTR;
+  hipStream_t s = (hipStream_t)hip_stream;
+  int grid = grid_for(B);
+  GG_DISPATCH(N, (k_invalid_mask<9><<<grid, kWave, 0, s>>>(states, ko, mask, B, N)),
+              (k_invalid_mask<13><<<grid, kWave, 0, s>>>(states, ko, mask, B, N)),
+              (k_invalid_mask<19><<<grid, kWave, 0, s>>>(states, ko, mask, B, N)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_areas(const uint8_t *states, int32_t *black, int32_t *white, int64_t B, int32_t N, void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (B == 0) return 0;
+  if (!states || !black || !white) return GG_E_NULLPTR;
+  hipStream_t s = (hipStream_t)hip_stream;
+  int grid = grid_for(B);
+  GG_DISPATCH(N, (k_areas<9><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
+              (k_areas<13><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
+              (k_areas<19><<<grid, kWave, 0, s>>>(states, black, white, B, N)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_children(const uint8_t *states, uint8_t *children, int64_t B, int32_t N, int32_t canonical,
+                          void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (B == 0) return 0;
+  if (!states || !children) return GG_E_NULLPTR;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int A = N * N + 1;
+  int cus = device_cus();
+  if (cus <= 0) cus = 256;
+  int64_t want = (int64_t)cus * 64;  // work items wanted to keep every SIMD busy
+  int chunks = (int)((want + B - 1) / B);
+  if (chunks < 1) chunks = 1;
+  if (chunks > A) chunks = A;
+  int grid = grid_for(B * chunks);
+  GG_DISPATCH(N, (k_children<9><<<grid, kWave, 0, s>>>(states, children, B, N, canonical, chunks)),
+              (k_children<13><<<grid, kWave, 0, s>>>(states, children, B, N, canonical, chunks)),
+              (k_children<19><<<grid, kWave, 0, s>>>(states, children, B, N, canonical, chunks)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B,
+                         int32_t N, int32_t plies, int32_t auto_reset, void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (plies < 0) return GG_E_BADARG;
+  if (B == 0 || plies == 0) return 0;
+  if (!states || !rng) return GG_E_NULLPTR;
+  hipStream_t s = (hipStream_t)hip_stream;
+  int grid = grid_for(B);
+  GG_DISPATCH(N, (k_rollout<9><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, plies, auto_reset)),
+              (k_rollout<13><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, plies, auto_reset)),
+              (k_rollout<19><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, plies, auto_reset)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_sample_actions(const uint8_t *states, uint64_t *rng, int32_t *actions, int64_t B, int32_t N,
+                                void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (B == 0) return 0;
+  if (!states || !rng || !actions) return GG_E_NULLPTR;
+  hipStream_t s = (hipStream_t)hip_stream;
+  int grid = grid_for(B);
+  GG_DISPATCH(N, (k_sample<9><<<grid, kWave, 0, s>>>(states, rng, actions, B, N)),
+              (k_sample<13><<<grid, kWave, 0, s>>>(states, rng, actions, B, N)),
+              (k_sample<19><<<grid, kWave, 0, s>>>(states, rng, actions, B, N)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B, void *hip_stream) {
+  if (B < 0) return GG_E_BADSIZE;
+  if (B == 0) return 0;
+  if (!rng) return GG_E_NULLPTR;
+  hipStream_t s = (hipStream_t)hip_stream;
+  k_rng_seed<<<(unsigned)((B + 255) / 256), 256, 0, s>>>(rng, base_seed, first_game, B);
+  return (int32_t)hipGetLastError();
+}
+
+}  // extern "C"

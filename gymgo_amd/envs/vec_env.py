@@ -1,0 +1,77 @@
+"""GoVecEnv - B independent games as ONE uint8 [B, 6, N, N] device tensor (no reference counterpart:
+the reference has one game per GoEnv; this is the batched form its gogame.batch_* functions imply).
+
+One process drives one GPU; to use several GPUs run one process per GPU with `shard(rank, world)`
+slices of the game range - games never interact, so there is no collective on the data path.
+"""
+import torch
+
+from gymgo_amd import gogame, govars
+
+
+def shard(total_games, rank, world_size):
+    """Contiguous equal split of the game index range [0, total_games) -> (first_game, count)."""
+    base, rem = divmod(total_games, world_size)
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+class GoVecEnv:
+    def __init__(self, batch_size, size, komi=0, reward_method='real', device=None, seed=20260927, first_game=0,
+                 auto_reset=True):
+        self.batch_size, self.size, self.komi = batch_size, size, komi
+        self.reward_method = reward_method
+        self.device = torch.device(device) if device is not None else gogame._device()
+        self.auto_reset = auto_reset
+        self.states = gogame.batch_init_state(batch_size, size, device=self.device)
+        self.rng = gogame.rng_seed(batch_size, seed, first_game, self.device)
+        self.steps_done = torch.zeros(batch_size, dtype=torch.int64, device=self.device)
+        self.last_actions = torch.full((batch_size,), -1, dtype=torch.int32, device=self.device)
+
+    def reset(self, mask=None):
+        if mask is None:
+            self.states.zero_()
+        else:
+            self.states[mask] = 0
+        return self.states
+
+    def valid_moves(self):
+        return gogame.batch_valid_moves(self.states)
+
+    def sample_actions(self):
+        """Uniform over valid actions incl. pass, per game, on the device."""
+        return gogame.batch_sample_actions(self.states, self.rng)
+
+    def step(self, actions, check=False):
+        """-> (states, rewards, dones, status).  Finished games are reset first when auto_reset."""
+        if self.auto_reset:
+            ended = gogame.batch_game_ended(self.states).bool()
+            self.states = torch.where(ended[:, None, None, None], torch.zeros_like(self.states), self.states)
+        actions = actions.to(device=self.device, dtype=torch.int32)
+        self.states, status = gogame.batch_next_states(self.states, actions, check=False)
+        if check and bool((status != 0).any()):
+            raise AssertionError('illegal move in batch')
+        self.last_actions = actions
+        self.steps_done += (status == 0).to(torch.int64)
+        dones = gogame.batch_game_ended(self.states)
+        return self.states, self.rewards(dones), dones, status
+
+    def rollout(self, plies):
+        """`plies` uniform-random steps per game, fused on the device (board stays on-chip)."""
+        gogame.batch_rollout(self.states, self.rng, plies, self.auto_reset, self.last_actions, self.steps_done)
+        return self.states
+
+    def rewards(self, dones=None):
+        """GoEnv.reward for every game (gym_go/envs/go_env.py:128-149), black's perspective."""
+        black, white = gogame.batch_areas(self.states)
+        margin = black.to(torch.float64) - white.to(torch.float64) - self.komi
+        if dones is None:
+            dones = gogame.batch_game_ended(self.states)
+        over = dones.bool()
+        if self.reward_method == 'real':
+            return torch.where(over, torch.sign(margin), torch.zeros_like(margin))
+        final = torch.where(margin > 0, 1.0, -1.0).to(torch.float64) * self.size ** 2
+        return torch.where(over, final, margin)
+
+    def turns(self):
+        return self.states[:, govars.TURN_CHNL, 0, 0]

@@ -1,0 +1,438 @@
+"""`gogame`-compatible function library over the HIP kernels (mirrors gym_go/gogame.py:22-468:
+same names, positional order, return shapes and error behaviour).
+
+Containers
+  * torch uint8 device tensors ([6,N,N] / [B,6,N,N]) are the native form: results are device tensors.
+  * NumPy arrays (the reference's float64 states) are accepted everywhere for drop-in use: they are
+    moved to the device, run through the same kernels, and the result comes back as a NumPy array of
+    the input dtype.  Nothing is ever computed on the CPU.
+Errors: an illegal move raises AssertionError (gym_go/gogame.py:59, :117); action_size() without
+arguments raises RuntimeError (:196).
+"""
+import numpy as np
+import torch
+
+from gymgo_amd import _lib, govars
+
+_U8, _I32, _I64 = torch.uint8, torch.int32, torch.int64
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise _lib.GymGoNativeError('no ROCm device visible; gymgo_amd has no CPU path')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+class _Box:
+    """Remembers how the caller passed a state so results go back in the same form."""
+
+    def __init__(self, x):
+        self.numpy = not isinstance(x, torch.Tensor)
+        if self.numpy:
+            x = np.asarray(x)
+            self.np_dtype = x.dtype if x.dtype != np.bool_ else np.dtype(np.uint8)
+            self.t = torch.from_numpy(np.ascontiguousarray(x).astype(np.uint8, copy=False)).to(_device())
+        else:
+            if not x.is_cuda:
+                raise _lib.GymGoNativeError('state tensors must live on the ROCm device')
+            self.t = x.to(_U8).contiguous()
+
+    def back(self, t, dtype=None):
+        if self.numpy:
+            return t.cpu().numpy().astype(dtype or self.np_dtype)
+        return t
+
+
+def _actions_tensor(actions, B, device):
+    if isinstance(actions, torch.Tensor):
+        a = actions.to(device=device, dtype=_I32).contiguous()
+    else:
+        a = torch.as_tensor(np.asarray(actions).astype(np.int32), device=device)
+    if a.numel() != B:
+        raise ValueError('need one action per state (%d != %d)' % (a.numel(), B))
+    return a.reshape(B)
+
+
+# ------------------------------------------------------------------ raw device calls
+
+def _next_states_dev(states, actions, canonical):
+    B, C, N, _ = states.shape
+    out = torch.empty_like(states)
+    status = torch.empty(B, dtype=_I32, device=states.device)
+    code = _lib.lib().gg_batch_next_states(
+        _lib.dev_ptr(states, _U8, 'states'), _lib.dev_ptr(actions, _I32, 'actions'), _lib.dev_ptr(out, _U8, 'out'),
+        _lib.dev_ptr(status, _I32, 'status'), B, N, int(bool(canonical)), _lib.stream_ptr(states.device))
+    _lib.check(code, 'gg_batch_next_states')
+    return out, status
+
+
+def _children_dev(states, canonical):
+    B, C, N, _ = states.shape
+    out = torch.empty((B, N * N + 1, C, N, N), dtype=_U8, device=states.device)
+    code = _lib.lib().gg_batch_children(_lib.dev_ptr(states, _U8, 'states'), _lib.dev_ptr(out, _U8, 'children'),
+                                        B, N, int(bool(canonical)), _lib.stream_ptr(states.device))
+    _lib.check(code, 'gg_batch_children')
+    return out
+
+
+def _areas_dev(states):
+    B, C, N, _ = states.shape
+    black = torch.empty(B, dtype=_I32, device=states.device)
+    white = torch.empty(B, dtype=_I32, device=states.device)
+    code = _lib.lib().gg_batch_areas(_lib.dev_ptr(states, _U8, 'states'), _lib.dev_ptr(black, _I32, 'black'),
+                                     _lib.dev_ptr(white, _I32, 'white'), B, N, _lib.stream_ptr(states.device))
+    _lib.check(code, 'gg_batch_areas')
+    return black, white
+
+
+def _invalid_mask_dev(states, ko=None):
+    B, C, N, _ = states.shape
+    mask = torch.empty((B, N, N), dtype=_U8, device=states.device)
+    code = _lib.lib().gg_batch_invalid_mask(_lib.dev_ptr(states, _U8, 'states'), _lib.dev_ptr(ko, _I32, 'ko'),
+                                            _lib.dev_ptr(mask, _U8, 'mask'), B, N, _lib.stream_ptr(states.device))
+    _lib.check(code, 'gg_batch_invalid_mask')
+    return mask
+
+
+# ------------------------------------------------------------------ gogame API
+
+def init_state(size, device=None):
+    """gym_go/gogame.py:22-25.  NumPy float64 zeros like the reference, or a device uint8 tensor."""
+    if device is None:
+        return np.zeros((govars.NUM_CHNLS, size, size))
+    return torch.zeros((govars.NUM_CHNLS, size, size), dtype=_U8, device=device)
+
+
+def batch_init_state(batch_size, board_size, device=None):
+    """gym_go/gogame.py:28-31."""
+    if device is None:
+        return np.zeros((batch_size, govars.NUM_CHNLS, board_size, board_size))
+    return torch.zeros((batch_size, govars.NUM_CHNLS, board_size, board_size), dtype=_U8, device=device)
+
+
+def next_state(state, action1d, canonical=False):
+    """gym_go/gogame.py:34-87.  Input is never mutated; illegal point -> AssertionError."""
+    box = _Box(state)
+    N = box.t.shape[-1]
+    actions = torch.tensor([int(action1d)], dtype=_I32, device=box.t.device)
+    out, status = _next_states_dev(box.t[None], actions, canonical)
+    if int(status[0]) != 0:
+        a = int(action1d)
+        raise AssertionError(('Invalid move', (a // N, a % N)))
+    return box.back(out[0])
+
+
+def batch_next_states(batch_states, batch_action1d, canonical=False, check=True):
+    """gym_go/gogame.py:90-150, with next_state's semantics for every game (also when the batch
+    contains passes, where the reference mis-aligns games: gym_go/state_utils.py:187-193).
+    check=True (default) synchronises to raise AssertionError like :117 if any move is illegal;
+    check=False returns (next_states, status) without a host sync - illegal rows pass through."""
+    box = _Box(batch_states)
+    B = box.t.shape[0]
+    actions = _actions_tensor(batch_action1d, B, box.t.device)
+    out, status = _next_states_dev(box.t, actions, canonical)
+    if not check:
+        return box.back(out), status
+    if B and bool((status != 0).any()):
+        raise AssertionError('Invalid move in batch at games %s' % torch.nonzero(status).flatten()[:8].tolist())
+    return box.back(out)
+
+
+def invalid_moves(state):
+    """gym_go/gogame.py:153-157: plane 3 flattened + [0] for pass; all zeros once the game ended."""
+    box = _Box(state)
+    t = box.t
+    n = t.shape[-1] * t.shape[-2] + 1
+    res = torch.zeros(n, dtype=_U8, device=t.device)
+    if not game_ended(t):
+        res[:-1] = t[govars.INVD_CHNL].reshape(-1)
+    return box.back(res, np.float64 if box.numpy else None)
+
+
+def valid_moves(state):
+    """gym_go/gogame.py:160-161."""
+    return 1 - invalid_moves(state)
+
+
+def batch_invalid_moves(batch_state):
+    """gym_go/gogame.py:164-168 (no game-over special case, like the reference)."""
+    box = _Box(batch_state)
+    t = box.t
+    n = t.shape[0]
+    flat = t[:, govars.INVD_CHNL].reshape(n, -1)
+    res = torch.cat([flat, torch.zeros((n, 1), dtype=_U8, device=t.device)], dim=1)
+    return box.back(res, np.float64 if box.numpy else None)
+
+
+def batch_valid_moves(batch_state):
+    """gym_go/gogame.py:171-172."""
+    return 1 - batch_invalid_moves(batch_state)
+
+
+def children(state, canonical=False, padded=True):
+    """gym_go/gogame.py:175-186.  padded=True -> [N*N+1, 6, N, N] with all-zero slots for invalid
+    actions; padded=False -> only the valid actions' successors, ascending action order."""
+    box = _Box(state)
+    kids = _children_dev(box.t[None], canonical)[0]
+    if not padded:
+        keep = torch.nonzero(torch.as_tensor(valid_moves(box.t)).to(kids.device)).flatten()
+        kids = kids[keep]
+    return box.back(kids)
+
+
+def batch_children(batch_states, canonical=False, padded=True):
+    """BASELINE.json config 5 (no reference counterpart: == stack(children(s) for s in states))."""
+    if not padded:
+        raise ValueError('batch_children returns a rectangular tensor; use padded=True')
+    box = _Box(batch_states)
+    return box.back(_children_dev(box.t, canonical))
+
+
+def action_size(state=None, board_size: int = None):
+    """gym_go/gogame.py:189-197."""
+    if state is not None:
+        m, n = state.shape[1:]
+    elif board_size is not None:
+        m, n = board_size, board_size
+    else:
+        raise RuntimeError('No argument passed')
+    return m * n + 1
+
+
+def _plane_any(state, chnl):
+    if isinstance(state, torch.Tensor):
+        return bool((state[chnl] == 1).any())
+    return bool(np.max(np.asarray(state)[chnl] == 1))
+
+
+def prev_player_passed(state):
+    """gym_go/gogame.py:200-201."""
+    return _plane_any(state, govars.PASS_CHNL)
+
+
+def batch_prev_player_passed(batch_state):
+    """gym_go/gogame.py:204-205."""
+    if isinstance(batch_state, torch.Tensor):
+        return batch_state[:, govars.PASS_CHNL].amax(dim=(1, 2)) == 1
+    return np.max(batch_state[:, govars.PASS_CHNL], axis=(1, 2)) == 1
+
+
+def game_ended(state):
+    """gym_go/gogame.py:208-214: 0/1."""
+    if isinstance(state, torch.Tensor):
+        return int(bool((state[govars.DONE_CHNL] == 1).all()))
+    m, n = state.shape[1:]
+    return int(np.count_nonzero(np.asarray(state)[govars.DONE_CHNL] == 1) == m * n)
+
+
+def batch_game_ended(batch_state):
+    """gym_go/gogame.py:217-222."""
+    if isinstance(batch_state, torch.Tensor):
+        return batch_state[:, govars.DONE_CHNL].amax(dim=(1, 2))
+    return np.max(batch_state[:, govars.DONE_CHNL], axis=(1, 2))
+
+
+def areas(state):
+    """gym_go/gogame.py:275-300 (Tromp-Taylor) -> (black_area, white_area)."""
+    box = _Box(state)
+    b, w = _areas_dev(box.t[None])
+    if box.numpy:
+        return np.float64(int(b[0])), np.float64(int(w[0]))
+    return b[0], w[0]
+
+
+def batch_areas(batch_state):
+    """gym_go/gogame.py:303-310 -> two [B] arrays."""
+    box = _Box(batch_state)
+    b, w = _areas_dev(box.t)
+    if box.numpy:
+        return b.cpu().numpy().astype(np.float64), w.cpu().numpy().astype(np.float64)
+    return b, w
+
+
+def winning(state, komi=0):
+    """gym_go/gogame.py:225-230: sign(black_area - white_area - komi)."""
+    black_area, white_area = areas(state)
+    if isinstance(black_area, torch.Tensor):
+        return torch.sign(black_area.to(torch.float64) - white_area.to(torch.float64) - komi)
+    return np.sign(black_area - white_area - komi)
+
+
+def batch_winning(state, komi=0):
+    """gym_go/gogame.py:233-238."""
+    b, w = batch_areas(state)
+    if isinstance(b, torch.Tensor):
+        return torch.sign(b.to(torch.float64) - w.to(torch.float64) - komi)
+    return np.sign(b - w - komi)
+
+
+def turn(state):
+    """gym_go/gogame.py:241-246."""
+    if isinstance(state, torch.Tensor):
+        return int(state[govars.TURN_CHNL].max())
+    return int(np.max(np.asarray(state)[govars.TURN_CHNL]))
+
+
+def batch_turn(batch_state):
+    """gym_go/gogame.py:249-250."""
+    if isinstance(batch_state, torch.Tensor):
+        return batch_state[:, govars.TURN_CHNL].amax(dim=(1, 2)).to(_I64)
+    return np.max(batch_state[:, govars.TURN_CHNL], axis=(1, 2)).astype(int)
+
+
+def liberties(state):
+    """gym_go/gogame.py:253-264: per colour, empty points next to ANY stone of that colour (a dilation
+    of the whole colour, not per group).  Host-side convenience, tensor ops only."""
+    box = _Box(state)
+    t = box.t.to(torch.bool)
+    empty = ~(t[govars.BLACK] | t[govars.WHITE])
+    res = []
+    for stones in (t[govars.BLACK], t[govars.WHITE]):
+        grown = torch.zeros_like(stones)
+        grown[1:] |= stones[:-1]
+        grown[:-1] |= stones[1:]
+        grown[:, 1:] |= stones[:, :-1]
+        grown[:, :-1] |= stones[:, 1:]
+        res.append(grown & empty)
+    if box.numpy:
+        return res[0].cpu().numpy(), res[1].cpu().numpy()
+    return res[0], res[1]
+
+
+def num_liberties(state):
+    """gym_go/gogame.py:267-272."""
+    b, w = liberties(state)
+    return int(b.sum()), int(w.sum())
+
+
+def canonical_form(state):
+    """gym_go/gogame.py:313-321: a copy; colours swapped and turn cleared when white is to move."""
+    if isinstance(state, torch.Tensor):
+        s = state.clone()
+        if turn(s) == govars.WHITE:
+            s[[govars.BLACK, govars.WHITE]] = state[[govars.WHITE, govars.BLACK]]
+            s[govars.TURN_CHNL] = 1 - s[govars.TURN_CHNL]
+        return s
+    s = np.copy(state)
+    if turn(s) == govars.WHITE:
+        s[[govars.BLACK, govars.WHITE]] = s[[govars.WHITE, govars.BLACK]]
+        s[govars.TURN_CHNL] = 1 - s[govars.TURN_CHNL]
+    return s
+
+
+def batch_canonical_form(batch_state):
+    """gym_go/gogame.py:324-337 (no host loop: one masked swap)."""
+    if isinstance(batch_state, torch.Tensor):
+        s = batch_state.clone()
+        white = batch_state[:, govars.TURN_CHNL].amax(dim=(1, 2)) == govars.WHITE
+        sel = white[:, None, None]
+        s[:, govars.BLACK] = torch.where(sel, batch_state[:, govars.WHITE], batch_state[:, govars.BLACK])
+        s[:, govars.WHITE] = torch.where(sel, batch_state[:, govars.BLACK], batch_state[:, govars.WHITE])
+        s[:, govars.TURN_CHNL] = torch.where(sel, torch.zeros_like(s[:, govars.TURN_CHNL]), s[:, govars.TURN_CHNL])
+        return s
+    s = np.copy(batch_state)
+    white = batch_turn(s) == govars.WHITE
+    s[white, govars.BLACK], s[white, govars.WHITE] = batch_state[white, govars.WHITE], batch_state[white, govars.BLACK]
+    s[white, govars.TURN_CHNL] = 0
+    return s
+
+
+def _orient(image, i):
+    flip = torch.flip if isinstance(image, torch.Tensor) else (lambda x, dims: np.flip(x, dims[0]))
+    rot = (lambda x: torch.rot90(x, 1, (1, 2))) if isinstance(image, torch.Tensor) else (
+        lambda x: np.rot90(x, axes=(1, 2)))
+    x = image
+    if (i >> 0) % 2:
+        x = flip(x, (2,))
+    if (i >> 1) % 2:
+        x = flip(x, (1,))
+    if (i >> 2) % 2:
+        x = rot(x)
+    return x
+
+
+def random_symmetry(image):
+    """gym_go/gogame.py:340-359: one of the 8 dihedral views of a [C, N, N] image."""
+    return _orient(image, int(np.random.randint(0, 8)))
+
+
+def all_symmetries(image):
+    """gym_go/gogame.py:362-382: all 8, same order (h-flip bit 0, v-flip bit 1, rot90 bit 2)."""
+    return [_orient(image, i) for i in range(8)]
+
+
+def random_weighted_action(move_weights):
+    """gym_go/gogame.py:385-392: L1-normalise, then draw."""
+    w = np.asarray(move_weights.cpu() if isinstance(move_weights, torch.Tensor) else move_weights, dtype=np.float64)
+    w = w / np.abs(w).sum()
+    return np.random.choice(np.arange(len(w)), p=w)
+
+
+def random_action(state):
+    """gym_go/gogame.py:395-404: uniform over plane-3-clear points and pass."""
+    inv = state[govars.INVD_CHNL].reshape(-1)
+    inv = inv.cpu().numpy() if isinstance(inv, torch.Tensor) else np.asarray(inv)
+    return random_weighted_action(1 - np.append(inv, 0))
+
+
+def str(state):
+    """gym_go/gogame.py:407-468: Unicode board + turn / game state / areas footer."""
+    s = state.cpu().numpy() if isinstance(state, torch.Tensor) else np.asarray(state)
+    size = s.shape[1]
+    rows = ['\t' + ''.join('{}'.format(i).ljust(2, ' ') for i in range(size))]
+    for i in range(size):
+        line = '{}\t'.format(i)
+        for j in range(size):
+            last = j == size - 1
+            if s[0, i, j] == 1 or s[1, i, j] == 1:
+                line += '○' if s[0, i, j] == 1 else '●'
+                if not last:
+                    line += '═' if i in (0, size - 1) else '─'
+            elif i == 0:
+                line += '╔═' if j == 0 else ('╗' if last else '╤═')
+            elif i == size - 1:
+                line += '╚═' if j == 0 else ('╝' if last else '╧═')
+            else:
+                line += '╟─' if j == 0 else ('╢' if last else '┼─')
+        rows.append(line)
+    black_area, white_area = areas(state)
+    phase = 'END' if game_ended(state) else ('PASSED' if prev_player_passed(state) else 'ONGOING')
+    rows.append('\tTurn: {}, Game State (ONGOING|PASSED|END): {}'.format('BLACK' if turn(state) == 0 else 'WHITE', phase))
+    rows.append('\tBlack Area: {}, White Area: {}'.format(int(black_area), int(white_area)))
+    return '\n'.join(rows) + '\n'
+
+
+# ------------------------------------------------------------------ device rollout helpers (build-side)
+
+def rng_seed(batch_size, base_seed=20260927, first_game=0, device=None):
+    """Per-game generator states for batch_rollout / batch_sample_actions (include/gymgo_amd.h)."""
+    device = device or _device()
+    # uint64 storage as int64 tensor (torch has no general uint64 ops; only the bits matter)
+    rng = torch.empty(batch_size, dtype=_I64, device=device)
+    code = _lib.lib().gg_rng_seed(_lib.dev_ptr(rng, _I64, 'rng'), int(base_seed) & (2 ** 64 - 1), int(first_game),
+                                  batch_size, _lib.stream_ptr(device))
+    _lib.check(code, 'gg_rng_seed')
+    return rng
+
+
+def batch_rollout(batch_states, rng, plies, auto_reset=True, last_actions=None, steps_done=None):
+    """IN PLACE: `plies` uniform-random steps per game with the board resident on-chip (gg_batch_rollout)."""
+    B, C, N, _ = batch_states.shape
+    code = _lib.lib().gg_batch_rollout(
+        _lib.dev_ptr(batch_states, _U8, 'states'), _lib.dev_ptr(rng, _I64, 'rng'),
+        _lib.dev_ptr(last_actions, _I32, 'last_actions'), _lib.dev_ptr(steps_done, _I64, 'steps_done'),
+        B, N, int(plies), int(bool(auto_reset)), _lib.stream_ptr(batch_states.device))
+    _lib.check(code, 'gg_batch_rollout')
+    return batch_states
+
+
+def batch_sample_actions(batch_states, rng):
+    """actions[b] ~ Uniform{valid actions incl. pass} on the device (GoEnv.uniform_random_action,
+    gym_go/envs/go_env.py:78-81, for every game at once)."""
+    B, C, N, _ = batch_states.shape
+    actions = torch.empty(B, dtype=_I32, device=batch_states.device)
+    code = _lib.lib().gg_batch_sample_actions(
+        _lib.dev_ptr(batch_states, _U8, 'states'), _lib.dev_ptr(rng, _I64, 'rng'),
+        _lib.dev_ptr(actions, _I32, 'actions'), B, N, _lib.stream_ptr(batch_states.device))
+    _lib.check(code, 'gg_batch_sample_actions')
+    return actions

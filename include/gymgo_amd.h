@@ -1,0 +1,114 @@
+/*
+ * gymgo_amd.h - C-ABI of the MI355X (gfx950) batched Go step path.
+ *
+ * The reference (huangeddie/GymGo) is pure Python and has no FFI seam; its boundary for this path
+ * is the function API of gym_go/gogame.py + gym_go/state_utils.py.  Each entry point below is what
+ * a ctypes binding of that API binds to (the stub is shown in INTEGRATION.md); the reference
+ * function it replaces is cited as path:line relative to the reference root.
+ *
+ * Conventions (all entry points):
+ *   - States are contiguous uint8 [B][6][N][N], values in {0,1}; channels per gym_go/govars.py:4-9
+ *     (0 black, 1 white, 2 turn, 3 invalid moves for the side to move, 4 previous move was a pass,
+ *     5 game over).  Planes 2, 4 and 5 are uniform by construction (the reference only ever writes
+ *     them whole: gym_go/gogame.py:49-56, gym_go/state_utils.py:241); the kernels read one byte of each.
+ *   - Every pointer is a DEVICE pointer owned by the caller; the library allocates nothing, keeps no
+ *     global state besides a cached device-property query, and never synchronises: work is enqueued
+ *     on `hip_stream` (a hipStream_t, NULL = default stream) and the call returns immediately.
+ *   - 2 <= N <= 19.  Actions are int32 in [0, N*N]; N*N = pass (gym_go/gogame.py:40-42).
+ *   - Return value: 0 on success, a hipError_t (> 0) for launch/runtime errors, or a negative
+ *     GG_E_* code for bad arguments.  Re-entrant; safe from several threads / one process per GPU.
+ */
+#ifndef GYMGO_AMD_H
+#define GYMGO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GG_ABI_VERSION 1
+#define GG_MAX_BOARD 19
+#define GG_NUM_CHNLS 6
+
+#define GG_E_BADSIZE (-1)  /* N outside [2, 19] or B < 0 */
+#define GG_E_NULLPTR (-2)  /* a required pointer is NULL */
+#define GG_E_BADARG (-3)   /* other argument out of range */
+
+/* per-game status written by gg_batch_next_states */
+#define GG_STATUS_OK 0
+#define GG_STATUS_ILLEGAL 1 /* point has INVD set / action out of range: the reference raises
+                               AssertionError (gym_go/gogame.py:59, :117); the row is copied through */
+
+int32_t gg_version(void);
+
+/* Number of compute units of the current device (0 if no device) - lets the host mirror size grids. */
+int32_t gg_device_cus(void);
+
+/*
+ * gogame.batch_next_states(batch_states, batch_action1d, canonical)   gym_go/gogame.py:90-150
+ * with the per-game semantics of gogame.next_state                      gym_go/gogame.py:34-87
+ * (place / pass, state_utils.update_pieces capture resolution :159-180, ko :72-75,
+ * state_utils.compute_invalid_moves :24-83, state_utils.set_turn :235-241, optional
+ * canonical_form :313-321) for EVERY game - the reference's batch path mis-aligns games when the
+ * batch contains passes (gym_go/state_utils.py:187-193); that defect is not reproduced.
+ * `in` and `out` must not overlap.  `status` may be NULL.
+ */
+int32_t gg_batch_next_states(const uint8_t *in, const int32_t *actions, uint8_t *out, int32_t *status,
+                             int64_t B, int32_t N, int32_t canonical, void *hip_stream);
+
+/*
+ * state_utils.batch_compute_invalid_moves                              gym_go/state_utils.py:86-156
+ * Recomputes plane 3 (invalid moves for the side to move, plane 2) from planes 0-2:
+ * mask[b] = compute_invalid_moves(states[b], player = 1 - turn(states[b]), ko[b]).
+ * `ko` (nullable) holds a flat point index per game or -1.  mask is uint8 [B][N][N].
+ */
+int32_t gg_batch_invalid_mask(const uint8_t *states, const int32_t *ko, uint8_t *mask, int64_t B, int32_t N,
+                              void *hip_stream);
+
+/*
+ * gogame.batch_areas                                                   gym_go/gogame.py:303-310
+ * (gogame.areas :275-300, Tromp-Taylor): black[b], white[b] = area of each colour, as int32
+ * (the reference returns the same integers as float64).
+ */
+int32_t gg_batch_areas(const uint8_t *states, int32_t *black, int32_t *white, int64_t B, int32_t N,
+                       void *hip_stream);
+
+/*
+ * gogame.children(state, canonical, padded=True) for every state      gym_go/gogame.py:175-186
+ * children is uint8 [B][N*N+1][6][N][N]; slot a = next_state(states[b], a, canonical) when action a
+ * is valid (plane 3 clear, or a = pass), all zeros otherwise (gym_go/tests/test_basics.py:209-223).
+ */
+int32_t gg_batch_children(const uint8_t *states, uint8_t *children, int64_t B, int32_t N, int32_t canonical,
+                          void *hip_stream);
+
+/*
+ * Uniform-random rollout, `plies` steps per game, IN PLACE, board resident on-chip between plies:
+ * per ply and game  a ~ Uniform{valid actions incl. pass}  (GoEnv.uniform_random_action,
+ * gym_go/envs/go_env.py:78-81; gogame.random_action gym_go/gogame.py:395-404), then
+ * state = next_state(state, a).  A finished game (plane 5 set) is reset to zeros first when
+ * auto_reset != 0, otherwise it is left frozen and draws nothing.
+ * rng: uint64 [B] per-game generator state (see gg_rng_seed), advanced once per ply played.
+ * last_actions (nullable): int32 [B], last action played (-1 if frozen).
+ * steps_done (nullable): int64 [B], incremented by the number of plies actually played.
+ * Sampler (build-defined, mirrored by oracle/gg_oracle.c): x += 0x9E3779B97F4A7C15;
+ * u = splitmix64_finalise(x); k = ((u >> 32) * n_valid) >> 32; action = k-th valid action ascending.
+ */
+int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B,
+                         int32_t N, int32_t plies, int32_t auto_reset, void *hip_stream);
+
+/*
+ * One sampling pass only (no step): actions[b] ~ Uniform{valid actions of states[b] incl. pass},
+ * same generator as gg_batch_rollout (advances rng[b] once).  Finished games: reset is NOT applied;
+ * every action counts as valid there (gogame.invalid_moves returns zeros once ended, :155-156).
+ */
+int32_t gg_batch_sample_actions(const uint8_t *states, uint64_t *rng, int32_t *actions, int64_t B, int32_t N,
+                                void *hip_stream);
+
+/* rng[b] = initial generator state for (base_seed, game index first_game + b). */
+int32_t gg_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GYMGO_AMD_H */

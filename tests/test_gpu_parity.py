@@ -1,0 +1,235 @@
+"""-m gpu: the HIP path (through the C-ABI) against the oracle and the golden vectors. Bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def gg():
+    assert torch.cuda.is_available(), 'gpu tests need a ROCm device'
+    from gymgo_amd import gogame
+    return gogame
+
+
+@pytest.fixture(scope='module')
+def oracle():
+    from oracle import c_oracle
+    c_oracle.lib()
+    return c_oracle
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def h64(a):
+    return np.frombuffer(hashlib.blake2b(np.ascontiguousarray(a).tobytes(), digest_size=8).digest(), dtype=np.uint64)[0]
+
+
+def test_scripted_golden(gg, golden, scripted_cases):
+    """Every scripted sequence of the reference's unit tests: per-step states equal the reference's."""
+    z = golden('scripted')
+    for c in scripted_cases:
+        n, size = c['name'], c['size']
+        acts, states = z[n + '/actions'], z[n + '/states']
+        s = torch.zeros((6, size, size), dtype=torch.uint8, device='cuda')
+        n_main = len(c['moves'])
+        for i, a in enumerate(acts):
+            if i == n_main or (i == len(acts) - 1 and len(acts) == n_main and False):
+                pass
+            if i == n_main:
+                for bad in c.get('then_raises', []):
+                    if bad is None or gg.game_ended(s):
+                        continue  # GoEnv-level "game over" assertion, covered in test_env
+                    b = bad[0] * size + bad[1] if isinstance(bad, list) else bad
+                    with pytest.raises(AssertionError):
+                        gg.next_state(s, b)
+            s2 = gg.next_state(s, int(a))
+            assert np.array_equal(s2.cpu().numpy(), states[i]), (n, i)
+            s = s2
+        if len(acts) == n_main:
+            for bad in c.get('then_raises', []):
+                if bad is None or gg.game_ended(s):
+                    continue
+                b = bad[0] * size + bad[1] if isinstance(bad, list) else bad
+                with pytest.raises(AssertionError):
+                    gg.next_state(s, b)
+
+
+def test_random_games_golden(gg, golden):
+    """Seeded full games recorded from the reference: hashes of every ply, sampled states, areas, canonical."""
+    z = golden('random_games')
+    games = sorted({k.split('/')[0] for k in z.files})
+    for gname in games:
+        size = int(gname.split('_')[0][1:])
+        acts, hashes = z[gname + '/actions'], z[gname + '/hashes']
+        samp = {int(p): i for i, p in enumerate(z[gname + '/sample_ply'])}
+        s = torch.zeros((1, 6, size, size), dtype=torch.uint8, device='cuda')
+        for ply, a in enumerate(acts):
+            s = gg.batch_next_states(s, torch.tensor([int(a)], device='cuda', dtype=torch.int32))
+            sn = s[0].cpu().numpy()
+            assert h64(sn) == hashes[ply], (gname, ply)
+            if ply in samp:
+                i = samp[ply]
+                assert np.array_equal(sn, z[gname + '/sample_states'][i])
+                b, w = gg.batch_areas(s)
+                assert [int(b[0]), int(w[0])] == list(z[gname + '/sample_areas'][i]), (gname, ply)
+                assert np.array_equal(gg.canonical_form(s[0]).cpu().numpy(), z[gname + '/sample_canonical'][i])
+                assert np.array_equal(gg.invalid_moves(s[0]).cpu().numpy(), z[gname + '/sample_invalid_moves'][i])
+        assert float(gg.winning(s[0], 0)) == float(z[gname + '/winning_komi0'])
+        assert float(gg.winning(s[0], 6.5)) == float(z[gname + '/winning_komi6p5'])
+
+
+def test_children_golden(gg, golden):
+    z = golden('children')
+    for key in sorted({k.split('/')[0] for k in z.files}):
+        st = dev(z[key + '/state'])
+        for canon, name in ((False, '/children'), (True, '/children_canonical')):
+            got = gg.children(st, canonical=canon, padded=True).cpu().numpy()
+            assert np.array_equal(got, z[key + name]), (key, canon)
+
+
+def test_batch_with_passes_golden(gg, golden):
+    """Mixed pass / move batches: stacked next_state semantics for every game."""
+    z = golden('batch_passes')
+    for size in (5, 9, 19):
+        st, acts = dev(z['n%d/states' % size]), dev(z['n%d/actions' % size])
+        for canon, name in ((False, 'next'), (True, 'next_canonical')):
+            got = gg.batch_next_states(st, acts, canonical=canon).cpu().numpy()
+            assert np.array_equal(got, z['n%d/%s' % (size, name)]), (size, canon)
+
+
+def test_rollout_golden(gg, golden):
+    """Device sampler + fused rollout reproduce the reference-replayed trajectories of the build's RNG."""
+    z = golden('rollout')
+    for size in (5, 9, 19):
+        k = 'n%d/' % size
+        rng0 = z[k + 'rng0']
+        B, plies = len(rng0), int(z[k + 'plies'])
+        rng = gg.rng_seed(B, int(z[k + 'seed']))
+        assert np.array_equal(rng.cpu().numpy().view(np.uint64), rng0)
+        st = torch.zeros((B, 6, size, size), dtype=torch.uint8, device='cuda')
+        last = torch.empty(B, dtype=torch.int32, device='cuda')
+        steps = torch.zeros(B, dtype=torch.int64, device='cuda')
+        gg.batch_rollout(st, rng, plies, True, last, steps)
+        assert np.array_equal(st.cpu().numpy(), z[k + 'final_states']), size
+        assert np.array_equal(rng.cpu().numpy().view(np.uint64), z[k + 'rng_final'])
+        assert np.array_equal(last.cpu().numpy(), z[k + 'last_actions'])
+        assert int(steps.min()) == plies and int(steps.max()) == plies
+
+
+@pytest.mark.parametrize('size', list(range(2, 20)))
+def test_rollout_vs_oracle_all_sizes(gg, oracle, size):
+    """Fused rollout vs the C oracle with the same generator, every board size the ABI accepts."""
+    B, plies = 96, 3 * size * size + 10
+    rng_np = oracle.rng_seed(1234 + size, B)
+    rng = gg.rng_seed(B, 1234 + size)
+    assert np.array_equal(rng.cpu().numpy().view(np.uint64), rng_np)
+    st = torch.zeros((B, 6, size, size), dtype=torch.uint8, device='cuda')
+    want = np.zeros((B, 6, size, size), dtype=np.uint8)
+    # in chunks so that states are compared at many depths, also through game ends / auto-resets
+    for chunk in (1, 2, 5, plies // 3, plies // 3, plies - 8 - 2 * (plies // 3)):
+        gg.batch_rollout(st, rng, chunk, True)
+        want, rng_np, _ = oracle.batch_rollout(want, rng_np, chunk, True)
+        got = st.cpu().numpy()
+        bad = np.nonzero((got != want).reshape(B, -1).any(axis=1))[0]
+        assert len(bad) == 0, (size, chunk, bad[:5])
+        assert np.array_equal(rng.cpu().numpy().view(np.uint64), rng_np)
+
+
+@pytest.mark.parametrize('size,B,plies', [(9, 4096, 150), (19, 2048, 500)])
+def test_step_api_vs_oracle_large(gg, oracle, size, B, plies):
+    """gg_batch_sample_actions + gg_batch_next_states (out-of-place API) vs oracle replay of the same actions,
+    plus areas / invalid-mask / children spot checks on the way."""
+    rng = gg.rng_seed(B, 99)
+    st = torch.zeros((B, 6, size, size), dtype=torch.uint8, device='cuda')
+    want = np.zeros((B, 6, size, size), dtype=np.uint8)
+    for ply in range(plies):
+        ended = gg.batch_game_ended(st).bool()
+        if bool(ended.any()):
+            st[ended] = 0
+            want[ended.cpu().numpy()] = 0
+        acts = gg.batch_sample_actions(st, rng)
+        nxt, status = gg.batch_next_states(st, acts, canonical=False, check=False)
+        assert int(status.abs().sum()) == 0
+        if ply % 25 == 0 or ply == plies - 1:
+            w2, st_or = oracle.batch_next_states(want, acts.cpu().numpy())
+            assert int(np.abs(st_or).sum()) == 0
+            assert np.array_equal(nxt.cpu().numpy(), w2), (size, ply)
+            want = w2
+            b, w = gg.batch_areas(nxt)
+            ob, ow = oracle.batch_areas(want)
+            assert np.array_equal(b.cpu().numpy(), ob) and np.array_equal(w.cpu().numpy(), ow)
+            from gymgo_amd import state_utils
+            m = state_utils.batch_compute_invalid_moves(nxt[:64], None, None).cpu().numpy()
+            for i in range(0, 64, 9):
+                player = 1 - int(want[i, 2, 0, 0])
+                assert np.array_equal(m[i], oracle.compute_invalid_moves(want[i], player)), (size, ply, i)
+        else:
+            want = nxt.cpu().numpy()
+        st = nxt
+    kids = gg.batch_children(st[:8], canonical=True).cpu().numpy()
+    assert np.array_equal(kids, oracle.batch_children(want[:8], True))
+    kids = gg.batch_children(st[8:12], canonical=False).cpu().numpy()
+    assert np.array_equal(kids, oracle.batch_children(want[8:12], False))
+
+
+def test_illegal_moves_status_and_passthrough(gg, oracle):
+    size, B = 9, 256
+    rng = gg.rng_seed(B, 5)
+    st = torch.zeros((B, 6, size, size), dtype=torch.uint8, device='cuda')
+    gg.batch_rollout(st, rng, 40, True)
+    s_np = st.cpu().numpy()
+    acts = np.zeros(B, dtype=np.int32)
+    for b in range(B):
+        occ = np.flatnonzero(s_np[b, 3].ravel() == 1)
+        acts[b] = occ[b % len(occ)] if (b % 2 == 0 and len(occ)) else size * size
+    acts[3], acts[5] = -1, size * size + 1   # out of range
+    out, status = gg.batch_next_states(st, dev(acts), check=False)
+    want, wst = oracle.batch_next_states(s_np, acts)
+    assert np.array_equal(status.cpu().numpy(), wst)
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert int(status.sum()) > 50
+    with pytest.raises(AssertionError):
+        gg.batch_next_states(st, dev(acts))
+
+
+def test_unaligned_views(gg, oracle):
+    """Boards that start at odd byte offsets / non-16-byte-aligned bases (head and tail byte paths)."""
+    size, B = 19, 33
+    rng = gg.rng_seed(B, 17)
+    base = torch.zeros(B * 6 * size * size + 64, dtype=torch.uint8, device='cuda')
+    for off in (0, 1, 7, 15, 16, 33):
+        st = base[off:off + B * 6 * size * size].view(B, 6, size, size)
+        st.zero_()
+        gg.batch_rollout(st, rng, 120, True)
+        s_np = st.cpu().numpy()
+        acts = gg.batch_sample_actions(st, rng)
+        for off2 in (3, 16):
+            outbuf = torch.full((B * 6 * size * size + 64,), 7, dtype=torch.uint8, device='cuda')
+            out = outbuf[off2:off2 + B * 6 * size * size].view(B, 6, size, size)
+            status = torch.empty(B, dtype=torch.int32, device='cuda')
+            from gymgo_amd import _lib
+            code = _lib.lib().gg_batch_next_states(st.data_ptr(), acts.data_ptr(), out.data_ptr(), status.data_ptr(),
+                                                   B, size, 0, None)
+            assert code == 0
+            want, _ = oracle.batch_next_states(s_np, acts.cpu().numpy())
+            assert np.array_equal(out.cpu().numpy(), want), (off, off2)
+            ob = outbuf.cpu().numpy()
+            assert (ob[:off2] == 7).all() and (ob[off2 + B * 6 * size * size:] == 7).all(), 'wrote outside the batch'
+
+
+def test_empty_batch_and_bad_args(gg):
+    from gymgo_amd import _lib
+    L = _lib.lib()
+    assert L.gg_version() == 1
+    assert L.gg_batch_next_states(None, None, None, None, 0, 9, 0, None) == 0
+    assert L.gg_batch_next_states(None, None, None, None, 4, 9, 0, None) == -2
+    assert L.gg_batch_next_states(None, None, None, None, 4, 20, 0, None) == -1
+    assert L.gg_batch_areas(None, None, None, 4, 1, None) == -1
+    assert L.gg_device_cus() > 0
