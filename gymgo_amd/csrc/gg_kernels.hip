@@ -82,23 +82,28 @@ __device__ __forceinline__ uint32_t run_fill(uint32_t m, uint32_t mrev, uint32_t
 }
 
 // Per-lane flood fill of `f` (seeds) through mask `m` to the fixed point.  All 64 lanes run their own
-// flood in lock-step; the loop ends when no lane changed during a full down+up sweep.
+// flood in lock-step.  A down sweep leaves f closed horizontally and downwards, an up sweep
+// horizontally and upwards; after each sweep a 2-op-per-row test asks whether any lane could still
+// grow in the opposite direction, and only then is another sweep spent.
 template <int R>
 __device__ __forceinline__ void flood(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R]) {
-  uint32_t prev = 0xFFFFFFFFu;
-#pragma unroll 1
-  for (int it = 0; it < R * R + 2; ++it) {
-    f[0] = run_fill(m[0], mrev[0], f[0]);
+  f[0] = run_fill(m[0], mrev[0], f[0]);
 #pragma unroll
-    for (int r = 1; r < R; ++r) f[r] = run_fill(m[r], mrev[r], f[r] | (f[r - 1] & m[r]));
+  for (int r = 1; r < R; ++r) f[r] = run_fill(m[r], mrev[r], f[r] | (f[r - 1] & m[r]));
+#pragma unroll 1
+  for (int it = 0; it < R * R; ++it) {
 #pragma unroll
     for (int r = R - 2; r >= 0; --r) f[r] = run_fill(m[r], mrev[r], f[r] | (f[r + 1] & m[r]));
-    uint32_t tot = 0;
+    uint32_t open_dn = 0;  // a filled stone whose lower neighbour is fillable but not filled
 #pragma unroll
-    for (int r = 0; r < R; ++r) tot += __popc(f[r]);
-    bool changed = tot != prev;
-    prev = tot;
-    if (__ballot(changed) == 0) break;
+    for (int r = 1; r < R; ++r) open_dn |= f[r - 1] & m[r] & ~f[r];
+    if (__ballot(open_dn != 0) == 0) break;
+#pragma unroll
+    for (int r = 1; r < R; ++r) f[r] = run_fill(m[r], mrev[r], f[r] | (f[r - 1] & m[r]));
+    uint32_t open_up = 0;
+#pragma unroll
+    for (int r = 0; r < R - 1; ++r) open_up |= f[r + 1] & m[r] & ~f[r];
+    if (__ballot(open_up != 0) == 0) break;
   }
 }
 
@@ -106,30 +111,51 @@ __device__ __forceinline__ void flood(const uint32_t (&m)[R], const uint32_t (&m
 // (lane r = row r), e = empty points.  Returns for lane r < R:
 //   multi0 / multi1: stones of c0 / c1 whose group has >= 2 distinct liberties
 //   alive0:          stones of c0 whose group has >= 1 liberty
+// L1 -> L2 goes through LDS: the rows (and their bit-reversals) are written once and every flood
+// lane fetches all rows of its colour with broadcast 16-byte reads.
 template <int R>
 __device__ __forceinline__ void analyze(uint32_t c0, uint32_t c1, uint32_t e, const LaneClass lc, uint32_t *sc,
-                                        int lane, uint32_t &multi0, uint32_t &alive0, uint32_t &multi1) {
+                                        uint32_t *rows5, int lane, uint32_t &multi0, uint32_t &alive0,
+                                        uint32_t &multi1) {
   constexpr int RS = Cfg<R>::kRowStride;
-  uint32_t m[R], mrev[R], f[R], ec[R];
+  constexpr int RV = (R + 3) / 4;  // uint4 reads per plane
+  WAVE_SYNC();                     // earlier readers of rows5 / sc are done
+  if (lane < 32) {
+    rows5[lane] = c0;
+    rows5[32 + lane] = c1;
+    rows5[64 + lane] = __brev(c0);
+    rows5[96 + lane] = __brev(c1);
+    rows5[128 + lane] = e;
+  }
+  WAVE_SYNC();
+  uint32_t m[RV * 4], mrev[RV * 4], ee[RV * 4];
+  {
+    const uint4 *pm = reinterpret_cast<const uint4 *>(rows5 + (lc.second ? 32 : 0));
+    const uint4 *pr = reinterpret_cast<const uint4 *>(rows5 + 64 + (lc.second ? 32 : 0));
+    const uint4 *pe = reinterpret_cast<const uint4 *>(rows5 + 128);
+#pragma unroll
+    for (int i = 0; i < RV; ++i) {
+      uint4 a = pm[i], b = pr[i], c = pe[i];
+      m[4 * i] = a.x; m[4 * i + 1] = a.y; m[4 * i + 2] = a.z; m[4 * i + 3] = a.w;
+      mrev[4 * i] = b.x; mrev[4 * i + 1] = b.y; mrev[4 * i + 2] = b.z; mrev[4 * i + 3] = b.w;
+      ee[4 * i] = c.x; ee[4 * i + 1] = c.y; ee[4 * i + 2] = c.z; ee[4 * i + 3] = c.w;
+    }
+  }
+  uint32_t mm[R], mr[R], f[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    uint32_t s0 = __builtin_amdgcn_readlane(c0, r);
-    uint32_t s1 = __builtin_amdgcn_readlane(c1, r);
-    uint32_t se = __builtin_amdgcn_readlane(e, r);
-    m[r] = lc.second ? s1 : s0;
-    mrev[r] = __brev(m[r]);
+    mm[r] = m[r];
+    mr[r] = mrev[r];
     uint32_t rowon = 0u - ((lc.rowsel >> r) & 1u);
-    ec[r] = se & rowon & lc.colmask;  // empties of this lane's liberty class
+    ee[r] &= rowon & lc.colmask;  // empties of this lane's liberty class
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    uint32_t nb = (ec[r] << 1) | (ec[r] >> 1);
-    if (r > 0) nb |= ec[r - 1];
-    if (r < R - 1) nb |= ec[r + 1];
-    f[r] = m[r] & nb;  // stones touching a liberty of the class
+    uint32_t x = (ee[r] << 1) | (r > 0 ? ee[r - 1] : 0u);
+    uint32_t y = (ee[r] >> 1) | (r < R - 1 ? ee[r + 1] : 0u);
+    f[r] = mm[r] & (x | y);  // stones touching a liberty of the class
   }
-  flood<R>(m, mrev, f);
-  WAVE_SYNC();  // earlier readers of the scratch are done
+  flood<R>(mm, mr, f);
 #pragma unroll
   for (int r = 0; r < R; ++r) sc[lane * RS + r] = f[r];
   WAVE_SYNC();
@@ -169,7 +195,7 @@ __device__ __forceinline__ uint32_t invalid_from(uint32_t nx, uint32_t pl, uint3
 // next mover (incl. ko).  `a` must be a legal point or P (pass).
 template <int R>
 __device__ __forceinline__ uint32_t step_core(uint32_t &mine, uint32_t &opp, int a, const Geo &g, const LaneClass lc,
-                                              uint32_t *sc, int lane) {
+                                              uint32_t *sc, uint32_t *rows5, int lane) {
   const bool is_pass = a == g.P;
   int ko_r = -1, ko_c = 0;
   bool boxed = false;
@@ -188,7 +214,7 @@ __device__ __forceinline__ uint32_t step_core(uint32_t &mine, uint32_t &opp, int
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     uint32_t e = g.full_l1 & ~(mine | opp);
-    analyze<R>(opp, mine, e, lc, sc, lane, multi_opp, alive_opp, multi_mine);
+    analyze<R>(opp, mine, e, lc, sc, rows5, lane, multi_opp, alive_opp, multi_mine);
     if (pass == 0 && !is_pass) {
       // state_utils.update_pieces :159-180 - opponent groups left without a liberty die.  Only groups
       // touching the new stone can be in that state (every group had a liberty before the move).
@@ -347,6 +373,7 @@ __global__ __launch_bounds__(kWave) void k_next_states(const uint8_t *__restrict
                                                        int64_t B, int N, int canonical) {
   __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
   __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
+  __shared__ __attribute__((aligned(16))) uint32_t rows5[160];
   __shared__ uint32_t rowsw[96];
   const int lane = threadIdx.x;
   Geo g;
@@ -377,7 +404,7 @@ __global__ __launch_bounds__(kWave) void k_next_states(const uint8_t *__restrict
     planes_to_rows<R>(iobuf + mis, iobuf + mis + g.P, g, lane, black, white);
     const int pl = flags & 1u;                       // gogame.py:44 turn
     uint32_t mine = pl ? white : black, opp = pl ? black : white;
-    uint32_t invalid = step_core<R>(mine, opp, a, g, lc, sc, lane);
+    uint32_t invalid = step_core<R>(mine, opp, a, g, lc, sc, rows5, lane);
     black = pl ? opp : mine;
     white = pl ? mine : opp;
     PlaneBytes pb;
@@ -402,6 +429,7 @@ __global__ __launch_bounds__(kWave) void k_invalid_mask(const uint8_t *__restric
                                                         int64_t B, int N) {
   __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
   __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
+  __shared__ __attribute__((aligned(16))) uint32_t rows5[160];
   __shared__ uint32_t rowsw[32];
   const int lane = threadIdx.x;
   Geo g;
@@ -423,7 +451,7 @@ __global__ __launch_bounds__(kWave) void k_invalid_mask(const uint8_t *__restric
     uint32_t nxs = nx ? white : black, pls = nx ? black : white;
     uint32_t e = g.full_l1 & ~(black | white);
     uint32_t multi_nx, alive_nx, multi_pl;
-    analyze<R>(nxs, pls, e, lc, sc, lane, multi_nx, alive_nx, multi_pl);
+    analyze<R>(nxs, pls, e, lc, sc, rows5, lane, multi_nx, alive_nx, multi_pl);
     uint32_t invalid = invalid_from(nxs, pls, multi_nx, multi_pl, g, lane);
     if (ko) {
       int k = __builtin_amdgcn_readfirstlane(ko[b]);
@@ -511,6 +539,7 @@ __global__ __launch_bounds__(kWave) void k_children(const uint8_t *__restrict__ 
                                                     int64_t B, int N, int canonical, int chunks) {
   __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
   __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
+  __shared__ __attribute__((aligned(16))) uint32_t rows5[160];
   __shared__ uint32_t rowsw[96];
   const int lane = threadIdx.x;
   Geo g;
@@ -556,7 +585,7 @@ __global__ __launch_bounds__(kWave) void k_children(const uint8_t *__restrict__ 
       }
       const bool is_pass = a == g.P;
       uint32_t mine = pl ? white : black, opp = pl ? black : white;
-      uint32_t invalid = step_core<R>(mine, opp, a, g, lc, sc, lane);
+      uint32_t invalid = step_core<R>(mine, opp, a, g, lc, sc, rows5, lane);
       uint32_t nb = pl ? opp : mine, nw = pl ? mine : opp;
       PlaneBytes pb;
       pb.passed = is_pass ? 1 : 0;
@@ -613,6 +642,7 @@ __global__ __launch_bounds__(kWave) void k_rollout(uint8_t *__restrict__ states,
                                                    int64_t B, int N, int plies, int auto_reset) {
   __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
   __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
+  __shared__ __attribute__((aligned(16))) uint32_t rows5[160];
   __shared__ uint32_t rowsw[96];
   const int lane = threadIdx.x;
   Geo g;
@@ -650,7 +680,7 @@ __global__ __launch_bounds__(kWave) void k_rollout(uint8_t *__restrict__ states,
       uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(cnt + 1)) >> 32);
       int a = pick_action(valid, k, g, lane);
       uint32_t mine = turn ? white : black, opp = turn ? black : white;
-      invalid = step_core<R>(mine, opp, a, g, lc, sc, lane);
+      invalid = step_core<R>(mine, opp, a, g, lc, sc, rows5, lane);
       black = turn ? opp : mine;
       white = turn ? mine : opp;
       if (a == g.P) { if (passed) done = 1; passed = 1; } else passed = 0;

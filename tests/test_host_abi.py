@@ -1,0 +1,116 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/gymgo_amd.h declares;
+host-side logic (sharding, env plumbing that needs no device).  No compute calls without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def built():
+    import __graft_entry__
+    __graft_entry__.build()
+    from gymgo_amd import _lib
+    return _lib
+
+
+def test_header_symbols_exported(built):
+    hdr = open(os.path.join(ROOT, 'include', 'gymgo_amd.h')).read()
+    declared = set(re.findall(r'^\s*(?:int32_t|int)\s+(gg_\w+)\s*\(', hdr, flags=re.M))
+    assert declared == set(built.EXPORTS), (declared ^ set(built.EXPORTS))
+    L = ctypes.CDLL(built.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert built.lib().gg_version() == 1
+
+
+def test_argument_validation_without_device(built):
+    L = built.lib()
+    # argument checks come before any device work
+    assert L.gg_batch_next_states(None, None, None, None, 4, 1, 0, None) == -1
+    assert L.gg_batch_next_states(None, None, None, None, 4, 20, 0, None) == -1
+    assert L.gg_batch_next_states(None, None, None, None, -1, 9, 0, None) == -1
+    assert L.gg_batch_next_states(None, None, None, None, 0, 9, 0, None) == 0
+    assert L.gg_batch_next_states(None, None, None, None, 2, 9, 0, None) == -2
+    assert L.gg_batch_rollout(None, None, None, None, 2, 9, -1, 1, None) == -3
+    assert L.gg_batch_children(None, None, 0, 19, 0, None) == 0
+
+
+def test_no_cpu_fallback(built):
+    """Host tensors / NumPy input without a device must fail loudly, never compute on the CPU."""
+    import torch
+    from gymgo_amd import gogame
+    if torch.cuda.is_available():
+        pytest.skip('device present')
+    with pytest.raises(built.GymGoNativeError):
+        gogame.next_state(np.zeros((6, 7, 7)), 3)
+    with pytest.raises(built.GymGoNativeError):
+        gogame.batch_next_states(torch.zeros((2, 6, 7, 7), dtype=torch.uint8), [1, 2])
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'gymgo_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('oracle/gg_oracle.c', '').replace('mirrored by oracle', ''), f
+
+
+def test_shard_partition():
+    from gymgo_amd.envs.vec_env import shard
+    for total, world in ((1048576, 8), (65536, 1), (10, 4), (7, 8)):
+        spans = [shard(total, r, world) for r in range(world)]
+        assert sum(c for _, c in spans) == total
+        pos = 0
+        for first, cnt in spans:
+            assert first == pos
+            pos += cnt
+        assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_api_surface_matches_reference_names():
+    """Same public names as gym_go/gogame.py + GoEnv methods."""
+    from gymgo_amd import gogame, govars, state_utils
+    from gymgo_amd.envs import GoEnv, make
+    for name in ('init_state', 'batch_init_state', 'next_state', 'batch_next_states', 'invalid_moves', 'valid_moves',
+                 'batch_invalid_moves', 'batch_valid_moves', 'children', 'action_size', 'prev_player_passed',
+                 'batch_prev_player_passed', 'game_ended', 'batch_game_ended', 'winning', 'batch_winning', 'turn',
+                 'batch_turn', 'liberties', 'num_liberties', 'areas', 'batch_areas', 'canonical_form',
+                 'batch_canonical_form', 'random_symmetry', 'all_symmetries', 'random_weighted_action',
+                 'random_action', 'str', 'batch_children'):
+        assert callable(getattr(gogame, name)), name
+    for name in ('compute_invalid_moves', 'batch_compute_invalid_moves', 'adj_data', 'batch_adj_data', 'set_turn',
+                 'batch_set_turn'):
+        assert callable(getattr(state_utils, name)), name
+    assert (govars.BLACK, govars.WHITE, govars.TURN_CHNL, govars.INVD_CHNL, govars.PASS_CHNL, govars.DONE_CHNL,
+            govars.NUM_CHNLS) == (0, 1, 2, 3, 4, 5, 6)
+    for name in ('reset', 'step', 'state', 'canonical_state', 'children', 'valid_moves', 'uniform_random_action',
+                 'turn', 'prev_player_passed', 'game_ended', 'winning', 'winner', 'reward', 'info', 'render', 'close'):
+        assert callable(getattr(GoEnv, name)), name
+    env = make('gym_go:go-v0', size=7, komi=2.5, reward_method='heuristic')
+    assert env.size == 7 and env.komi == 2.5 and env.state().shape == (6, 7, 7)
+    assert gogame.action_size(board_size=19) == 362
+    with pytest.raises(RuntimeError):
+        gogame.action_size()
+
+
+def test_host_side_predicates_on_numpy():
+    from gymgo_amd import gogame
+    s = np.zeros((6, 5, 5))
+    assert gogame.turn(s) == 0 and not gogame.prev_player_passed(s) and gogame.game_ended(s) == 0
+    s[2] = 1; s[4] = 1; s[5] = 1
+    assert gogame.turn(s) == 1 and gogame.prev_player_passed(s) and gogame.game_ended(s) == 1
+    c = gogame.canonical_form(s)
+    assert c[2].max() == 0 and s[2].max() == 1            # copy, input untouched
+    b = np.stack([s, np.zeros((6, 5, 5))])
+    b[0, 0, 1, 1] = 1
+    cb = gogame.batch_canonical_form(b)
+    assert cb[0, 1, 1, 1] == 1 and cb[0, 0, 1, 1] == 0 and cb[0, 2].max() == 0
+    assert np.array_equal(cb, gogame.batch_canonical_form(cb))   # idempotent (test_batch_fns.py:14-34)
+    assert list(gogame.batch_turn(b)) == [1, 0]
+    assert len(gogame.all_symmetries(s)) == 8

@@ -1,0 +1,133 @@
+"""CPU: both oracles (C restatement, NumPy/SciPy port) against the golden vectors recorded from the
+real reference (tests/golden/make_golden.py).  No GPU, no /root/reference needed."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle, np_oracle
+
+
+def h64(a):
+    return np.frombuffer(hashlib.blake2b(np.ascontiguousarray(a).tobytes(), digest_size=8).digest(), dtype=np.uint64)[0]
+
+
+def test_scripted_sequences(golden, scripted_cases):
+    z = golden('scripted')
+    assert len(scripted_cases) == 33
+    for c in scripted_cases:
+        n, size = c['name'], c['size']
+        acts, states = z[n + '/actions'], z[n + '/states']
+        s = np.zeros((6, size, size), np.uint8)
+        n_main = len(c['moves'])
+
+        def refuses(state):
+            for bad in c.get('then_raises', []):
+                if bad is None or state[5].all():
+                    continue   # env-level "game already over" assertion (tests/test_env_host.py)
+                b = bad[0] * size + bad[1] if isinstance(bad, list) else bad
+                with pytest.raises(AssertionError):
+                    c_oracle.next_state(state, b)
+                with pytest.raises(AssertionError):
+                    np_oracle.next_state(state.astype(float), b)
+        for i, a in enumerate(acts):
+            if i == n_main:
+                refuses(s)
+            s = c_oracle.next_state(s, int(a))
+            assert np.array_equal(s, states[i]), (n, i)
+            if size <= 7 and i % 3 == 0:
+                assert np.array_equal(np_oracle.next_state(states[i - 1].astype(float) if i else
+                                                           np.zeros((6, size, size)), int(a)).astype(np.uint8), states[i])
+        if len(acts) == n_main:
+            refuses(s)
+        # the values the reference's own unit tests assert
+        final, pins = states[n_main - 1], c.get('pins', {})
+        if 'invd_count' in pins:
+            assert int(final[3].sum()) == pins['invd_count']
+        for r_, c_, v in pins.get('invd_at', []):
+            assert final[3, r_, c_] == v
+        if 'black' in pins:
+            assert int(final[0].sum()) == pins['black']
+        if 'white' in pins:
+            assert int(final[1].sum()) == pins['white']
+        if 'nonzero_total' in pins:
+            assert int(np.count_nonzero(final)) == pins['nonzero_total']
+        if 'done' in pins:
+            assert int(final[5].all()) == pins['done']
+
+
+def test_random_games(golden):
+    z = golden('random_games')
+    games = sorted({k.split('/')[0] for k in z.files})
+    assert len(games) == 21
+    for gname in games:
+        size = int(gname.split('_')[0][1:])
+        acts, hashes = z[gname + '/actions'], z[gname + '/hashes']
+        samp = {int(p): i for i, p in enumerate(z[gname + '/sample_ply'])}
+        s = np.zeros((6, size, size), np.uint8)
+        for ply, a in enumerate(acts):
+            s = c_oracle.next_state(s, int(a))
+            assert h64(s) == hashes[ply], (gname, ply)
+            if ply in samp:
+                i = samp[ply]
+                assert np.array_equal(s, z[gname + '/sample_states'][i])
+                b, w = c_oracle.batch_areas(s[None])
+                assert [int(b[0]), int(w[0])] == list(z[gname + '/sample_areas'][i])
+                assert np.array_equal(c_oracle.canonical_form(s), z[gname + '/sample_canonical'][i])
+                if size <= 9:
+                    nb, nw = np_oracle.areas(s.astype(float))
+                    assert [int(nb), int(nw)] == list(z[gname + '/sample_areas'][i])
+        b, w = c_oracle.batch_areas(s[None])
+        assert np.sign(float(b[0]) - float(w[0])) == float(z[gname + '/winning_komi0'])
+        assert np.sign(float(b[0]) - float(w[0]) - 6.5) == float(z[gname + '/winning_komi6p5'])
+
+
+def test_np_port_on_19x19_game(golden):
+    """The cpu_baseline port replays one full recorded 19x19 game bit-exactly."""
+    z = golden('random_games')
+    acts, hashes = z['n19_g0/actions'][:160], z['n19_g0/hashes']
+    s = np.zeros((6, 19, 19))
+    for ply, a in enumerate(acts):
+        s = np_oracle.next_state(s, int(a))
+        assert h64(s.astype(np.uint8)) == hashes[ply], ply
+
+
+def test_children(golden):
+    z = golden('children')
+    for key in sorted({k.split('/')[0] for k in z.files}):
+        st = z[key + '/state']
+        assert np.array_equal(c_oracle.batch_children(st[None], False)[0], z[key + '/children']), key
+        assert np.array_equal(c_oracle.batch_children(st[None], True)[0], z[key + '/children_canonical']), key
+
+
+def test_batch_with_passes(golden):
+    z = golden('batch_passes')
+    for size in (5, 9, 19):
+        st, acts = z['n%d/states' % size], z['n%d/actions' % size]
+        assert (acts == size * size).sum() >= 4
+        for canon, name in ((False, 'next'), (True, 'next_canonical')):
+            got, status = c_oracle.batch_next_states(st, acts, canon)
+            assert not status.any()
+            assert np.array_equal(got, z['n%d/%s' % (size, name)]), (size, canon)
+
+
+def test_rollout_sampler(golden):
+    z = golden('rollout')
+    for size in (5, 9, 19):
+        k = 'n%d/' % size
+        rng0 = z[k + 'rng0']
+        assert np.array_equal(c_oracle.rng_seed(int(z[k + 'seed']), len(rng0)), rng0)
+        st, rng, last = c_oracle.batch_rollout(np.zeros((len(rng0), 6, size, size), np.uint8), rng0,
+                                               int(z[k + 'plies']), True)
+        assert np.array_equal(st, z[k + 'final_states'])
+        assert np.array_equal(rng, z[k + 'rng_final'])
+        assert np.array_equal(last, z[k + 'last_actions'])
+
+
+def test_frozen_when_no_auto_reset():
+    st = np.zeros((2, 6, 5, 5), np.uint8)
+    rng = c_oracle.rng_seed(3, 2)
+    st, rng, _ = c_oracle.batch_rollout(st, rng, 400, False)
+    assert st[:, 5].all()      # both games ended and stayed ended
+    st2, rng2, last = c_oracle.batch_rollout(st, rng, 5, False)
+    assert np.array_equal(st2, st) and np.array_equal(rng2, rng) and (last == -1).all()
