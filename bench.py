@@ -40,8 +40,8 @@ def cpu_baseline(size, cpu_seconds_total=20.0):
     pinned bit-exact and speed-calibrated against the real reference) on this box's host cores:
     one worker per core, each plays uniform-random games with auto-reset for a fixed wall time."""
     import multiprocessing as mp
-    cores = min(os.cpu_count() or 1, 32)
-    seconds = max(1.0, cpu_seconds_total / cores)
+    cores = min(os.cpu_count() or 1, 16)
+    seconds = max(2.0, cpu_seconds_total / cores)
     ctx = mp.get_context('spawn')
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
@@ -67,7 +67,7 @@ def main():
                     help='plies per kernel launch')
     ap.add_argument('--burn-in', type=int, default=256, help='untimed plies before warmup (stationary board mix)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--cpu-seconds', type=float, default=32.0)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))

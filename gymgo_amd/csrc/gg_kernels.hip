@@ -174,6 +174,7 @@ __device__ __forceinline__ void analyze(uint32_t c0, uint32_t c1, uint32_t e, co
 
 struct Geo {
   int N, P;
+  uint32_t inv;      // ceil(2^16 / N): row = (a * inv) >> 16 for every a <= N*N (checked on the host)
   uint32_t full_l1;  // lane < N ? (1<<N)-1 : 0
 };
 
@@ -200,7 +201,7 @@ __device__ __forceinline__ uint32_t step_core(uint32_t &mine, uint32_t &opp, int
   int ko_r = -1, ko_c = 0;
   bool boxed = false;
   if (!is_pass) {
-    int ra = a / g.N, ca = a - ra * g.N;
+    int ra = (int)(((uint32_t)a * g.inv) >> 16), ca = a - ra * g.N;
     uint32_t bit = 1u << ca;
     if (lane == ra) mine |= bit;                       // gogame.py:62
     // state_utils.adj_data :214-223 - every on-board neighbour holds an opponent stone
@@ -240,88 +241,105 @@ __device__ __forceinline__ uint32_t step_core(uint32_t &mine, uint32_t &opp, int
 }
 
 // ---------------------------------------------------------------- staging: HBM <-> LDS <-> bitboards
+// Boards start at arbitrary byte offsets (6 N^2 is only a multiple of 2), so every wide access below is
+// an UNALIGNED 16- or 4-byte access; gfx950 runs with unaligned global and LDS access enabled and the
+// compiler emits global_load/store_dwordx4, ds_read_b128, ds_write_b32 for these packed types.
+struct __attribute__((packed, aligned(1))) V16u { uint32_t w[4]; };
+struct __attribute__((packed, aligned(1))) W32u { uint32_t v; };
+struct __attribute__((aligned(16))) V16a { uint32_t w[4]; };
 
-// Stage `nbytes` bytes starting at g into LDS so that lds[mis + j] = g[j], using 16-byte loads for
-// every 16-byte-aligned vector that lies inside [lo, hi); returns mis = g & 15.
-__device__ __forceinline__ uint32_t stage_in(const uint8_t *g, int nbytes, const uint8_t *lo, const uint8_t *hi,
-                                             uint8_t *lds, int lane) {
-  uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
-  const uint8_t *ga = g - mis;
-  int nv = (int)(mis + nbytes + 15) >> 4;
-  for (int v = lane; v < nv; v += kWave) {
-    const uint8_t *p = ga + 16 * v;
-    uint4 val;
-    if (p >= lo && p + 16 <= hi) {
-      val = *reinterpret_cast<const uint4 *>(p);
-    } else {
-      uint32_t w[4] = {0, 0, 0, 0};
-      for (int i = 0; i < 16; ++i)
-        if (p + i >= lo && p + i < hi) w[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
-      val = make_uint4(w[0], w[1], w[2], w[3]);
+__device__ __forceinline__ uint32_t ld32u(const uint8_t *p) { return reinterpret_cast<const W32u *>(p)->v; }
+__device__ __forceinline__ void st32u(uint8_t *p, uint32_t v) { reinterpret_cast<W32u *>(p)->v = v; }
+
+// HBM -> LDS copy of one board slice (lds is 16-byte aligned, g is not): 16 bytes per lane per pass, the
+// ragged tail as one more overlapping 16-byte vector that ends exactly at the last byte.
+__device__ __forceinline__ void stage_in(const uint8_t *g, int nbytes, uint8_t *lds, int lane) {
+  if (nbytes >= 16) {
+    const int nfull = nbytes >> 4;
+    for (int v = lane; v < nfull; v += kWave)
+    {
+      V16u t = *reinterpret_cast<const V16u *>(g + 16 * v);
+      V16a o;
+      o.w[0] = t.w[0]; o.w[1] = t.w[1]; o.w[2] = t.w[2]; o.w[3] = t.w[3];
+      *reinterpret_cast<V16a *>(lds + 16 * v) = o;
     }
-    *reinterpret_cast<uint4 *>(lds + 16 * v) = val;
+    if ((nbytes & 15) && lane == (nfull & (kWave - 1)))
+      *reinterpret_cast<V16u *>(lds + nbytes - 16) = *reinterpret_cast<const V16u *>(g + nbytes - 16);
+  } else {
+    for (int i = lane; i < nbytes; i += kWave) lds[i] = g[i];
   }
-  return mis;
 }
 
-// Write `nbytes` staged as lds[mis + j] to g[j]: 16-byte stores for the vectors fully inside the
-// board, byte stores for the (at most two) partial ones - neighbours belong to other waves.
+// LDS -> HBM, same shape.  Only bytes of this board are written (neighbours belong to other waves).
 __device__ __forceinline__ void stage_out(uint8_t *g, int nbytes, const uint8_t *lds, int lane) {
-  uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
-  uint8_t *ga = g - mis;
-  int nv = (int)(mis + nbytes + 15) >> 4;
-  for (int v = lane; v < nv; v += kWave) {
-    int lo = 16 * v - (int)mis;
-    uint8_t *p = ga + 16 * v;
-    if (lo >= 0 && lo + 16 <= nbytes) {
-      *reinterpret_cast<uint4 *>(p) = *reinterpret_cast<const uint4 *>(lds + 16 * v);
-    } else {
-      for (int i = 0; i < 16; ++i) {
-        int j = lo + i;
-        if (j >= 0 && j < nbytes) p[i] = lds[16 * v + i];
+  if (nbytes >= 16) {
+    const int nfull = nbytes >> 4;
+    for (int v = lane; v < nfull; v += kWave) {
+      V16a t = *reinterpret_cast<const V16a *>(lds + 16 * v);
+      V16u o;
+      o.w[0] = t.w[0]; o.w[1] = t.w[1]; o.w[2] = t.w[2]; o.w[3] = t.w[3];
+      *reinterpret_cast<V16u *>(g + 16 * v) = o;
+    }
+    if ((nbytes & 15) && lane == (nfull & (kWave - 1)))
+      *reinterpret_cast<V16u *>(g + nbytes - 16) = *reinterpret_cast<const V16u *>(lds + nbytes - 16);
+  } else {
+    for (int i = lane; i < nbytes; i += kWave) g[i] = lds[i];
+  }
+}
+
+// One byte plane (P bytes of 0/1 in LDS) -> L1 row mask: lane r reads its row as ceil(N/4) dwords (the last
+// one overlapping, ending at the row's last cell) and packs 4 cells per v_dot4_u32_u8 with weights 1,2,4,8.
+template <int R>
+__device__ __forceinline__ uint32_t plane_to_row(const uint8_t *plane, int N, int lane) {
+  uint32_t row = 0;
+  if (lane < N) {
+    const uint8_t *p = plane + lane * N;
+    if (N >= 4) {
+#pragma unroll
+      for (int k = 0; k < (R + 3) / 4; ++k) {
+        if (4 * k < N) {
+          const int o = min(4 * k, N - 4);
+          uint32_t w = ld32u(p + o) & 0x01010101u;
+          row |= __builtin_amdgcn_udot4(w, 0x08040201u, 0u, false) << o;
+        }
       }
+    } else {
+      for (int c = 0; c < N; ++c) row |= (uint32_t)(p[c] & 1) << c;
+    }
+  }
+  return row;
+}
+
+// L1 row mask -> one byte plane in LDS: 4 cells per store, (bits * 0x204081) & 0x01010101 spreads 4 bits
+// to 4 bytes (bit i lands at bit 8 i; the 24-bit multiply has no colliding partial products).
+template <int R>
+__device__ __forceinline__ void row_to_plane(uint8_t *plane, uint32_t row, int N, int lane) {
+  if (lane < N) {
+    uint8_t *p = plane + lane * N;
+    if (N >= 4) {
+#pragma unroll
+      for (int k = 0; k < (R + 3) / 4; ++k) {
+        if (4 * k < N) {
+          const int o = min(4 * k, N - 4);
+          uint32_t bits = (row >> o) & 0xFu;
+          st32u(p + o, __umul24(bits, 0x204081u) & 0x01010101u);
+        }
+      }
+    } else {
+      for (int c = 0; c < N; ++c) p[c] = (uint8_t)((row >> c) & 1u);
     }
   }
 }
 
-// Two byte planes (0/1 per cell, P bytes each, plane 1 right after plane 0) -> L1 row masks.
-// A ballot over `rpb` whole rows at a time; lane r then cuts its row out of the ballot it belongs to.
-template <int R>
-__device__ __forceinline__ void planes_to_rows(const uint8_t *p0, const uint8_t *p1, const Geo &g, int lane,
-                                               uint32_t &r0, uint32_t &r1) {
-  const int rpb = kWave / g.N;
-  const int span = rpb * g.N;
-  const int myj = lane / rpb, sh = (lane - myj * rpb) * g.N;
-  const uint32_t full = (1u << g.N) - 1u;
-  r0 = 0; r1 = 0;
-#pragma unroll
-  for (int j = 0; j < Cfg<R>::kMaxBallots; ++j) {
-    int cell = j * span + lane;
-    bool ok = lane < span && cell < g.P;
-    uint8_t v0 = ok ? p0[cell] : (uint8_t)0;
-    uint8_t v1 = ok ? p1[cell] : (uint8_t)0;
-    uint64_t b0 = __ballot(v0 != 0), b1 = __ballot(v1 != 0);
-    if (lane < g.N && myj == j) {
-      r0 = (uint32_t)(b0 >> sh) & full;
-      r1 = (uint32_t)(b1 >> sh) & full;
-    }
+// uniform plane (turn / passed / done): every byte = val
+__device__ __forceinline__ void splat_plane(uint8_t *plane, uint32_t val, int P, int lane) {
+  const uint32_t w = val * 0x01010101u;
+  if (P >= 4) {
+    for (int d = lane; d < (P >> 2); d += kWave) st32u(plane + 4 * d, w);
+    if ((P & 3) && lane == kWave - 1) st32u(plane + P - 4, w);
+  } else {
+    if (lane < P) plane[lane] = (uint8_t)val;
   }
-}
-
-struct CellMap {  // board cells handled by this lane when expanding rows to bytes
-  uint16_t rc[8]; // (row << 8) | col, for cell = lane + 64 j
-};
-
-template <int R>
-__device__ __forceinline__ CellMap make_cell_map(int lane, int N) {
-  CellMap cm;
-#pragma unroll
-  for (int j = 0; j < Cfg<R>::kCellsPerLane; ++j) {
-    int cell = lane + kWave * j;
-    int r = cell / N, c = cell - r * N;
-    cm.rc[j] = (uint16_t)((r << 8) | c);
-  }
-  return cm;
 }
 
 // ---------------------------------------------------------------- kernels
@@ -330,28 +348,15 @@ struct PlaneBytes { uint8_t turn, passed, done; };
 
 // Emit a whole 6-plane board into the LDS staging buffer (ob[j] = board byte j) from L1 rows.
 template <int R>
-__device__ __forceinline__ void emit_board(uint8_t *ob, uint32_t *rowsw, uint32_t black, uint32_t white,
-                                           uint32_t invalid, PlaneBytes pb, const Geo &g, const CellMap &cm, int lane) {
+__device__ __forceinline__ void emit_board(uint8_t *ob, uint32_t black, uint32_t white, uint32_t invalid,
+                                           PlaneBytes pb, const Geo &g, int lane) {
   WAVE_SYNC();
-  if (lane < 32) {
-    rowsw[lane] = black;
-    rowsw[32 + lane] = white;
-    rowsw[64 + lane] = invalid;
-  }
-  WAVE_SYNC();
-#pragma unroll
-  for (int j = 0; j < Cfg<R>::kCellsPerLane; ++j) {
-    int cell = lane + kWave * j;
-    if (cell < g.P) {
-      int r = cm.rc[j] >> 8, c = cm.rc[j] & 0xFF;
-      ob[cell] = (uint8_t)((rowsw[r] >> c) & 1u);
-      ob[g.P + cell] = (uint8_t)((rowsw[32 + r] >> c) & 1u);
-      ob[2 * g.P + cell] = pb.turn;
-      ob[3 * g.P + cell] = (uint8_t)((rowsw[64 + r] >> c) & 1u);
-      ob[4 * g.P + cell] = pb.passed;
-      ob[5 * g.P + cell] = pb.done;
-    }
-  }
+  row_to_plane<R>(ob, black, g.N, lane);
+  row_to_plane<R>(ob + g.P, white, g.N, lane);
+  splat_plane(ob + 2 * g.P, pb.turn, g.P, lane);
+  row_to_plane<R>(ob + 3 * g.P, invalid, g.N, lane);
+  splat_plane(ob + 4 * g.P, pb.passed, g.P, lane);
+  splat_plane(ob + 5 * g.P, pb.done, g.P, lane);
   WAVE_SYNC();
 }
 
@@ -366,23 +371,26 @@ __device__ __forceinline__ uint32_t load_flags(const uint8_t *g, int P, int pt, 
   return (uint32_t)__ballot(fb != 0) & 0xFu;
 }
 
+// row / column of a flat action with the host-supplied reciprocal: inv = ceil(2^16 / N), exact for a <= N*N
+__device__ __forceinline__ void split_action(int a, int N, uint32_t inv, int &r, int &c) {
+  r = (int)(((uint32_t)a * inv) >> 16);
+  c = a - r * N;
+}
+
 template <int R>
 __global__ __launch_bounds__(kWave) void k_next_states(const uint8_t *__restrict__ in,
                                                        const int32_t *__restrict__ actions,
                                                        uint8_t *__restrict__ out, int32_t *__restrict__ status,
-                                                       int64_t B, int N, int canonical) {
+                                                       int64_t B, int N, uint32_t inv, int canonical) {
   __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
   __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
   __shared__ __attribute__((aligned(16))) uint32_t rows5[160];
-  __shared__ uint32_t rowsw[96];
   const int lane = threadIdx.x;
   Geo g;
-  g.N = N; g.P = N * N;
+  g.N = N; g.P = N * N; g.inv = inv;
   g.full_l1 = lane < N ? (1u << N) - 1u : 0u;
   const int S = 6 * g.P;
   const LaneClass lc = make_lane_class(lane);
-  const CellMap cm = make_cell_map<R>(lane, N);
-  const uint8_t *in_end = in + B * (int64_t)S;
 
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     const uint8_t *gi = in + b * (int64_t)S;
@@ -393,15 +401,18 @@ __global__ __launch_bounds__(kWave) void k_next_states(const uint8_t *__restrict
     uint32_t flags = load_flags(gi, g.P, (in_range && !is_pass) ? a : 0, lane);
     if (!in_range || (!is_pass && (flags & 2u))) {
       // gogame.py:59 / :117 would raise: row passes through unchanged, status flags it
-      for (int i = lane; i < S; i += kWave) go[i] = gi[i];
+      WAVE_SYNC();
+      stage_in(gi, S, iobuf, lane);
+      WAVE_SYNC();
+      stage_out(go, S, iobuf, lane);
       if (status && lane == 0) status[b] = GG_STATUS_ILLEGAL;
       continue;
     }
     WAVE_SYNC();
-    uint32_t mis = stage_in(gi, 2 * g.P, in, in_end, iobuf, lane);
+    stage_in(gi, 2 * g.P, iobuf, lane);
     WAVE_SYNC();
-    uint32_t black, white;
-    planes_to_rows<R>(iobuf + mis, iobuf + mis + g.P, g, lane, black, white);
+    uint32_t black = plane_to_row<R>(iobuf, N, lane);
+    uint32_t white = plane_to_row<R>(iobuf + g.P, N, lane);
     const int pl = flags & 1u;                       // gogame.py:44 turn
     uint32_t mine = pl ? white : black, opp = pl ? black : white;
     uint32_t invalid = step_core<R>(mine, opp, a, g, lc, sc, rows5, lane);
@@ -416,8 +427,7 @@ __global__ __launch_bounds__(kWave) void k_next_states(const uint8_t *__restrict
       nturn = 0;
     }
     pb.turn = (uint8_t)nturn;
-    uint32_t mo = (uint32_t)((uintptr_t)go & 15u);
-    emit_board<R>(iobuf + mo, rowsw, black, white, invalid, pb, g, cm, lane);
+    emit_board<R>(iobuf, black, white, invalid, pb, g, lane);
     stage_out(go, S, iobuf, lane);
     if (status && lane == 0) status[b] = GG_STATUS_OK;
   }
@@ -426,27 +436,24 @@ __global__ __launch_bounds__(kWave) void k_next_states(const uint8_t *__restrict
 template <int R>
 __global__ __launch_bounds__(kWave) void k_invalid_mask(const uint8_t *__restrict__ states,
                                                         const int32_t *__restrict__ ko, uint8_t *__restrict__ mask,
-                                                        int64_t B, int N) {
+                                                        int64_t B, int N, uint32_t inv) {
   __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
   __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
   __shared__ __attribute__((aligned(16))) uint32_t rows5[160];
-  __shared__ uint32_t rowsw[32];
   const int lane = threadIdx.x;
   Geo g;
-  g.N = N; g.P = N * N;
+  g.N = N; g.P = N * N; g.inv = inv;
   g.full_l1 = lane < N ? (1u << N) - 1u : 0u;
   const int S = 6 * g.P;
   const LaneClass lc = make_lane_class(lane);
-  const CellMap cm = make_cell_map<R>(lane, N);
-  const uint8_t *in_end = states + B * (int64_t)S;
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     const uint8_t *gi = states + b * (int64_t)S;
     uint32_t flags = load_flags(gi, g.P, 0, lane);
     WAVE_SYNC();
-    uint32_t mis = stage_in(gi, 2 * g.P, states, in_end, iobuf, lane);
+    stage_in(gi, 2 * g.P, iobuf, lane);
     WAVE_SYNC();
-    uint32_t black, white;
-    planes_to_rows<R>(iobuf + mis, iobuf + mis + g.P, g, lane, black, white);
+    uint32_t black = plane_to_row<R>(iobuf, N, lane);
+    uint32_t white = plane_to_row<R>(iobuf + g.P, N, lane);
     const int nx = flags & 1u;  // side to move
     uint32_t nxs = nx ? white : black, pls = nx ? black : white;
     uint32_t e = g.full_l1 & ~(black | white);
@@ -456,22 +463,15 @@ __global__ __launch_bounds__(kWave) void k_invalid_mask(const uint8_t *__restric
     if (ko) {
       int k = __builtin_amdgcn_readfirstlane(ko[b]);
       if (k >= 0 && k < g.P) {
-        int kr = k / N, kc = k - kr * N;
+        int kr, kc;
+        split_action(k, N, inv, kr, kc);
         if (lane == kr) invalid |= 1u << kc;
       }
     }
     WAVE_SYNC();
-    if (lane < 32) rowsw[lane] = invalid;
+    row_to_plane<R>(iobuf, invalid, N, lane);
     WAVE_SYNC();
-    uint8_t *go = mask + b * (int64_t)g.P;
-    uint32_t mo = (uint32_t)((uintptr_t)go & 15u);
-#pragma unroll
-    for (int j = 0; j < Cfg<R>::kCellsPerLane; ++j) {
-      int cell = lane + kWave * j;
-      if (cell < g.P) iobuf[mo + cell] = (uint8_t)((rowsw[cm.rc[j] >> 8] >> (cm.rc[j] & 0xFF)) & 1u);
-    }
-    WAVE_SYNC();
-    stage_out(go, g.P, iobuf, lane);
+    stage_out(mask + b * (int64_t)g.P, g.P, iobuf, lane);
   }
 }
 
@@ -483,17 +483,16 @@ __global__ __launch_bounds__(kWave) void k_areas(const uint8_t *__restrict__ sta
   __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
   const int lane = threadIdx.x;
   Geo g;
-  g.N = N; g.P = N * N;
+  g.N = N; g.P = N * N; g.inv = 0;
   g.full_l1 = lane < N ? (1u << N) - 1u : 0u;
   const int S = 6 * g.P;
-  const uint8_t *in_end = states + B * (int64_t)S;
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     const uint8_t *gi = states + b * (int64_t)S;
     WAVE_SYNC();
-    uint32_t mis = stage_in(gi, 2 * g.P, states, in_end, iobuf, lane);
+    stage_in(gi, 2 * g.P, iobuf, lane);
     WAVE_SYNC();
-    uint32_t black, white;
-    planes_to_rows<R>(iobuf + mis, iobuf + mis + g.P, g, lane, black, white);
+    uint32_t black = plane_to_row<R>(iobuf, N, lane);
+    uint32_t white = plane_to_row<R>(iobuf + g.P, N, lane);
     uint32_t e = g.full_l1 & ~(black | white);
     uint32_t m[R], mrev[R], f[R], src[R];
 #pragma unroll
@@ -536,20 +535,17 @@ __global__ __launch_bounds__(kWave) void k_areas(const uint8_t *__restrict__ sta
 // is staged and converted once, each action of the chunk is one step_core on a copy of the bitboards.
 template <int R>
 __global__ __launch_bounds__(kWave) void k_children(const uint8_t *__restrict__ states, uint8_t *__restrict__ children,
-                                                    int64_t B, int N, int canonical, int chunks) {
+                                                    int64_t B, int N, uint32_t inv, int canonical, int chunks) {
   __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
   __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
   __shared__ __attribute__((aligned(16))) uint32_t rows5[160];
-  __shared__ uint32_t rowsw[96];
   const int lane = threadIdx.x;
   Geo g;
-  g.N = N; g.P = N * N;
+  g.N = N; g.P = N * N; g.inv = inv;
   g.full_l1 = lane < N ? (1u << N) - 1u : 0u;
   const int S = 6 * g.P;
   const int A = g.P + 1;
   const LaneClass lc = make_lane_class(lane);
-  const CellMap cm = make_cell_map<R>(lane, N);
-  const uint8_t *in_end = states + B * (int64_t)S;
   const int per = (A + chunks - 1) / chunks;
   for (int64_t w = blockIdx.x; w < B * chunks; w += gridDim.x) {
     const int64_t b = w / chunks;
@@ -558,31 +554,36 @@ __global__ __launch_bounds__(kWave) void k_children(const uint8_t *__restrict__ 
     uint32_t flags = load_flags(gi, g.P, 0, lane);
     WAVE_SYNC();
     // planes 0,1 for the stones and plane 3 for slot validity (planes 0..3 are contiguous)
-    uint32_t mis = stage_in(gi, 4 * g.P, states, in_end, iobuf, lane);
+    stage_in(gi, 4 * g.P, iobuf, lane);
     WAVE_SYNC();
-    uint32_t black, white, dummy, invd;
-    planes_to_rows<R>(iobuf + mis, iobuf + mis + g.P, g, lane, black, white);
-    planes_to_rows<R>(iobuf + mis + 2 * g.P, iobuf + mis + 3 * g.P, g, lane, dummy, invd);
+    uint32_t black = plane_to_row<R>(iobuf, N, lane);
+    uint32_t white = plane_to_row<R>(iobuf + g.P, N, lane);
+    uint32_t invd = plane_to_row<R>(iobuf + 3 * g.P, N, lane);
     const int pl = flags & 1u;
     const int a0 = ch * per, a1 = min(A, a0 + per);
+    bool zeroed = false;
 #pragma unroll 1
     for (int a = a0; a < a1; ++a) {
       uint8_t *go = children + (b * A + a) * (int64_t)S;
       bool valid = true;
       if (a < g.P) {
-        int ra = a / N, ca = a - ra * N;
+        int ra, ca;
+        split_action(a, N, inv, ra, ca);
         uint32_t row = __builtin_amdgcn_readlane(invd, ra);
         valid = ((row >> ca) & 1u) == 0;
       }
-      uint32_t mo = (uint32_t)((uintptr_t)go & 15u);
       if (!valid) {
-        WAVE_SYNC();
-        for (int i = lane; i < Cfg<R>::kIoBytes / 16; i += kWave)
-          reinterpret_cast<uint4 *>(iobuf)[i] = make_uint4(0, 0, 0, 0);
-        WAVE_SYNC();
+        if (!zeroed) {
+          WAVE_SYNC();
+          for (int i = lane; i < Cfg<R>::kIoBytes / 16; i += kWave)
+            reinterpret_cast<V16a *>(iobuf)[i] = V16a{{0, 0, 0, 0}};
+          WAVE_SYNC();
+          zeroed = true;
+        }
         stage_out(go, S, iobuf, lane);
         continue;
       }
+      zeroed = false;
       const bool is_pass = a == g.P;
       uint32_t mine = pl ? white : black, opp = pl ? black : white;
       uint32_t invalid = step_core<R>(mine, opp, a, g, lc, sc, rows5, lane);
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(kWave) void k_children(const uint8_t *__restrict__ 
         nturn = 0;
       }
       pb.turn = (uint8_t)nturn;
-      emit_board<R>(iobuf + mo, rowsw, nb, nw, invalid, pb, g, cm, lane);
+      emit_board<R>(iobuf, nb, nw, invalid, pb, g, lane);
       stage_out(go, S, iobuf, lane);
     }
   }
@@ -639,28 +640,25 @@ __device__ __forceinline__ int pick_action(uint32_t valid, uint32_t k, const Geo
 template <int R>
 __global__ __launch_bounds__(kWave) void k_rollout(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                    int32_t *__restrict__ last_actions, int64_t *__restrict__ steps_done,
-                                                   int64_t B, int N, int plies, int auto_reset) {
+                                                   int64_t B, int N, uint32_t inv, int plies, int auto_reset) {
   __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
   __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
   __shared__ __attribute__((aligned(16))) uint32_t rows5[160];
-  __shared__ uint32_t rowsw[96];
   const int lane = threadIdx.x;
   Geo g;
-  g.N = N; g.P = N * N;
+  g.N = N; g.P = N * N; g.inv = inv;
   g.full_l1 = lane < N ? (1u << N) - 1u : 0u;
   const int S = 6 * g.P;
   const LaneClass lc = make_lane_class(lane);
-  const CellMap cm = make_cell_map<R>(lane, N);
-  const uint8_t *in_end = states + B * (int64_t)S;
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     uint8_t *gs = states + b * (int64_t)S;
     uint32_t flags = load_flags(gs, g.P, 0, lane);
     WAVE_SYNC();
-    uint32_t mis = stage_in(gs, 4 * g.P, states, in_end, iobuf, lane);
+    stage_in(gs, 4 * g.P, iobuf, lane);
     WAVE_SYNC();
-    uint32_t black, white, dummy, invalid;
-    planes_to_rows<R>(iobuf + mis, iobuf + mis + g.P, g, lane, black, white);
-    planes_to_rows<R>(iobuf + mis + 2 * g.P, iobuf + mis + 3 * g.P, g, lane, dummy, invalid);
+    uint32_t black = plane_to_row<R>(iobuf, N, lane);
+    uint32_t white = plane_to_row<R>(iobuf + g.P, N, lane);
+    uint32_t invalid = plane_to_row<R>(iobuf + 3 * g.P, N, lane);
     int turn = flags & 1u, passed = (flags >> 2) & 1u, done = (flags >> 3) & 1u;
     uint64_t x = uniform64(rng[b]);
     int last = -1, played = 0;
@@ -691,8 +689,7 @@ __global__ __launch_bounds__(kWave) void k_rollout(uint8_t *__restrict__ states,
     PlaneBytes pb;
     pb.turn = (uint8_t)turn; pb.passed = (uint8_t)passed; pb.done = (uint8_t)done;
     if (played) {
-      uint32_t mo = (uint32_t)((uintptr_t)gs & 15u);
-      emit_board<R>(iobuf + mo, rowsw, black, white, invalid, pb, g, cm, lane);
+      emit_board<R>(iobuf, black, white, invalid, pb, g, lane);
       stage_out(gs, S, iobuf, lane);
     }
     if (lane == 0) {
@@ -709,18 +706,16 @@ __global__ __launch_bounds__(kWave) void k_sample(const uint8_t *__restrict__ st
   __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
   const int lane = threadIdx.x;
   Geo g;
-  g.N = N; g.P = N * N;
+  g.N = N; g.P = N * N; g.inv = 0;
   g.full_l1 = lane < N ? (1u << N) - 1u : 0u;
   const int S = 6 * g.P;
-  const uint8_t *in_end = states + B * (int64_t)S;
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     const uint8_t *gs = states + b * (int64_t)S;
     uint32_t flags = load_flags(gs, g.P, 0, lane);
     WAVE_SYNC();
-    uint32_t mis = stage_in(gs + 2 * g.P, 2 * g.P, states, in_end, iobuf, lane);
+    stage_in(gs + 3 * g.P, g.P, iobuf, lane);
     WAVE_SYNC();
-    uint32_t dummy, invalid;
-    planes_to_rows<R>(iobuf + mis, iobuf + mis + g.P, g, lane, dummy, invalid);
+    uint32_t invalid = plane_to_row<R>(iobuf, N, lane);
     if (flags & 8u) invalid = 0;  // gogame.invalid_moves: zeros once the game ended (gogame.py:155-156)
     uint32_t valid = g.full_l1 & ~invalid;
     int cnt = __popc(valid);
@@ -770,6 +765,14 @@ int grid_for(int64_t work) {
 
 int32_t check(int64_t B, int32_t N) { return (N < 2 || N > GG_MAX_BOARD || B < 0) ? GG_E_BADSIZE : 0; }
 
+// reciprocal for the in-kernel action -> (row, col) split; exactness is verified for every action
+uint32_t recip16(int32_t N) {
+  uint32_t inv = (65536u + (uint32_t)N - 1u) / (uint32_t)N;
+  for (uint32_t a = 0; a <= (uint32_t)(N * N); ++a)
+    if (((a * inv) >> 16) != a / (uint32_t)N) return 0;
+  return inv;
+}
+
 #define GG_DISPATCH(N, CALL9, CALL13, CALL19) \
   do {                                        \
     if ((N) <= 9) { CALL9; }                  \
@@ -790,11 +793,13 @@ int32_t gg_batch_next_states(const uint8_t *in, const int32_t *actions, uint8_t 
   if (int32_t e = check(B, N)) return e;
   if (B == 0) return 0;
   if (!in || !actions || !out) return GG_E_NULLPTR;
+  const uint32_t inv = recip16(N);
+  if (!inv) return GG_E_BADSIZE;
   hipStream_t s = (hipStream_t)hip_stream;
   int grid = grid_for(B);
-  GG_DISPATCH(N, (k_next_states<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, canonical)),
-              (k_next_states<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, canonical)),
-              (k_next_states<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, canonical)));
+  GG_DISPATCH(N, (k_next_states<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+              (k_next_states<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+              (k_next_states<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
   return (int32_t)hipGetLastError();
 }
 
@@ -803,11 +808,13 @@ int32_t gg_batch_invalid_mask(const uint8_t *states, const int32_t *ko, uint8_t 
   if (int32_t e = check(B, N)) return e;
   if (B == 0) return 0;
   if (!states || !mask) return GG_E_NULLPTR;
+  const uint32_t inv = recip16(N);
+  if (!inv) return GG_E_BADSIZE;
   hipStream_t s = (hipStream_t)hip_stream;
   int grid = grid_for(B);
-  GG_DISPATCH(N, (k_invalid_mask<9><<<grid, kWave, 0, s>>>(states, ko, mask, B, N)),
-              (k_invalid_mask<13><<<grid, kWave, 0, s>>>(states, ko, mask, B, N)),
-              (k_invalid_mask<19><<<grid, kWave, 0, s>>>(states, ko, mask, B, N)));
+  GG_DISPATCH(N, (k_invalid_mask<9><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
+              (k_invalid_mask<13><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
+              (k_invalid_mask<19><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)));
   return (int32_t)hipGetLastError();
 }
 
@@ -828,6 +835,8 @@ int32_t gg_batch_children(const uint8_t *states, uint8_t *children, int64_t B, i
   if (int32_t e = check(B, N)) return e;
   if (B == 0) return 0;
   if (!states || !children) return GG_E_NULLPTR;
+  const uint32_t inv = recip16(N);
+  if (!inv) return GG_E_BADSIZE;
   hipStream_t s = (hipStream_t)hip_stream;
   const int A = N * N + 1;
   int cus = device_cus();
@@ -837,9 +846,9 @@ int32_t gg_batch_children(const uint8_t *states, uint8_t *children, int64_t B, i
   if (chunks < 1) chunks = 1;
   if (chunks > A) chunks = A;
   int grid = grid_for(B * chunks);
-  GG_DISPATCH(N, (k_children<9><<<grid, kWave, 0, s>>>(states, children, B, N, canonical, chunks)),
-              (k_children<13><<<grid, kWave, 0, s>>>(states, children, B, N, canonical, chunks)),
-              (k_children<19><<<grid, kWave, 0, s>>>(states, children, B, N, canonical, chunks)));
+  GG_DISPATCH(N, (k_children<9><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
+              (k_children<13><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
+              (k_children<19><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)));
   return (int32_t)hipGetLastError();
 }
 
@@ -849,11 +858,13 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
   if (plies < 0) return GG_E_BADARG;
   if (B == 0 || plies == 0) return 0;
   if (!states || !rng) return GG_E_NULLPTR;
+  const uint32_t inv = recip16(N);
+  if (!inv) return GG_E_BADSIZE;
   hipStream_t s = (hipStream_t)hip_stream;
   int grid = grid_for(B);
-  GG_DISPATCH(N, (k_rollout<9><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, plies, auto_reset)),
-              (k_rollout<13><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, plies, auto_reset)),
-              (k_rollout<19><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, plies, auto_reset)));
+  GG_DISPATCH(N, (k_rollout<9><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
+              (k_rollout<13><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
+              (k_rollout<19><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)));
   return (int32_t)hipGetLastError();
 }
 

@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Condense gpurun_out/<tag>/ (written by tools/profile_round.sh on the GPU box) into tracked files under
+profiles/: <tag>_bench.json, <tag>_kernel_stats.csv, <tag>_summary.md and hbm_traffic.json (read by bench.py)."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+src = os.path.join(ROOT, 'gpurun_out', tag)
+dst = os.path.join(ROOT, 'profiles')
+os.makedirs(dst, exist_ok=True)
+
+bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
+json.dump(bench, open(os.path.join(dst, tag + '_bench.json'), 'w'), indent=1)
+F = bench['config']['plies_per_launch']
+games = bench['config']['games_per_gpu']
+shutil.copy(os.path.join(src, 'kt', 'kt_kernel_stats.csv'), os.path.join(dst, tag + '_kernel_stats.csv'))
+stats = list(csv.DictReader(open(os.path.join(src, 'kt', 'kt_kernel_stats.csv'))))
+
+
+def counters(sub, want='rollout'):
+    rows = list(csv.DictReader(open(os.path.join(src, sub, 'p_counter_collection.csv'))))
+    per = collections.defaultdict(dict)
+    for r in rows:
+        if want in r['Kernel_Name']:
+            d = per[int(r['Dispatch_Id'])]
+            d[r['Counter_Name']] = float(r['Counter_Value'])
+            d['_vgpr'], d['_sgpr'], d['_lds'] = r.get('VGPR_Count'), r.get('SGPR_Count'), r.get('LDS_Block_Size')
+    ids = sorted(per)
+    return [per[i] for i in ids[1:]]   # drop the burn-in launch; the rest are F plies each
+
+
+md = ['# %s profile summary (MI355X, `bench.py --fuse %d`, %d games of %dx%d)\n' % (
+    tag, F, games, bench['config']['board'], bench['config']['board'])]
+md.append('bench line: value = %.4g %s, ms_per_step = %.5f, roofline.frac = %.4f (achieved %.1f GB/s algorithmic)\n'
+          % (bench['value'], bench['unit'], bench['ms_per_step'], bench['roofline']['frac'], bench['roofline']['achieved']))
+md.append('## rocprofv3 --kernel-trace --stats (same command)\n')
+md.append('| kernel | calls | avg ns | total % |\n|---|---|---|---|')
+for r in stats[:4]:
+    md.append('| `%s` | %s | %.0f | %s |' % (r['Name'][:70], r['Calls'], float(r['AverageNs']), r['Percentage']))
+md.append('\nbench.py live launch_ms = %.4f; the stats row above also averages in the one %d-ply burn-in launch, so '
+          'the per-launch figures of the %d-ply launches are taken from the kernel trace:'
+          % (bench['roofline']['launch_ms'], bench['config']['burn_in_plies'], F))
+kt = list(csv.DictReader(open(os.path.join(src, 'kt', 'kt_kernel_trace.csv'))))
+durs = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in kt if 'k_rollout' in r['Kernel_Name']]
+timed = sorted(durs)[:-1] if len(durs) > 1 else durs
+md.append('k_rollout launches of %d plies: n=%d, mean %.4f ms, min %.4f, max %.4f'
+          % (F, len(timed), sum(timed) / len(timed) / 1e6, min(timed) / 1e6, max(timed) / 1e6))
+
+steps = games * F
+traffic = {}
+for name, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
+    vals = [d[name] for d in counters(sub)]
+    traffic[name] = sum(vals) / len(vals)
+fetch_b = traffic['FETCH_SIZE'] * 1024 * 2   # gfx950: FETCH_SIZE reports 1/2 of a wide coalesced stream (MI355X_MICROARCH.md, HBM)
+write_b = traffic['WRITE_SIZE'] * 1024
+md.append('\n## HBM traffic per launch (PMC, separate passes; FETCH_SIZE x2 gfx950 correction, KiB units)\n')
+md.append('FETCH_SIZE = %.0f KiB -> %.1f MB read; WRITE_SIZE = %.0f KiB -> %.1f MB written; total %.1f MB per launch '
+          '= %.0f B per game per launch (algorithmic: %d B x %d steps = %.1f MB)'
+          % (traffic['FETCH_SIZE'], fetch_b / 1e6, traffic['WRITE_SIZE'], write_b / 1e6, (fetch_b + write_b) / 1e6,
+             (fetch_b + write_b) / games, bench['roofline']['algorithmic_bytes_per_step'], steps,
+             bench['roofline']['algorithmic_bytes_per_step'] * steps / 1e6))
+json.dump({'size': bench['config']['board'], 'fuse': F, 'games': games,
+           'bytes_per_launch': round(fetch_b + write_b), 'fetch_bytes': round(fetch_b), 'write_bytes': round(write_b),
+           'source': 'profiles/%s_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)' % tag},
+          open(os.path.join(dst, 'hbm_traffic.json'), 'w'), indent=1)
+
+md.append('\n## instruction mix per env step (PMC / (games x plies))\n')
+for sub in ('pmc_inst', 'pmc_act'):
+    c = counters(sub)
+    keys = [k for k in c[0] if not k.startswith('_')]
+    avg = {k: sum(d[k] for d in c) / len(c) / steps for k in keys}
+    md.append('- ' + ', '.join('%s %.1f' % (k, v) for k, v in sorted(avg.items())))
+    md.append('  (VGPR %s, SGPR %s, LDS %s B per 64-thread workgroup)' % (c[0]['_vgpr'], c[0]['_sgpr'], c[0]['_lds']))
+md.append('\nSQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles. SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU ~ 1.0: a wave64 '
+          'integer VALU op occupies its SIMD for 4 cycles, so the kernel is VALU-issue-bound, not HBM-bound.')
+open(os.path.join(dst, tag + '_summary.md'), 'w').write('\n'.join(md) + '\n')
+print('\n'.join(md))
