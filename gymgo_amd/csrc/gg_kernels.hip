@@ -23,6 +23,7 @@
 // Reference citations are path:line relative to the reference root (huangeddie/GymGo).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gymgo_amd.h"
 
@@ -741,9 +742,429 @@ __global__ void k_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game
   rng[i] = x;
 }
 
+// ===================================================================== v2: TWO BOARDS PER WAVEFRONT
+// Lanes 0-31 own board A, lanes 32-63 board B (h = lane >> 5, hl = lane & 31).  Everything that is
+// wave-uniform in v1 (action, turn, pass / done flags, ko point, RNG state) is a per-lane value that is
+// equal inside a half; ballots are split into their 32-bit halves.
+//
+// Liberty classes: instead of 20 (bit, value) classes, a CONSTANT-WEIGHT CODE - point q = 19 r + c gets
+// the q-th 11-bit word of weight 5 (C(11,5) = 462 >= 361); flood i (11 per colour, 22 lanes per board) is
+// seeded from the empty points whose word has bit i.  A group with one liberty is reached by exactly 5
+// floods, a group with two or more distinct liberties by >= 6 (two different weight-5 words), a group with
+// none by 0: a bit-sliced population count over the 11 floods (carry-save adders, ~20 L1 ops) classifies
+// every stone of the board at once.
+constexpr int kCwClasses = 11, kCwWeight = 5, kCwLanes = 2 * kCwClasses;
+
+struct CwTable { uint32_t m[kCwClasses + 1][20]; };  // [class][row] -> columns of the class; last row = zeros
+
+constexpr CwTable make_cw_table() {
+  CwTable t{};
+  int q = 0;
+  for (uint32_t w = 0; w < (1u << kCwClasses) && q < 19 * 19; ++w) {
+    int pc = 0;
+    for (int i = 0; i < kCwClasses; ++i) pc += (w >> i) & 1u;
+    if (pc != kCwWeight) continue;
+    const int r = q / 19, c = q % 19;
+    for (int i = 0; i < kCwClasses; ++i)
+      if ((w >> i) & 1u) t.m[i][r] |= 1u << c;
+    ++q;
+  }
+  return t;
+}
+__constant__ CwTable kCw = make_cw_table();
+
+struct Half {
+  int lane, h, hl;
+  int N, P;
+  uint32_t inv, full_l1;
+  int cls;       // flood class of this lane (kCwClasses = idle lane)
+  bool second;   // lane floods the second colour
+};
+
+__device__ __forceinline__ uint32_t half_of(uint64_t ballot, int h) {
+  return h ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
+}
+
+// sum bit (a^b^c) and carry bit (majority) of a bit-sliced full adder: one v_bitop3_b32 each
+__device__ __forceinline__ uint32_t csa_sum(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
+__device__ __forceinline__ uint32_t csa_carry(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | (c & (a | b)); }
+
+// From the 11 floods of one colour (w[i] = this row's bits reached by flood i): alive = reached by any,
+// multi = reached by >= 6.
+__device__ __forceinline__ void classify11(const uint32_t (&w)[kCwClasses], uint32_t &alive, uint32_t &multi) {
+  uint32_t s0 = csa_sum(w[0], w[1], w[2]), c0 = csa_carry(w[0], w[1], w[2]);
+  uint32_t s1 = csa_sum(w[3], w[4], w[5]), c1 = csa_carry(w[3], w[4], w[5]);
+  uint32_t s2 = csa_sum(w[6], w[7], w[8]), c2 = csa_carry(w[6], w[7], w[8]);
+  uint32_t s3 = w[9] ^ w[10], c3 = w[9] & w[10];
+  uint32_t ss = csa_sum(s0, s1, s2), cs = csa_carry(s0, s1, s2);
+  uint32_t t = ss & s3;                      // ones column done (bit 0 itself is not needed)
+  uint32_t u0 = csa_sum(c0, c1, c2), v0 = csa_carry(c0, c1, c2);
+  uint32_t u1 = csa_sum(c3, cs, t), v1 = csa_carry(c3, cs, t);
+  uint32_t bit1 = u0 ^ u1, v2 = u0 & u1;
+  uint32_t bit2 = csa_sum(v0, v1, v2), bit3 = csa_carry(v0, v1, v2);
+  multi = bit3 | (bit2 & bit1);              // count >= 6
+  alive = ss | s3 | bit1 | bit2 | bit3;      // count >= 1
+}
+
+// Liberty analysis of both boards of the wave (L1 in, L1 out; see analyze<R> for the single-board form).
+template <int R>
+__device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, const Half &hf, uint32_t *sc,
+                                         uint32_t *rows5 /*[2][160]*/, const uint32_t *cwt /*[12][20]*/,
+                                         uint32_t &multi0, uint32_t &alive0, uint32_t &multi1) {
+  constexpr int RS = Cfg<R>::kRowStride;
+  constexpr int RV = (R + 3) / 4;
+  uint32_t *my5 = rows5 + hf.h * 160;
+  WAVE_SYNC();
+  my5[hf.hl] = c0;
+  my5[32 + hf.hl] = c1;
+  my5[64 + hf.hl] = __brev(c0);
+  my5[96 + hf.hl] = __brev(c1);
+  my5[128 + hf.hl] = e;
+  WAVE_SYNC();
+  uint32_t m[RV * 4], mrev[RV * 4], ee[RV * 4];
+  {
+    const uint4 *pm = reinterpret_cast<const uint4 *>(my5 + (hf.second ? 32 : 0));
+    const uint4 *pr = reinterpret_cast<const uint4 *>(my5 + 64 + (hf.second ? 32 : 0));
+    const uint4 *pe = reinterpret_cast<const uint4 *>(my5 + 128);
+    const uint4 *pc = reinterpret_cast<const uint4 *>(cwt + hf.cls * 20);
+#pragma unroll
+    for (int i = 0; i < RV; ++i) {
+      uint4 a = pm[i], b = pr[i], c = pe[i], d = pc[i];
+      m[4 * i] = a.x; m[4 * i + 1] = a.y; m[4 * i + 2] = a.z; m[4 * i + 3] = a.w;
+      mrev[4 * i] = b.x; mrev[4 * i + 1] = b.y; mrev[4 * i + 2] = b.z; mrev[4 * i + 3] = b.w;
+      ee[4 * i] = c.x & d.x; ee[4 * i + 1] = c.y & d.y; ee[4 * i + 2] = c.z & d.z; ee[4 * i + 3] = c.w & d.w;
+    }
+  }
+  uint32_t mm[R], mr[R], f[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { mm[r] = m[r]; mr[r] = mrev[r]; }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    uint32_t x = (ee[r] << 1) | (r > 0 ? ee[r - 1] : 0u);
+    uint32_t y = (ee[r] >> 1) | (r < R - 1 ? ee[r + 1] : 0u);
+    f[r] = mm[r] & (x | y);
+  }
+  flood<R>(mm, mr, f);
+#pragma unroll
+  for (int r = 0; r < R; ++r) sc[hf.lane * RS + r] = f[r];
+  WAVE_SYNC();
+  multi0 = 0; multi1 = 0; alive0 = 0;
+  if (hf.hl < R) {
+    const uint32_t *base = sc + (hf.h * 32) * RS + hf.hl;
+    uint32_t w0[kCwClasses], w1[kCwClasses];
+#pragma unroll
+    for (int i = 0; i < kCwClasses; ++i) {
+      w0[i] = base[i * RS];
+      w1[i] = base[(kCwClasses + i) * RS];
+    }
+    uint32_t alive1;
+    classify11(w0, alive0, multi0);
+    classify11(w1, alive1, multi1);
+  }
+}
+
+__device__ __forceinline__ uint32_t invalid_from2(uint32_t nx, uint32_t pl, uint32_t multi_nx, uint32_t multi_pl,
+                                                  const Half &hf) {
+  uint32_t e = hf.full_l1 & ~(nx | pl);
+  uint32_t x = e | (nx & multi_nx) | (pl & ~multi_pl);
+  uint32_t up = __shfl_up(x, 1), dn = __shfl_down(x, 1);
+  if (hf.hl == 0) up = 0;
+  if (hf.hl >= hf.N - 1) dn = 0;
+  uint32_t nb = (x << 1) | (x >> 1) | up | dn;
+  return hf.full_l1 & ~(e & nb);
+}
+
+// One transition per half (see step_core<R>).  `a` is this half's action (a legal point or P).
+template <int R>
+__device__ __forceinline__ uint32_t step_core2(uint32_t &mine, uint32_t &opp, int a, const Half &hf, uint32_t *sc,
+                                               uint32_t *rows5, const uint32_t *cwt) {
+  const bool is_pass = a >= hf.P;
+  int ko_r = -1, ko_c = 0;
+  bool boxed = false;
+  {
+    const int aa = is_pass ? 0 : a;
+    const int ra = (int)(((uint32_t)aa * hf.inv) >> 16), ca = aa - ra * hf.N;
+    const uint32_t bit = is_pass ? 0u : (1u << ca);
+    if (hf.hl == ra) mine |= bit;
+    uint32_t nbm = 0;
+    if (hf.hl == ra) nbm = (bit << 1) | (bit >> 1);
+    if (hf.hl == ra - 1 || hf.hl == ra + 1) nbm = bit;
+    nbm &= hf.full_l1;
+    boxed = half_of(__ballot((nbm & ~opp) != 0), hf.h) == 0;
+  }
+  uint32_t multi_opp, alive_opp, multi_mine;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    uint32_t e = hf.full_l1 & ~(mine | opp);
+    analyze2<R>(opp, mine, e, hf, sc, rows5, cwt, multi_opp, alive_opp, multi_mine);
+    if (pass == 0) {
+      uint32_t dead = is_pass ? 0u : (opp & ~alive_opp);
+      uint64_t dmw = __ballot(dead != 0);
+      if (dmw) {  // some board of the wave captured: fix it up, analyse both again
+        uint32_t dm = half_of(dmw, hf.h);
+        uint32_t many = half_of(__ballot(__popc(dead) > 1), hf.h);
+        int r = dm ? (__ffs(dm) - 1) : 0;
+        uint32_t drow = __shfl(dead, (hf.lane & 32) + r);
+        if (dm && boxed && many == 0 && (dm & (dm - 1)) == 0) {
+          ko_r = r;
+          ko_c = __ffs(drow) - 1;
+        }
+        opp &= ~dead;
+        continue;
+      }
+    }
+    break;
+  }
+  uint32_t invalid = invalid_from2(opp, mine, multi_opp, multi_mine, hf);
+  if (hf.hl == ko_r) invalid |= 1u << ko_c;
+  return invalid;
+}
+
+// per-half staging: the 32 lanes of a half move their own board
+__device__ __forceinline__ void stage_in_h(const uint8_t *g, int nbytes, uint8_t *lds, int hl) {
+  if (nbytes >= 16) {
+    const int nfull = nbytes >> 4;
+    for (int v = hl; v < nfull; v += 32) {
+      V16u t = *reinterpret_cast<const V16u *>(g + 16 * v);
+      V16a o;
+      o.w[0] = t.w[0]; o.w[1] = t.w[1]; o.w[2] = t.w[2]; o.w[3] = t.w[3];
+      *reinterpret_cast<V16a *>(lds + 16 * v) = o;
+    }
+    if ((nbytes & 15) && hl == (nfull & 31))
+      *reinterpret_cast<V16u *>(lds + nbytes - 16) = *reinterpret_cast<const V16u *>(g + nbytes - 16);
+  } else {
+    for (int i = hl; i < nbytes; i += 32) lds[i] = g[i];
+  }
+}
+
+__device__ __forceinline__ void stage_out_h(uint8_t *g, int nbytes, const uint8_t *lds, int hl, bool on) {
+  if (!on) return;
+  if (nbytes >= 16) {
+    const int nfull = nbytes >> 4;
+    for (int v = hl; v < nfull; v += 32) {
+      V16a t = *reinterpret_cast<const V16a *>(lds + 16 * v);
+      V16u o;
+      o.w[0] = t.w[0]; o.w[1] = t.w[1]; o.w[2] = t.w[2]; o.w[3] = t.w[3];
+      *reinterpret_cast<V16u *>(g + 16 * v) = o;
+    }
+    if ((nbytes & 15) && hl == (nfull & 31))
+      *reinterpret_cast<V16u *>(g + nbytes - 16) = *reinterpret_cast<const V16u *>(lds + nbytes - 16);
+  } else {
+    for (int i = hl; i < nbytes; i += 32) g[i] = lds[i];
+  }
+}
+
+__device__ __forceinline__ void splat_plane_h(uint8_t *plane, uint32_t val, int P, int hl, bool wr) {
+  const uint32_t w = val * 0x01010101u;
+  if (!wr) return;
+  if (P >= 4) {
+    for (int d = hl; d < (P >> 2); d += 32) st32u(plane + 4 * d, w);
+    if ((P & 3) && hl == 31) st32u(plane + P - 4, w);
+  } else {
+    if (hl < P) plane[hl] = (uint8_t)val;
+  }
+}
+
+// `wr` = this half really emits (the barriers are reached by both halves either way)
+template <int R>
+__device__ __forceinline__ void emit_board_h(uint8_t *ob, uint32_t black, uint32_t white, uint32_t invalid,
+                                             uint32_t turn, uint32_t passed, uint32_t done, const Half &hf, bool wr) {
+  WAVE_SYNC();
+  const int rows = wr ? hf.N : 0;  // row_to_plane writes rows of lanes < its N argument only
+  if (wr) {
+    row_to_plane<R>(ob, black, hf.N, hf.hl);
+    row_to_plane<R>(ob + hf.P, white, hf.N, hf.hl);
+    row_to_plane<R>(ob + 3 * hf.P, invalid, hf.N, hf.hl);
+  }
+  (void)rows;
+  splat_plane_h(ob + 2 * hf.P, turn, hf.P, hf.hl, wr);
+  splat_plane_h(ob + 4 * hf.P, passed, hf.P, hf.hl, wr);
+  splat_plane_h(ob + 5 * hf.P, done, hf.P, hf.hl, wr);
+  WAVE_SYNC();
+}
+
+__device__ __forceinline__ uint32_t load_flags_h(const uint8_t *g, int P, int pt, const Half &hf) {
+  uint8_t fb = 0;
+  if (hf.hl < 4) {
+    int off = hf.hl == 0 ? 2 * P : hf.hl == 1 ? 3 * P + pt : hf.hl == 2 ? 4 * P : 5 * P;
+    fb = g[off];
+  }
+  return half_of(__ballot(fb != 0), hf.h) & 0xFu;
+}
+
+__device__ __forceinline__ Half make_half(int lane, int N, uint32_t inv) {
+  Half hf;
+  hf.lane = lane; hf.h = lane >> 5; hf.hl = lane & 31;
+  hf.N = N; hf.P = N * N; hf.inv = inv;
+  hf.full_l1 = hf.hl < N ? (1u << N) - 1u : 0u;
+  hf.cls = hf.hl < kCwLanes ? (hf.hl % kCwClasses) : kCwClasses;
+  hf.second = hf.hl >= kCwClasses;
+  return hf;
+}
+
+__device__ __forceinline__ void load_cw_table(uint32_t *cwt, int lane) {
+  for (int i = lane; i < (kCwClasses + 1) * 20; i += kWave) cwt[i] = kCw.m[i / 20][i % 20];
+  WAVE_SYNC();
+}
+
+// k-th valid action of this half's board (see pick_action)
+__device__ __forceinline__ int pick_action2(uint32_t valid, uint32_t k, const Half &hf) {
+  int incl = __popc(valid);
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    int t = __shfl_up(incl, off);
+    if (hf.hl >= off) incl += t;
+  }
+  uint32_t hit = half_of(__ballot((uint32_t)incl > k), hf.h);
+  int r = hit ? (__ffs(hit) - 1) : 0;
+  int src = (hf.lane & 32) + r;
+  uint32_t row = __shfl(valid, src);
+  uint32_t before = (uint32_t)__shfl(incl, src) - (uint32_t)__popc(row);
+  uint32_t t = k - before;
+  bool me = ((row >> hf.hl) & 1u) && (uint32_t)__popc(row & ((1u << hf.hl) - 1u)) == t;
+  uint32_t cb = half_of(__ballot(me), hf.h);
+  int c = cb ? (__ffs(cb) - 1) : 0;
+  return hit ? r * hf.N + c : hf.P;
+}
+
+template <int R>
+__global__ __launch_bounds__(kWave) void k_next_states2(const uint8_t *__restrict__ in,
+                                                        const int32_t *__restrict__ actions,
+                                                        uint8_t *__restrict__ out, int32_t *__restrict__ status,
+                                                        int64_t B, int N, uint32_t inv, int canonical) {
+  __shared__ __attribute__((aligned(16))) uint8_t iobuf[2][Cfg<R>::kIoBytes];
+  __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
+  __shared__ __attribute__((aligned(16))) uint32_t rows5[2 * 160];
+  __shared__ __attribute__((aligned(16))) uint32_t cwt[(kCwClasses + 1) * 20];
+  const Half hf = make_half(threadIdx.x, N, inv);
+  load_cw_table(cwt, hf.lane);
+  const int S = 6 * hf.P;
+  uint8_t *io = iobuf[hf.h];
+  const int64_t npairs = (B + 1) >> 1;
+  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+    const int64_t b0 = 2 * p + hf.h;
+    const bool on = b0 < B;
+    const int64_t b = on ? b0 : B - 1;
+    const uint8_t *gi = in + b * (int64_t)S;
+    uint8_t *go = out + b * (int64_t)S;
+    int a = actions[b];
+    const bool in_range = a >= 0 && a <= hf.P;
+    const bool is_pass = a == hf.P;
+    uint32_t flags = load_flags_h(gi, hf.P, (in_range && !is_pass) ? a : 0, hf);
+    const bool illegal = !in_range || (!is_pass && (flags & 2u));
+    WAVE_SYNC();
+    stage_in_h(gi, illegal ? S : 2 * hf.P, io, hf.hl);
+    WAVE_SYNC();
+    if (__ballot(!illegal) == 0) {  // both rows pass through unchanged (gogame.py:59 / :117 would raise)
+      stage_out_h(go, S, io, hf.hl, on);
+      if (status && on && hf.hl == 0) status[b] = GG_STATUS_ILLEGAL;
+      continue;
+    }
+    uint32_t black = plane_to_row<R>(io, N, hf.hl);
+    uint32_t white = plane_to_row<R>(io + hf.P, N, hf.hl);
+    const int pl = flags & 1u;
+    uint32_t mine = pl ? white : black, opp = pl ? black : white;
+    // an illegal half still runs the (wave-wide) analysis on a harmless pass, its result is discarded
+    uint32_t invalid = step_core2<R>(mine, opp, illegal ? hf.P : a, hf, sc, rows5, cwt);
+    black = pl ? opp : mine;
+    white = pl ? mine : opp;
+    uint32_t passed = is_pass ? 1 : 0;
+    uint32_t done = ((flags & 8u) || (is_pass && (flags & 4u))) ? 1 : 0;
+    int nturn = 1 - pl;
+    if (canonical && nturn == 1) {
+      uint32_t t = black; black = white; white = t;
+      nturn = 0;
+    }
+    // an illegal half keeps the untouched copy of its input row that stage_in_h left in LDS
+    emit_board_h<R>(io, black, white, invalid, (uint32_t)nturn, passed, done, hf, !illegal);
+    stage_out_h(go, S, io, hf.hl, on);
+    if (status && on && hf.hl == 0) status[b] = illegal ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(kWave) void k_rollout2(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+                                                    int32_t *__restrict__ last_actions,
+                                                    int64_t *__restrict__ steps_done, int64_t B, int N, uint32_t inv,
+                                                    int plies, int auto_reset) {
+  __shared__ __attribute__((aligned(16))) uint8_t iobuf[2][Cfg<R>::kIoBytes];
+  __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
+  __shared__ __attribute__((aligned(16))) uint32_t rows5[2 * 160];
+  __shared__ __attribute__((aligned(16))) uint32_t cwt[(kCwClasses + 1) * 20];
+  const Half hf = make_half(threadIdx.x, N, inv);
+  load_cw_table(cwt, hf.lane);
+  const int S = 6 * hf.P;
+  uint8_t *io = iobuf[hf.h];
+  const int64_t npairs = (B + 1) >> 1;
+  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+    const int64_t b0 = 2 * p + hf.h;
+    const bool on = b0 < B;
+    const int64_t b = on ? b0 : B - 1;
+    uint8_t *gs = states + b * (int64_t)S;
+    uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
+    WAVE_SYNC();
+    stage_in_h(gs, 4 * hf.P, io, hf.hl);
+    WAVE_SYNC();
+    uint32_t black = plane_to_row<R>(io, N, hf.hl);
+    uint32_t white = plane_to_row<R>(io + hf.P, N, hf.hl);
+    uint32_t invalid = plane_to_row<R>(io + 3 * hf.P, N, hf.hl);
+    int turn = flags & 1u, passed = (flags >> 2) & 1u, done = (flags >> 3) & 1u;
+    uint64_t x = rng[b];
+    int last = -1, played = 0;
+#pragma unroll 1
+    for (int t = 0; t < plies; ++t) {
+      const bool live = on && !(done && !auto_reset);
+      if (__ballot(live) == 0) break;
+      if (done && live) {
+        black = white = invalid = 0;
+        turn = passed = done = 0;
+      }
+      uint32_t valid = hf.full_l1 & ~invalid;
+      int cnt = __popc(valid);
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+      uint64_t xn = x;
+      uint64_t u = splitmix_next(xn);
+      uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(cnt + 1)) >> 32);
+      int a = pick_action2(valid, k, hf);
+      uint32_t mine = turn ? white : black, opp = turn ? black : white;
+      uint32_t ninv = step_core2<R>(mine, opp, live ? a : hf.P, hf, sc, rows5, cwt);
+      if (live) {
+        invalid = ninv;
+        black = turn ? opp : mine;
+        white = turn ? mine : opp;
+        if (a == hf.P) { if (passed) done = 1; passed = 1; } else passed = 0;
+        turn ^= 1;
+        last = a;
+        ++played;
+        x = xn;
+      }
+    }
+    if (__ballot(played != 0)) {
+      emit_board_h<R>(io, black, white, invalid, (uint32_t)turn, (uint32_t)passed, (uint32_t)done, hf, true);
+      stage_out_h(gs, S, io, hf.hl, on && played != 0);
+    }
+    if (on && hf.hl == 0) {
+      rng[b] = x;
+      if (last_actions) last_actions[b] = last;
+      if (steps_done) steps_done[b] += played;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- host side
 
 int g_cus = -1;
+
+// kernel family: 2 = two boards per wavefront (default), 1 = one board per wavefront.  GG_KERNEL_VARIANT=1|2.
+int variant() {
+  static int v = 0;
+  if (v == 0) {
+    const char *e = getenv("GG_KERNEL_VARIANT");
+    v = (e && e[0] == '1') ? 1 : 2;
+  }
+  return v;
+}
 
 int device_cus() {
   if (g_cus < 0) {
@@ -797,9 +1218,16 @@ int32_t gg_batch_next_states(const uint8_t *in, const int32_t *actions, uint8_t 
   if (!inv) return GG_E_BADSIZE;
   hipStream_t s = (hipStream_t)hip_stream;
   int grid = grid_for(B);
-  GG_DISPATCH(N, (k_next_states<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
-              (k_next_states<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
-              (k_next_states<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
+  if (variant() == 2) {
+    grid = grid_for((B + 1) / 2);
+    GG_DISPATCH(N, (k_next_states2<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+                (k_next_states2<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+                (k_next_states2<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
+  } else {
+    GG_DISPATCH(N, (k_next_states<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+                (k_next_states<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+                (k_next_states<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
+  }
   return (int32_t)hipGetLastError();
 }
 
@@ -862,9 +1290,16 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
   if (!inv) return GG_E_BADSIZE;
   hipStream_t s = (hipStream_t)hip_stream;
   int grid = grid_for(B);
-  GG_DISPATCH(N, (k_rollout<9><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
-              (k_rollout<13><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
-              (k_rollout<19><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)));
+  if (variant() == 2) {
+    grid = grid_for((B + 1) / 2);
+    GG_DISPATCH(N, (k_rollout2<9><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
+                (k_rollout2<13><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
+                (k_rollout2<19><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)));
+  } else {
+    GG_DISPATCH(N, (k_rollout<9><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
+                (k_rollout<13><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
+                (k_rollout<19><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)));
+  }
   return (int32_t)hipGetLastError();
 }
 
