@@ -744,8 +744,8 @@ __global__ void k_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game
 
 // ===================================================================== v2: TWO BOARDS PER WAVEFRONT
 // Lanes 0-31 own board A, lanes 32-63 board B (h = lane >> 5, hl = lane & 31).  Everything that is
-// wave-uniform in v1 (action, turn, pass / done flags, ko point, RNG state) is a per-lane value that is
-// equal inside a half; ballots are split into their 32-bit halves.
+// wave-uniform in v1 (action, turn, pass / done flags, ko point) is a per-lane value that is equal
+// inside a half; ballots are split into their 32-bit halves.
 //
 // Liberty classes: instead of 20 (bit, value) classes, a CONSTANT-WEIGHT CODE - point q = 19 r + c gets
 // the q-th 11-bit word of weight 5 (C(11,5) = 462 >= 361); flood i (11 per colour, 22 lanes per board) is
@@ -753,6 +753,11 @@ __global__ void k_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game
 // floods, a group with two or more distinct liberties by >= 6 (two different weight-5 words), a group with
 // none by 0: a bit-sliced population count over the 11 floods (carry-save adders, ~20 L1 ops) classifies
 // every stone of the board at once.
+//
+// Instruction selection (tools/ubench/valu_rate2.hip, measured on MI355X): v_and/or/xor/add/sub/lshrrev/
+// bitop3/mov issue in 2 cycles per wave64; v_bfrev, v_and_or, v_or3, v_lshl_or, v_lshlrev, v_bfi, v_bcnt,
+// v_bfe, v_mul_u32_u24, v_dot4, v_readlane cost 4.  The hot loops below therefore spell every 3-input
+// boolean as v_bitop3_b32 and every "<< 1" as an add.
 constexpr int kCwClasses = 11, kCwWeight = 5, kCwLanes = 2 * kCwClasses;
 
 struct CwTable { uint32_t m[kCwClasses + 1][20]; };  // [class][row] -> columns of the class; last row = zeros
@@ -773,6 +778,30 @@ constexpr CwTable make_cw_table() {
 }
 __constant__ CwTable kCw = make_cw_table();
 
+// v_bitop3_b32 truth tables: result bit = table[(a << 2) | (b << 1) | c] with a = 0xF0, b = 0xCC, c = 0xAA
+constexpr uint32_t TA = 0xF0, TB = 0xCC, TC = 0xAA;
+constexpr uint32_t T_ANDOR = (TA & TB) | TC;                    // (a & b) | c
+constexpr uint32_t T_SEL = (TA & TB) | (~TA & TC & 0xFF);       // a ? b : c
+constexpr uint32_t T_AND_ANDN = TA & TB & (~TC & 0xFF);         // a & b & ~c
+constexpr uint32_t T_OR3 = TA | TB | TC;
+constexpr uint32_t T_XOR3 = TA ^ TB ^ TC;
+constexpr uint32_t T_MAJ = (TA & TB) | (TC & (TA | TB));
+constexpr uint32_t T_AND_OR2 = TA & (TB | TC);                  // a & (b | c)
+constexpr uint32_t T_OR_AND = TA | (TB & TC);                   // a | (b & c)
+#define B3(a, b, c, t) __builtin_amdgcn_bitop3_b32((a), (b), (c), (t))
+
+__device__ __forceinline__ uint32_t shl1(uint32_t x) {  // x << 1 as a 2-cycle add (v_lshlrev_b32 costs 4)
+  uint32_t r;
+  asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// DPP moves (GFX9 encodings): row_shr:n = 0x110 + n, row_bcast:15 = 0x142, wave_shl:1 = 0x130, wave_shr:1 = 0x138
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
+
 struct Half {
   int lane, h, hl;
   int N, P;
@@ -785,9 +814,51 @@ __device__ __forceinline__ uint32_t half_of(uint64_t ballot, int h) {
   return h ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
 }
 
+// complete horizontal run fill of seeds s (subset of m), 6 ops: 2 carry fills, 2 bit reversals
+__device__ __forceinline__ uint32_t run_fill2(uint32_t m, uint32_t mrev, uint32_t s) {
+  uint32_t t = m + s;
+  uint32_t u = B3(t, s, m, T_SEL);
+  uint32_t rs = __brev(u);
+  uint32_t t2 = mrev + rs;
+  uint32_t rr = B3(t2, rs, mrev, T_SEL);
+  return __brev(rr);
+}
+#define VISIT(r, nb) f[r] = run_fill2(m[r], mrev[r], B3(f[nb], m[r], f[r], T_ANDOR))
+
+// Per-lane flood to the fixed point, two interleaved dependency chains per round for ILP:
+//   phase 1: chain A sweeps DOWN over the top rows [0..H], chain B sweeps UP over the bottom rows [R-1..H+1]
+//   phase 2: chain B goes on UP over the top rows [H..0], chain A goes on DOWN over the bottom rows [H+1..R-1]
+// After a round the top half is closed upwards, the bottom half downwards and the seam downwards; the test
+// looks at the 18 remaining (row, direction) pairs and only then another round is spent.
+template <int R>
+__device__ __forceinline__ void flood2(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R]) {
+  constexpr int H = (R - 1) / 2;
+#pragma unroll 1
+  for (int it = 0; it < R * R; ++it) {
+    f[0] = run_fill2(m[0], mrev[0], f[0]);
+    f[R - 1] = run_fill2(m[R - 1], mrev[R - 1], f[R - 1]);
+#pragma unroll
+    for (int i = 1; i <= H; ++i) {
+      VISIT(i, i - 1);
+      if (R - 1 - i > H) VISIT(R - 1 - i, R - i);
+    }
+#pragma unroll
+    for (int i = 0; i <= H; ++i) {
+      VISIT(H - i, H - i + 1);
+      if (H + 1 + i < R) VISIT(H + 1 + i, H + i);
+    }
+    uint32_t open = 0;
+#pragma unroll
+    for (int r = 1; r <= H; ++r) open |= B3(f[r - 1], m[r], f[r], T_AND_ANDN);      // top half, downwards
+#pragma unroll
+    for (int r = H; r < R - 1; ++r) open |= B3(f[r + 1], m[r], f[r], T_AND_ANDN);   // seam + bottom half, upwards
+    if (__ballot(open != 0) == 0) break;
+  }
+}
+
 // sum bit (a^b^c) and carry bit (majority) of a bit-sliced full adder: one v_bitop3_b32 each
-__device__ __forceinline__ uint32_t csa_sum(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
-__device__ __forceinline__ uint32_t csa_carry(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | (c & (a | b)); }
+__device__ __forceinline__ uint32_t csa_sum(uint32_t a, uint32_t b, uint32_t c) { return B3(a, b, c, T_XOR3); }
+__device__ __forceinline__ uint32_t csa_carry(uint32_t a, uint32_t b, uint32_t c) { return B3(a, b, c, T_MAJ); }
 
 // From the 11 floods of one colour (w[i] = this row's bits reached by flood i): alive = reached by any,
 // multi = reached by >= 6.
@@ -802,18 +873,31 @@ __device__ __forceinline__ void classify11(const uint32_t (&w)[kCwClasses], uint
   uint32_t u1 = csa_sum(c3, cs, t), v1 = csa_carry(c3, cs, t);
   uint32_t bit1 = u0 ^ u1, v2 = u0 & u1;
   uint32_t bit2 = csa_sum(v0, v1, v2), bit3 = csa_carry(v0, v1, v2);
-  multi = bit3 | (bit2 & bit1);              // count >= 6
-  alive = ss | s3 | bit1 | bit2 | bit3;      // count >= 1
+  multi = B3(bit3, bit2, bit1, T_OR_AND);                 // count >= 6
+  alive = B3(ss, s3, bit1, T_OR3) | bit2 | bit3;          // count >= 1
 }
+
+// LDS carve-up of a v2 workgroup: the flood transpose buffer and the board staging buffers are never live
+// at the same time and share region 0.
+template <int R>
+struct Lds2 {
+  static constexpr int kScWords = kWave * Cfg<R>::kRowStride;
+  static constexpr int kIoWords = 2 * Cfg<R>::kIoBytes / 4;
+  static constexpr int kRegion0 = kScWords > kIoWords ? kScWords : kIoWords;
+  static constexpr int kRows5 = kRegion0;                 // [2][160]
+  static constexpr int kCwt = kRows5 + 2 * 160;           // [12][20]
+  static constexpr int kTotal = kCwt + (kCwClasses + 1) * 20;
+};
 
 // Liberty analysis of both boards of the wave (L1 in, L1 out; see analyze<R> for the single-board form).
 template <int R>
-__device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, const Half &hf, uint32_t *sc,
-                                         uint32_t *rows5 /*[2][160]*/, const uint32_t *cwt /*[12][20]*/,
+__device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, const Half &hf, uint32_t *lds,
                                          uint32_t &multi0, uint32_t &alive0, uint32_t &multi1) {
   constexpr int RS = Cfg<R>::kRowStride;
   constexpr int RV = (R + 3) / 4;
-  uint32_t *my5 = rows5 + hf.h * 160;
+  uint32_t *sc = lds;
+  uint32_t *my5 = lds + Lds2<R>::kRows5 + hf.h * 160;
+  const uint32_t *cwt = lds + Lds2<R>::kCwt;
   WAVE_SYNC();
   my5[hf.hl] = c0;
   my5[32 + hf.hl] = c1;
@@ -821,30 +905,37 @@ __device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, c
   my5[96 + hf.hl] = __brev(c1);
   my5[128 + hf.hl] = e;
   WAVE_SYNC();
-  uint32_t m[RV * 4], mrev[RV * 4], ee[RV * 4];
+  uint32_t m[R], mrev[R], f[R];
   {
+    uint32_t ee[RV * 4 + 1], mt[RV * 4];
     const uint4 *pm = reinterpret_cast<const uint4 *>(my5 + (hf.second ? 32 : 0));
-    const uint4 *pr = reinterpret_cast<const uint4 *>(my5 + 64 + (hf.second ? 32 : 0));
     const uint4 *pe = reinterpret_cast<const uint4 *>(my5 + 128);
     const uint4 *pc = reinterpret_cast<const uint4 *>(cwt + hf.cls * 20);
 #pragma unroll
     for (int i = 0; i < RV; ++i) {
-      uint4 a = pm[i], b = pr[i], c = pe[i], d = pc[i];
-      m[4 * i] = a.x; m[4 * i + 1] = a.y; m[4 * i + 2] = a.z; m[4 * i + 3] = a.w;
-      mrev[4 * i] = b.x; mrev[4 * i + 1] = b.y; mrev[4 * i + 2] = b.z; mrev[4 * i + 3] = b.w;
+      uint4 a = pm[i], c = pe[i], d = pc[i];
+      mt[4 * i] = a.x; mt[4 * i + 1] = a.y; mt[4 * i + 2] = a.z; mt[4 * i + 3] = a.w;
       ee[4 * i] = c.x & d.x; ee[4 * i + 1] = c.y & d.y; ee[4 * i + 2] = c.z & d.z; ee[4 * i + 3] = c.w & d.w;
     }
-  }
-  uint32_t mm[R], mr[R], f[R];
+    ee[RV * 4] = 0;
 #pragma unroll
-  for (int r = 0; r < R; ++r) { mm[r] = m[r]; mr[r] = mrev[r]; }
+    for (int r = 0; r < R; ++r) {
+      m[r] = mt[r];
+      // stones touching a liberty of the class: m & ((e << 1) | (e >> 1) | e_above | e_below)
+      uint32_t x = r > 0 ? B3(shl1(ee[r]), ee[r] >> 1, ee[r - 1], T_OR3) : (shl1(ee[r]) | (ee[r] >> 1));
+      f[r] = B3(m[r], x, r < R - 1 ? ee[r + 1] : 0u, T_AND_OR2);
+    }
+    const uint4 *pr = reinterpret_cast<const uint4 *>(my5 + 64 + (hf.second ? 32 : 0));
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    uint32_t x = (ee[r] << 1) | (r > 0 ? ee[r - 1] : 0u);
-    uint32_t y = (ee[r] >> 1) | (r < R - 1 ? ee[r + 1] : 0u);
-    f[r] = mm[r] & (x | y);
+    for (int i = 0; i < RV; ++i) {
+      uint4 b = pr[i];
+      if (4 * i < R) mrev[4 * i] = b.x;
+      if (4 * i + 1 < R) mrev[4 * i + 1] = b.y;
+      if (4 * i + 2 < R) mrev[4 * i + 2] = b.z;
+      if (4 * i + 3 < R) mrev[4 * i + 3] = b.w;
+    }
   }
-  flood<R>(mm, mr, f);
+  flood2<R>(m, mrev, f);
 #pragma unroll
   for (int r = 0; r < R; ++r) sc[hf.lane * RS + r] = f[r];
   WAVE_SYNC();
@@ -866,18 +957,17 @@ __device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, c
 __device__ __forceinline__ uint32_t invalid_from2(uint32_t nx, uint32_t pl, uint32_t multi_nx, uint32_t multi_pl,
                                                   const Half &hf) {
   uint32_t e = hf.full_l1 & ~(nx | pl);
-  uint32_t x = e | (nx & multi_nx) | (pl & ~multi_pl);
-  uint32_t up = __shfl_up(x, 1), dn = __shfl_down(x, 1);
-  if (hf.hl == 0) up = 0;
-  if (hf.hl >= hf.N - 1) dn = 0;
-  uint32_t nb = (x << 1) | (x >> 1) | up | dn;
+  uint32_t x = B3(e, nx & multi_nx, pl & ~multi_pl, T_OR3);
+  // rows above / below: one-lane DPP shifts over the whole wave; rows >= N are zero, so nothing leaks
+  // across the half boundary (N <= 19 < 32)
+  uint32_t up = dpp0<0x138>(x), dn = dpp0<0x130>(x);
+  uint32_t nb = B3(shl1(x), x >> 1, up, T_OR3) | dn;
   return hf.full_l1 & ~(e & nb);
 }
 
 // One transition per half (see step_core<R>).  `a` is this half's action (a legal point or P).
 template <int R>
-__device__ __forceinline__ uint32_t step_core2(uint32_t &mine, uint32_t &opp, int a, const Half &hf, uint32_t *sc,
-                                               uint32_t *rows5, const uint32_t *cwt) {
+__device__ __forceinline__ uint32_t step_core2(uint32_t &mine, uint32_t &opp, int a, const Half &hf, uint32_t *lds) {
   const bool is_pass = a >= hf.P;
   int ko_r = -1, ko_c = 0;
   bool boxed = false;
@@ -896,7 +986,7 @@ __device__ __forceinline__ uint32_t step_core2(uint32_t &mine, uint32_t &opp, in
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     uint32_t e = hf.full_l1 & ~(mine | opp);
-    analyze2<R>(opp, mine, e, hf, sc, rows5, cwt, multi_opp, alive_opp, multi_mine);
+    analyze2<R>(opp, mine, e, hf, lds, multi_opp, alive_opp, multi_mine);
     if (pass == 0) {
       uint32_t dead = is_pass ? 0u : (opp & ~alive_opp);
       uint64_t dmw = __ballot(dead != 0);
@@ -970,13 +1060,11 @@ template <int R>
 __device__ __forceinline__ void emit_board_h(uint8_t *ob, uint32_t black, uint32_t white, uint32_t invalid,
                                              uint32_t turn, uint32_t passed, uint32_t done, const Half &hf, bool wr) {
   WAVE_SYNC();
-  const int rows = wr ? hf.N : 0;  // row_to_plane writes rows of lanes < its N argument only
   if (wr) {
     row_to_plane<R>(ob, black, hf.N, hf.hl);
     row_to_plane<R>(ob + hf.P, white, hf.N, hf.hl);
     row_to_plane<R>(ob + 3 * hf.P, invalid, hf.N, hf.hl);
   }
-  (void)rows;
   splat_plane_h(ob + 2 * hf.P, turn, hf.P, hf.hl, wr);
   splat_plane_h(ob + 4 * hf.P, passed, hf.P, hf.hl, wr);
   splat_plane_h(ob + 5 * hf.P, done, hf.P, hf.hl, wr);
@@ -1002,24 +1090,30 @@ __device__ __forceinline__ Half make_half(int lane, int N, uint32_t inv) {
   return hf;
 }
 
-__device__ __forceinline__ void load_cw_table(uint32_t *cwt, int lane) {
+template <int R>
+__device__ __forceinline__ void load_cw_table(uint32_t *lds, int lane) {
+  uint32_t *cwt = lds + Lds2<R>::kCwt;
   for (int i = lane; i < (kCwClasses + 1) * 20; i += kWave) cwt[i] = kCw.m[i / 20][i % 20];
   WAVE_SYNC();
 }
 
-// k-th valid action of this half's board (see pick_action)
-__device__ __forceinline__ int pick_action2(uint32_t valid, uint32_t k, const Half &hf) {
-  int incl = __popc(valid);
-#pragma unroll
-  for (int off = 1; off < 32; off <<= 1) {
-    int t = __shfl_up(incl, off);
-    if (hf.hl >= off) incl += t;
-  }
-  uint32_t hit = half_of(__ballot((uint32_t)incl > k), hf.h);
+// inclusive prefix sum of v over the 32 lanes of each half: 4 DPP row shifts + 1 row broadcast
+__device__ __forceinline__ uint32_t half_scan(uint32_t v) {
+  v += dpp0<0x111>(v);
+  v += dpp0<0x112>(v);
+  v += dpp0<0x114>(v);
+  v += dpp0<0x118>(v);
+  v += dpp0<0x142, 0xA>(v);  // lane 15 of rows 0 / 2 added to every lane of rows 1 / 3
+  return v;
+}
+
+// k-th valid action of this half's board (see pick_action); incl = half_scan(popc(valid))
+__device__ __forceinline__ int pick_action2(uint32_t valid, uint32_t incl, uint32_t k, const Half &hf) {
+  uint32_t hit = half_of(__ballot(incl > k), hf.h);
   int r = hit ? (__ffs(hit) - 1) : 0;
   int src = (hf.lane & 32) + r;
   uint32_t row = __shfl(valid, src);
-  uint32_t before = (uint32_t)__shfl(incl, src) - (uint32_t)__popc(row);
+  uint32_t before = (uint32_t)__shfl((int)incl, src) - (uint32_t)__popc(row);
   uint32_t t = k - before;
   bool me = ((row >> hf.hl) & 1u) && (uint32_t)__popc(row & ((1u << hf.hl) - 1u)) == t;
   uint32_t cb = half_of(__ballot(me), hf.h);
@@ -1032,14 +1126,11 @@ __global__ __launch_bounds__(kWave) void k_next_states2(const uint8_t *__restric
                                                         const int32_t *__restrict__ actions,
                                                         uint8_t *__restrict__ out, int32_t *__restrict__ status,
                                                         int64_t B, int N, uint32_t inv, int canonical) {
-  __shared__ __attribute__((aligned(16))) uint8_t iobuf[2][Cfg<R>::kIoBytes];
-  __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
-  __shared__ __attribute__((aligned(16))) uint32_t rows5[2 * 160];
-  __shared__ __attribute__((aligned(16))) uint32_t cwt[(kCwClasses + 1) * 20];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv);
-  load_cw_table(cwt, hf.lane);
+  load_cw_table<R>(lds, hf.lane);
   const int S = 6 * hf.P;
-  uint8_t *io = iobuf[hf.h];
+  uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
   for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
     const int64_t b0 = 2 * p + hf.h;
@@ -1065,7 +1156,7 @@ __global__ __launch_bounds__(kWave) void k_next_states2(const uint8_t *__restric
     const int pl = flags & 1u;
     uint32_t mine = pl ? white : black, opp = pl ? black : white;
     // an illegal half still runs the (wave-wide) analysis on a harmless pass, its result is discarded
-    uint32_t invalid = step_core2<R>(mine, opp, illegal ? hf.P : a, hf, sc, rows5, cwt);
+    uint32_t invalid = step_core2<R>(mine, opp, illegal ? hf.P : a, hf, lds);
     black = pl ? opp : mine;
     white = pl ? mine : opp;
     uint32_t passed = is_pass ? 1 : 0;
@@ -1075,7 +1166,8 @@ __global__ __launch_bounds__(kWave) void k_next_states2(const uint8_t *__restric
       uint32_t t = black; black = white; white = t;
       nturn = 0;
     }
-    // an illegal half keeps the untouched copy of its input row that stage_in_h left in LDS
+    WAVE_SYNC();
+    if (illegal) stage_in_h(gi, S, io, hf.hl);  // the analysis reused the staging area: fetch the row again
     emit_board_h<R>(io, black, white, invalid, (uint32_t)nturn, passed, done, hf, !illegal);
     stage_out_h(go, S, io, hf.hl, on);
     if (status && on && hf.hl == 0) status[b] = illegal ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
@@ -1087,19 +1179,16 @@ __global__ __launch_bounds__(kWave) void k_rollout2(uint8_t *__restrict__ states
                                                     int32_t *__restrict__ last_actions,
                                                     int64_t *__restrict__ steps_done, int64_t B, int N, uint32_t inv,
                                                     int plies, int auto_reset) {
-  __shared__ __attribute__((aligned(16))) uint8_t iobuf[2][Cfg<R>::kIoBytes];
-  __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
-  __shared__ __attribute__((aligned(16))) uint32_t rows5[2 * 160];
-  __shared__ __attribute__((aligned(16))) uint32_t cwt[(kCwClasses + 1) * 20];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv);
-  load_cw_table(cwt, hf.lane);
+  load_cw_table<R>(lds, hf.lane);
   const int S = 6 * hf.P;
-  uint8_t *io = iobuf[hf.h];
+  uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
   for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
-    const int64_t b0 = 2 * p + hf.h;
-    const bool on = b0 < B;
-    const int64_t b = on ? b0 : B - 1;
+    const int64_t bA = 2 * p, bB = (2 * p + 1 < B) ? 2 * p + 1 : B - 1;
+    const bool on = 2 * p + hf.h < B;
+    const int64_t b = hf.h ? bB : bA;
     uint8_t *gs = states + b * (int64_t)S;
     uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
     WAVE_SYNC();
@@ -1109,26 +1198,30 @@ __global__ __launch_bounds__(kWave) void k_rollout2(uint8_t *__restrict__ states
     uint32_t white = plane_to_row<R>(io + hf.P, N, hf.hl);
     uint32_t invalid = plane_to_row<R>(io + 3 * hf.P, N, hf.hl);
     int turn = flags & 1u, passed = (flags >> 2) & 1u, done = (flags >> 3) & 1u;
-    uint64_t x = rng[b];
+    uint64_t xa = uniform64(rng[bA]), xb = uniform64(rng[bB]);  // generator states live in SGPRs
     int last = -1, played = 0;
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
       const bool live = on && !(done && !auto_reset);
-      if (__ballot(live) == 0) break;
+      const uint64_t lv = __ballot(live);
+      if (lv == 0) break;
       if (done && live) {
         black = white = invalid = 0;
         turn = passed = done = 0;
       }
       uint32_t valid = hf.full_l1 & ~invalid;
-      int cnt = __popc(valid);
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-      uint64_t xn = x;
-      uint64_t u = splitmix_next(xn);
-      uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(cnt + 1)) >> 32);
-      int a = pick_action2(valid, k, hf);
+      uint32_t incl = half_scan((uint32_t)__popc(valid));
+      uint32_t cnt_a = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+      uint32_t cnt_b = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      uint64_t xna = xa, xnb = xb;
+      uint64_t ua = splitmix_next(xna), ub = splitmix_next(xnb);
+      uint32_t ka = (uint32_t)(((ua >> 32) * (uint64_t)(cnt_a + 1)) >> 32);
+      uint32_t kb = (uint32_t)(((ub >> 32) * (uint64_t)(cnt_b + 1)) >> 32);
+      if ((uint32_t)lv) xa = xna;
+      if ((uint32_t)(lv >> 32)) xb = xnb;
+      int a = pick_action2(valid, incl, hf.h ? kb : ka, hf);
       uint32_t mine = turn ? white : black, opp = turn ? black : white;
-      uint32_t ninv = step_core2<R>(mine, opp, live ? a : hf.P, hf, sc, rows5, cwt);
+      uint32_t ninv = step_core2<R>(mine, opp, live ? a : hf.P, hf, lds);
       if (live) {
         invalid = ninv;
         black = turn ? opp : mine;
@@ -1137,7 +1230,6 @@ __global__ __launch_bounds__(kWave) void k_rollout2(uint8_t *__restrict__ states
         turn ^= 1;
         last = a;
         ++played;
-        x = xn;
       }
     }
     if (__ballot(played != 0)) {
@@ -1145,7 +1237,7 @@ __global__ __launch_bounds__(kWave) void k_rollout2(uint8_t *__restrict__ states
       stage_out_h(gs, S, io, hf.hl, on && played != 0);
     }
     if (on && hf.hl == 0) {
-      rng[b] = x;
+      rng[b] = hf.h ? xb : xa;
       if (last_actions) last_actions[b] = last;
       if (steps_done) steps_done[b] += played;
     }
