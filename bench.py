@@ -87,6 +87,7 @@ def main():
     from gymgo_amd import gogame
     from gymgo_amd.envs.vec_env import shard
 
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:

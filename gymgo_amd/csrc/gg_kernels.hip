@@ -1122,7 +1122,7 @@ __device__ __forceinline__ int pick_action2(uint32_t valid, uint32_t incl, uint3
 }
 
 template <int R>
-__global__ __launch_bounds__(kWave) void k_next_states2(const uint8_t *__restrict__ in,
+__global__ __launch_bounds__(kWave, 4) void k_next_states2(const uint8_t *__restrict__ in,
                                                         const int32_t *__restrict__ actions,
                                                         uint8_t *__restrict__ out, int32_t *__restrict__ status,
                                                         int64_t B, int N, uint32_t inv, int canonical) {
@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(kWave) void k_next_states2(const uint8_t *__restric
 }
 
 template <int R>
-__global__ __launch_bounds__(kWave) void k_rollout2(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+__global__ __launch_bounds__(kWave, 4) void k_rollout2(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                     int32_t *__restrict__ last_actions,
                                                     int64_t *__restrict__ steps_done, int64_t B, int N, uint32_t inv,
                                                     int plies, int auto_reset) {

@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""Per-entry-point throughput of the C-ABI on one GPU (BASELINE.json configs 2, 3, 5 + the small ops), each
+against its own HBM roofline (algorithmic bytes per unit).  Prints one JSON object; run on the GPU box:
+    python tools/bench_ops.py > gpurun_out/ops.json
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from gymgo_amd import gogame, state_utils  # noqa: E402
+
+PEAK = 8.0e12
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def midgame(B, N, plies, seed=3):
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, seed)
+    gogame.batch_rollout(st, rng, plies, True)
+    return st, rng
+
+
+def main():
+    out = {}
+    for N, B, plies in ((9, 4096, 60), (19, 65536, 250)):
+        st, rng = midgame(B, N, plies)
+        S = 6 * N * N
+        # out-of-place step API fed by the on-device sampler (finished games reset by a masked fill, as a user would)
+        acts = gogame.batch_sample_actions(st, rng)
+
+        def api_ply():
+            nonlocal st
+            ended = gogame.batch_game_ended(st).bool()
+            st = torch.where(ended[:, None, None, None], torch.zeros_like(st), st)
+            a = gogame.batch_sample_actions(st, rng)
+            st, _ = gogame.batch_next_states(st, a, check=False)
+        t = timed(api_ply, 50)
+        out['vecenv_step_api_%dx%d_B%d' % (N, N, B)] = {'steps_per_s': B / t, 'note': 'reset + sample + next_states per ply'}
+        st2, _ = midgame(B, N, plies, 5)
+        acts = gogame.batch_sample_actions(st2, gogame.rng_seed(B, 9))
+        t = timed(lambda: gogame.batch_next_states(st2, acts, check=False), 50)
+        out['gg_batch_next_states_%dx%d_B%d' % (N, N, B)] = {
+            'steps_per_s': B / t, 'algorithmic_GBps': B * (2 * S + 4) / t / 1e9, 'roofline_frac': B * (2 * S + 4) / t / PEAK}
+        t = timed(lambda: gogame.batch_next_states(st2, acts, canonical=True, check=False), 50)
+        out['gg_batch_next_states_canonical_%dx%d_B%d' % (N, N, B)] = {'steps_per_s': B / t}
+        t = timed(lambda: gogame.batch_areas(st2), 50)
+        out['gg_batch_areas_%dx%d_B%d' % (N, N, B)] = {
+            'boards_per_s': B / t, 'algorithmic_GBps': B * (S + 8) / t / 1e9, 'roofline_frac': B * (S + 8) / t / PEAK}
+        t = timed(lambda: state_utils.batch_compute_invalid_moves(st2, None, None), 50)
+        out['gg_batch_invalid_mask_%dx%d_B%d' % (N, N, B)] = {'boards_per_s': B / t}
+        r2 = gogame.rng_seed(B, 11)
+        t = timed(lambda: gogame.batch_sample_actions(st2, r2), 50)
+        out['gg_batch_sample_actions_%dx%d_B%d' % (N, N, B)] = {'boards_per_s': B / t}
+    # config 5: 19x19, 8192 parents, full 362-slot padded expansion
+    N, B = 19, 8192
+    st, _ = midgame(B, N, 250, 7)
+    S = 6 * N * N
+    for canon in (False, True):
+        t = timed(lambda: gogame.batch_children(st, canonical=canon), 5)
+        nbytes = B * (S + (N * N + 1) * S)
+        valid = float(gogame.batch_valid_moves(st).float().sum() / B)
+        out['gg_batch_children_19x19_B8192%s' % ('_canonical' if canon else '')] = {
+            'parents_per_s': B / t, 'child_states_per_s': B * (N * N + 1) / t, 'ms_per_batch': t * 1e3,
+            'algorithmic_GBps': nbytes / t / 1e9, 'roofline_frac': nbytes / t / PEAK, 'mean_valid_children': valid}
+    # single-state latency (GoEnv.children / next_state path)
+    one = st[0]
+    t0 = time.perf_counter()
+    for _ in range(20):
+        gogame.children(one, canonical=True)
+    torch.cuda.synchronize()
+    out['children_single_state_19x19_ms'] = (time.perf_counter() - t0) / 20 * 1e3
+    t0 = time.perf_counter()
+    for _ in range(50):
+        gogame.batch_next_states(st[:1], torch.tensor([361], device='cuda', dtype=torch.int32), check=False)
+    torch.cuda.synchronize()
+    out['next_state_single_19x19_ms'] = (time.perf_counter() - t0) / 50 * 1e3
+    out['variant'] = os.environ.get('GG_KERNEL_VARIANT', '2')
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
