@@ -1244,6 +1244,95 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout2(uint8_t *__restrict__ sta
   }
 }
 
+// all-zero child slot straight from registers (no LDS round trip)
+__device__ __forceinline__ void stage_zero_h(uint8_t *g, int nbytes, int hl, bool on) {
+  if (!on) return;
+  const V16u z = {{0u, 0u, 0u, 0u}};
+  if (nbytes >= 16) {
+    const int nfull = nbytes >> 4;
+    for (int v = hl; v < nfull; v += 32) *reinterpret_cast<V16u *>(g + 16 * v) = z;
+    if ((nbytes & 15) && hl == (nfull & 31)) *reinterpret_cast<V16u *>(g + nbytes - 16) = z;
+  } else {
+    for (int i = hl; i < nbytes; i += 32) g[i] = 0;
+  }
+}
+
+// gogame.children, two slots per wave pass.  The legal actions of the chunk are compacted first (k-th set bit of the
+// valid-point rows, as in the sampler) so that both halves always expand a legal action; the all-zero slots of
+// the illegal actions are written in a separate store-only loop.
+template <int R>
+__global__ __launch_bounds__(kWave, 4) void k_children2(const uint8_t *__restrict__ states,
+                                                        uint8_t *__restrict__ children, int64_t B, int N,
+                                                        uint32_t inv, int canonical, int chunks) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
+  const Half hf = make_half(threadIdx.x, N, inv);
+  load_cw_table<R>(lds, hf.lane);
+  const int S = 6 * hf.P;
+  const int A = hf.P + 1;
+  uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
+  const int per = (A + chunks - 1) / chunks;
+  for (int64_t w = blockIdx.x; w < B * chunks; w += gridDim.x) {
+    const int64_t b = w / chunks;
+    const int ch = (int)(w - b * chunks);
+    const uint8_t *gi = states + b * (int64_t)S;
+    uint8_t *gc = children + b * A * (int64_t)S;
+    uint32_t flags = load_flags_h(gi, hf.P, 0, hf);
+    WAVE_SYNC();
+    stage_in_h(gi, 4 * hf.P, io, hf.hl);  // both halves stage the same parent (second copy comes from L2)
+    WAVE_SYNC();
+    const uint32_t black = plane_to_row<R>(io, N, hf.hl);
+    const uint32_t white = plane_to_row<R>(io + hf.P, N, hf.hl);
+    const uint32_t invd = plane_to_row<R>(io + 3 * hf.P, N, hf.hl);
+    const int pl = flags & 1u;
+    const int a0 = ch * per, a1 = min(A, a0 + per);
+    const int p1 = min(a1, hf.P);  // points of the chunk: [a0, p1); the pass slot is in the chunk iff a1 == A
+    // rows of this chunk's points
+    const int base = hf.hl * N;
+    const int lo = max(0, min(N, a0 - base)), hi = max(0, min(N, p1 - base));
+    const uint32_t inrange = (hi > lo) ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+    const uint32_t vr = hf.full_l1 & ~invd & inrange;
+    const uint32_t incl = half_scan((uint32_t)__popc(vr));
+    const int npts = __builtin_amdgcn_readlane((int)incl, 31);
+    const int nv = npts + (a1 == A ? 1 : 0);
+    // The all-zero slots of the illegal points are store-only work; they are interleaved with the compute passes
+    // (q zero steps after every pass) so that the write stream is spread over the whole life of the wave.
+    int az = a0;
+    const int npass = (nv + 1) >> 1, nzero = (p1 - a0 + 1) >> 1;
+    const int q = npass > 0 ? (nzero + npass - 1) / npass : nzero;
+    auto zero_step = [&](int aj) {
+      const int a = aj + hf.h;
+      bool zero = false;
+      if (a < p1) {
+        const int ra = (int)(((uint32_t)a * inv) >> 16), ca = a - ra * N;
+        uint32_t row = __shfl(invd, (hf.lane & 32) + ra);
+        zero = ((row >> ca) & 1u) != 0;
+      }
+      stage_zero_h(gc + (int64_t)(a < p1 ? a : a0) * S, S, hf.hl, zero);
+    };
+#pragma unroll 1
+    for (int j = 0; j < nv; j += 2) {
+      const int k = j + hf.h;
+      const bool on = k < nv;
+      const int a = on ? pick_action2(vr, incl, (uint32_t)k, hf) : hf.P;  // k == npts -> pass
+      const bool is_pass = a == hf.P;
+      uint32_t mine = pl ? white : black, opp = pl ? black : white;
+      uint32_t invalid = step_core2<R>(mine, opp, a, hf, lds);
+      uint32_t nb = pl ? opp : mine, nw = pl ? mine : opp;
+      uint32_t passed = is_pass ? 1 : 0;
+      uint32_t done = ((flags & 8u) || (is_pass && (flags & 4u))) ? 1 : 0;
+      int nturn = 1 - pl;
+      if (canonical && nturn == 1) {
+        uint32_t t = nb; nb = nw; nw = t;
+        nturn = 0;
+      }
+      emit_board_h<R>(io, nb, nw, invalid, (uint32_t)nturn, passed, done, hf, on);
+      stage_out_h(gc + (int64_t)a * S, S, io, hf.hl, on);
+      for (int t = 0; t < q && az < p1; ++t, az += 2) zero_step(az);
+    }
+    for (; az < p1; az += 2) zero_step(az);
+  }
+}
+
 // ---------------------------------------------------------------- host side
 
 int g_cus = -1;
@@ -1366,9 +1455,15 @@ int32_t gg_batch_children(const uint8_t *states, uint8_t *children, int64_t B, i
   if (chunks < 1) chunks = 1;
   if (chunks > A) chunks = A;
   int grid = grid_for(B * chunks);
-  GG_DISPATCH(N, (k_children<9><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
-              (k_children<13><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
-              (k_children<19><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)));
+  if (variant() == 2) {
+    GG_DISPATCH(N, (k_children2<9><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
+                (k_children2<13><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
+                (k_children2<19><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)));
+  } else {
+    GG_DISPATCH(N, (k_children<9><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
+                (k_children<13><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
+                (k_children<19><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)));
+  }
   return (int32_t)hipGetLastError();
 }
 
