@@ -160,7 +160,8 @@ def main():
                 'burn_in_plies': args.burn_in, 'sharding': 'batch split across ranks, no collective',
             },
             'roofline': {
-                'bound': 'hbm', 'kernel': 'k_rollout<%d>' % (9 if N <= 9 else 13 if N <= 13 else 19),
+                'bound': 'hbm', 'kernel': 'k_rollout%s<%d>' % ('' if os.environ.get('GG_KERNEL_VARIANT') == '1' else '2',
+                                                             9 if N <= 9 else 13 if N <= 13 else 19),
                 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                 'algorithmic_bytes_per_step': algo, 'steps_per_launch': count * F,

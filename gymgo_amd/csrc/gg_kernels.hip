@@ -33,7 +33,16 @@ constexpr int kWave = 64;
 constexpr int kClassBits = 5;                 // row / column indices < 32
 constexpr int kClasses = 4 * kClassBits;      // (row|col bit k) x (value v) = 20 floods per colour
 
-#define WAVE_SYNC() __syncthreads()  // 64-thread workgroups: a wave-local LDS fence
+// 64-thread workgroups: the only "other threads" are lanes of the same wave.  DS instructions of one wave
+// execute in program order, so LDS hand-offs between lanes need no s_barrier and no s_waitcnt (a
+// __syncthreads() would also drain vmcnt, i.e. wait for every outstanding global store) - only the compiler
+// must not move LDS accesses across the hand-off point.
+#define WAVE_SYNC()                        \
+  do {                                     \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_wave_barrier();       \
+    asm volatile("" ::: "memory");         \
+  } while (0)
 
 template <int R>
 struct Cfg {

@@ -75,8 +75,8 @@ for sub in ('pmc_inst', 'pmc_act'):
     keys = [k for k in c[0] if not k.startswith('_')]
     avg = {k: sum(d[k] for d in c) / len(c) / steps for k in keys}
     md.append('- ' + ', '.join('%s %.1f' % (k, v) for k, v in sorted(avg.items())))
-    md.append('  (VGPR %s, SGPR %s, LDS %s B per 64-thread workgroup)' % (c[0]['_vgpr'], c[0]['_sgpr'], c[0]['_lds']))
-md.append('\nSQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles. SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU ~ 1.0: a wave64 '
-          'integer VALU op occupies its SIMD for 4 cycles, so the kernel is VALU-issue-bound, not HBM-bound.')
+    md.append('  (LDS %s B per 64-thread workgroup)' % c[0]['_lds'])
+md.append('\nSQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles. The kernel is VALU-issue / dependency-latency bound, '
+          'not HBM-bound: per-op issue costs (2 or 4 cycles per wave64) are in profiles/r01_ubench_valu_rates.txt.')
 open(os.path.join(dst, tag + '_summary.md'), 'w').write('\n'.join(md) + '\n')
 print('\n'.join(md))
