@@ -297,59 +297,44 @@ __device__ __forceinline__ void stage_out(uint8_t *g, int nbytes, const uint8_t 
   }
 }
 
-// One byte plane (P bytes of 0/1 in LDS) -> L1 row mask: lane r reads its row as ceil(N/4) dwords (the last
-// one overlapping, ending at the row's last cell) and packs 4 cells per v_dot4_u32_u8 with weights 1,2,4,8.
+// One byte plane (P bytes of 0/1 in LDS, any byte alignment) -> L1 row mask.
+// UNALIGNED 4-byte LDS accesses are ~22x slower than aligned ones on gfx950 (tools/ubench/lds_unaligned2.hip:
+// 26.9 ns vs 1.24 ns per wave instruction), so lane r reads the ALIGNED dwords that cover its row, packs
+// 4 cells per v_dot4_u32_u8 (weights 1,2,4,8 / 16,32,64,128) and shifts the sub-dword offset out at the end.
 template <int R>
 __device__ __forceinline__ uint32_t plane_to_row(const uint8_t *plane, int N, int lane) {
+  constexpr int ND = ((R + 3 + 3) / 4 + 1) & ~1;  // aligned dwords covering 3 + R bytes, even count
   uint32_t row = 0;
   if (lane < N) {
     const uint8_t *p = plane + lane * N;
-    if (N >= 4) {
+    const uint32_t s = (uint32_t)((uintptr_t)p & 3u);
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(p - s);
+    uint32_t acc = 0;
 #pragma unroll
-      for (int k = 0; k < (R + 3) / 4; ++k) {
-        if (4 * k < N) {
-          const int o = min(4 * k, N - 4);
-          uint32_t w = ld32u(p + o) & 0x01010101u;
-          row |= __builtin_amdgcn_udot4(w, 0x08040201u, 0u, false) << o;
-        }
-      }
-    } else {
-      for (int c = 0; c < N; ++c) row |= (uint32_t)(p[c] & 1) << c;
+    for (int k = 0; k < ND; k += 2) {
+      uint32_t g = __builtin_amdgcn_udot4(d[k] & 0x01010101u, 0x08040201u, 0u, false);
+      g = __builtin_amdgcn_udot4(d[k + 1] & 0x01010101u, 0x80402010u, g, false);
+      acc |= g << (4 * k);
     }
+    row = (acc >> s) & ((1u << N) - 1u);
   }
   return row;
 }
 
-// L1 row mask -> one byte plane in LDS: 4 cells per store, (bits * 0x204081) & 0x01010101 spreads 4 bits
-// to 4 bytes (bit i lands at bit 8 i; the 24-bit multiply has no colliding partial products).
+// L1 row mask -> one byte plane in LDS (v1 kernels and the mask output): plain byte stores, always aligned.
 template <int R>
 __device__ __forceinline__ void row_to_plane(uint8_t *plane, uint32_t row, int N, int lane) {
   if (lane < N) {
     uint8_t *p = plane + lane * N;
-    if (N >= 4) {
 #pragma unroll
-      for (int k = 0; k < (R + 3) / 4; ++k) {
-        if (4 * k < N) {
-          const int o = min(4 * k, N - 4);
-          uint32_t bits = (row >> o) & 0xFu;
-          st32u(p + o, __umul24(bits, 0x204081u) & 0x01010101u);
-        }
-      }
-    } else {
-      for (int c = 0; c < N; ++c) p[c] = (uint8_t)((row >> c) & 1u);
-    }
+    for (int c = 0; c < R; ++c)
+      if (c < N) p[c] = (uint8_t)((row >> c) & 1u);
   }
 }
 
 // uniform plane (turn / passed / done): every byte = val
 __device__ __forceinline__ void splat_plane(uint8_t *plane, uint32_t val, int P, int lane) {
-  const uint32_t w = val * 0x01010101u;
-  if (P >= 4) {
-    for (int d = lane; d < (P >> 2); d += kWave) st32u(plane + 4 * d, w);
-    if ((P & 3) && lane == kWave - 1) st32u(plane + P - 4, w);
-  } else {
-    if (lane < P) plane[lane] = (uint8_t)val;
-  }
+  for (int i = lane; i < P; i += kWave) plane[i] = (uint8_t)val;
 }
 
 // ---------------------------------------------------------------- kernels
@@ -895,7 +880,8 @@ struct Lds2 {
   static constexpr int kRegion0 = kScWords > kIoWords ? kScWords : kIoWords;
   static constexpr int kRows5 = kRegion0;                 // [2][160]
   static constexpr int kCwt = kRows5 + 2 * 160;           // [12][20]
-  static constexpr int kTotal = kCwt + (kCwClasses + 1) * 20;
+  static constexpr int kTbl = kCwt + (kCwClasses + 1) * 20;  // [16] 4 bits -> 4 bytes
+  static constexpr int kTotal = kTbl + 16;
 };
 
 // Liberty analysis of both boards of the wave (L1 in, L1 out; see analyze<R> for the single-board form).
@@ -1019,65 +1005,119 @@ __device__ __forceinline__ uint32_t step_core2(uint32_t &mine, uint32_t &opp, in
   return invalid;
 }
 
-// per-half staging: the 32 lanes of a half move their own board
-__device__ __forceinline__ void stage_in_h(const uint8_t *g, int nbytes, uint8_t *lds, int hl) {
-  if (nbytes >= 16) {
-    const int nfull = nbytes >> 4;
-    for (int v = hl; v < nfull; v += 32) {
-      V16u t = *reinterpret_cast<const V16u *>(g + 16 * v);
-      V16a o;
-      o.w[0] = t.w[0]; o.w[1] = t.w[1]; o.w[2] = t.w[2]; o.w[3] = t.w[3];
-      *reinterpret_cast<V16a *>(lds + 16 * v) = o;
-    }
-    if ((nbytes & 15) && hl == (nfull & 31))
-      *reinterpret_cast<V16u *>(lds + nbytes - 16) = *reinterpret_cast<const V16u *>(g + nbytes - 16);
-  } else {
-    for (int i = hl; i < nbytes; i += 32) lds[i] = g[i];
-  }
+// per-half staging: the 32 lanes of a half move their own board.
+// Boards start at arbitrary byte offsets, but unaligned 16-byte global accesses run at about half the rate of
+// aligned ones on gfx950 (tools/time_align.py: I/O overhead 70-80 us per 65 536-board launch vs 42 us for the
+// 16-byte-aligned N = 16 stride).  So HBM is only ever touched with ALIGNED 16-byte vectors: the load fetches the
+// aligned superset of the slice (the extra <= 30 bytes belong to neighbouring boards or to the same 16-byte
+// chunk as the first / last valid byte, hence to a mapped page) and the board lives at offset mis = g & 15
+// inside the LDS buffer; the store writes the fully covered aligned vectors and ONE global_store_byte
+// instruction whose lanes 0-14 / 16-30 carry the ragged head / tail bytes.
+__device__ __forceinline__ uint32_t stage_in_h(const uint8_t *g, int nbytes, uint8_t *lds, int hl) {
+  const uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
+  const uint8_t *ga = g - mis;
+  const int nv = (int)(mis + nbytes + 15) >> 4;
+  for (int v = hl; v < nv; v += 32)
+    *reinterpret_cast<V16a *>(lds + 16 * v) = *reinterpret_cast<const V16a *>(ga + 16 * v);
+  return mis;
 }
 
+// lds[mis + j] = board byte j, mis = g & 15
 __device__ __forceinline__ void stage_out_h(uint8_t *g, int nbytes, const uint8_t *lds, int hl, bool on) {
   if (!on) return;
-  if (nbytes >= 16) {
-    const int nfull = nbytes >> 4;
-    for (int v = hl; v < nfull; v += 32) {
-      V16a t = *reinterpret_cast<const V16a *>(lds + 16 * v);
-      V16u o;
-      o.w[0] = t.w[0]; o.w[1] = t.w[1]; o.w[2] = t.w[2]; o.w[3] = t.w[3];
-      *reinterpret_cast<V16u *>(g + 16 * v) = o;
-    }
-    if ((nbytes & 15) && hl == (nfull & 31))
-      *reinterpret_cast<V16u *>(g + nbytes - 16) = *reinterpret_cast<const V16u *>(lds + nbytes - 16);
-  } else {
-    for (int i = hl; i < nbytes; i += 32) g[i] = lds[i];
+  const uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
+  uint8_t *ga = g - mis;
+  const int end = (int)mis + nbytes;
+  const int v0 = mis ? 1 : 0, v1 = end >> 4;
+  for (int v = v0 + hl; v < v1; v += 32)
+    *reinterpret_cast<V16a *>(ga + 16 * v) = *reinterpret_cast<const V16a *>(lds + 16 * v);
+  if (v1 >= v0) {
+    const int head = mis ? 16 - (int)mis : 0, tail = end & 15;
+    int j = -1;
+    if (hl < 16) { if (hl < head) j = hl; }
+    else if (hl - 16 < tail) j = nbytes - tail + (hl - 16);
+    if (j >= 0) g[j] = lds[mis + j];
+  } else {  // the slice lies inside one 16-byte chunk
+    for (int i = hl; i < nbytes; i += 32) g[i] = lds[mis + i];
   }
 }
 
-__device__ __forceinline__ void splat_plane_h(uint8_t *plane, uint32_t val, int P, int hl, bool wr) {
-  const uint32_t w = val * 0x01010101u;
-  if (!wr) return;
-  if (P >= 4) {
-    for (int d = hl; d < (P >> 2); d += 32) st32u(plane + 4 * d, w);
-    if ((P & 3) && hl == 31) st32u(plane + P - 4, w);
-  } else {
-    if (hl < P) plane[hl] = (uint8_t)val;
-  }
+// rare path: an illegal move's row passes through unchanged, global -> global, bytes
+__device__ __forceinline__ void copy_row_h(const uint8_t *src, uint8_t *dst, int nbytes, int hl, bool on) {
+  if (!on) return;
+  for (int i = hl; i < nbytes; i += 32) dst[i] = src[i];
 }
 
-// `wr` = this half really emits (the barriers are reached by both halves either way)
+// Board emission of one half, L1 rows -> HBM, with ALIGNED LDS and HBM accesses only:
+//   1. the 6 planes are OR-ed row by row (ds_or_b32) into a linear bit-string bs[] (bit 16 + i = board byte i;
+//      the 16 leading zero bits stand for the bytes in front of the board inside its first 16-byte chunk);
+//   2. lane v of round k builds the aligned 16-byte vector 16 (hl + 32 k): 16 cells = one funnel shift out of
+//      two words of bs[], 4 cells -> 4 bytes through a 16-entry table (aligned ds_read_b32);
+//   3. vectors that lie inside the board go straight from registers to HBM (global_store_dwordx4); the (at
+//      most two) ragged ones are parked in LDS and leave in ONE global_store_byte instruction.
+// `work` = the half's LDS staging area (>= 96 + 8 words), `tbl` = the bits -> bytes table.
 template <int R>
-__device__ __forceinline__ void emit_board_h(uint8_t *ob, uint32_t black, uint32_t white, uint32_t invalid,
-                                             uint32_t turn, uint32_t passed, uint32_t done, const Half &hf, bool wr) {
+__device__ __forceinline__ void emit_store_h(uint8_t *g, uint32_t black, uint32_t white, uint32_t invalid,
+                                             uint32_t turn, uint32_t passed, uint32_t done, const Half &hf,
+                                             uint32_t *work, const uint32_t *tbl, bool wr) {
+  constexpr int kRounds = (Cfg<R>::kIoBytes / 16 + 31) / 32;
+  uint32_t *bs = work;
+  uint8_t *edge = reinterpret_cast<uint8_t *>(work + 96);  // [2][16]
+  const int S = 6 * hf.P;
+  WAVE_SYNC();
+  bs[hf.hl] = 0; bs[32 + hf.hl] = 0; bs[64 + hf.hl] = 0;
+  WAVE_SYNC();
+  if (wr && hf.hl < hf.N) {
+    const uint32_t rows[6] = {black, white, turn ? hf.full_l1 : 0u, invalid, passed ? hf.full_l1 : 0u,
+                              done ? hf.full_l1 : 0u};
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const uint32_t q = 16u + (uint32_t)(p * hf.P + hf.hl * hf.N), w = q >> 5, sh = q & 31u;
+      if (rows[p]) {
+        atomicOr(&bs[w], rows[p] << sh);
+        if (sh + (uint32_t)hf.N > 32u) atomicOr(&bs[w + 1], rows[p] >> (32u - sh));
+      }
+    }
+  }
+  WAVE_SYNC();
+  const uint32_t mo = (uint32_t)((uintptr_t)g & 15u);
+  uint8_t *ga = g - mo;
+  const int nv = (int)(mo + S + 15) >> 4;
+  if (wr) {
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) {
+      const int v = hf.hl + 32 * k;
+      if (v < nv) {
+        const uint32_t qb = 16u + 16u * (uint32_t)v - mo, w = qb >> 5, sh = qb & 31u;
+        const uint32_t b16 = __builtin_amdgcn_alignbit(bs[w + 1], bs[w], sh);
+        V16a o;
+        o.w[0] = tbl[b16 & 15u];
+        o.w[1] = tbl[(b16 >> 4) & 15u];
+        o.w[2] = tbl[(b16 >> 8) & 15u];
+        o.w[3] = tbl[(b16 >> 12) & 15u];
+        const int lo = 16 * v - (int)mo;
+        const bool full = lo >= 0 && lo + 16 <= S;
+        if (full) *reinterpret_cast<V16a *>(ga + 16 * v) = o;   // HBM, aligned
+        asm volatile("" ::: "memory");                          // keep the two address spaces apart (no flat store)
+        if (!full) {
+          uint32_t *e = work + 96 + (lo < 0 ? 0 : 4);
+          e[0] = o.w[0]; e[1] = o.w[1]; e[2] = o.w[2]; e[3] = o.w[3];
+        }
+      }
+    }
+  }
   WAVE_SYNC();
   if (wr) {
-    row_to_plane<R>(ob, black, hf.N, hf.hl);
-    row_to_plane<R>(ob + hf.P, white, hf.N, hf.hl);
-    row_to_plane<R>(ob + 3 * hf.P, invalid, hf.N, hf.hl);
+    const int head = mo ? 16 - (int)mo : 0, tail = ((int)mo + S) & 15;
+    if (nv >= 2) {
+      int j = -1, e = 0;
+      if (hf.hl < 16) { if (hf.hl < head) { j = hf.hl; e = (int)mo + hf.hl; } }
+      else if (hf.hl - 16 < tail) { j = S - tail + (hf.hl - 16); e = 16 + (hf.hl - 16); }
+      if (j >= 0) g[j] = edge[e];
+    } else {  // the whole board sits in one 16-byte chunk (N = 2 with a lucky offset never happens: S >= 24)
+      for (int i = hf.hl; i < S; i += 32) g[i] = edge[(mo ? 0 : 16) + ((int)mo + i)];
+    }
   }
-  splat_plane_h(ob + 2 * hf.P, turn, hf.P, hf.hl, wr);
-  splat_plane_h(ob + 4 * hf.P, passed, hf.P, hf.hl, wr);
-  splat_plane_h(ob + 5 * hf.P, done, hf.P, hf.hl, wr);
-  WAVE_SYNC();
 }
 
 __device__ __forceinline__ uint32_t load_flags_h(const uint8_t *g, int P, int pt, const Half &hf) {
@@ -1103,6 +1143,8 @@ template <int R>
 __device__ __forceinline__ void load_cw_table(uint32_t *lds, int lane) {
   uint32_t *cwt = lds + Lds2<R>::kCwt;
   for (int i = lane; i < (kCwClasses + 1) * 20; i += kWave) cwt[i] = kCw.m[i / 20][i % 20];
+  if (lane < 16)  // bits -> bytes expansion table of emit_store_h
+    lds[Lds2<R>::kTbl + lane] = (lane & 1u) | ((lane & 2u) << 7) | ((lane & 4u) << 14) | ((lane & 8u) << 21);
   WAVE_SYNC();
 }
 
@@ -1153,15 +1195,15 @@ __global__ __launch_bounds__(kWave, 4) void k_next_states2(const uint8_t *__rest
     uint32_t flags = load_flags_h(gi, hf.P, (in_range && !is_pass) ? a : 0, hf);
     const bool illegal = !in_range || (!is_pass && (flags & 2u));
     WAVE_SYNC();
-    stage_in_h(gi, illegal ? S : 2 * hf.P, io, hf.hl);
+    const uint32_t mi = stage_in_h(gi, 2 * hf.P, io, hf.hl);
     WAVE_SYNC();
     if (__ballot(!illegal) == 0) {  // both rows pass through unchanged (gogame.py:59 / :117 would raise)
-      stage_out_h(go, S, io, hf.hl, on);
+      copy_row_h(gi, go, S, hf.hl, on);
       if (status && on && hf.hl == 0) status[b] = GG_STATUS_ILLEGAL;
       continue;
     }
-    uint32_t black = plane_to_row<R>(io, N, hf.hl);
-    uint32_t white = plane_to_row<R>(io + hf.P, N, hf.hl);
+    uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
+    uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
     const int pl = flags & 1u;
     uint32_t mine = pl ? white : black, opp = pl ? black : white;
     // an illegal half still runs the (wave-wide) analysis on a harmless pass, its result is discarded
@@ -1175,10 +1217,9 @@ __global__ __launch_bounds__(kWave, 4) void k_next_states2(const uint8_t *__rest
       uint32_t t = black; black = white; white = t;
       nturn = 0;
     }
-    WAVE_SYNC();
-    if (illegal) stage_in_h(gi, S, io, hf.hl);  // the analysis reused the staging area: fetch the row again
-    emit_board_h<R>(io, black, white, invalid, (uint32_t)nturn, passed, done, hf, !illegal);
-    stage_out_h(go, S, io, hf.hl, on);
+    emit_store_h<R>(go, black, white, invalid, (uint32_t)nturn, passed, done, hf,
+                    reinterpret_cast<uint32_t *>(io), lds + Lds2<R>::kTbl, on && !illegal);
+    if (illegal) copy_row_h(gi, go, S, hf.hl, on);  // rare: the row passes through unchanged
     if (status && on && hf.hl == 0) status[b] = illegal ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
   }
 }
@@ -1201,11 +1242,11 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout2(uint8_t *__restrict__ sta
     uint8_t *gs = states + b * (int64_t)S;
     uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
     WAVE_SYNC();
-    stage_in_h(gs, 4 * hf.P, io, hf.hl);
+    const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
     WAVE_SYNC();
-    uint32_t black = plane_to_row<R>(io, N, hf.hl);
-    uint32_t white = plane_to_row<R>(io + hf.P, N, hf.hl);
-    uint32_t invalid = plane_to_row<R>(io + 3 * hf.P, N, hf.hl);
+    uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
+    uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+    uint32_t invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
     int turn = flags & 1u, passed = (flags >> 2) & 1u, done = (flags >> 3) & 1u;
     uint64_t xa = uniform64(rng[bA]), xb = uniform64(rng[bB]);  // generator states live in SGPRs
     int last = -1, played = 0;
@@ -1242,8 +1283,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout2(uint8_t *__restrict__ sta
       }
     }
     if (__ballot(played != 0)) {
-      emit_board_h<R>(io, black, white, invalid, (uint32_t)turn, (uint32_t)passed, (uint32_t)done, hf, true);
-      stage_out_h(gs, S, io, hf.hl, on && played != 0);
+      emit_store_h<R>(gs, black, white, invalid, (uint32_t)turn, (uint32_t)passed, (uint32_t)done, hf,
+                      reinterpret_cast<uint32_t *>(io), lds + Lds2<R>::kTbl, on && played != 0);
     }
     if (on && hf.hl == 0) {
       rng[b] = hf.h ? xb : xa;
@@ -1253,14 +1294,21 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout2(uint8_t *__restrict__ sta
   }
 }
 
-// all-zero child slot straight from registers (no LDS round trip)
+// all-zero child slot straight from registers (no LDS round trip), aligned vectors + one byte-store for the edges
 __device__ __forceinline__ void stage_zero_h(uint8_t *g, int nbytes, int hl, bool on) {
   if (!on) return;
-  const V16u z = {{0u, 0u, 0u, 0u}};
-  if (nbytes >= 16) {
-    const int nfull = nbytes >> 4;
-    for (int v = hl; v < nfull; v += 32) *reinterpret_cast<V16u *>(g + 16 * v) = z;
-    if ((nbytes & 15) && hl == (nfull & 31)) *reinterpret_cast<V16u *>(g + nbytes - 16) = z;
+  const uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
+  uint8_t *ga = g - mis;
+  const int end = (int)mis + nbytes;
+  const int v0 = mis ? 1 : 0, v1 = end >> 4;
+  const V16a z = {{0u, 0u, 0u, 0u}};
+  for (int v = v0 + hl; v < v1; v += 32) *reinterpret_cast<V16a *>(ga + 16 * v) = z;
+  if (v1 >= v0) {
+    const int head = mis ? 16 - (int)mis : 0, tail = end & 15;
+    int j = -1;
+    if (hl < 16) { if (hl < head) j = hl; }
+    else if (hl - 16 < tail) j = nbytes - tail + (hl - 16);
+    if (j >= 0) g[j] = 0;
   } else {
     for (int i = hl; i < nbytes; i += 32) g[i] = 0;
   }
@@ -1287,11 +1335,11 @@ __global__ __launch_bounds__(kWave, 4) void k_children2(const uint8_t *__restric
     uint8_t *gc = children + b * A * (int64_t)S;
     uint32_t flags = load_flags_h(gi, hf.P, 0, hf);
     WAVE_SYNC();
-    stage_in_h(gi, 4 * hf.P, io, hf.hl);  // both halves stage the same parent (second copy comes from L2)
+    const uint32_t mi = stage_in_h(gi, 4 * hf.P, io, hf.hl);  // both halves stage the same parent (second copy: L2)
     WAVE_SYNC();
-    const uint32_t black = plane_to_row<R>(io, N, hf.hl);
-    const uint32_t white = plane_to_row<R>(io + hf.P, N, hf.hl);
-    const uint32_t invd = plane_to_row<R>(io + 3 * hf.P, N, hf.hl);
+    const uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
+    const uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+    const uint32_t invd = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
     const int pl = flags & 1u;
     const int a0 = ch * per, a1 = min(A, a0 + per);
     const int p1 = min(a1, hf.P);  // points of the chunk: [a0, p1); the pass slot is in the chunk iff a1 == A
@@ -1334,8 +1382,9 @@ __global__ __launch_bounds__(kWave, 4) void k_children2(const uint8_t *__restric
         uint32_t t = nb; nb = nw; nw = t;
         nturn = 0;
       }
-      emit_board_h<R>(io, nb, nw, invalid, (uint32_t)nturn, passed, done, hf, on);
-      stage_out_h(gc + (int64_t)a * S, S, io, hf.hl, on);
+      uint8_t *go = gc + (int64_t)a * S;
+      emit_store_h<R>(go, nb, nw, invalid, (uint32_t)nturn, passed, done, hf, reinterpret_cast<uint32_t *>(io),
+                      lds + Lds2<R>::kTbl, on);
       for (int t = 0; t < q && az < p1; ++t, az += 2) zero_step(az);
     }
     for (; az < p1; az += 2) zero_step(az);
