@@ -961,45 +961,72 @@ __device__ __forceinline__ uint32_t invalid_from2(uint32_t nx, uint32_t pl, uint
 }
 
 // One transition per half (see step_core<R>).  `a` is this half's action (a legal point or P).
+// atari_in (valid when have_atari, which must be wave-uniform) = the opponent's stones whose group had exactly one
+// liberty BEFORE the move, as classified by the previous ply's analysis: a group of that set touching the new
+// stone loses its last liberty, so the captures are known up front (a few L1 flood steps through the atari set)
+// and ONE analysis of the final position suffices.  Without it the first analysis finds the liberty-less groups and
+// a second one re-analyses (~21 % of wave passes).  atari_out = the mover's stones in atari after the move.
 template <int R>
-__device__ __forceinline__ uint32_t step_core2(uint32_t &mine, uint32_t &opp, int a, const Half &hf, uint32_t *lds) {
+__device__ __forceinline__ uint32_t step_core2(uint32_t &mine, uint32_t &opp, int a, const Half &hf, uint32_t *lds,
+                                               uint32_t atari_in, bool have_atari, uint32_t &atari_out) {
   const bool is_pass = a >= hf.P;
   int ko_r = -1, ko_c = 0;
   bool boxed = false;
+  uint32_t nbm = 0;
   {
     const int aa = is_pass ? 0 : a;
     const int ra = (int)(((uint32_t)aa * hf.inv) >> 16), ca = aa - ra * hf.N;
     const uint32_t bit = is_pass ? 0u : (1u << ca);
     if (hf.hl == ra) mine |= bit;
-    uint32_t nbm = 0;
     if (hf.hl == ra) nbm = (bit << 1) | (bit >> 1);
     if (hf.hl == ra - 1 || hf.hl == ra + 1) nbm = bit;
     nbm &= hf.full_l1;
     boxed = half_of(__ballot((nbm & ~opp) != 0), hf.h) == 0;
   }
+  // gogame.py:72-75 - remove `dead`, ko iff exactly one stone died and the new stone is boxed in
+  auto capture = [&](uint32_t dead) {
+    uint32_t dm = half_of(__ballot(dead != 0), hf.h);
+    uint32_t many = half_of(__ballot(__popc(dead) > 1), hf.h);
+    int r = dm ? (__ffs(dm) - 1) : 0;
+    uint32_t drow = __shfl(dead, (hf.lane & 32) + r);
+    if (dm && boxed && many == 0 && (dm & (dm - 1)) == 0) {
+      ko_r = r;
+      ko_c = __ffs(drow) - 1;
+    }
+    opp &= ~dead;
+  };
   uint32_t multi_opp, alive_opp, multi_mine;
+  if (have_atari) {
+    uint32_t f = nbm & atari_in;  // atari groups touching the new stone ...
+    if (__ballot(f != 0)) {
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
+      for (int it = 0; it < R * R; ++it) {  // ... completed through the atari set
+        uint32_t grow = B3(shl1(f), f >> 1, dpp0<0x138>(f), T_OR3) | dpp0<0x130>(f);
+        uint32_t g = B3(grow, atari_in, f, T_ANDOR);
+        const bool ch = g != f;
+        f = g;
+        if (__ballot(ch) == 0) break;
+      }
+      capture(f);
+    }
     uint32_t e = hf.full_l1 & ~(mine | opp);
     analyze2<R>(opp, mine, e, hf, lds, multi_opp, alive_opp, multi_mine);
-    if (pass == 0) {
-      uint32_t dead = is_pass ? 0u : (opp & ~alive_opp);
-      uint64_t dmw = __ballot(dead != 0);
-      if (dmw) {  // some board of the wave captured: fix it up, analyse both again
-        uint32_t dm = half_of(dmw, hf.h);
-        uint32_t many = half_of(__ballot(__popc(dead) > 1), hf.h);
-        int r = dm ? (__ffs(dm) - 1) : 0;
-        uint32_t drow = __shfl(dead, (hf.lane & 32) + r);
-        if (dm && boxed && many == 0 && (dm & (dm - 1)) == 0) {
-          ko_r = r;
-          ko_c = __ffs(drow) - 1;
+  } else {
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      uint32_t e = hf.full_l1 & ~(mine | opp);
+      analyze2<R>(opp, mine, e, hf, lds, multi_opp, alive_opp, multi_mine);
+      if (pass == 0) {
+        uint32_t dead = is_pass ? 0u : (opp & ~alive_opp);
+        if (__ballot(dead != 0)) {  // some board of the wave captured: fix it up, analyse both again
+          capture(dead);
+          continue;
         }
-        opp &= ~dead;
-        continue;
       }
+      break;
     }
-    break;
   }
+  atari_out = mine & ~multi_mine;
   uint32_t invalid = invalid_from2(opp, mine, multi_opp, multi_mine, hf);
   if (hf.hl == ko_r) invalid |= 1u << ko_c;
   return invalid;
@@ -1207,7 +1234,8 @@ __global__ __launch_bounds__(kWave, 4) void k_next_states2(const uint8_t *__rest
     const int pl = flags & 1u;
     uint32_t mine = pl ? white : black, opp = pl ? black : white;
     // an illegal half still runs the (wave-wide) analysis on a harmless pass, its result is discarded
-    uint32_t invalid = step_core2<R>(mine, opp, illegal ? hf.P : a, hf, lds);
+    uint32_t atari_unused;
+    uint32_t invalid = step_core2<R>(mine, opp, illegal ? hf.P : a, hf, lds, 0u, false, atari_unused);
     black = pl ? opp : mine;
     white = pl ? mine : opp;
     uint32_t passed = is_pass ? 1 : 0;
@@ -1250,6 +1278,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout2(uint8_t *__restrict__ sta
     int turn = flags & 1u, passed = (flags >> 2) & 1u, done = (flags >> 3) & 1u;
     uint64_t xa = uniform64(rng[bA]), xb = uniform64(rng[bB]);  // generator states live in SGPRs
     int last = -1, played = 0;
+    uint32_t atari = 0;   // next mover's opponents in atari, known from the previous ply of this launch
+    bool have_atari = false;
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
       const bool live = on && !(done && !auto_reset);
@@ -1258,6 +1288,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout2(uint8_t *__restrict__ sta
       if (done && live) {
         black = white = invalid = 0;
         turn = passed = done = 0;
+        atari = 0;  // empty board: nothing is in atari
       }
       uint32_t valid = hf.full_l1 & ~invalid;
       uint32_t incl = half_scan((uint32_t)__popc(valid));
@@ -1271,8 +1302,11 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout2(uint8_t *__restrict__ sta
       if ((uint32_t)(lv >> 32)) xb = xnb;
       int a = pick_action2(valid, incl, hf.h ? kb : ka, hf);
       uint32_t mine = turn ? white : black, opp = turn ? black : white;
-      uint32_t ninv = step_core2<R>(mine, opp, live ? a : hf.P, hf, lds);
+      uint32_t natari;
+      uint32_t ninv = step_core2<R>(mine, opp, live ? a : hf.P, hf, lds, atari, have_atari, natari);
+      have_atari = true;   // from now on every live half carries its atari set (frozen halves only ever pass)
       if (live) {
+        atari = natari;
         invalid = ninv;
         black = turn ? opp : mine;
         white = turn ? mine : opp;
@@ -1373,7 +1407,8 @@ __global__ __launch_bounds__(kWave, 4) void k_children2(const uint8_t *__restric
       const int a = on ? pick_action2(vr, incl, (uint32_t)k, hf) : hf.P;  // k == npts -> pass
       const bool is_pass = a == hf.P;
       uint32_t mine = pl ? white : black, opp = pl ? black : white;
-      uint32_t invalid = step_core2<R>(mine, opp, a, hf, lds);
+      uint32_t atari_unused;
+      uint32_t invalid = step_core2<R>(mine, opp, a, hf, lds, 0u, false, atari_unused);
       uint32_t nb = pl ? opp : mine, nw = pl ? mine : opp;
       uint32_t passed = is_pass ? 1 : 0;
       uint32_t done = ((flags & 8u) || (is_pass && (flags & 4u))) ? 1 : 0;
