@@ -63,7 +63,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=64)
     ap.add_argument('--size', type=int, default=19)
     ap.add_argument('--games-per-gpu', type=int, default=0, help='0 = 65536 at 1 GPU, 131072 per GPU otherwise')
-    ap.add_argument('--fuse', type=int, default=int(os.environ.get('GG_BENCH_FUSE', '16')),
+    ap.add_argument('--fuse', type=int, default=int(os.environ.get('GG_BENCH_FUSE', '64')),
                     help='plies per kernel launch')
     ap.add_argument('--burn-in', type=int, default=256, help='untimed plies before warmup (stationary board mix)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
