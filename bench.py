@@ -129,6 +129,25 @@ def main():
     played = int(steps_done.sum()) - before
     assert played == K * count, 'work was skipped inside the timed region (%d != %d)' % (played, K * count)
 
+    # Untimed extras (outside the K timed steps): the same games through the per-ply paths, rank 0 only.
+    also = {}
+    if rank == 0:
+        def rate(fn, reps):
+            fn()
+            torch.cuda.synchronize(dev)
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            for _ in range(reps):
+                fn()
+            a1.record()
+            torch.cuda.synchronize(dev)
+            return count * reps / (a0.elapsed_time(a1) * 1e-3)
+        also['rollout_1_ply_per_launch_steps_per_s'] = round(rate(lambda: gogame.batch_rollout(states, rng, 1, True), 32), 1)
+        acts = gogame.batch_sample_actions(states, rng)
+        also['gg_batch_next_states_steps_per_s'] = round(
+            rate(lambda: gogame.batch_next_states(states, acts, check=False), 16), 1)
+        also['note'] = 'same resident batch; kernel-event time of 1-ply launches / of the out-of-place step API'
+
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -170,6 +189,7 @@ def main():
         }
         if cpu is not None:
             line['cpu_baseline'] = cpu
+        line['also'] = also
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -598,6 +598,75 @@ __global__ __launch_bounds__(kWave) void k_children(const uint8_t *__restrict__ 
   }
 }
 
+// state_utils.update_pieces / batch_update_pieces (gym_go/state_utils.py:159-211) as a stand-alone entry: the stone
+// of `player` is already on the board at `point`; opponent groups touching it that have no liberty are removed IN
+// PLACE (planes 0/1 only) and reported in `killed` (0/1 per point, nullable).  point < 0 or >= N*N: nothing to do.
+template <int R>
+__global__ __launch_bounds__(kWave) void k_update_pieces(uint8_t *__restrict__ states,
+                                                         const int32_t *__restrict__ points,
+                                                         const int32_t *__restrict__ players,
+                                                         uint8_t *__restrict__ killed, int64_t B, int N, uint32_t inv) {
+  __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
+  __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
+  __shared__ __attribute__((aligned(16))) uint32_t rows5[160];
+  const int lane = threadIdx.x;
+  Geo g;
+  g.N = N; g.P = N * N; g.inv = inv;
+  g.full_l1 = lane < N ? (1u << N) - 1u : 0u;
+  const int S = 6 * g.P;
+  const LaneClass lc = make_lane_class(lane);
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    uint8_t *gs = states + b * (int64_t)S;
+    const int a = __builtin_amdgcn_readfirstlane(points[b]);
+    const int pl = __builtin_amdgcn_readfirstlane(players[b]) & 1;
+    WAVE_SYNC();
+    stage_in(gs, 2 * g.P, iobuf, lane);
+    WAVE_SYNC();
+    uint32_t black = plane_to_row<R>(iobuf, N, lane);
+    uint32_t white = plane_to_row<R>(iobuf + g.P, N, lane);
+    uint32_t mine = pl ? white : black, opp = pl ? black : white;
+    uint32_t dead = 0;
+    if (a >= 0 && a < g.P) {
+      int ra, ca;
+      split_action(a, N, inv, ra, ca);
+      const uint32_t bit = 1u << ca;
+      uint32_t nbm = 0;
+      if (lane == ra) nbm = (bit << 1) | (bit >> 1);
+      if (lane == ra - 1 || lane == ra + 1) nbm = bit;
+      nbm &= g.full_l1;
+      uint32_t multi_opp, alive_opp, multi_mine;
+      analyze<R>(opp, mine, g.full_l1 & ~(mine | opp), lc, sc, rows5, lane, multi_opp, alive_opp, multi_mine);
+      const uint32_t noair = opp & ~alive_opp;   // every opponent stone in a liberty-less group
+      dead = nbm & noair;                        // ... of which only the groups touching the stone die (:169-171)
+#pragma unroll 1
+      for (int it = 0; it < R * R; ++it) {
+        uint32_t up = __shfl_up(dead, 1), dn = __shfl_down(dead, 1);
+        if (lane == 0) up = 0;
+        uint32_t grown = dead | (((dead << 1) | (dead >> 1) | up | dn) & noair);
+        const bool ch = grown != dead;
+        dead = grown;
+        if (__ballot(ch) == 0) break;
+      }
+      opp &= ~dead;
+    }
+    if (__ballot(dead != 0)) {
+      black = pl ? opp : mine;
+      white = pl ? mine : opp;
+      WAVE_SYNC();
+      row_to_plane<R>(iobuf, black, N, lane);
+      row_to_plane<R>(iobuf + g.P, white, N, lane);
+      WAVE_SYNC();
+      stage_out(gs, 2 * g.P, iobuf, lane);
+    }
+    if (killed) {
+      WAVE_SYNC();
+      row_to_plane<R>(iobuf, dead, N, lane);
+      WAVE_SYNC();
+      stage_out(killed + b * (int64_t)g.P, g.P, iobuf, lane);
+    }
+  }
+}
+
 // wave-uniform copy of a 64-bit value (readfirstlane returns a SIGNED int: cast before widening)
 __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
   uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
@@ -1593,6 +1662,21 @@ int32_t gg_batch_sample_actions(const uint8_t *states, uint64_t *rng, int32_t *a
   GG_DISPATCH(N, (k_sample<9><<<grid, kWave, 0, s>>>(states, rng, actions, B, N)),
               (k_sample<13><<<grid, kWave, 0, s>>>(states, rng, actions, B, N)),
               (k_sample<19><<<grid, kWave, 0, s>>>(states, rng, actions, B, N)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_update_pieces(uint8_t *states, const int32_t *points, const int32_t *players, uint8_t *killed,
+                               int64_t B, int32_t N, void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (B == 0) return 0;
+  if (!states || !points || !players) return GG_E_NULLPTR;
+  const uint32_t inv = recip16(N);
+  if (!inv) return GG_E_BADSIZE;
+  hipStream_t s = (hipStream_t)hip_stream;
+  int grid = grid_for(B);
+  GG_DISPATCH(N, (k_update_pieces<9><<<grid, kWave, 0, s>>>(states, points, players, killed, B, N, inv)),
+              (k_update_pieces<13><<<grid, kWave, 0, s>>>(states, points, players, killed, B, N, inv)),
+              (k_update_pieces<19><<<grid, kWave, 0, s>>>(states, points, players, killed, B, N, inv)));
   return (int32_t)hipGetLastError();
 }
 

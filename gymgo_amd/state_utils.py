@@ -1,14 +1,14 @@
 """`state_utils`-compatible entry points (mirrors gym_go/state_utils.py:24-250).
 
 compute_invalid_moves / batch_compute_invalid_moves run the HIP liberty analysis
-(gg_batch_invalid_mask).  update_pieces / batch_update_pieces (capture resolution,
-gym_go/state_utils.py:159-211) have no stand-alone device entry: they are fused into
-gg_batch_next_states, exactly where the reference calls them (gym_go/gogame.py:68, :127-128).
+(gg_batch_invalid_mask); update_pieces / batch_update_pieces (capture resolution,
+gym_go/state_utils.py:159-211) run gg_batch_update_pieces (inside gg_batch_next_states the same
+step is fused, exactly where the reference calls it: gym_go/gogame.py:68, :127-128).
 """
 import numpy as np
 import torch
 
-from gymgo_amd import govars
+from gymgo_amd import _lib, govars
 from gymgo_amd.gogame import _Box, _invalid_mask_dev
 
 neighbor_deltas = np.array([[-1, 0], [1, 0], [0, -1], [0, 1]])  # gym_go/state_utils.py:21
@@ -74,3 +74,74 @@ def set_turn(state):
 def batch_set_turn(batch_state):
     """gym_go/state_utils.py:244-250."""
     batch_state[:, govars.TURN_CHNL] = 1 - batch_state[:, govars.TURN_CHNL]
+
+
+def _killed_groups(mask):
+    """0/1 mask [N, N] -> list of [k, 2] coordinate arrays, one per 4-connected group, groups and points in
+    raster order (the order scipy.ndimage.label / np.argwhere give the reference)."""
+    mask = np.asarray(mask).astype(bool)
+    n = mask.shape[0]
+    seen = np.zeros_like(mask)
+    groups = []
+    for r0, c0 in np.argwhere(mask):
+        if seen[r0, c0]:
+            continue
+        stack, cells = [(r0, c0)], []
+        seen[r0, c0] = True
+        while stack:
+            r, c = stack.pop()
+            cells.append((r, c))
+            for dr, dc in neighbor_deltas:
+                rr, cc = r + dr, c + dc
+                if 0 <= rr < n and 0 <= cc < n and mask[rr, cc] and not seen[rr, cc]:
+                    seen[rr, cc] = True
+                    stack.append((rr, cc))
+        groups.append(np.array(sorted(cells)))
+    return groups
+
+
+def _point_of(state_np, adj_locs, player):
+    """The just-placed stone is the one point of `player` adjacent to every location of adj_locs."""
+    n = state_np.shape[-1]
+    adj = np.asarray(adj_locs).reshape(-1, 2)
+    cand = None
+    for r, c in adj:
+        around = {(r + dr, c + dc) for dr, dc in neighbor_deltas if 0 <= r + dr < n and 0 <= c + dc < n}
+        cand = around if cand is None else cand & around
+    cand = [p for p in (cand or ()) if state_np[player, p[0], p[1]] == 1] or list(cand or ())
+    return cand[0][0] * n + cand[0][1] if cand else -1
+
+
+def batch_update_pieces(batch_non_pass, batch_state, batch_adj_locs, batch_player):
+    """gym_go/state_utils.py:183-211: removes captured opponent groups IN PLACE for the games listed in
+    batch_non_pass and returns their killed groups (list per game of [k, 2] arrays).  Each game is treated
+    with update_pieces semantics (the reference's zip mis-alignment with passes, :187-193, is not reproduced)."""
+    is_t = isinstance(batch_state, torch.Tensor)
+    host = batch_state.cpu().numpy() if is_t else np.asarray(batch_state)
+    idx = np.asarray(batch_non_pass, dtype=np.int64).reshape(-1)
+    players = np.asarray(batch_player, dtype=np.int32).reshape(-1)
+    points = np.array([_point_of(host[i], adj, int(p)) for i, adj, p in zip(idx, batch_adj_locs, players)], np.int32)
+    sub = _Box(host[idx] if not is_t else batch_state[torch.as_tensor(idx, device=batch_state.device)])
+    t = sub.t.clone()
+    B, _, N, _ = t.shape
+    killed = torch.empty((B, N, N), dtype=torch.uint8, device=t.device)
+    pts = torch.from_numpy(points).to(t.device)
+    pls = torch.from_numpy(players).to(t.device)
+    code = _lib.lib().gg_batch_update_pieces(_lib.dev_ptr(t, torch.uint8, 'states'), _lib.dev_ptr(pts, torch.int32, 'points'),
+                                             _lib.dev_ptr(pls, torch.int32, 'players'),
+                                             _lib.dev_ptr(killed, torch.uint8, 'killed'), B, N, _lib.stream_ptr(t.device))
+    _lib.check(code, 'gg_batch_update_pieces')
+    if is_t:
+        batch_state[torch.as_tensor(idx, device=batch_state.device)] = t.to(batch_state.dtype)
+    else:
+        batch_state[idx] = t.cpu().numpy().astype(batch_state.dtype)
+    return [_killed_groups(k) for k in killed.cpu().numpy()]
+
+
+def update_pieces(state, adj_locs, player):
+    """gym_go/state_utils.py:159-180: mutates `state`, returns the list of killed groups."""
+    batch = state[None] if isinstance(state, torch.Tensor) else np.asarray(state)[None]
+    out = batch_update_pieces([0], batch, [adj_locs], [player])[0]
+    if not isinstance(state, torch.Tensor):
+        state[...] = batch[0]
+    return out

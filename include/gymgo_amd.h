@@ -105,6 +105,15 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
 int32_t gg_batch_sample_actions(const uint8_t *states, uint64_t *rng, int32_t *actions, int64_t B, int32_t N,
                                 void *hip_stream);
 
+/*
+ * state_utils.update_pieces / batch_update_pieces                       gym_go/state_utils.py:159-211
+ * Stand-alone capture resolution (inside gg_batch_next_states it is fused): the stone of players[b] already
+ * stands at points[b]; opponent groups touching it that have no liberty are removed IN PLACE (planes 0/1)
+ * and marked in killed (uint8 [B][N][N], nullable).  points[b] outside [0, N*N): game b is left untouched.
+ */
+int32_t gg_batch_update_pieces(uint8_t *states, const int32_t *points, const int32_t *players, uint8_t *killed,
+                               int64_t B, int32_t N, void *hip_stream);
+
 /* rng[b] = initial generator state for (base_seed, game index first_game + b). */
 int32_t gg_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B, void *hip_stream);
 

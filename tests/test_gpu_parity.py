@@ -233,3 +233,68 @@ def test_empty_batch_and_bad_args(gg):
     assert L.gg_batch_next_states(None, None, None, None, 4, 20, 0, None) == -1
     assert L.gg_batch_areas(None, None, None, 4, 1, None) == -1
     assert L.gg_device_cus() > 0
+
+
+def test_variant1_kernels_in_subprocess(oracle):
+    """The one-wavefront-per-board family (GG_KERNEL_VARIANT=1) stays bit-exact too (the default is variant 2)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from gymgo_amd import gogame
+from oracle import c_oracle
+for N, B, plies in ((19, 257, 130), (9, 130, 90), (5, 64, 60)):
+    rng = gogame.rng_seed(B, 41); rng_np = c_oracle.rng_seed(41, B)
+    st = torch.zeros((B, 6, N, N), dtype=torch.uint8, device="cuda"); want = np.zeros((B, 6, N, N), np.uint8)
+    gogame.batch_rollout(st, rng, plies, True); want, rng_np, _ = c_oracle.batch_rollout(want, rng_np, plies, True)
+    assert np.array_equal(st.cpu().numpy(), want), ("rollout", N)
+    acts = gogame.batch_sample_actions(st, rng)
+    nxt, status = gogame.batch_next_states(st, acts, canonical=True, check=False)
+    w2, ws = c_oracle.batch_next_states(want, acts.cpu().numpy(), True)
+    assert np.array_equal(nxt.cpu().numpy(), w2) and np.array_equal(status.cpu().numpy(), ws), ("next", N)
+    assert np.array_equal(gogame.batch_children(st[:5], False).cpu().numpy(), c_oracle.batch_children(want[:5], False)), ("children", N)
+print("variant1 ok")
+'''
+    env = dict(os.environ, GG_KERNEL_VARIANT='1')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'variant1 ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_update_pieces_standalone(gg, oracle):
+    """state_utils.update_pieces / batch_update_pieces (gg_batch_update_pieces): stones after capture resolution equal
+    planes 0/1 of the oracle's next_state; killed groups are reported per group in raster order."""
+    from gymgo_amd import state_utils
+    size, B = 9, 400
+    rng = gg.rng_seed(B, 123)
+    st = torch.zeros((B, 6, size, size), dtype=torch.uint8, device='cuda')
+    gg.batch_rollout(st, rng, 70, True)
+    acts = gg.batch_sample_actions(st, rng).cpu().numpy()
+    s_np = st.cpu().numpy()
+    keep = np.flatnonzero((acts < size * size) & (s_np[:, 5, 0, 0] == 0))
+    want, _ = oracle.batch_next_states(s_np[keep], acts[keep])
+    placed = s_np[keep].copy()
+    players = placed[:, 2, 0, 0].astype(np.int32)
+    rc = np.stack([acts[keep] // size, acts[keep] % size], axis=1)
+    placed[np.arange(len(keep)), players, rc[:, 0], rc[:, 1]] = 1
+    adj = [state_utils.adj_data(placed[i], rc[i], int(players[i]))[0] for i in range(len(keep))]
+    batch = placed.astype(np.float64)          # the reference's container: float64, mutated in place
+    killed = state_utils.batch_update_pieces(np.arange(len(keep)), batch, adj, players)
+    assert np.array_equal(batch[:, :2].astype(np.uint8), want[:, :2])
+    n_capt = 0
+    for i in range(len(keep)):
+        removed = int(placed[i, 1 - players[i]].sum() - want[i, 1 - players[i]].sum())
+        assert sum(len(g) for g in killed[i]) == removed
+        n_capt += removed > 0
+    assert n_capt > 10
+    # single-state form on a device tensor, multi-group capture: the 4 black stones around (1,1) die one by one
+    s = torch.zeros((6, 5, 5), dtype=torch.uint8, device='cuda')
+    for r, c in ((0, 1), (1, 0), (1, 2), (2, 1)):
+        s[0, r, c] = 1
+    for r, c in ((0, 0), (0, 2), (2, 0), (2, 2), (1, 3), (3, 1), (0, 3), (3, 0)):
+        s[1, r, c] = 1
+    s[1, 1, 1] = 1   # white plays the centre: all four black stones have no liberty left
+    groups = state_utils.update_pieces(s, np.array([[0, 1], [2, 1], [1, 0], [1, 2]]), 1)
+    assert int(s[0].sum()) == 0 and len(groups) == 4 and all(len(g) == 1 for g in groups)
+    assert [tuple(g[0]) for g in groups] == [(0, 1), (1, 0), (1, 2), (2, 1)]
