@@ -261,39 +261,35 @@ struct __attribute__((aligned(16))) V16a { uint32_t w[4]; };
 __device__ __forceinline__ uint32_t ld32u(const uint8_t *p) { return reinterpret_cast<const W32u *>(p)->v; }
 __device__ __forceinline__ void st32u(uint8_t *p, uint32_t v) { reinterpret_cast<W32u *>(p)->v = v; }
 
-// HBM -> LDS copy of one board slice (lds is 16-byte aligned, g is not): 16 bytes per lane per pass, the
-// ragged tail as one more overlapping 16-byte vector that ends exactly at the last byte.
-__device__ __forceinline__ void stage_in(const uint8_t *g, int nbytes, uint8_t *lds, int lane) {
-  if (nbytes >= 16) {
-    const int nfull = nbytes >> 4;
-    for (int v = lane; v < nfull; v += kWave)
-    {
-      V16u t = *reinterpret_cast<const V16u *>(g + 16 * v);
-      V16a o;
-      o.w[0] = t.w[0]; o.w[1] = t.w[1]; o.w[2] = t.w[2]; o.w[3] = t.w[3];
-      *reinterpret_cast<V16a *>(lds + 16 * v) = o;
-    }
-    if ((nbytes & 15) && lane == (nfull & (kWave - 1)))
-      *reinterpret_cast<V16u *>(lds + nbytes - 16) = *reinterpret_cast<const V16u *>(g + nbytes - 16);
-  } else {
-    for (int i = lane; i < nbytes; i += kWave) lds[i] = g[i];
-  }
+// HBM -> LDS copy of one board slice with ALIGNED 16-byte loads only: the aligned superset of the slice is
+// fetched (the <= 30 extra bytes share a 16-byte chunk, hence a mapped page, with valid bytes) and the slice
+// sits at byte offset mis = g & 15 of the LDS buffer.  Returns mis.
+__device__ __forceinline__ uint32_t stage_in(const uint8_t *g, int nbytes, uint8_t *lds, int lane) {
+  const uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
+  const uint8_t *ga = g - mis;
+  const int nv = (int)(mis + nbytes + 15) >> 4;
+  for (int v = lane; v < nv; v += kWave)
+    *reinterpret_cast<V16a *>(lds + 16 * v) = *reinterpret_cast<const V16a *>(ga + 16 * v);
+  return mis;
 }
 
-// LDS -> HBM, same shape.  Only bytes of this board are written (neighbours belong to other waves).
+// LDS -> HBM (lds[mis + j] = byte j, mis = g & 15): aligned 16-byte stores for the covered vectors, ONE
+// global_store_byte instruction (lanes 0-14 head, 16-30 tail) for the ragged edges - neighbours are never touched.
 __device__ __forceinline__ void stage_out(uint8_t *g, int nbytes, const uint8_t *lds, int lane) {
-  if (nbytes >= 16) {
-    const int nfull = nbytes >> 4;
-    for (int v = lane; v < nfull; v += kWave) {
-      V16a t = *reinterpret_cast<const V16a *>(lds + 16 * v);
-      V16u o;
-      o.w[0] = t.w[0]; o.w[1] = t.w[1]; o.w[2] = t.w[2]; o.w[3] = t.w[3];
-      *reinterpret_cast<V16u *>(g + 16 * v) = o;
-    }
-    if ((nbytes & 15) && lane == (nfull & (kWave - 1)))
-      *reinterpret_cast<V16u *>(g + nbytes - 16) = *reinterpret_cast<const V16u *>(lds + nbytes - 16);
+  const uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
+  uint8_t *ga = g - mis;
+  const int end = (int)mis + nbytes;
+  const int v0 = mis ? 1 : 0, v1 = end >> 4;
+  for (int v = v0 + lane; v < v1; v += kWave)
+    *reinterpret_cast<V16a *>(ga + 16 * v) = *reinterpret_cast<const V16a *>(lds + 16 * v);
+  if (v1 >= v0) {
+    const int head = mis ? 16 - (int)mis : 0, tail = end & 15;
+    int j = -1;
+    if (lane < 16) { if (lane < head) j = lane; }
+    else if (lane < 32 && lane - 16 < tail) j = nbytes - tail + (lane - 16);
+    if (j >= 0) g[j] = lds[mis + j];
   } else {
-    for (int i = lane; i < nbytes; i += kWave) g[i] = lds[i];
+    for (int i = lane; i < nbytes; i += kWave) g[i] = lds[mis + i];
   }
 }
 
@@ -396,18 +392,15 @@ __global__ __launch_bounds__(kWave) void k_next_states(const uint8_t *__restrict
     uint32_t flags = load_flags(gi, g.P, (in_range && !is_pass) ? a : 0, lane);
     if (!in_range || (!is_pass && (flags & 2u))) {
       // gogame.py:59 / :117 would raise: row passes through unchanged, status flags it
-      WAVE_SYNC();
-      stage_in(gi, S, iobuf, lane);
-      WAVE_SYNC();
-      stage_out(go, S, iobuf, lane);
+      for (int i = lane; i < S; i += kWave) go[i] = gi[i];
       if (status && lane == 0) status[b] = GG_STATUS_ILLEGAL;
       continue;
     }
     WAVE_SYNC();
-    stage_in(gi, 2 * g.P, iobuf, lane);
+    const uint32_t mi = stage_in(gi, 2 * g.P, iobuf, lane);
     WAVE_SYNC();
-    uint32_t black = plane_to_row<R>(iobuf, N, lane);
-    uint32_t white = plane_to_row<R>(iobuf + g.P, N, lane);
+    uint32_t black = plane_to_row<R>(iobuf + mi, N, lane);
+    uint32_t white = plane_to_row<R>(iobuf + mi + g.P, N, lane);
     const int pl = flags & 1u;                       // gogame.py:44 turn
     uint32_t mine = pl ? white : black, opp = pl ? black : white;
     uint32_t invalid = step_core<R>(mine, opp, a, g, lc, sc, rows5, lane);
@@ -422,7 +415,7 @@ __global__ __launch_bounds__(kWave) void k_next_states(const uint8_t *__restrict
       nturn = 0;
     }
     pb.turn = (uint8_t)nturn;
-    emit_board<R>(iobuf, black, white, invalid, pb, g, lane);
+    emit_board<R>(iobuf + ((uintptr_t)go & 15u), black, white, invalid, pb, g, lane);
     stage_out(go, S, iobuf, lane);
     if (status && lane == 0) status[b] = GG_STATUS_OK;
   }
@@ -445,10 +438,10 @@ __global__ __launch_bounds__(kWave) void k_invalid_mask(const uint8_t *__restric
     const uint8_t *gi = states + b * (int64_t)S;
     uint32_t flags = load_flags(gi, g.P, 0, lane);
     WAVE_SYNC();
-    stage_in(gi, 2 * g.P, iobuf, lane);
+    const uint32_t mi = stage_in(gi, 2 * g.P, iobuf, lane);
     WAVE_SYNC();
-    uint32_t black = plane_to_row<R>(iobuf, N, lane);
-    uint32_t white = plane_to_row<R>(iobuf + g.P, N, lane);
+    uint32_t black = plane_to_row<R>(iobuf + mi, N, lane);
+    uint32_t white = plane_to_row<R>(iobuf + mi + g.P, N, lane);
     const int nx = flags & 1u;  // side to move
     uint32_t nxs = nx ? white : black, pls = nx ? black : white;
     uint32_t e = g.full_l1 & ~(black | white);
@@ -463,10 +456,11 @@ __global__ __launch_bounds__(kWave) void k_invalid_mask(const uint8_t *__restric
         if (lane == kr) invalid |= 1u << kc;
       }
     }
+    uint8_t *gm = mask + b * (int64_t)g.P;
     WAVE_SYNC();
-    row_to_plane<R>(iobuf, invalid, N, lane);
+    row_to_plane<R>(iobuf + ((uintptr_t)gm & 15u), invalid, N, lane);
     WAVE_SYNC();
-    stage_out(mask + b * (int64_t)g.P, g.P, iobuf, lane);
+    stage_out(gm, g.P, iobuf, lane);
   }
 }
 
@@ -484,10 +478,10 @@ __global__ __launch_bounds__(kWave) void k_areas(const uint8_t *__restrict__ sta
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     const uint8_t *gi = states + b * (int64_t)S;
     WAVE_SYNC();
-    stage_in(gi, 2 * g.P, iobuf, lane);
+    const uint32_t mi = stage_in(gi, 2 * g.P, iobuf, lane);
     WAVE_SYNC();
-    uint32_t black = plane_to_row<R>(iobuf, N, lane);
-    uint32_t white = plane_to_row<R>(iobuf + g.P, N, lane);
+    uint32_t black = plane_to_row<R>(iobuf + mi, N, lane);
+    uint32_t white = plane_to_row<R>(iobuf + mi + g.P, N, lane);
     uint32_t e = g.full_l1 & ~(black | white);
     uint32_t m[R], mrev[R], f[R], src[R];
 #pragma unroll
@@ -549,11 +543,11 @@ __global__ __launch_bounds__(kWave) void k_children(const uint8_t *__restrict__ 
     uint32_t flags = load_flags(gi, g.P, 0, lane);
     WAVE_SYNC();
     // planes 0,1 for the stones and plane 3 for slot validity (planes 0..3 are contiguous)
-    stage_in(gi, 4 * g.P, iobuf, lane);
+    const uint32_t mi = stage_in(gi, 4 * g.P, iobuf, lane);
     WAVE_SYNC();
-    uint32_t black = plane_to_row<R>(iobuf, N, lane);
-    uint32_t white = plane_to_row<R>(iobuf + g.P, N, lane);
-    uint32_t invd = plane_to_row<R>(iobuf + 3 * g.P, N, lane);
+    uint32_t black = plane_to_row<R>(iobuf + mi, N, lane);
+    uint32_t white = plane_to_row<R>(iobuf + mi + g.P, N, lane);
+    uint32_t invd = plane_to_row<R>(iobuf + mi + 3 * g.P, N, lane);
     const int pl = flags & 1u;
     const int a0 = ch * per, a1 = min(A, a0 + per);
     bool zeroed = false;
@@ -592,7 +586,7 @@ __global__ __launch_bounds__(kWave) void k_children(const uint8_t *__restrict__ 
         nturn = 0;
       }
       pb.turn = (uint8_t)nturn;
-      emit_board<R>(iobuf, nb, nw, invalid, pb, g, lane);
+      emit_board<R>(iobuf + ((uintptr_t)go & 15u), nb, nw, invalid, pb, g, lane);
       stage_out(go, S, iobuf, lane);
     }
   }
@@ -620,10 +614,10 @@ __global__ __launch_bounds__(kWave) void k_update_pieces(uint8_t *__restrict__ s
     const int a = __builtin_amdgcn_readfirstlane(points[b]);
     const int pl = __builtin_amdgcn_readfirstlane(players[b]) & 1;
     WAVE_SYNC();
-    stage_in(gs, 2 * g.P, iobuf, lane);
+    const uint32_t mi = stage_in(gs, 2 * g.P, iobuf, lane);
     WAVE_SYNC();
-    uint32_t black = plane_to_row<R>(iobuf, N, lane);
-    uint32_t white = plane_to_row<R>(iobuf + g.P, N, lane);
+    uint32_t black = plane_to_row<R>(iobuf + mi, N, lane);
+    uint32_t white = plane_to_row<R>(iobuf + mi + g.P, N, lane);
     uint32_t mine = pl ? white : black, opp = pl ? black : white;
     uint32_t dead = 0;
     if (a >= 0 && a < g.P) {
@@ -653,16 +647,17 @@ __global__ __launch_bounds__(kWave) void k_update_pieces(uint8_t *__restrict__ s
       black = pl ? opp : mine;
       white = pl ? mine : opp;
       WAVE_SYNC();
-      row_to_plane<R>(iobuf, black, N, lane);
-      row_to_plane<R>(iobuf + g.P, white, N, lane);
+      row_to_plane<R>(iobuf + mi, black, N, lane);
+      row_to_plane<R>(iobuf + mi + g.P, white, N, lane);
       WAVE_SYNC();
       stage_out(gs, 2 * g.P, iobuf, lane);
     }
     if (killed) {
+      uint8_t *gk = killed + b * (int64_t)g.P;
       WAVE_SYNC();
-      row_to_plane<R>(iobuf, dead, N, lane);
+      row_to_plane<R>(iobuf + ((uintptr_t)gk & 15u), dead, N, lane);
       WAVE_SYNC();
-      stage_out(killed + b * (int64_t)g.P, g.P, iobuf, lane);
+      stage_out(gk, g.P, iobuf, lane);
     }
   }
 }
@@ -718,11 +713,11 @@ __global__ __launch_bounds__(kWave) void k_rollout(uint8_t *__restrict__ states,
     uint8_t *gs = states + b * (int64_t)S;
     uint32_t flags = load_flags(gs, g.P, 0, lane);
     WAVE_SYNC();
-    stage_in(gs, 4 * g.P, iobuf, lane);
+    const uint32_t mi = stage_in(gs, 4 * g.P, iobuf, lane);
     WAVE_SYNC();
-    uint32_t black = plane_to_row<R>(iobuf, N, lane);
-    uint32_t white = plane_to_row<R>(iobuf + g.P, N, lane);
-    uint32_t invalid = plane_to_row<R>(iobuf + 3 * g.P, N, lane);
+    uint32_t black = plane_to_row<R>(iobuf + mi, N, lane);
+    uint32_t white = plane_to_row<R>(iobuf + mi + g.P, N, lane);
+    uint32_t invalid = plane_to_row<R>(iobuf + mi + 3 * g.P, N, lane);
     int turn = flags & 1u, passed = (flags >> 2) & 1u, done = (flags >> 3) & 1u;
     uint64_t x = uniform64(rng[b]);
     int last = -1, played = 0;
@@ -753,7 +748,7 @@ __global__ __launch_bounds__(kWave) void k_rollout(uint8_t *__restrict__ states,
     PlaneBytes pb;
     pb.turn = (uint8_t)turn; pb.passed = (uint8_t)passed; pb.done = (uint8_t)done;
     if (played) {
-      emit_board<R>(iobuf, black, white, invalid, pb, g, lane);
+      emit_board<R>(iobuf + mi, black, white, invalid, pb, g, lane);
       stage_out(gs, S, iobuf, lane);
     }
     if (lane == 0) {
@@ -777,9 +772,9 @@ __global__ __launch_bounds__(kWave) void k_sample(const uint8_t *__restrict__ st
     const uint8_t *gs = states + b * (int64_t)S;
     uint32_t flags = load_flags(gs, g.P, 0, lane);
     WAVE_SYNC();
-    stage_in(gs + 3 * g.P, g.P, iobuf, lane);
+    const uint32_t mi = stage_in(gs + 3 * g.P, g.P, iobuf, lane);
     WAVE_SYNC();
-    uint32_t invalid = plane_to_row<R>(iobuf, N, lane);
+    uint32_t invalid = plane_to_row<R>(iobuf + mi, N, lane);
     if (flags & 8u) invalid = 0;  // gogame.invalid_moves: zeros once the game ended (gogame.py:155-156)
     uint32_t valid = g.full_l1 & ~invalid;
     int cnt = __popc(valid);
