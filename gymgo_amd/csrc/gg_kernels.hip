@@ -792,6 +792,35 @@ __global__ __launch_bounds__(kWave) void k_sample(const uint8_t *__restrict__ st
   }
 }
 
+// GoVecEnv auto-reset: games whose game-over plane is set are zeroed IN PLACE (build-side policy);
+// one wave per finished board does the stores, everyone else only reads one byte.
+__global__ void k_reset_finished(uint8_t *__restrict__ states, int64_t B, int N) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / kWave;
+  const int64_t nwaves = (gridDim.x * (int64_t)blockDim.x) / kWave;
+  const int P = N * N, S = 6 * P;
+  for (int64_t b0 = wave * kWave; b0 < B; b0 += nwaves * kWave) {
+    const int64_t b = b0 + lane;
+    const bool done = b < B && states[b * (int64_t)S + 5 * P] != 0;
+    uint64_t m = __ballot(done);
+    while (m) {
+      const int l = __ffsll((unsigned long long)m) - 1;
+      m &= m - 1;
+      uint8_t *g = states + (b0 + l) * (int64_t)S;
+      const uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
+      uint8_t *ga = g - mis;
+      const int end = (int)mis + S, v0 = mis ? 1 : 0, v1 = end >> 4;
+      const V16a z = {{0u, 0u, 0u, 0u}};
+      for (int v = v0 + lane; v < v1; v += kWave) *reinterpret_cast<V16a *>(ga + 16 * v) = z;
+      const int head = mis ? 16 - (int)mis : 0, tail = end & 15;
+      int j = -1;
+      if (lane < 16) { if (lane < head) j = lane; }
+      else if (lane < 32 && lane - 16 < tail) j = S - tail + (lane - 16);
+      if (j >= 0) g[j] = 0;
+    }
+  }
+}
+
 __global__ void k_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= B) return;
@@ -1672,6 +1701,18 @@ int32_t gg_batch_update_pieces(uint8_t *states, const int32_t *points, const int
   GG_DISPATCH(N, (k_update_pieces<9><<<grid, kWave, 0, s>>>(states, points, players, killed, B, N, inv)),
               (k_update_pieces<13><<<grid, kWave, 0, s>>>(states, points, players, killed, B, N, inv)),
               (k_update_pieces<19><<<grid, kWave, 0, s>>>(states, points, players, killed, B, N, inv)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_reset_finished(uint8_t *states, int64_t B, int32_t N, void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (B == 0) return 0;
+  if (!states) return GG_E_NULLPTR;
+  hipStream_t s = (hipStream_t)hip_stream;
+  int64_t waves = (B + kWave - 1) / kWave;
+  int blocks = (int)((waves + 3) / 4);
+  if (blocks > 4096) blocks = 4096;
+  k_reset_finished<<<blocks, 4 * kWave, 0, s>>>(states, B, N);
   return (int32_t)hipGetLastError();
 }
 

@@ -45,8 +45,7 @@ class GoVecEnv:
     def step(self, actions, check=False):
         """-> (states, rewards, dones, status).  Finished games are reset first when auto_reset."""
         if self.auto_reset:
-            ended = gogame.batch_game_ended(self.states).bool()
-            self.states = torch.where(ended[:, None, None, None], torch.zeros_like(self.states), self.states)
+            gogame.batch_reset_finished(self.states)
         actions = actions.to(device=self.device, dtype=torch.int32)
         self.states, status = gogame.batch_next_states(self.states, actions, check=False)
         if check and bool((status != 0).any()):

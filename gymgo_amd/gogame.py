@@ -436,3 +436,12 @@ def batch_sample_actions(batch_states, rng):
         _lib.dev_ptr(actions, _I32, 'actions'), B, N, _lib.stream_ptr(batch_states.device))
     _lib.check(code, 'gg_batch_sample_actions')
     return actions
+
+
+def batch_reset_finished(batch_states):
+    """IN PLACE: every finished game (plane 5 set) becomes init_state (GoVecEnv auto-reset, gg_batch_reset_finished)."""
+    B, C, N, _ = batch_states.shape
+    code = _lib.lib().gg_batch_reset_finished(_lib.dev_ptr(batch_states, _U8, 'states'), B, N,
+                                              _lib.stream_ptr(batch_states.device))
+    _lib.check(code, 'gg_batch_reset_finished')
+    return batch_states

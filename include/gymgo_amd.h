@@ -114,6 +114,12 @@ int32_t gg_batch_sample_actions(const uint8_t *states, uint64_t *rng, int32_t *a
 int32_t gg_batch_update_pieces(uint8_t *states, const int32_t *points, const int32_t *players, uint8_t *killed,
                                int64_t B, int32_t N, void *hip_stream);
 
+/*
+ * Auto-reset of a batched env (build-side policy; the reference has one game per GoEnv and resets by hand,
+ * gym_go/envs/go_env.py:40-47): every game whose game-over plane is set becomes gogame.init_state (all zeros).
+ */
+int32_t gg_batch_reset_finished(uint8_t *states, int64_t B, int32_t N, void *hip_stream);
+
 /* rng[b] = initial generator state for (base_seed, game index first_game + b). */
 int32_t gg_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B, void *hip_stream);
 

@@ -45,12 +45,11 @@ def main():
 
         def api_ply():
             nonlocal st
-            ended = gogame.batch_game_ended(st).bool()
-            st = torch.where(ended[:, None, None, None], torch.zeros_like(st), st)
+            gogame.batch_reset_finished(st)
             a = gogame.batch_sample_actions(st, rng)
             st, _ = gogame.batch_next_states(st, a, check=False)
         t = timed(api_ply, 50)
-        out['vecenv_step_api_%dx%d_B%d' % (N, N, B)] = {'steps_per_s': B / t, 'note': 'reset + sample + next_states per ply'}
+        out['vecenv_step_api_%dx%d_B%d' % (N, N, B)] = {'steps_per_s': B / t, 'note': 'reset_finished + sample_actions + next_states per ply'}
         st2, _ = midgame(B, N, plies, 5)
         acts = gogame.batch_sample_actions(st2, gogame.rng_seed(B, 9))
         t = timed(lambda: gogame.batch_next_states(st2, acts, check=False), 50)
