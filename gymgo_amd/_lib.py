@@ -42,10 +42,10 @@ class GymGoNativeError(RuntimeError):
 def build(force=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     import subprocess
-    src = os.path.join(_HERE, 'csrc', 'gg_kernels.hip')
-    hdr = os.path.join(os.path.dirname(_HERE), 'include', 'gymgo_amd.h')
-    stale = (not os.path.exists(LIB_PATH) or
-             os.path.getmtime(LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    csrc = os.path.join(_HERE, 'csrc')
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(('.hip', '.h'))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), 'include', 'gymgo_amd.h'))
+    stale = not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
         subprocess.check_call(['make', '-C', os.path.join(_HERE, 'csrc'), '-s', '-B'])
     return LIB_PATH
