@@ -95,28 +95,64 @@ __device__ __forceinline__ uint32_t run_fill2(uint32_t m, uint32_t mrev, uint32_
 // {D, test, U, test}*; snake-shaped groups just take more sweeps (bounded by R*R).  Splitting the rows into two
 // interleaved chains (ILP 2) was measured too: better latency hiding, but one more sweep-equivalent on average -
 // 1.41e9 vs 1.59e9 steps/s.
+// One v_bfrev per visit instead of two: the fill state alternates its BIT ORDER.  Before a down sweep row r is
+// stored in domain (r & 1) (0 = normal, 1 = bit-reversed); a visit fills towards the MSB in the row's current
+// domain, flips the row and fills towards the MSB again (i.e. the other board direction), leaving the row in the
+// other domain - which is exactly the domain the next row (down sweep) / previous row (up sweep) is waiting in.
+// All domains are compile-time constants of the unrolled code.  The closure test works on a normal-order copy of
+// the rows (half of them need a v_bfrev); when it passes, that copy is the result.
+// REV = the row is currently bit-reversed; NB = index of the neighbour row swept just before (or -1)
+#define FLOOD_VISIT(r, NB, REV)                                                        \
+  do {                                                                                 \
+    const uint32_t ma_ = (REV) ? mrev[r] : m[r], mb_ = (REV) ? m[r] : mrev[r];         \
+    const uint32_t s_ = ((NB) >= 0 && (NB) < R) ? B3(f[(NB) >= 0 && (NB) < R ? (NB) : 0], ma_, f[r], T_ANDOR) : f[r]; \
+    const uint32_t t_ = ma_ + s_;                                                      \
+    const uint32_t u_ = B3(t_, s_, ma_, T_SEL);                                        \
+    const uint32_t v_ = __brev(u_);                                                    \
+    const uint32_t t2_ = mb_ + v_;                                                     \
+    f[r] = B3(t2_, v_, mb_, T_SEL);                                                    \
+  } while (0)
+
+// `out` = this lane's row of the L2 -> L1 transpose buffer: the converged fill is stored there in normal bit order
+// (the normal-order copy made for the closure test is the result, so it never has to stay live across sweeps).
 template <int R>
-__device__ __forceinline__ void flood2(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R]) {
+__device__ __forceinline__ void flood2(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R],
+                                       uint32_t *out) {
+#pragma unroll
+  for (int r = 1; r < R; r += 2) f[r] = __brev(f[r]);  // seeds arrive in normal order
 #pragma unroll 1
   for (int it = 0; it < R * R; ++it) {
-    f[0] = run_fill2(m[0], mrev[0], f[0]);
 #pragma unroll
-    for (int r = 1; r < R; ++r) VISIT(r, r - 1);
+    for (int r = 0; r < R; ++r) FLOOD_VISIT(r, r - 1, (r & 1) != 0);       // down: domain (r&1) -> ((r+1)&1)
     if (it > 0) {
-      uint32_t open = 0;  // a filled stone whose upper neighbour is fillable but not filled
+      // normal-order copy streamed into `out` (speculatively: it is the result if the test passes)
+      uint32_t open = 0, above = 0;  // a filled stone whose upper neighbour is fillable but not filled
 #pragma unroll
-      for (int r = 0; r < R - 1; ++r) open |= B3(f[r + 1], m[r], f[r], T_AND_ANDN);
-      if (__ballot(open != 0) == 0) break;
+      for (int r = R - 1; r >= 0; --r) {
+        const uint32_t g = ((r + 1) & 1) ? __brev(f[r]) : f[r];
+        out[r] = g;
+        if (r < R - 1) open |= B3(above, m[r], g, T_AND_ANDN);
+        above = g;
+      }
+      if (__ballot(open != 0) == 0) return;
     }
 #pragma unroll
-    for (int r = R - 2; r >= 0; --r) VISIT(r, r + 1);
+    for (int r = R - 1; r >= 0; --r) FLOOD_VISIT(r, r + 1, ((r + 1) & 1) != 0);  // up: domain ((r+1)&1) -> (r&1)
     if (it > 0) {
-      uint32_t open = 0;
+      uint32_t open = 0, below = 0;
 #pragma unroll
-      for (int r = 1; r < R; ++r) open |= B3(f[r - 1], m[r], f[r], T_AND_ANDN);
-      if (__ballot(open != 0) == 0) break;
+      for (int r = 0; r < R; ++r) {
+        const uint32_t g = (r & 1) ? __brev(f[r]) : f[r];
+        out[r] = g;
+        if (r > 0) open |= B3(below, m[r], g, T_AND_ANDN);
+        below = g;
+      }
+      if (__ballot(open != 0) == 0) return;
     }
   }
+  // iteration bound hit (cannot happen for R <= 19): rows are in domain (r & 1)
+#pragma unroll
+  for (int r = 0; r < R; ++r) out[r] = (r & 1) ? __brev(f[r]) : f[r];
 }
 
 // sum bit (a^b^c) and carry bit (majority) of a bit-sliced full adder: one v_bitop3_b32 each
@@ -199,9 +235,7 @@ __device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, c
       if (4 * i + 3 < R) mrev[4 * i + 3] = b.w;
     }
   }
-  flood2<R>(m, mrev, f);
-#pragma unroll
-  for (int r = 0; r < R; ++r) sc[hf.lane * RS + r] = f[r];
+  flood2<R>(m, mrev, f, sc + hf.lane * RS);
   WAVE_SYNC();
   multi0 = 0; multi1 = 0; alive0 = 0;
   if (hf.hl < R) {
