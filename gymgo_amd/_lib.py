@@ -10,7 +10,7 @@ import os
 import torch  # must be imported before the library so both share ONE HIP runtime (libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgymgo_amd.so')
+LIB_PATH = os.environ.get('GYMGO_AMD_LIB') or os.path.join(_HERE, 'libgymgo_amd.so')  # override: A/B experiments
 
 EXPORTS = (
     'gg_version', 'gg_device_cus', 'gg_batch_next_states', 'gg_batch_invalid_mask', 'gg_batch_areas',

@@ -87,14 +87,50 @@ __device__ __forceinline__ uint32_t run_fill2(uint32_t m, uint32_t mrev, uint32_
 }
 #define VISIT(r, nb) f[r] = run_fill2(m[r], mrev[r], B3(f[nb], m[r], f[r], T_ANDOR))
 
-// Per-lane flood to the fixed point: whole-board Gauss-Seidel sweeps in one dependency chain, alternately DOWN and
+// Per-lane flood to the fixed point, variant for the per-ply kernels (next_states, children, 1-ply rollouts),
+// which are stall-bound rather than issue-bound: two interleaved dependency chains per round for ILP (measured 15-25 % faster there than the serial
+// schedule below, which in turn is 20 % faster in the fused rollout):
+//   phase 1: chain A sweeps DOWN over the top rows [0..H], chain B sweeps UP over the bottom rows [R-1..H+1]
+//   phase 2: chain B goes on UP over the top rows [H..0], chain A goes on DOWN over the bottom rows [H+1..R-1]
+// After a round the top half is closed upwards, the bottom half downwards and the seam downwards; the test
+// looks at the 18 remaining (row, direction) pairs and only then another round is spent.
+template <int R>
+__device__ __forceinline__ void flood2_dual(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R],
+                                            uint32_t *out) {
+  constexpr int H = (R - 1) / 2;
+#pragma unroll 1
+  for (int it = 0; it < R * R; ++it) {
+    f[0] = run_fill2(m[0], mrev[0], f[0]);
+    f[R - 1] = run_fill2(m[R - 1], mrev[R - 1], f[R - 1]);
+#pragma unroll
+    for (int i = 1; i <= H; ++i) {
+      VISIT(i, i - 1);
+      if (R - 1 - i > H) VISIT(R - 1 - i, R - i);
+    }
+#pragma unroll
+    for (int i = 0; i <= H; ++i) {
+      VISIT(H - i, H - i + 1);
+      if (H + 1 + i < R) VISIT(H + 1 + i, H + i);
+    }
+    uint32_t open = 0;
+#pragma unroll
+    for (int r = 1; r <= H; ++r) open |= B3(f[r - 1], m[r], f[r], T_AND_ANDN);      // top half, downwards
+#pragma unroll
+    for (int r = H; r < R - 1; ++r) open |= B3(f[r + 1], m[r], f[r], T_AND_ANDN);   // seam + bottom half, upwards
+    if (__ballot(open != 0) == 0) break;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) out[r] = f[r];
+}
+
+
+// Flood variant for the fused rollout (issue-bound): whole-board Gauss-Seidel sweeps in one dependency chain, alternately DOWN and
 // UP.  A sweep leaves the fill closed in its own direction (and horizontally - every visit is a complete run fill),
 // so after a sweep only the opposite direction has to be tested: 18 three-input tests.  Measured on mid-game 19x19
 // boards (all 44 floods of the wave must agree): down + up is almost never enough (0.2 %), down + up + down nearly
 // always is (an arch-shaped group seeded at one foot needs exactly that), so the schedule is D, U, then
-// {D, test, U, test}*; snake-shaped groups just take more sweeps (bounded by R*R).  Splitting the rows into two
-// interleaved chains (ILP 2) was measured too: better latency hiding, but one more sweep-equivalent on average -
-// 1.41e9 vs 1.59e9 steps/s.
+// {D, test, U, test}*; snake-shaped groups just take more sweeps (bounded by R*R).  The two-chain variant above needs
+// one more sweep-equivalent on average: 1.41e9 vs 1.59e9 steps/s in the fused rollout.
 // One v_bfrev per visit instead of two: the fill state alternates its BIT ORDER.  Before a down sweep row r is
 // stored in domain (r & 1) (0 = normal, 1 = bit-reversed); a visit fills towards the MSB in the row's current
 // domain, flips the row and fills towards the MSB again (i.e. the other board direction), leaving the row in the
@@ -116,8 +152,8 @@ __device__ __forceinline__ uint32_t run_fill2(uint32_t m, uint32_t mrev, uint32_
 // `out` = this lane's row of the L2 -> L1 transpose buffer: the converged fill is stored there in normal bit order
 // (the normal-order copy made for the closure test is the result, so it never has to stay live across sweeps).
 template <int R>
-__device__ __forceinline__ void flood2(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R],
-                                       uint32_t *out) {
+__device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R],
+                                              uint32_t *out) {
 #pragma unroll
   for (int r = 1; r < R; r += 2) f[r] = __brev(f[r]);  // seeds arrive in normal order
 #pragma unroll 1
@@ -190,7 +226,7 @@ struct Lds2 {
 };
 
 // Liberty analysis of both boards of the wave (L1 in, L1 out; see analyze<R> for the single-board form).
-template <int R>
+template <int R, bool DUAL>
 __device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, const Half &hf, uint32_t *lds,
                                          uint32_t &multi0, uint32_t &alive0, uint32_t &multi1) {
   constexpr int RS = Cfg<R>::kRowStride;
@@ -235,7 +271,8 @@ __device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, c
       if (4 * i + 3 < R) mrev[4 * i + 3] = b.w;
     }
   }
-  flood2<R>(m, mrev, f, sc + hf.lane * RS);
+  if (DUAL) flood2_dual<R>(m, mrev, f, sc + hf.lane * RS);
+  else flood2_serial<R>(m, mrev, f, sc + hf.lane * RS);
   WAVE_SYNC();
   multi0 = 0; multi1 = 0; alive0 = 0;
   if (hf.hl < R) {
@@ -269,7 +306,7 @@ __device__ __forceinline__ uint32_t invalid_from2(uint32_t nx, uint32_t pl, uint
 // stone loses its last liberty, so the captures are known up front (a few L1 flood steps through the atari set)
 // and ONE analysis of the final position suffices.  Without it the first analysis finds the liberty-less groups and
 // a second one re-analyses (~21 % of wave passes).  atari_out = the mover's stones in atari after the move.
-template <int R>
+template <int R, bool DUAL>
 __device__ __forceinline__ uint32_t step_core2(uint32_t &mine, uint32_t &opp, int a, const Half &hf, uint32_t *lds,
                                                uint32_t atari_in, bool have_atari, uint32_t &atari_out) {
   const bool is_pass = a >= hf.P;
@@ -313,12 +350,12 @@ __device__ __forceinline__ uint32_t step_core2(uint32_t &mine, uint32_t &opp, in
       capture(f);
     }
     uint32_t e = hf.full_l1 & ~(mine | opp);
-    analyze2<R>(opp, mine, e, hf, lds, multi_opp, alive_opp, multi_mine);
+    analyze2<R, DUAL>(opp, mine, e, hf, lds, multi_opp, alive_opp, multi_mine);
   } else {
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
       uint32_t e = hf.full_l1 & ~(mine | opp);
-      analyze2<R>(opp, mine, e, hf, lds, multi_opp, alive_opp, multi_mine);
+      analyze2<R, DUAL>(opp, mine, e, hf, lds, multi_opp, alive_opp, multi_mine);
       if (pass == 0) {
         uint32_t dead = is_pass ? 0u : (opp & ~alive_opp);
         if (__ballot(dead != 0)) {  // some board of the wave captured: fix it up, analyse both again
@@ -538,7 +575,7 @@ __global__ __launch_bounds__(kWave, 4) void k_next_states2(const uint8_t *__rest
     uint32_t mine = pl ? white : black, opp = pl ? black : white;
     // an illegal half still runs the (wave-wide) analysis on a harmless pass, its result is discarded
     uint32_t atari_unused;
-    uint32_t invalid = step_core2<R>(mine, opp, illegal ? hf.P : a, hf, lds, 0u, false, atari_unused);
+    uint32_t invalid = step_core2<R, true>(mine, opp, illegal ? hf.P : a, hf, lds, 0u, false, atari_unused);
     black = pl ? opp : mine;
     white = pl ? mine : opp;
     uint32_t passed = is_pass ? 1 : 0;
@@ -555,7 +592,8 @@ __global__ __launch_bounds__(kWave, 4) void k_next_states2(const uint8_t *__rest
   }
 }
 
-template <int R>
+// DUAL = flood variant: true for 1-2 plies per launch (stall-bound), false for fused rollouts (issue-bound)
+template <int R, bool DUAL>
 __global__ __launch_bounds__(kWave, 4) void k_rollout2(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                     int32_t *__restrict__ last_actions,
                                                     int64_t *__restrict__ steps_done, int64_t B, int N, uint32_t inv,
@@ -606,7 +644,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout2(uint8_t *__restrict__ sta
       int a = pick_action2(valid, incl, hf.h ? kb : ka, hf);
       uint32_t mine = turn ? white : black, opp = turn ? black : white;
       uint32_t natari;
-      uint32_t ninv = step_core2<R>(mine, opp, live ? a : hf.P, hf, lds, atari, have_atari, natari);
+      uint32_t ninv = step_core2<R, DUAL>(mine, opp, live ? a : hf.P, hf, lds, atari, have_atari, natari);
       have_atari = true;   // from now on every live half carries its atari set (frozen halves only ever pass)
       if (live) {
         atari = natari;
@@ -711,7 +749,7 @@ __global__ __launch_bounds__(kWave, 4) void k_children2(const uint8_t *__restric
       const bool is_pass = a == hf.P;
       uint32_t mine = pl ? white : black, opp = pl ? black : white;
       uint32_t atari_unused;
-      uint32_t invalid = step_core2<R>(mine, opp, a, hf, lds, 0u, false, atari_unused);
+      uint32_t invalid = step_core2<R, true>(mine, opp, a, hf, lds, 0u, false, atari_unused);
       uint32_t nb = pl ? opp : mine, nw = pl ? mine : opp;
       uint32_t passed = is_pass ? 1 : 0;
       uint32_t done = ((flags & 8u) || (is_pass && (flags & 4u))) ? 1 : 0;
