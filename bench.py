@@ -68,6 +68,7 @@ def main():
     ap.add_argument('--burn-in', type=int, default=256, help='untimed plies before warmup (stationary board mix)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=32.0)
+    ap.add_argument('--no-also', action='store_true', help='skip the untimed per-ply extras (clean profiling passes)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -131,7 +132,7 @@ def main():
 
     # Untimed extras (outside the K timed steps): the same games through the per-ply paths, rank 0 only.
     also = {}
-    if rank == 0:
+    if rank == 0 and not args.no_also:
         def rate(fn, reps):
             fn()
             torch.cuda.synchronize(dev)
