@@ -216,6 +216,32 @@ int32_t gg_batch_reset_finished(uint8_t *states, int64_t B, int32_t N, void *hip
   return (int32_t)hipGetLastError();
 }
 
+int32_t gg_packed_words(int32_t N) { return (N < 2 || N > GG_MAX_BOARD) ? GG_E_BADSIZE : 3 * N + 1; }
+
+int32_t gg_batch_pack_states(const uint8_t *states, uint32_t *packed, int64_t B, int32_t N, void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (B == 0) return 0;
+  if (!states || !packed) return GG_E_NULLPTR;
+  hipStream_t s = (hipStream_t)hip_stream;
+  int grid = grid_for((B + 1) / 2);
+  GG_DISPATCH(N, (k_pack<9><<<grid, kWave, 0, s>>>(states, packed, B, N)),
+              (k_pack<13><<<grid, kWave, 0, s>>>(states, packed, B, N)),
+              (k_pack<19><<<grid, kWave, 0, s>>>(states, packed, B, N)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_unpack_states(const uint32_t *packed, uint8_t *states, int64_t B, int32_t N, void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (B == 0) return 0;
+  if (!states || !packed) return GG_E_NULLPTR;
+  hipStream_t s = (hipStream_t)hip_stream;
+  int grid = grid_for((B + 1) / 2);
+  GG_DISPATCH(N, (k_unpack<9><<<grid, kWave, 0, s>>>(packed, states, B, N)),
+              (k_unpack<13><<<grid, kWave, 0, s>>>(packed, states, B, N)),
+              (k_unpack<19><<<grid, kWave, 0, s>>>(packed, states, B, N)));
+  return (int32_t)hipGetLastError();
+}
+
 int32_t gg_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B, void *hip_stream) {
   if (B < 0) return GG_E_BADSIZE;
   if (B == 0) return 0;

@@ -767,4 +767,65 @@ __global__ __launch_bounds__(kWave, 4) void k_children2(const uint8_t *__restric
   }
 }
 
+// ---------------------------------------------------------------- bit-packed state format
+// One board = 3 N + 1 uint32: N row masks (bit c = column c) of plane 0 (black), plane 1 (white), plane 3 (invalid
+// moves), then one flag word (bit 0 turn, bit 1 previous move was a pass, bit 2 game over).  19x19: 232 B instead of
+// 2 166 B.  Both directions are pure streaming kernels (half a wave per board, the L1 row layout IS the format).
+template <int R>
+__global__ __launch_bounds__(kWave) void k_pack(const uint8_t *__restrict__ states, uint32_t *__restrict__ packed,
+                                                int64_t B, int N) {
+  __shared__ __attribute__((aligned(16))) uint8_t iobuf[2][Cfg<R>::kIoBytes];
+  const Half hf = make_half(threadIdx.x, N, 0);
+  const int S = 6 * hf.P, W = 3 * N + 1;
+  uint8_t *io = iobuf[hf.h];
+  const int64_t npairs = (B + 1) >> 1;
+  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+    const bool on = 2 * p + hf.h < B;
+    const int64_t b = on ? 2 * p + hf.h : B - 1;
+    const uint8_t *gs = states + b * (int64_t)S;
+    const uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
+    WAVE_SYNC();
+    const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
+    WAVE_SYNC();
+    const uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
+    const uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+    const uint32_t invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
+    uint32_t *gp = packed + b * (int64_t)W;
+    if (on && hf.hl < N) {
+      gp[hf.hl] = black;
+      gp[N + hf.hl] = white;
+      gp[2 * N + hf.hl] = invalid;
+    }
+    if (on && hf.hl == 31) gp[3 * N] = (flags & 1u) | ((flags >> 1) & 6u);  // flags: bit0 turn, bit2 passed, bit3 done
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(kWave) void k_unpack(const uint32_t *__restrict__ packed, uint8_t *__restrict__ states,
+                                                  int64_t B, int N) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * (Cfg<R>::kIoBytes / 4) + 16];
+  const Half hf = make_half(threadIdx.x, N, 0);
+  const int S = 6 * hf.P, W = 3 * N + 1;
+  uint32_t *tbl = lds + 2 * (Cfg<R>::kIoBytes / 4);
+  if (hf.lane < 16) tbl[hf.lane] = (hf.lane & 1u) | ((hf.lane & 2u) << 7) | ((hf.lane & 4u) << 14) | ((hf.lane & 8u) << 21);
+  WAVE_SYNC();
+  uint32_t *work = lds + hf.h * (Cfg<R>::kIoBytes / 4);
+  const int64_t npairs = (B + 1) >> 1;
+  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+    const bool on = 2 * p + hf.h < B;
+    const int64_t b = on ? 2 * p + hf.h : B - 1;
+    const uint32_t *gp = packed + b * (int64_t)W;
+    const uint32_t full = hf.full_l1;
+    uint32_t black = 0, white = 0, invalid = 0;
+    if (hf.hl < N) {
+      black = gp[hf.hl] & full;
+      white = gp[N + hf.hl] & full;
+      invalid = gp[2 * N + hf.hl] & full;
+    }
+    const uint32_t fl = gp[3 * N];
+    emit_store_h<R>(states + b * (int64_t)S, black, white, invalid, fl & 1u, (fl >> 1) & 1u, (fl >> 2) & 1u, hf, work,
+                    tbl, on);
+  }
+}
+
 }  // namespace gg

@@ -120,6 +120,16 @@ int32_t gg_batch_update_pieces(uint8_t *states, const int32_t *points, const int
  */
 int32_t gg_batch_reset_finished(uint8_t *states, int64_t B, int32_t N, void *hip_stream);
 
+/*
+ * Bit-packed state format for replay buffers / checkpoints / the wire (no reference counterpart; the reference
+ * stores 0/1 in float64, gym_go/gogame.py:22-25).  One board = gg_packed_words(N) = 3 N + 1 uint32:
+ * N row masks (bit c = column c) of plane 0, of plane 1, of plane 3, then a flag word (bit 0 turn, bit 1 previous
+ * move was a pass, bit 2 game over).  unpack(pack(s)) == s for every state whose planes 2/4/5 are uniform.
+ */
+int32_t gg_packed_words(int32_t N);
+int32_t gg_batch_pack_states(const uint8_t *states, uint32_t *packed, int64_t B, int32_t N, void *hip_stream);
+int32_t gg_batch_unpack_states(const uint32_t *packed, uint8_t *states, int64_t B, int32_t N, void *hip_stream);
+
 /* rng[b] = initial generator state for (base_seed, game index first_game + b). */
 int32_t gg_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B, void *hip_stream);
 

@@ -298,3 +298,24 @@ def test_update_pieces_standalone(gg, oracle):
     groups = state_utils.update_pieces(s, np.array([[0, 1], [2, 1], [1, 0], [1, 2]]), 1)
     assert int(s[0].sum()) == 0 and len(groups) == 4 and all(len(g) == 1 for g in groups)
     assert [tuple(g[0]) for g in groups] == [(0, 1), (1, 0), (1, 2), (2, 1)]
+
+
+@pytest.mark.parametrize('size', [2, 5, 9, 13, 19])
+def test_packed_format_roundtrip(gg, size):
+    """gg_batch_pack_states / gg_batch_unpack_states: row-mask words match a NumPy packing of the same states and
+    unpack(pack(s)) == s bit-exactly (odd batch size, mid-game + finished + empty boards)."""
+    B = 257
+    rng = gg.rng_seed(B, 31 + size)
+    st = torch.zeros((B, 6, size, size), dtype=torch.uint8, device='cuda')
+    gg.batch_rollout(st[:200], rng[:200].clone(), 2 * size * size, False)      # some of these end (frozen, DONE set)
+    gg.batch_rollout(st[200:250], rng[200:250].clone(), size * size // 2, True)
+    packed = gg.batch_pack(st)
+    assert packed.shape == (B, 3 * size + 1) and packed.dtype == torch.int32
+    s = st.cpu().numpy()
+    weights = (1 << np.arange(size)).astype(np.int64)
+    want = np.concatenate([(s[:, p].astype(np.int64) * weights).sum(axis=2) for p in (0, 1, 3)] +
+                          [(s[:, 2, 0, 0] | (s[:, 4, 0, 0] << 1) | (s[:, 5, 0, 0] << 2)).astype(np.int64)[:, None]], axis=1)
+    assert np.array_equal(packed.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, want)
+    back = gg.batch_unpack(packed, size)
+    assert torch.equal(back, st)
+    assert int(s[:, 5, 0, 0].sum()) > 0 or size > 9
