@@ -59,8 +59,8 @@ def cpu_baseline(size, cpu_seconds_total=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=512)
-    ap.add_argument('--warmup', type=int, default=64)
+    ap.add_argument('--steps', type=int, default=1024)
+    ap.add_argument('--warmup', type=int, default=128)
     ap.add_argument('--size', type=int, default=19)
     ap.add_argument('--games-per-gpu', type=int, default=0, help='0 = 65536 at 1 GPU, 131072 per GPU otherwise')
     ap.add_argument('--fuse', type=int, default=int(os.environ.get('GG_BENCH_FUSE', '64')),
@@ -105,8 +105,8 @@ def main():
     states = gogame.batch_init_state(count, N, device=dev)
     rng = gogame.rng_seed(count, 20260927, first, dev)
     steps_done = torch.zeros(count, dtype=torch.int64, device=dev)
-    if args.burn_in:
-        gogame.batch_rollout(states, rng, args.burn_in, True, None, steps_done)
+    for _ in range((args.burn_in + F - 1) // F):   # same launch shape as the timed ones (rocprof averages then agree)
+        gogame.batch_rollout(states, rng, F, True, None, steps_done)
     for _ in range(W // F):
         gogame.batch_rollout(states, rng, F, True, None, steps_done)
 

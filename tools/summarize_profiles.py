@@ -31,7 +31,7 @@ def counters(sub, want='rollout'):
             d[r['Counter_Name']] = float(r['Counter_Value'])
             d['_vgpr'], d['_sgpr'], d['_lds'] = r.get('VGPR_Count'), r.get('SGPR_Count'), r.get('LDS_Block_Size')
     ids = sorted(per)
-    return [per[i] for i in ids[1:]]   # drop the burn-in launch; the rest are F plies each
+    return [per[i] for i in ids[2:]]   # skip the first two (cold) launches; every launch is F plies
 
 
 md = ['# %s profile summary (MI355X, `bench.py --fuse %d`, %d games of %dx%d)\n' % (
@@ -42,14 +42,10 @@ md.append('## rocprofv3 --kernel-trace --stats (same command)\n')
 md.append('| kernel | calls | avg ns | total % |\n|---|---|---|---|')
 for r in stats[:4]:
     md.append('| `%s` | %s | %.0f | %s |' % (r['Name'][:70], r['Calls'], float(r['AverageNs']), r['Percentage']))
-md.append('\nbench.py live launch_ms = %.4f; the stats row above also averages in the one %d-ply burn-in launch, so '
-          'the per-launch figures of the %d-ply launches are taken from the kernel trace:'
-          % (bench['roofline']['launch_ms'], bench['config']['burn_in_plies'], F))
-kt = list(csv.DictReader(open(os.path.join(src, 'kt', 'kt_kernel_trace.csv'))))
-durs = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in kt if 'k_rollout' in r['Kernel_Name']]
-timed = sorted(durs)[:-1] if len(durs) > 1 else durs
-md.append('k_rollout launches of %d plies: n=%d, mean %.4f ms, min %.4f, max %.4f'
-          % (F, len(timed), sum(timed) / len(timed) / 1e6, min(timed) / 1e6, max(timed) / 1e6))
+roll = [r for r in stats if 'k_rollout' in r['Name']][0]
+md.append('\nbench.py live launch_ms = %.4f; rocprofv3 average of the same kernel = %.4f ms over %s launches (burn-in, '
+          'warm-up and timed launches all have the same shape: %d plies)'
+          % (bench['roofline']['launch_ms'], float(roll['AverageNs']) / 1e6, roll['Calls'], F))
 
 steps = games * F
 traffic = {}
