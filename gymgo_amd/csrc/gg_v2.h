@@ -221,8 +221,7 @@ struct Lds2 {
   static constexpr int kRegion0 = kScWords > kIoWords ? kScWords : kIoWords;
   static constexpr int kRows5 = kRegion0;                 // [2][160]
   static constexpr int kCwt = kRows5 + 2 * 160;           // [12][20]
-  static constexpr int kTbl = kCwt + (kCwClasses + 1) * 20;  // [16] 4 bits -> 4 bytes
-  static constexpr int kTotal = kTbl + 16;
+  static constexpr int kTotal = kCwt + (kCwClasses + 1) * 20;
 };
 
 // Liberty analysis of both boards of the wave (L1 in, L1 out; see analyze<R> for the single-board form).
@@ -419,14 +418,14 @@ __device__ __forceinline__ void copy_row_h(const uint8_t *src, uint8_t *dst, int
 //   1. the 6 planes are OR-ed row by row (ds_or_b32) into a linear bit-string bs[] (bit 16 + i = board byte i;
 //      the 16 leading zero bits stand for the bytes in front of the board inside its first 16-byte chunk);
 //   2. lane v of round k builds the aligned 16-byte vector 16 (hl + 32 k): 16 cells = one funnel shift out of
-//      two words of bs[], 4 cells -> 4 bytes through a 16-entry table (aligned ds_read_b32);
+//      two words of bs[], 4 cells -> 4 bytes by a 24-bit multiply;
 //   3. vectors that lie inside the board go straight from registers to HBM (global_store_dwordx4); the (at
 //      most two) ragged ones are parked in LDS and leave in ONE global_store_byte instruction.
-// `work` = the half's LDS staging area (>= 96 + 8 words), `tbl` = the bits -> bytes table.
+// `work` = the half's LDS staging area (>= 96 + 8 words).
 template <int R>
 __device__ __forceinline__ void emit_store_h(uint8_t *g, uint32_t black, uint32_t white, uint32_t invalid,
                                              uint32_t turn, uint32_t passed, uint32_t done, const Half &hf,
-                                             uint32_t *work, const uint32_t *tbl, bool wr) {
+                                             uint32_t *work, bool wr) {
   constexpr int kRounds = (Cfg<R>::kIoBytes / 16 + 31) / 32;
   uint32_t *bs = work;
   uint8_t *edge = reinterpret_cast<uint8_t *>(work + 96);  // [2][16]
@@ -458,10 +457,11 @@ __device__ __forceinline__ void emit_store_h(uint8_t *g, uint32_t black, uint32_
         const uint32_t qb = 16u + 16u * (uint32_t)v - mo, w = qb >> 5, sh = qb & 31u;
         const uint32_t b16 = __builtin_amdgcn_alignbit(bs[w + 1], bs[w], sh);
         V16a o;
-        o.w[0] = tbl[b16 & 15u];
-        o.w[1] = tbl[(b16 >> 4) & 15u];
-        o.w[2] = tbl[(b16 >> 8) & 15u];
-        o.w[3] = tbl[(b16 >> 12) & 15u];
+        // 4 cells -> 4 bytes: (bits * 0x204081) & 0x01010101 (bit i lands at bit 8 i; no colliding partial products)
+        o.w[0] = __umul24(b16 & 15u, 0x204081u) & 0x01010101u;
+        o.w[1] = __umul24((b16 >> 4) & 15u, 0x204081u) & 0x01010101u;
+        o.w[2] = __umul24((b16 >> 8) & 15u, 0x204081u) & 0x01010101u;
+        o.w[3] = __umul24((b16 >> 12) & 15u, 0x204081u) & 0x01010101u;
         const int lo = 16 * v - (int)mo;
         const bool full = lo >= 0 && lo + 16 <= S;
         if (full) *reinterpret_cast<V16a *>(ga + 16 * v) = o;   // HBM, aligned
@@ -510,8 +510,6 @@ template <int R>
 __device__ __forceinline__ void load_cw_table(uint32_t *lds, int lane) {
   uint32_t *cwt = lds + Lds2<R>::kCwt;
   for (int i = lane; i < (kCwClasses + 1) * 20; i += kWave) cwt[i] = kCw.m[i / 20][i % 20];
-  if (lane < 16)  // bits -> bytes expansion table of emit_store_h
-    lds[Lds2<R>::kTbl + lane] = (lane & 1u) | ((lane & 2u) << 7) | ((lane & 4u) << 14) | ((lane & 8u) << 21);
   WAVE_SYNC();
 }
 
@@ -586,7 +584,7 @@ __global__ __launch_bounds__(kWave, 4) void k_next_states2(const uint8_t *__rest
       nturn = 0;
     }
     emit_store_h<R>(go, black, white, invalid, (uint32_t)nturn, passed, done, hf,
-                    reinterpret_cast<uint32_t *>(io), lds + Lds2<R>::kTbl, on && !illegal);
+                    reinterpret_cast<uint32_t *>(io), on && !illegal);
     if (illegal) copy_row_h(gi, go, S, hf.hl, on);  // rare: the row passes through unchanged
     if (status && on && hf.hl == 0) status[b] = illegal ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
   }
@@ -659,7 +657,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout2(uint8_t *__restrict__ sta
     }
     if (__ballot(played != 0)) {
       emit_store_h<R>(gs, black, white, invalid, (uint32_t)turn, (uint32_t)passed, (uint32_t)done, hf,
-                      reinterpret_cast<uint32_t *>(io), lds + Lds2<R>::kTbl, on && played != 0);
+                      reinterpret_cast<uint32_t *>(io), on && played != 0);
     }
     if (on && hf.hl == 0) {
       rng[b] = hf.h ? xb : xa;
@@ -759,8 +757,7 @@ __global__ __launch_bounds__(kWave, 4) void k_children2(const uint8_t *__restric
         nturn = 0;
       }
       uint8_t *go = gc + (int64_t)a * S;
-      emit_store_h<R>(go, nb, nw, invalid, (uint32_t)nturn, passed, done, hf, reinterpret_cast<uint32_t *>(io),
-                      lds + Lds2<R>::kTbl, on);
+      emit_store_h<R>(go, nb, nw, invalid, (uint32_t)nturn, passed, done, hf, reinterpret_cast<uint32_t *>(io), on);
       for (int t = 0; t < q && az < p1; ++t, az += 2) zero_step(az);
     }
     for (; az < p1; az += 2) zero_step(az);
@@ -803,12 +800,9 @@ __global__ __launch_bounds__(kWave) void k_pack(const uint8_t *__restrict__ stat
 template <int R>
 __global__ __launch_bounds__(kWave) void k_unpack(const uint32_t *__restrict__ packed, uint8_t *__restrict__ states,
                                                   int64_t B, int N) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * (Cfg<R>::kIoBytes / 4) + 16];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * (Cfg<R>::kIoBytes / 4)];
   const Half hf = make_half(threadIdx.x, N, 0);
   const int S = 6 * hf.P, W = 3 * N + 1;
-  uint32_t *tbl = lds + 2 * (Cfg<R>::kIoBytes / 4);
-  if (hf.lane < 16) tbl[hf.lane] = (hf.lane & 1u) | ((hf.lane & 2u) << 7) | ((hf.lane & 4u) << 14) | ((hf.lane & 8u) << 21);
-  WAVE_SYNC();
   uint32_t *work = lds + hf.h * (Cfg<R>::kIoBytes / 4);
   const int64_t npairs = (B + 1) >> 1;
   for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
@@ -824,7 +818,7 @@ __global__ __launch_bounds__(kWave) void k_unpack(const uint32_t *__restrict__ p
     }
     const uint32_t fl = gp[3 * N];
     emit_store_h<R>(states + b * (int64_t)S, black, white, invalid, fl & 1u, (fl >> 1) & 1u, (fl >> 2) & 1u, hf, work,
-                    tbl, on);
+                    on);
   }
 }
 
