@@ -36,6 +36,150 @@ struct Cfg {
   static constexpr int kMaxBallots = (R + kRowsPerBallotMin - 1) / kRowsPerBallotMin;
 };
 
+// ---------------------------------------------------------------- 2-cycle op spelling + the flood fill
+// Instruction selection (tools/ubench/valu_rate2.hip, measured on MI355X): v_and/or/xor/add/sub/lshrrev/bitop3/mov
+// issue in 2 cycles per wave64; v_bfrev, v_and_or, v_or3, v_lshl_or, v_lshlrev, v_bfi, v_bcnt, v_bfe, v_mul_u32_u24,
+// v_dot4, v_readlane cost 4.  The hot loops therefore spell every 3-input boolean as v_bitop3_b32 and "<< 1" as an add.
+// v_bitop3_b32 truth tables: result bit = table[(a << 2) | (b << 1) | c] with a = 0xF0, b = 0xCC, c = 0xAA
+constexpr uint32_t TA = 0xF0, TB = 0xCC, TC = 0xAA;
+constexpr uint32_t T_ANDOR = (TA & TB) | TC;                    // (a & b) | c
+constexpr uint32_t T_SEL = (TA & TB) | (~TA & TC & 0xFF);       // a ? b : c
+constexpr uint32_t T_AND_ANDN = TA & TB & (~TC & 0xFF);         // a & b & ~c
+constexpr uint32_t T_OR3 = TA | TB | TC;
+constexpr uint32_t T_XOR3 = TA ^ TB ^ TC;
+constexpr uint32_t T_MAJ = (TA & TB) | (TC & (TA | TB));
+constexpr uint32_t T_AND_OR2 = TA & (TB | TC);                  // a & (b | c)
+constexpr uint32_t T_OR_AND = TA | (TB & TC);                   // a | (b & c)
+#define B3(a, b, c, t) __builtin_amdgcn_bitop3_b32((a), (b), (c), (t))
+
+__device__ __forceinline__ uint32_t shl1(uint32_t x) {  // x << 1 as a 2-cycle add (v_lshlrev_b32 costs 4)
+  uint32_t r;
+  asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// DPP moves (GFX9 encodings): row_shr:n = 0x110 + n, row_bcast:15 = 0x142, wave_shl:1 = 0x130, wave_shr:1 = 0x138
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
+
+// complete horizontal run fill of seeds s (subset of m), 6 ops: 2 carry fills, 2 bit reversals
+__device__ __forceinline__ uint32_t run_fill2(uint32_t m, uint32_t mrev, uint32_t s) {
+  uint32_t t = m + s;
+  uint32_t u = B3(t, s, m, T_SEL);
+  uint32_t rs = __brev(u);
+  uint32_t t2 = mrev + rs;
+  uint32_t rr = B3(t2, rs, mrev, T_SEL);
+  return __brev(rr);
+}
+#define VISIT(r, nb) f[r] = run_fill2(m[r], mrev[r], B3(f[nb], m[r], f[r], T_ANDOR))
+
+// Per-lane flood to the fixed point, variant for the per-ply kernels (next_states, children, 1-ply rollouts),
+// which are stall-bound rather than issue-bound: two interleaved dependency chains per round for ILP (measured 15-25 % faster there than the serial
+// schedule below, which in turn is 20 % faster in the fused rollout):
+//   phase 1: chain A sweeps DOWN over the top rows [0..H], chain B sweeps UP over the bottom rows [R-1..H+1]
+//   phase 2: chain B goes on UP over the top rows [H..0], chain A goes on DOWN over the bottom rows [H+1..R-1]
+// After a round the top half is closed upwards, the bottom half downwards and the seam downwards; the test
+// looks at the 18 remaining (row, direction) pairs and only then another round is spent.
+template <int R>
+__device__ __forceinline__ void flood2_dual(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R],
+                                            uint32_t *out) {
+  constexpr int H = (R - 1) / 2;
+#pragma unroll 1
+  for (int it = 0; it < R * R; ++it) {
+    f[0] = run_fill2(m[0], mrev[0], f[0]);
+    f[R - 1] = run_fill2(m[R - 1], mrev[R - 1], f[R - 1]);
+#pragma unroll
+    for (int i = 1; i <= H; ++i) {
+      VISIT(i, i - 1);
+      if (R - 1 - i > H) VISIT(R - 1 - i, R - i);
+    }
+#pragma unroll
+    for (int i = 0; i <= H; ++i) {
+      VISIT(H - i, H - i + 1);
+      if (H + 1 + i < R) VISIT(H + 1 + i, H + i);
+    }
+    uint32_t open = 0;
+#pragma unroll
+    for (int r = 1; r <= H; ++r) open |= B3(f[r - 1], m[r], f[r], T_AND_ANDN);      // top half, downwards
+#pragma unroll
+    for (int r = H; r < R - 1; ++r) open |= B3(f[r + 1], m[r], f[r], T_AND_ANDN);   // seam + bottom half, upwards
+    if (__ballot(open != 0) == 0) break;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) out[r] = f[r];
+}
+
+
+// Flood variant for the fused rollout (issue-bound): whole-board Gauss-Seidel sweeps in one dependency chain, alternately DOWN and
+// UP.  A sweep leaves the fill closed in its own direction (and horizontally - every visit is a complete run fill),
+// so after a sweep only the opposite direction has to be tested: 18 three-input tests.  Measured on mid-game 19x19
+// boards (all 44 floods of the wave must agree): down + up is almost never enough (0.2 %), down + up + down nearly
+// always is (an arch-shaped group seeded at one foot needs exactly that), so the schedule is D, U, then
+// {D, test, U, test}*; snake-shaped groups just take more sweeps (bounded by R*R).  The two-chain variant above needs
+// one more sweep-equivalent on average: 1.41e9 vs 1.59e9 steps/s in the fused rollout.
+// One v_bfrev per visit instead of two: the fill state alternates its BIT ORDER.  Before a down sweep row r is
+// stored in domain (r & 1) (0 = normal, 1 = bit-reversed); a visit fills towards the MSB in the row's current
+// domain, flips the row and fills towards the MSB again (i.e. the other board direction), leaving the row in the
+// other domain - which is exactly the domain the next row (down sweep) / previous row (up sweep) is waiting in.
+// All domains are compile-time constants of the unrolled code.  The closure test works on a normal-order copy of
+// the rows (half of them need a v_bfrev); when it passes, that copy is the result.
+// REV = the row is currently bit-reversed; NB = index of the neighbour row swept just before (or -1)
+#define FLOOD_VISIT(r, NB, REV)                                                        \
+  do {                                                                                 \
+    const uint32_t ma_ = (REV) ? mrev[r] : m[r], mb_ = (REV) ? m[r] : mrev[r];         \
+    const uint32_t s_ = ((NB) >= 0 && (NB) < R) ? B3(f[(NB) >= 0 && (NB) < R ? (NB) : 0], ma_, f[r], T_ANDOR) : f[r]; \
+    const uint32_t t_ = ma_ + s_;                                                      \
+    const uint32_t u_ = B3(t_, s_, ma_, T_SEL);                                        \
+    const uint32_t v_ = __brev(u_);                                                    \
+    const uint32_t t2_ = mb_ + v_;                                                     \
+    f[r] = B3(t2_, v_, mb_, T_SEL);                                                    \
+  } while (0)
+
+// `out` = this lane's row of the L2 -> L1 transpose buffer: the converged fill is stored there in normal bit order
+// (the normal-order copy made for the closure test is the result, so it never has to stay live across sweeps).
+template <int R>
+__device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R],
+                                              uint32_t *out) {
+#pragma unroll
+  for (int r = 1; r < R; r += 2) f[r] = __brev(f[r]);  // seeds arrive in normal order
+#pragma unroll 1
+  for (int it = 0; it < R * R; ++it) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) FLOOD_VISIT(r, r - 1, (r & 1) != 0);       // down: domain (r&1) -> ((r+1)&1)
+    if (it > 0) {
+      // normal-order copy streamed into `out` (speculatively: it is the result if the test passes)
+      uint32_t open = 0, above = 0;  // a filled stone whose upper neighbour is fillable but not filled
+#pragma unroll
+      for (int r = R - 1; r >= 0; --r) {
+        const uint32_t g = ((r + 1) & 1) ? __brev(f[r]) : f[r];
+        out[r] = g;
+        if (r < R - 1) open |= B3(above, m[r], g, T_AND_ANDN);
+        above = g;
+      }
+      if (__ballot(open != 0) == 0) return;
+    }
+#pragma unroll
+    for (int r = R - 1; r >= 0; --r) FLOOD_VISIT(r, r + 1, ((r + 1) & 1) != 0);  // up: domain ((r+1)&1) -> (r&1)
+    if (it > 0) {
+      uint32_t open = 0, below = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t g = (r & 1) ? __brev(f[r]) : f[r];
+        out[r] = g;
+        if (r > 0) open |= B3(below, m[r], g, T_AND_ANDN);
+        below = g;
+      }
+      if (__ballot(open != 0) == 0) return;
+    }
+  }
+  // iteration bound hit (cannot happen for R <= 19): rows are in domain (r & 1)
+#pragma unroll
+  for (int r = 0; r < R; ++r) out[r] = (r & 1) ? __brev(f[r]) : f[r];
+}
+
+
 // ---------------------------------------------------------------- staging: HBM <-> LDS <-> bitboards
 // Boards start at arbitrary byte offsets (6 N^2 is only a multiple of 2) and rows are N bytes long, but on gfx950
 // unaligned 4/8/16-byte LDS accesses are ~22x slower than aligned ones and unaligned 16-byte global accesses run

@@ -101,9 +101,16 @@ int32_t gg_batch_invalid_mask(const uint8_t *states, const int32_t *ko, uint8_t 
   if (!inv) return GG_E_BADSIZE;
   hipStream_t s = (hipStream_t)hip_stream;
   int grid = grid_for(B);
-  GG_DISPATCH(N, (k_invalid_mask<9><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
-              (k_invalid_mask<13><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
-              (k_invalid_mask<19><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)));
+  if (variant() == 2) {
+    grid = grid_for((B + 1) / 2);
+    GG_DISPATCH(N, (k_invalid_mask2<9><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
+                (k_invalid_mask2<13><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
+                (k_invalid_mask2<19><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)));
+  } else {
+    GG_DISPATCH(N, (k_invalid_mask<9><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
+                (k_invalid_mask<13><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
+                (k_invalid_mask<19><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)));
+  }
   return (int32_t)hipGetLastError();
 }
 
@@ -113,9 +120,16 @@ int32_t gg_batch_areas(const uint8_t *states, int32_t *black, int32_t *white, in
   if (!states || !black || !white) return GG_E_NULLPTR;
   hipStream_t s = (hipStream_t)hip_stream;
   int grid = grid_for(B);
-  GG_DISPATCH(N, (k_areas<9><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
-              (k_areas<13><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
-              (k_areas<19><<<grid, kWave, 0, s>>>(states, black, white, B, N)));
+  if (variant() == 2) {
+    grid = grid_for((B + 1) / 2);
+    GG_DISPATCH(N, (k_areas2<9><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
+                (k_areas2<13><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
+                (k_areas2<19><<<grid, kWave, 0, s>>>(states, black, white, B, N)));
+  } else {
+    GG_DISPATCH(N, (k_areas<9><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
+                (k_areas<13><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
+                (k_areas<19><<<grid, kWave, 0, s>>>(states, black, white, B, N)));
+  }
   return (int32_t)hipGetLastError();
 }
 

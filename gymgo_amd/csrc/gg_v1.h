@@ -40,44 +40,6 @@ __device__ __forceinline__ LaneClass make_lane_class(int lane) {
   return lc;
 }
 
-// Fill every maximal run of `m` that contains a bit of `s` (s subset of m), both directions.
-// Up-fill: t = m + s carries from each seed to the end of its run; (t&s)|(~t&m) keeps exactly the
-// bits from the lowest seed of a run upwards.  Down-fill = the same in the bit-reversed domain.
-__device__ __forceinline__ uint32_t run_fill(uint32_t m, uint32_t mrev, uint32_t s) {
-  uint32_t t = m + s;
-  uint32_t u = (t & s) | (~t & m);
-  uint32_t rs = __brev(u);
-  uint32_t t2 = mrev + rs;
-  uint32_t rr = (t2 & rs) | (~t2 & mrev);
-  return __brev(rr);
-}
-
-// Per-lane flood fill of `f` (seeds) through mask `m` to the fixed point.  All 64 lanes run their own
-// flood in lock-step.  A down sweep leaves f closed horizontally and downwards, an up sweep
-// horizontally and upwards; after each sweep a 2-op-per-row test asks whether any lane could still
-// grow in the opposite direction, and only then is another sweep spent.
-template <int R>
-__device__ __forceinline__ void flood(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R]) {
-  f[0] = run_fill(m[0], mrev[0], f[0]);
-#pragma unroll
-  for (int r = 1; r < R; ++r) f[r] = run_fill(m[r], mrev[r], f[r] | (f[r - 1] & m[r]));
-#pragma unroll 1
-  for (int it = 0; it < R * R; ++it) {
-#pragma unroll
-    for (int r = R - 2; r >= 0; --r) f[r] = run_fill(m[r], mrev[r], f[r] | (f[r + 1] & m[r]));
-    uint32_t open_dn = 0;  // a filled stone whose lower neighbour is fillable but not filled
-#pragma unroll
-    for (int r = 1; r < R; ++r) open_dn |= f[r - 1] & m[r] & ~f[r];
-    if (__ballot(open_dn != 0) == 0) break;
-#pragma unroll
-    for (int r = 1; r < R; ++r) f[r] = run_fill(m[r], mrev[r], f[r] | (f[r - 1] & m[r]));
-    uint32_t open_up = 0;
-#pragma unroll
-    for (int r = 0; r < R - 1; ++r) open_up |= f[r + 1] & m[r] & ~f[r];
-    if (__ballot(open_up != 0) == 0) break;
-  }
-}
-
 // Liberty analysis of the whole board (L1 in, L1 out).  c0 / c1 = stones of the two colours
 // (lane r = row r), e = empty points.  Returns for lane r < R:
 //   multi0 / multi1: stones of c0 / c1 whose group has >= 2 distinct liberties
@@ -126,9 +88,7 @@ __device__ __forceinline__ void analyze(uint32_t c0, uint32_t c1, uint32_t e, co
     uint32_t y = (ee[r] >> 1) | (r < R - 1 ? ee[r + 1] : 0u);
     f[r] = mm[r] & (x | y);  // stones touching a liberty of the class
   }
-  flood<R>(mm, mr, f);
-#pragma unroll
-  for (int r = 0; r < R; ++r) sc[lane * RS + r] = f[r];
+  flood2_dual<R>(mm, mr, f, sc + lane * RS);
   WAVE_SYNC();
   multi0 = 0; multi1 = 0; alive0 = 0;
   if (lane < R) {
@@ -342,6 +302,7 @@ template <int R>
 __global__ __launch_bounds__(kWave) void k_areas(const uint8_t *__restrict__ states, int32_t *__restrict__ black_area,
                                                  int32_t *__restrict__ white_area, int64_t B, int N) {
   __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
+  __shared__ __attribute__((aligned(16))) uint32_t sc[kWave * Cfg<R>::kRowStride];
   const int lane = threadIdx.x;
   Geo g;
   g.N = N; g.P = N * N; g.inv = 0;
@@ -370,7 +331,7 @@ __global__ __launch_bounds__(kWave) void k_areas(const uint8_t *__restrict__ sta
       if (r < R - 1) nb |= src[r + 1];
       f[r] = m[r] & nb;
     }
-    flood<R>(m, mrev, f);
+    flood2_dual<R>(m, mrev, f, sc + lane * Cfg<R>::kRowStride);  // f stays valid in registers too
     int ba = 0, wa = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {

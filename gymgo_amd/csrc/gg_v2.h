@@ -40,30 +40,6 @@ constexpr CwTable make_cw_table() {
 }
 __constant__ CwTable kCw = make_cw_table();
 
-// v_bitop3_b32 truth tables: result bit = table[(a << 2) | (b << 1) | c] with a = 0xF0, b = 0xCC, c = 0xAA
-constexpr uint32_t TA = 0xF0, TB = 0xCC, TC = 0xAA;
-constexpr uint32_t T_ANDOR = (TA & TB) | TC;                    // (a & b) | c
-constexpr uint32_t T_SEL = (TA & TB) | (~TA & TC & 0xFF);       // a ? b : c
-constexpr uint32_t T_AND_ANDN = TA & TB & (~TC & 0xFF);         // a & b & ~c
-constexpr uint32_t T_OR3 = TA | TB | TC;
-constexpr uint32_t T_XOR3 = TA ^ TB ^ TC;
-constexpr uint32_t T_MAJ = (TA & TB) | (TC & (TA | TB));
-constexpr uint32_t T_AND_OR2 = TA & (TB | TC);                  // a & (b | c)
-constexpr uint32_t T_OR_AND = TA | (TB & TC);                   // a | (b & c)
-#define B3(a, b, c, t) __builtin_amdgcn_bitop3_b32((a), (b), (c), (t))
-
-__device__ __forceinline__ uint32_t shl1(uint32_t x) {  // x << 1 as a 2-cycle add (v_lshlrev_b32 costs 4)
-  uint32_t r;
-  asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
-  return r;
-}
-
-// DPP moves (GFX9 encodings): row_shr:n = 0x110 + n, row_bcast:15 = 0x142, wave_shl:1 = 0x130, wave_shr:1 = 0x138
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ uint32_t dpp0(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
-}
-
 struct Half {
   int lane, h, hl;
   int N, P;
@@ -74,121 +50,6 @@ struct Half {
 
 __device__ __forceinline__ uint32_t half_of(uint64_t ballot, int h) {
   return h ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
-}
-
-// complete horizontal run fill of seeds s (subset of m), 6 ops: 2 carry fills, 2 bit reversals
-__device__ __forceinline__ uint32_t run_fill2(uint32_t m, uint32_t mrev, uint32_t s) {
-  uint32_t t = m + s;
-  uint32_t u = B3(t, s, m, T_SEL);
-  uint32_t rs = __brev(u);
-  uint32_t t2 = mrev + rs;
-  uint32_t rr = B3(t2, rs, mrev, T_SEL);
-  return __brev(rr);
-}
-#define VISIT(r, nb) f[r] = run_fill2(m[r], mrev[r], B3(f[nb], m[r], f[r], T_ANDOR))
-
-// Per-lane flood to the fixed point, variant for the per-ply kernels (next_states, children, 1-ply rollouts),
-// which are stall-bound rather than issue-bound: two interleaved dependency chains per round for ILP (measured 15-25 % faster there than the serial
-// schedule below, which in turn is 20 % faster in the fused rollout):
-//   phase 1: chain A sweeps DOWN over the top rows [0..H], chain B sweeps UP over the bottom rows [R-1..H+1]
-//   phase 2: chain B goes on UP over the top rows [H..0], chain A goes on DOWN over the bottom rows [H+1..R-1]
-// After a round the top half is closed upwards, the bottom half downwards and the seam downwards; the test
-// looks at the 18 remaining (row, direction) pairs and only then another round is spent.
-template <int R>
-__device__ __forceinline__ void flood2_dual(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R],
-                                            uint32_t *out) {
-  constexpr int H = (R - 1) / 2;
-#pragma unroll 1
-  for (int it = 0; it < R * R; ++it) {
-    f[0] = run_fill2(m[0], mrev[0], f[0]);
-    f[R - 1] = run_fill2(m[R - 1], mrev[R - 1], f[R - 1]);
-#pragma unroll
-    for (int i = 1; i <= H; ++i) {
-      VISIT(i, i - 1);
-      if (R - 1 - i > H) VISIT(R - 1 - i, R - i);
-    }
-#pragma unroll
-    for (int i = 0; i <= H; ++i) {
-      VISIT(H - i, H - i + 1);
-      if (H + 1 + i < R) VISIT(H + 1 + i, H + i);
-    }
-    uint32_t open = 0;
-#pragma unroll
-    for (int r = 1; r <= H; ++r) open |= B3(f[r - 1], m[r], f[r], T_AND_ANDN);      // top half, downwards
-#pragma unroll
-    for (int r = H; r < R - 1; ++r) open |= B3(f[r + 1], m[r], f[r], T_AND_ANDN);   // seam + bottom half, upwards
-    if (__ballot(open != 0) == 0) break;
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) out[r] = f[r];
-}
-
-
-// Flood variant for the fused rollout (issue-bound): whole-board Gauss-Seidel sweeps in one dependency chain, alternately DOWN and
-// UP.  A sweep leaves the fill closed in its own direction (and horizontally - every visit is a complete run fill),
-// so after a sweep only the opposite direction has to be tested: 18 three-input tests.  Measured on mid-game 19x19
-// boards (all 44 floods of the wave must agree): down + up is almost never enough (0.2 %), down + up + down nearly
-// always is (an arch-shaped group seeded at one foot needs exactly that), so the schedule is D, U, then
-// {D, test, U, test}*; snake-shaped groups just take more sweeps (bounded by R*R).  The two-chain variant above needs
-// one more sweep-equivalent on average: 1.41e9 vs 1.59e9 steps/s in the fused rollout.
-// One v_bfrev per visit instead of two: the fill state alternates its BIT ORDER.  Before a down sweep row r is
-// stored in domain (r & 1) (0 = normal, 1 = bit-reversed); a visit fills towards the MSB in the row's current
-// domain, flips the row and fills towards the MSB again (i.e. the other board direction), leaving the row in the
-// other domain - which is exactly the domain the next row (down sweep) / previous row (up sweep) is waiting in.
-// All domains are compile-time constants of the unrolled code.  The closure test works on a normal-order copy of
-// the rows (half of them need a v_bfrev); when it passes, that copy is the result.
-// REV = the row is currently bit-reversed; NB = index of the neighbour row swept just before (or -1)
-#define FLOOD_VISIT(r, NB, REV)                                                        \
-  do {                                                                                 \
-    const uint32_t ma_ = (REV) ? mrev[r] : m[r], mb_ = (REV) ? m[r] : mrev[r];         \
-    const uint32_t s_ = ((NB) >= 0 && (NB) < R) ? B3(f[(NB) >= 0 && (NB) < R ? (NB) : 0], ma_, f[r], T_ANDOR) : f[r]; \
-    const uint32_t t_ = ma_ + s_;                                                      \
-    const uint32_t u_ = B3(t_, s_, ma_, T_SEL);                                        \
-    const uint32_t v_ = __brev(u_);                                                    \
-    const uint32_t t2_ = mb_ + v_;                                                     \
-    f[r] = B3(t2_, v_, mb_, T_SEL);                                                    \
-  } while (0)
-
-// `out` = this lane's row of the L2 -> L1 transpose buffer: the converged fill is stored there in normal bit order
-// (the normal-order copy made for the closure test is the result, so it never has to stay live across sweeps).
-template <int R>
-__device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R],
-                                              uint32_t *out) {
-#pragma unroll
-  for (int r = 1; r < R; r += 2) f[r] = __brev(f[r]);  // seeds arrive in normal order
-#pragma unroll 1
-  for (int it = 0; it < R * R; ++it) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) FLOOD_VISIT(r, r - 1, (r & 1) != 0);       // down: domain (r&1) -> ((r+1)&1)
-    if (it > 0) {
-      // normal-order copy streamed into `out` (speculatively: it is the result if the test passes)
-      uint32_t open = 0, above = 0;  // a filled stone whose upper neighbour is fillable but not filled
-#pragma unroll
-      for (int r = R - 1; r >= 0; --r) {
-        const uint32_t g = ((r + 1) & 1) ? __brev(f[r]) : f[r];
-        out[r] = g;
-        if (r < R - 1) open |= B3(above, m[r], g, T_AND_ANDN);
-        above = g;
-      }
-      if (__ballot(open != 0) == 0) return;
-    }
-#pragma unroll
-    for (int r = R - 1; r >= 0; --r) FLOOD_VISIT(r, r + 1, ((r + 1) & 1) != 0);  // up: domain ((r+1)&1) -> (r&1)
-    if (it > 0) {
-      uint32_t open = 0, below = 0;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const uint32_t g = (r & 1) ? __brev(f[r]) : f[r];
-        out[r] = g;
-        if (r > 0) open |= B3(below, m[r], g, T_AND_ANDN);
-        below = g;
-      }
-      if (__ballot(open != 0) == 0) return;
-    }
-  }
-  // iteration bound hit (cannot happen for R <= 19): rows are in domain (r & 1)
-#pragma unroll
-  for (int r = 0; r < R; ++r) out[r] = (r & 1) ? __brev(f[r]) : f[r];
 }
 
 // sum bit (a^b^c) and carry bit (majority) of a bit-sliced full adder: one v_bitop3_b32 each
@@ -761,6 +622,116 @@ __global__ __launch_bounds__(kWave, 4) void k_children2(const uint8_t *__restric
       for (int t = 0; t < q && az < p1; ++t, az += 2) zero_step(az);
     }
     for (; az < p1; az += 2) zero_step(az);
+  }
+}
+
+// state_utils.batch_compute_invalid_moves (gym_go/state_utils.py:86-156), two boards per wave: plane 3 recomputed from
+// planes 0-2 (+ an optional ko point per game).
+template <int R>
+__global__ __launch_bounds__(kWave, 4) void k_invalid_mask2(const uint8_t *__restrict__ states,
+                                                            const int32_t *__restrict__ ko, uint8_t *__restrict__ mask,
+                                                            int64_t B, int N, uint32_t inv) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
+  const Half hf = make_half(threadIdx.x, N, inv);
+  load_cw_table<R>(lds, hf.lane);
+  const int S = 6 * hf.P;
+  uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
+  const int64_t npairs = (B + 1) >> 1;
+  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+    const bool on = 2 * p + hf.h < B;
+    const int64_t b = on ? 2 * p + hf.h : B - 1;
+    const uint8_t *gi = states + b * (int64_t)S;
+    const uint32_t flags = load_flags_h(gi, hf.P, 0, hf);
+    const int k = ko ? ko[b] : -1;
+    WAVE_SYNC();
+    const uint32_t mi = stage_in_h(gi, 2 * hf.P, io, hf.hl);
+    WAVE_SYNC();
+    const uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
+    const uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+    const int nx = flags & 1u;  // side to move
+    const uint32_t nxs = nx ? white : black, pls = nx ? black : white;
+    uint32_t multi_nx, alive_nx, multi_pl;
+    analyze2<R, true>(nxs, pls, hf.full_l1 & ~(black | white), hf, lds, multi_nx, alive_nx, multi_pl);
+    uint32_t invalid = invalid_from2(nxs, pls, multi_nx, multi_pl, hf);
+    if (k >= 0 && k < hf.P) {
+      const int kr = (int)(((uint32_t)k * inv) >> 16), kc = k - kr * N;
+      if (hf.hl == kr) invalid |= 1u << kc;
+    }
+    uint8_t *gm = mask + b * (int64_t)hf.P;
+    WAVE_SYNC();
+    row_to_plane<R>(io + ((uintptr_t)gm & 15u), invalid, N, hf.hl);
+    WAVE_SYNC();
+    stage_out_h(gm, hf.P, io, hf.hl, on);
+  }
+}
+
+// gogame.areas (gym_go/gogame.py:275-300), two boards per wave: in each half lane 0 floods the empty points from
+// those touching black, lane 1 from those touching white; a region reached by exactly one colour belongs to it.
+template <int R>
+__global__ __launch_bounds__(kWave) void k_areas2(const uint8_t *__restrict__ states, int32_t *__restrict__ black_area,
+                                                  int32_t *__restrict__ white_area, int64_t B, int N) {
+  constexpr int RS = Cfg<R>::kRowStride;
+  constexpr int RV = (R + 3) / 4;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
+  const Half hf = make_half(threadIdx.x, N, 0);
+  const int S = 6 * hf.P;
+  uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
+  uint32_t *sc = lds;
+  uint32_t *my5 = lds + Lds2<R>::kRows5 + hf.h * 160;
+  const int64_t npairs = (B + 1) >> 1;
+  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+    const bool on = 2 * p + hf.h < B;
+    const int64_t b = on ? 2 * p + hf.h : B - 1;
+    WAVE_SYNC();
+    const uint32_t mi = stage_in_h(states + b * (int64_t)S, 2 * hf.P, io, hf.hl);
+    WAVE_SYNC();
+    const uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
+    const uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+    const uint32_t e = hf.full_l1 & ~(black | white);
+    WAVE_SYNC();
+    my5[hf.hl] = e;
+    my5[32 + hf.hl] = __brev(e);
+    my5[64 + hf.hl] = black;
+    my5[96 + hf.hl] = white;
+    WAVE_SYNC();
+    uint32_t m[R], mrev[R], f[R];
+    {
+      uint32_t mt[RV * 4], mr[RV * 4], src[RV * 4 + 1];
+      const uint4 *pm = reinterpret_cast<const uint4 *>(my5);
+      const uint4 *pr = reinterpret_cast<const uint4 *>(my5 + 32);
+      const uint4 *ps = reinterpret_cast<const uint4 *>(my5 + (hf.hl == 1 ? 96 : 64));
+#pragma unroll
+      for (int i = 0; i < RV; ++i) {
+        uint4 a = pm[i], c = pr[i], d = ps[i];
+        mt[4 * i] = a.x; mt[4 * i + 1] = a.y; mt[4 * i + 2] = a.z; mt[4 * i + 3] = a.w;
+        mr[4 * i] = c.x; mr[4 * i + 1] = c.y; mr[4 * i + 2] = c.z; mr[4 * i + 3] = c.w;
+        src[4 * i] = d.x; src[4 * i + 1] = d.y; src[4 * i + 2] = d.z; src[4 * i + 3] = d.w;
+      }
+      src[RV * 4] = 0;
+      const uint32_t use = hf.hl < 2 ? 0xFFFFFFFFu : 0u;  // only lanes 0 / 1 of a half carry a flood
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        m[r] = mt[r];
+        mrev[r] = mr[r];
+        uint32_t x = r > 0 ? B3(shl1(src[r]), src[r] >> 1, src[r - 1], T_OR3) : (shl1(src[r]) | (src[r] >> 1));
+        f[r] = B3(m[r], x, r < R - 1 ? src[r + 1] : 0u, T_AND_OR2) & use;
+      }
+    }
+    WAVE_SYNC();
+    flood2_dual<R>(m, mrev, f, sc + hf.lane * RS);
+    WAVE_SYNC();
+    uint32_t cb = 0, cw = 0;
+    if (hf.hl < R) {
+      const uint32_t fb = sc[(hf.h * 32) * RS + hf.hl], fw = sc[(hf.h * 32 + 1) * RS + hf.hl];
+      cb = (uint32_t)__popc(black) + (uint32_t)__popc(fb & ~fw);
+      cw = (uint32_t)__popc(white) + (uint32_t)__popc(fw & ~fb);
+    }
+    cb = half_scan(cb);
+    cw = half_scan(cw);
+    if (on && hf.hl == 31) {
+      black_area[b] = (int32_t)cb;
+      white_area[b] = (int32_t)cw;
+    }
   }
 }
 
