@@ -52,7 +52,7 @@ class GoVecEnv:
             raise AssertionError('illegal move in batch')
         self.last_actions = actions
         self.steps_done += (status == 0).to(torch.int64)
-        dones = gogame.batch_game_ended(self.states)
+        dones = self.states[:, govars.DONE_CHNL, 0, 0]   # planes 2/4/5 are uniform: one byte per game
         return self.states, self.rewards(dones), dones, status
 
     def rollout(self, plies):
@@ -65,7 +65,7 @@ class GoVecEnv:
         black, white = gogame.batch_areas(self.states)
         margin = black.to(torch.float64) - white.to(torch.float64) - self.komi
         if dones is None:
-            dones = gogame.batch_game_ended(self.states)
+            dones = self.states[:, govars.DONE_CHNL, 0, 0]
         over = dones.bool()
         if self.reward_method == 'real':
             return torch.where(over, torch.sign(margin), torch.zeros_like(margin))

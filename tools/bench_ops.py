@@ -50,6 +50,12 @@ def main():
             st, _ = gogame.batch_next_states(st, a, check=False)
         t = timed(api_ply, 50)
         out['vecenv_step_api_%dx%d_B%d' % (N, N, B)] = {'steps_per_s': B / t, 'note': 'reset_finished + sample_actions + next_states per ply'}
+        from gymgo_amd.envs import GoVecEnv
+        for method in ('real', 'heuristic'):
+            env = GoVecEnv(B, N, komi=7.5, reward_method=method)
+            env.rollout(plies)
+            t = timed(lambda: env.step(env.sample_actions()), 30)
+            out['GoVecEnv_step_%s_reward_%dx%d_B%d' % (method, N, N, B)] = {'steps_per_s': B / t, 'note': 'sample + auto-reset + step + areas + rewards + dones'}
         st2, _ = midgame(B, N, plies, 5)
         acts = gogame.batch_sample_actions(st2, gogame.rng_seed(B, 9))
         t = timed(lambda: gogame.batch_next_states(st2, acts, check=False), 50)
