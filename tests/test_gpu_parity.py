@@ -319,3 +319,38 @@ def test_packed_format_roundtrip(gg, size):
     back = gg.batch_unpack(packed, size)
     assert torch.equal(back, st)
     assert int(s[:, 5, 0, 0].sum()) > 0 or size > 9
+
+
+def test_hipgraph_capture_of_per_ply_loop(gg):
+    """The C-ABI launches go to torch's current stream, so a K-ply loop of 1-ply launches plus out-of-place steps can be
+    captured into a hipGraph (torch.cuda.CUDAGraph) and replayed; the replay is bit-exact with the fused rollout."""
+    B, N, K = 1024, 9, 12
+    st = torch.zeros((B, 6, N, N), dtype=torch.uint8, device='cuda')
+    rng = gg.rng_seed(B, 77)
+    gg.batch_rollout(st, rng, 30, True)
+    ref_st, ref_rng = st.clone(), rng.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        gg.batch_rollout(st, rng, 1, True)
+        acts = gg.batch_sample_actions(st, rng)
+        nxt, status = gg.batch_next_states(st, acts, check=False)
+    torch.cuda.current_stream().wait_stream(side)
+    st.copy_(ref_st); rng.copy_(ref_rng)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(K):
+            gg.batch_rollout(st, rng, 1, True)
+        acts = gg.batch_sample_actions(st, rng)
+        nxt, status = gg.batch_next_states(st, acts, check=False)
+    for _ in range(2):   # replay twice from the same start: identical results
+        st.copy_(ref_st); rng.copy_(ref_rng)
+        graph.replay()
+        torch.cuda.synchronize()
+        want, wr = ref_st.clone(), ref_rng.clone()
+        gg.batch_rollout(want, wr, K, True)
+        assert torch.equal(st, want)
+        wa = gg.batch_sample_actions(want, wr)
+        assert torch.equal(acts, wa) and torch.equal(rng, wr)
+        wn, ws = gg.batch_next_states(want, wa, check=False)
+        assert torch.equal(nxt, wn) and int(status.sum()) == 0
