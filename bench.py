@@ -168,6 +168,9 @@ def main():
                     traffic = rec.get('bytes_per_launch')
             except Exception:
                 traffic = None
+        rcap = 9 if N <= 9 else 13 if N <= 13 else 19
+        kernel_name = ('k_rollout<%d>' % rcap if os.environ.get('GG_KERNEL_VARIANT') == '1'
+                       else 'k_rollout2<%d, %s>' % (rcap, 'true' if F <= 2 else 'false'))
         line = {
             'metric': 'env steps/sec across batched games, 19x19 uniform-random rollouts',
             'value': round(value, 1), 'unit': 'env steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
@@ -180,8 +183,7 @@ def main():
                 'burn_in_plies': args.burn_in, 'sharding': 'batch split across ranks, no collective',
             },
             'roofline': {
-                'bound': 'hbm', 'kernel': 'k_rollout%s<%d>' % ('' if os.environ.get('GG_KERNEL_VARIANT') == '1' else '2',
-                                                             9 if N <= 9 else 13 if N <= 13 else 19),
+                'bound': 'hbm', 'kernel': kernel_name,
                 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                 'algorithmic_bytes_per_step': algo, 'steps_per_launch': count * F,
