@@ -66,6 +66,7 @@ def main():
     ap.add_argument('--fuse', type=int, default=int(os.environ.get('GG_BENCH_FUSE', '64')),
                     help='plies per kernel launch')
     ap.add_argument('--burn-in', type=int, default=256, help='untimed plies before warmup (stationary board mix)')
+    ap.add_argument('--desync', type=int, default=640, help='spread of extra burn-in plies across the batch (0 = lock-step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=32.0)
     ap.add_argument('--no-also', action='store_true', help='skip the untimed per-ply extras (clean profiling passes)')
@@ -105,6 +106,15 @@ def main():
     states = gogame.batch_init_state(count, N, device=dev)
     rng = gogame.rng_seed(count, 20260927, first, dev)
     steps_done = torch.zeros(count, dtype=torch.int64, device=dev)
+    # De-synchronise the games first: slice g of 16 plays g * desync/16 extra plies, so that the batch holds every
+    # game phase at once (stationary mix: mean game length of uniform-random 19x19 play is ~640 plies) and the
+    # timed window does not depend on where a lock-step batch happens to be.  Untimed, and not counted in steps_done.
+    if args.desync:
+        chunk = (count + 15) // 16
+        for gslice in range(1, 16):
+            lo, hi = gslice * chunk, min(count, (gslice + 1) * chunk)
+            if lo < hi:
+                gogame.batch_rollout(states[lo:hi], rng[lo:hi], gslice * args.desync // 16, True)
     for _ in range((args.burn_in + F - 1) // F):   # same launch shape as the timed ones (rocprof averages then agree)
         gogame.batch_rollout(states, rng, F, True, None, steps_done)
     for _ in range(W // F):
@@ -180,7 +190,7 @@ def main():
                 'workload': '%dx%d, %d parallel games%s, uniform-random rollouts with auto-reset, %d plies per launch'
                             % (N, N, total_games, '' if world == 1 else ' (%d per GPU)' % per_gpu, F),
                 'board': N, 'games': total_games, 'games_per_gpu': per_gpu, 'plies_per_launch': F,
-                'burn_in_plies': args.burn_in, 'sharding': 'batch split across ranks, no collective',
+                'burn_in_plies': args.burn_in, 'desync_plies': args.desync, 'sharding': 'batch split across ranks, no collective',
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': kernel_name,
