@@ -399,7 +399,7 @@ __device__ __forceinline__ int pick_action2(uint32_t valid, uint32_t incl, uint3
 }
 
 template <int R>
-__global__ __launch_bounds__(kWave, 4) void k_next_states2(const uint8_t *__restrict__ in,
+__global__ __launch_bounds__(kWave, 3) void k_next_states2(const uint8_t *__restrict__ in,
                                                         const int32_t *__restrict__ actions,
                                                         uint8_t *__restrict__ out, int32_t *__restrict__ status,
                                                         int64_t B, int N, uint32_t inv, int canonical) {
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(kWave, 4) void k_next_states2(const uint8_t *__rest
     uint32_t mine = pl ? white : black, opp = pl ? black : white;
     // an illegal half still runs the (wave-wide) analysis on a harmless pass, its result is discarded
     uint32_t atari_unused;
-    uint32_t invalid = step_core2<R, true>(mine, opp, illegal ? hf.P : a, hf, lds, 0u, false, atari_unused);
+    uint32_t invalid = step_core2<R, false>(mine, opp, illegal ? hf.P : a, hf, lds, 0u, false, atari_unused);
     black = pl ? opp : mine;
     white = pl ? mine : opp;
     uint32_t passed = is_pass ? 1 : 0;
