@@ -451,9 +451,10 @@ __global__ __launch_bounds__(kWave, 3) void k_next_states2(const uint8_t *__rest
   }
 }
 
-// DUAL = flood variant: true for 1-2 plies per launch (stall-bound), false for fused rollouts (issue-bound)
-template <int R, bool DUAL>
-__global__ __launch_bounds__(kWave, 4) void k_rollout2(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+// PERPLY = instantiation for 1-2 plies per launch: the board I/O dominates there and the kernel runs best spill-free
+// at 3 waves per SIMD; the fused instantiation keeps its hot ply loop spill-free at 4 waves per SIMD.
+template <int R, bool PERPLY>
+__global__ __launch_bounds__(kWave, PERPLY ? 3 : 4) void k_rollout2(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                     int32_t *__restrict__ last_actions,
                                                     int64_t *__restrict__ steps_done, int64_t B, int N, uint32_t inv,
                                                     int plies, int auto_reset) {
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout2(uint8_t *__restrict__ sta
       int a = pick_action2(valid, incl, hf.h ? kb : ka, hf);
       uint32_t mine = turn ? white : black, opp = turn ? black : white;
       uint32_t natari;
-      uint32_t ninv = step_core2<R, DUAL>(mine, opp, live ? a : hf.P, hf, lds, atari, have_atari, natari);
+      uint32_t ninv = step_core2<R, false>(mine, opp, live ? a : hf.P, hf, lds, atari, have_atari, natari);
       have_atari = true;   // from now on every live half carries its atari set (frozen halves only ever pass)
       if (live) {
         atari = natari;
