@@ -16,10 +16,7 @@ namespace gg {
 // none by 0: a bit-sliced population count over the 11 floods (carry-save adders, ~20 L1 ops) classifies
 // every stone of the board at once.
 //
-// Instruction selection (tools/ubench/valu_rate2.hip, measured on MI355X): v_and/or/xor/add/sub/lshrrev/
-// bitop3/mov issue in 2 cycles per wave64; v_bfrev, v_and_or, v_or3, v_lshl_or, v_lshlrev, v_bfi, v_bcnt,
-// v_bfe, v_mul_u32_u24, v_dot4, v_readlane cost 4.  The hot loops below therefore spell every 3-input
-// boolean as v_bitop3_b32 and every "<< 1" as an add.
+// The flood variants, the 2-cycle op spelling (bitop3 / add-for-shift) and the staging helpers are in gg_common.h.
 constexpr int kCwClasses = 11, kCwWeight = 5, kCwLanes = 2 * kCwClasses;
 
 struct CwTable { uint32_t m[kCwClasses + 1][20]; };  // [class][row] -> columns of the class; last row = zeros
