@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('GYMGO_AMD_LIB') or os.path.join(_HERE, 'libgymgo_amd.
 
 EXPORTS = (
     'gg_version', 'gg_device_cus', 'gg_batch_next_states', 'gg_batch_invalid_mask', 'gg_batch_areas',
-    'gg_batch_children', 'gg_batch_rollout', 'gg_batch_sample_actions', 'gg_batch_update_pieces', 'gg_batch_reset_finished', 'gg_packed_words', 'gg_batch_pack_states',
+    'gg_batch_children', 'gg_batch_rollout', 'gg_batch_env_step', 'gg_batch_sample_actions', 'gg_batch_update_pieces', 'gg_batch_reset_finished', 'gg_packed_words', 'gg_batch_pack_states',
     'gg_batch_unpack_states', 'gg_rng_seed',
 )
 
@@ -27,6 +27,7 @@ _SIGNATURES = {
     'gg_batch_areas': ([_vp, _vp, _vp, _i64, _i32, _vp], _i32),
     'gg_batch_children': ([_vp, _vp, _i64, _i32, _i32, _vp], _i32),
     'gg_batch_rollout': ([_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
+    'gg_batch_env_step': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_float, _i32, _i32, _vp], _i32),
     'gg_batch_sample_actions': ([_vp, _vp, _vp, _i64, _i32, _vp], _i32),
     'gg_batch_update_pieces': ([_vp, _vp, _vp, _vp, _i64, _i32, _vp], _i32),
     'gg_batch_reset_finished': ([_vp, _i64, _i32, _vp], _i32),

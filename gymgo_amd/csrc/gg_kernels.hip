@@ -45,6 +45,22 @@ int grid_for(int64_t work) {
   return (int)(work < cap ? (work > 0 ? work : 1) : cap);
 }
 
+// pipelined kernels: exactly the resident set (waves per SIMD x 4 SIMDs x CUs), so that each workgroup runs many
+// iterations and pays the un-overlapped first load / last store once
+int grid_resident(int64_t work, int waves_per_simd) {
+  int cus = device_cus();
+  if (cus <= 0) cus = 256;
+  int64_t cap = (int64_t)cus * 4 * waves_per_simd;
+  return (int)(work < cap ? (work > 0 ? work : 1) : cap);
+}
+
+// GG_SYNC_IO=1 selects the non-pipelined (load, analyse, store) per-ply kernels - A/B measurements only
+bool sync_io() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("GG_SYNC_IO"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
 int32_t check(int64_t B, int32_t N) { return (N < 2 || N > GG_MAX_BOARD || B < 0) ? GG_E_BADSIZE : 0; }
 
 // reciprocal for the in-kernel action -> (row, col) split; exactness is verified for every action
@@ -80,10 +96,17 @@ int32_t gg_batch_next_states(const uint8_t *in, const int32_t *actions, uint8_t 
   hipStream_t s = (hipStream_t)hip_stream;
   int grid = grid_for(B);
   if (variant() == 2) {
-    grid = grid_for((B + 1) / 2);
-    GG_DISPATCH(N, (k_next_states2<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
-                (k_next_states2<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
-                (k_next_states2<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
+    if (sync_io()) {
+      grid = grid_for((B + 1) / 2);
+      GG_DISPATCH(N, (k_next_states2s<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+                  (k_next_states2s<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+                  (k_next_states2s<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
+    } else {
+      grid = grid_resident((B + 1) / 2, GG_LB_PLY);
+      GG_DISPATCH(N, (k_next_states2<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+                  (k_next_states2<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+                  (k_next_states2<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
+    }
   } else {
     GG_DISPATCH(N, (k_next_states<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
                 (k_next_states<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
@@ -187,6 +210,24 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
                 (k_rollout<13><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
                 (k_rollout<19><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)));
   }
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_env_step(uint8_t *states, const int32_t *actions, uint64_t *rng, float *rewards, uint8_t *dones,
+                          int32_t *status, int32_t *taken_actions, int64_t B, int32_t N, float komi,
+                          int32_t reward_method, int32_t auto_reset, void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (reward_method != GG_REWARD_REAL && reward_method != GG_REWARD_HEURISTIC) return GG_E_BADARG;
+  if (B == 0) return 0;
+  if (!states || (!actions && !rng)) return GG_E_NULLPTR;
+  const uint32_t inv = recip16(N);
+  if (!inv) return GG_E_BADSIZE;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int grid = grid_for((B + 1) / 2);
+  const int heur = reward_method == GG_REWARD_HEURISTIC;
+  GG_DISPATCH(N, (k_env_step2<9><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, heur, auto_reset)),
+              (k_env_step2<13><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, heur, auto_reset)),
+              (k_env_step2<19><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, heur, auto_reset)));
   return (int32_t)hipGetLastError();
 }
 

@@ -37,13 +37,21 @@ constexpr CwTable make_cw_table() {
 }
 __constant__ CwTable kCw = make_cw_table();
 
+#ifndef GG_LB_PLY
+#define GG_LB_PLY 3   // waves per SIMD the per-ply kernels are compiled for
+#endif
+
 struct Half {
   int lane, h, hl;
   int N, P;
   uint32_t inv, full_l1;
-  int cls;       // flood class of this lane (kCwClasses = idle lane)
-  bool second;   // lane floods the second colour
+  int cls;       // row of the class-mask table: 0..10 liberty class, 11 = all zeros (idle lane), 12 = all ones
+  // word offsets of this lane's flood inputs inside its half's 6-plane row buffer (planes of 32 words:
+  // 0 c0, 1 c1, 2 c0 reversed, 3 c1 reversed, 4 empties, 5 empties reversed)
+  int m_off, r_off, s_off;
 };
+
+constexpr int kRowPlanes = 6, kRowBuf = kRowPlanes * 32;
 
 __device__ __forceinline__ uint32_t half_of(uint64_t ballot, int h) {
   return h ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
@@ -77,19 +85,21 @@ struct Lds2 {
   static constexpr int kScWords = kWave * Cfg<R>::kRowStride;
   static constexpr int kIoWords = 2 * Cfg<R>::kIoBytes / 4;
   static constexpr int kRegion0 = kScWords > kIoWords ? kScWords : kIoWords;
-  static constexpr int kRows5 = kRegion0;                 // [2][160]
-  static constexpr int kCwt = kRows5 + 2 * 160;           // [12][20]
-  static constexpr int kTotal = kCwt + (kCwClasses + 1) * 20;
+  static constexpr int kRows5 = kRegion0;                 // [2][kRowBuf]
+  static constexpr int kCwt = kRows5 + 2 * kRowBuf;       // [13][20]: 11 classes, zeros, ones
+  static constexpr int kTotal = kCwt + (kCwClasses + 2) * 20;
 };
 
 // Liberty analysis of both boards of the wave (L1 in, L1 out; see analyze<R> for the single-board form).
-template <int R, bool DUAL>
+// AREAS: also return reach0 / reach1 = the empty points connected (through empty points) to a neighbour of a c0 / c1
+// stone (needs make_half(..., areas = true)).
+template <int R, bool DUAL, bool AREAS = false>
 __device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, const Half &hf, uint32_t *lds,
-                                         uint32_t &multi0, uint32_t &alive0, uint32_t &multi1) {
+                                         uint32_t &multi0, uint32_t &alive0, uint32_t &multi1, uint32_t *reach = nullptr) {
   constexpr int RS = Cfg<R>::kRowStride;
   constexpr int RV = (R + 3) / 4;
   uint32_t *sc = lds;
-  uint32_t *my5 = lds + Lds2<R>::kRows5 + hf.h * 160;
+  uint32_t *my5 = lds + Lds2<R>::kRows5 + hf.h * kRowBuf;
   const uint32_t *cwt = lds + Lds2<R>::kCwt;
   WAVE_SYNC();
   my5[hf.hl] = c0;
@@ -97,12 +107,13 @@ __device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, c
   my5[64 + hf.hl] = __brev(c0);
   my5[96 + hf.hl] = __brev(c1);
   my5[128 + hf.hl] = e;
+  if (AREAS) my5[160 + hf.hl] = __brev(e);
   WAVE_SYNC();
   uint32_t m[R], mrev[R], f[R];
   {
     uint32_t ee[RV * 4 + 1], mt[RV * 4];
-    const uint4 *pm = reinterpret_cast<const uint4 *>(my5 + (hf.second ? 32 : 0));
-    const uint4 *pe = reinterpret_cast<const uint4 *>(my5 + 128);
+    const uint4 *pm = reinterpret_cast<const uint4 *>(my5 + hf.m_off);
+    const uint4 *pe = reinterpret_cast<const uint4 *>(my5 + hf.s_off);
     const uint4 *pc = reinterpret_cast<const uint4 *>(cwt + hf.cls * 20);
 #pragma unroll
     for (int i = 0; i < RV; ++i) {
@@ -114,11 +125,11 @@ __device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, c
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       m[r] = mt[r];
-      // stones touching a liberty of the class: m & ((e << 1) | (e >> 1) | e_above | e_below)
+      // points of the flood mask touching a seed source of the lane: m & ((s << 1) | (s >> 1) | s_above | s_below)
       uint32_t x = r > 0 ? B3(shl1(ee[r]), ee[r] >> 1, ee[r - 1], T_OR3) : (shl1(ee[r]) | (ee[r] >> 1));
       f[r] = B3(m[r], x, r < R - 1 ? ee[r + 1] : 0u, T_AND_OR2);
     }
-    const uint4 *pr = reinterpret_cast<const uint4 *>(my5 + 64 + (hf.second ? 32 : 0));
+    const uint4 *pr = reinterpret_cast<const uint4 *>(my5 + hf.r_off);
 #pragma unroll
     for (int i = 0; i < RV; ++i) {
       uint4 b = pr[i];
@@ -132,6 +143,7 @@ __device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, c
   else flood2_serial<R>(m, mrev, f, sc + hf.lane * RS);
   WAVE_SYNC();
   multi0 = 0; multi1 = 0; alive0 = 0;
+  if (AREAS) { reach[0] = 0; reach[1] = 0; }
   if (hf.hl < R) {
     const uint32_t *base = sc + (hf.h * 32) * RS + hf.hl;
     uint32_t w0[kCwClasses], w1[kCwClasses];
@@ -143,6 +155,10 @@ __device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, c
     uint32_t alive1;
     classify11(w0, alive0, multi0);
     classify11(w1, alive1, multi1);
+    if (AREAS) {
+      reach[0] = base[kCwLanes * RS];
+      reach[1] = base[(kCwLanes + 1) * RS];
+    }
   }
 }
 
@@ -163,9 +179,10 @@ __device__ __forceinline__ uint32_t invalid_from2(uint32_t nx, uint32_t pl, uint
 // stone loses its last liberty, so the captures are known up front (a few L1 flood steps through the atari set)
 // and ONE analysis of the final position suffices.  Without it the first analysis finds the liberty-less groups and
 // a second one re-analyses (~21 % of wave passes).  atari_out = the mover's stones in atari after the move.
-template <int R, bool DUAL>
+template <int R, bool DUAL, bool AREAS = false>
 __device__ __forceinline__ uint32_t step_core2(uint32_t &mine, uint32_t &opp, int a, const Half &hf, uint32_t *lds,
-                                               uint32_t atari_in, bool have_atari, uint32_t &atari_out) {
+                                               uint32_t atari_in, bool have_atari, uint32_t &atari_out,
+                                               uint32_t *reach = nullptr) {
   const bool is_pass = a >= hf.P;
   int ko_r = -1, ko_c = 0;
   bool boxed = false;
@@ -207,12 +224,12 @@ __device__ __forceinline__ uint32_t step_core2(uint32_t &mine, uint32_t &opp, in
       capture(f);
     }
     uint32_t e = hf.full_l1 & ~(mine | opp);
-    analyze2<R, DUAL>(opp, mine, e, hf, lds, multi_opp, alive_opp, multi_mine);
+    analyze2<R, DUAL, AREAS>(opp, mine, e, hf, lds, multi_opp, alive_opp, multi_mine, reach);
   } else {
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
       uint32_t e = hf.full_l1 & ~(mine | opp);
-      analyze2<R, DUAL>(opp, mine, e, hf, lds, multi_opp, alive_opp, multi_mine);
+      analyze2<R, DUAL, AREAS>(opp, mine, e, hf, lds, multi_opp, alive_opp, multi_mine, reach);
       if (pass == 0) {
         uint32_t dead = is_pass ? 0u : (opp & ~alive_opp);
         if (__ballot(dead != 0)) {  // some board of the wave captured: fix it up, analyse both again
@@ -272,75 +289,75 @@ __device__ __forceinline__ void copy_row_h(const uint8_t *src, uint8_t *dst, int
   for (int i = hl; i < nbytes; i += 32) dst[i] = src[i];
 }
 
+// 8 cells (bits) -> 8 bytes, as a 256-entry table in LDS (the board emitters are VALU-bound: one ds_read_b64
+// replaces two bit-field extracts, two 24-bit multiplies and two ANDs)
+__device__ __forceinline__ void load_spread_lut(uint2 *lut, int lane) {
+  for (int e = lane; e < 256; e += kWave)
+    lut[e] = make_uint2(__umul24((uint32_t)e & 15u, 0x204081u) & 0x01010101u,
+                        __umul24((uint32_t)e >> 4, 0x204081u) & 0x01010101u);
+  WAVE_SYNC();
+}
+
 // Board emission of one half, L1 rows -> HBM, with ALIGNED LDS and HBM accesses only:
-//   1. the 6 planes are OR-ed row by row (ds_or_b32) into a linear bit-string bs[] (bit 16 + i = board byte i;
-//      the 16 leading zero bits stand for the bytes in front of the board inside its first 16-byte chunk);
-//   2. lane v of round k builds the aligned 16-byte vector 16 (hl + 32 k): 16 cells = one funnel shift out of
-//      two words of bs[], 4 cells -> 4 bytes by a 24-bit multiply;
-//   3. vectors that lie inside the board go straight from registers to HBM (global_store_dwordx4); the (at
-//      most two) ragged ones are parked in LDS and leave in ONE global_store_byte instruction.
-// `work` = the half's LDS staging area (>= 96 + 8 words).
+//   1. the 6 planes are OR-ed row by row (ds_or_b32) into a linear bit-string bs[]: bit (g & 15) + i = board
+//      byte i, so that every aligned 16-byte vector of HBM is exactly one 16-bit halfword of bs[];
+//   2. lane v of round k emits the aligned vector 16 (hl + 32 k): two bytes of bs[] index the spread table, the
+//      two 8-byte entries go straight from registers to HBM (global_store_dwordx4);
+//   3. the ragged head / tail bytes (vectors shared with the neighbouring boards) leave in ONE global_store_byte
+//      instruction, each lane picking its bit out of bs[].
+// `work` = the half's LDS scratch (>= 96 words), `lut` = load_spread_lut's table.
 template <int R>
 __device__ __forceinline__ void emit_store_h(uint8_t *g, uint32_t black, uint32_t white, uint32_t invalid,
                                              uint32_t turn, uint32_t passed, uint32_t done, const Half &hf,
-                                             uint32_t *work, bool wr) {
+                                             uint32_t *work, const uint2 *lut, bool wr) {
   constexpr int kRounds = (Cfg<R>::kIoBytes / 16 + 31) / 32;
+  constexpr int kZero = ((15 + 6 * R * R + 31) / 32 + 31) / 32;
+  static_assert(kZero <= 3, "work area is 96 words");
   uint32_t *bs = work;
-  uint8_t *edge = reinterpret_cast<uint8_t *>(work + 96);  // [2][16]
   const int S = 6 * hf.P;
+  const uint32_t mo = (uint32_t)((uintptr_t)g & 15u);
   WAVE_SYNC();
-  bs[hf.hl] = 0; bs[32 + hf.hl] = 0; bs[64 + hf.hl] = 0;
+#pragma unroll
+  for (int k = 0; k < kZero; ++k) bs[hf.hl + 32 * k] = 0;
   WAVE_SYNC();
   if (wr && hf.hl < hf.N) {
     const uint32_t rows[6] = {black, white, turn ? hf.full_l1 : 0u, invalid, passed ? hf.full_l1 : 0u,
                               done ? hf.full_l1 : 0u};
+    const uint32_t q0 = mo + (uint32_t)(hf.hl * hf.N);
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
-      const uint32_t q = 16u + (uint32_t)(p * hf.P + hf.hl * hf.N), w = q >> 5, sh = q & 31u;
       if (rows[p]) {
-        atomicOr(&bs[w], rows[p] << sh);
-        if (sh + (uint32_t)hf.N > 32u) atomicOr(&bs[w + 1], rows[p] >> (32u - sh));
+        const uint32_t q = q0 + (uint32_t)(p * hf.P);
+        const uint64_t x = (uint64_t)rows[p] << (q & 31u);
+        uint32_t *w = bs + (q >> 5);
+        atomicOr(w, (uint32_t)x);
+        if ((uint32_t)(x >> 32)) atomicOr(w + 1, (uint32_t)(x >> 32));
       }
     }
   }
   WAVE_SYNC();
-  const uint32_t mo = (uint32_t)((uintptr_t)g & 15u);
-  uint8_t *ga = g - mo;
-  const int nv = (int)(mo + S + 15) >> 4;
   if (wr) {
+    uint8_t *ga = g - mo;
+    const int end = (int)mo + S;
+    const int v0 = mo ? 1 : 0, v1 = end >> 4;
+    const uint8_t *bb = reinterpret_cast<const uint8_t *>(bs);
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) {
       const int v = hf.hl + 32 * k;
-      if (v < nv) {
-        const uint32_t qb = 16u + 16u * (uint32_t)v - mo, w = qb >> 5, sh = qb & 31u;
-        const uint32_t b16 = __builtin_amdgcn_alignbit(bs[w + 1], bs[w], sh);
+      if (v >= v0 && v < v1) {
+        const uint2 lo = lut[bb[2 * v]], hi = lut[bb[2 * v + 1]];
         V16a o;
-        // 4 cells -> 4 bytes: (bits * 0x204081) & 0x01010101 (bit i lands at bit 8 i; no colliding partial products)
-        o.w[0] = __umul24(b16 & 15u, 0x204081u) & 0x01010101u;
-        o.w[1] = __umul24((b16 >> 4) & 15u, 0x204081u) & 0x01010101u;
-        o.w[2] = __umul24((b16 >> 8) & 15u, 0x204081u) & 0x01010101u;
-        o.w[3] = __umul24((b16 >> 12) & 15u, 0x204081u) & 0x01010101u;
-        const int lo = 16 * v - (int)mo;
-        const bool full = lo >= 0 && lo + 16 <= S;
-        if (full) *reinterpret_cast<V16a *>(ga + 16 * v) = o;   // HBM, aligned
-        asm volatile("" ::: "memory");                          // keep the two address spaces apart (no flat store)
-        if (!full) {
-          uint32_t *e = work + 96 + (lo < 0 ? 0 : 4);
-          e[0] = o.w[0]; e[1] = o.w[1]; e[2] = o.w[2]; e[3] = o.w[3];
-        }
+        o.w[0] = lo.x; o.w[1] = lo.y; o.w[2] = hi.x; o.w[3] = hi.y;
+        *reinterpret_cast<V16a *>(ga + 16 * v) = o;
       }
     }
-  }
-  WAVE_SYNC();
-  if (wr) {
-    const int head = mo ? 16 - (int)mo : 0, tail = ((int)mo + S) & 15;
-    if (nv >= 2) {
-      int j = -1, e = 0;
-      if (hf.hl < 16) { if (hf.hl < head) { j = hf.hl; e = (int)mo + hf.hl; } }
-      else if (hf.hl - 16 < tail) { j = S - tail + (hf.hl - 16); e = 16 + (hf.hl - 16); }
-      if (j >= 0) g[j] = edge[e];
-    } else {  // the whole board sits in one 16-byte chunk (N = 2 with a lucky offset never happens: S >= 24)
-      for (int i = hf.hl; i < S; i += 32) g[i] = edge[(mo ? 0 : 16) + ((int)mo + i)];
+    const int head = mo ? 16 - (int)mo : 0, tail = end & 15;
+    int j = -1;
+    if (hf.hl < 16) { if (hf.hl < head) j = hf.hl; }
+    else if (hf.hl - 16 < tail) j = S - tail + (hf.hl - 16);
+    if (j >= 0) {
+      const uint32_t q = mo + (uint32_t)j;
+      g[j] = (uint8_t)((bs[q >> 5] >> (q & 31u)) & 1u);
     }
   }
 }
@@ -354,20 +371,32 @@ __device__ __forceinline__ uint32_t load_flags_h(const uint8_t *g, int P, int pt
   return half_of(__ballot(fb != 0), hf.h) & 0xFu;
 }
 
-__device__ __forceinline__ Half make_half(int lane, int N, uint32_t inv) {
+// Lanes 0-10 of a half flood the stones of colour c0 from liberty classes 0-10, lanes 11-21 the stones of c1.  With
+// `areas`, lanes 22 / 23 additionally flood the EMPTY points from the neighbours of the c0 / c1 stones (Tromp-Taylor
+// territory, gym_go/gogame.py:275-300) - same instructions, different inputs, so area scoring rides along for free.
+__device__ __forceinline__ Half make_half(int lane, int N, uint32_t inv, bool areas = false) {
   Half hf;
   hf.lane = lane; hf.h = lane >> 5; hf.hl = lane & 31;
   hf.N = N; hf.P = N * N; hf.inv = inv;
   hf.full_l1 = hf.hl < N ? (1u << N) - 1u : 0u;
+  const bool second = hf.hl >= kCwClasses;
   hf.cls = hf.hl < kCwLanes ? (hf.hl % kCwClasses) : kCwClasses;
-  hf.second = hf.hl >= kCwClasses;
+  hf.m_off = second ? 32 : 0;
+  hf.r_off = 64 + (second ? 32 : 0);
+  hf.s_off = 128;
+  if (areas && (hf.hl == kCwLanes || hf.hl == kCwLanes + 1)) {
+    hf.cls = kCwClasses + 1;
+    hf.m_off = 128; hf.r_off = 160;
+    hf.s_off = hf.hl == kCwLanes ? 0 : 32;
+  }
   return hf;
 }
 
 template <int R>
 __device__ __forceinline__ void load_cw_table(uint32_t *lds, int lane) {
   uint32_t *cwt = lds + Lds2<R>::kCwt;
-  for (int i = lane; i < (kCwClasses + 1) * 20; i += kWave) cwt[i] = kCw.m[i / 20][i % 20];
+  for (int i = lane; i < (kCwClasses + 2) * 20; i += kWave)
+    cwt[i] = i < (kCwClasses + 1) * 20 ? kCw.m[i / 20][i % 20] : 0xFFFFFFFFu;
   WAVE_SYNC();
 }
 
@@ -396,13 +425,15 @@ __device__ __forceinline__ int pick_action2(uint32_t valid, uint32_t incl, uint3
 }
 
 template <int R>
-__global__ __launch_bounds__(kWave, 3) void k_next_states2(const uint8_t *__restrict__ in,
+__global__ __launch_bounds__(kWave, 3) void k_next_states2s(const uint8_t *__restrict__ in,
                                                         const int32_t *__restrict__ actions,
                                                         uint8_t *__restrict__ out, int32_t *__restrict__ status,
                                                         int64_t B, int N, uint32_t inv, int canonical) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv);
+  __shared__ uint2 lut[256];
   load_cw_table<R>(lds, hf.lane);
+  load_spread_lut(lut, hf.lane);
   const int S = 6 * hf.P;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
@@ -442,22 +473,171 @@ __global__ __launch_bounds__(kWave, 3) void k_next_states2(const uint8_t *__rest
       nturn = 0;
     }
     emit_store_h<R>(go, black, white, invalid, (uint32_t)nturn, passed, done, hf,
-                    reinterpret_cast<uint32_t *>(io), on && !illegal);
+                    reinterpret_cast<uint32_t *>(io), lut, on && !illegal);
     if (illegal) copy_row_h(gi, go, S, hf.hl, on);  // rare: the row passes through unchanged
     if (status && on && hf.hl == 0) status[b] = illegal ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
+  }
+}
+
+// ---------------------------------------------------------------- software-pipelined board I/O (LDS-DMA)
+// A per-ply kernel is a chain  load board -> analyse -> store board  per wave, and with 3-4 waves per SIMD the HBM
+// round trip of the load (and the acknowledgement of the store) is NOT hidden by the other waves: bytes in flight =
+// waves x one board, far below bandwidth x latency.  The loads therefore go global -> LDS directly
+// (global_load_lds_dwordx4: no VGPRs are held while they fly, so the next pair's board can be in flight during the
+// whole analysis of this pair) and the stores of the previous pair are issued right after them, before the analysis.
+// One `s_waitcnt vmcnt(0)` at the top of each iteration then finds everything issued a full analysis ago.
+// The DMA is inline asm on purpose: the compiler makes every later ds_read wait for an LDS-DMA it knows about.
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+// lane L's 16 (4) bytes at g land at LDS address m0 + 16 L (m0 + 4 L); m0 must be wave-uniform
+__device__ __forceinline__ void dma16(const void *g, uint32_t m0) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0), "v"(g) : "memory");
+}
+__device__ __forceinline__ void dma4(const void *g, uint32_t m0) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0), "v"(g) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// aligned superset of g[0 .. nbytes) -> this half's landing buffer (ROUNDS * 512 bytes per half, half 1 right after
+// half 0); board byte j ends up at stage_half + (g & 15) + j, exactly like stage_in_h
+template <int ROUNDS>
+__device__ __forceinline__ void dma_stage_h(const uint8_t *g, int nbytes, uint32_t stage_lds, const Half &hf) {
+  const uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
+  const uint8_t *ga = g - mis;
+  const int nv = (int)(mis + nbytes + 15) >> 4;
+#pragma unroll
+  for (int k = 0; k < ROUNDS; ++k) {
+    const int v = hf.hl + 32 * k;
+    if (hf.h == 0) { if (v < nv) dma16(ga + 16 * v, stage_lds + 512u * k); }
+    else { if (v < nv) dma16(ga + 16 * v, stage_lds + 512u * (ROUNDS + k) - 512u); }
+  }
+}
+
+// gogame.batch_next_states, two boards per wave, pipelined (see above).  Per pair the DMA brings planes 0-1, the four
+// flag bytes (as aligned dwords, lanes 0-3 of each half) and the action of the pair after next (lane 4).
+template <int R>
+__global__ __launch_bounds__(kWave, GG_LB_PLY) void k_next_states2(const uint8_t *__restrict__ in,
+                                                        const int32_t *__restrict__ actions,
+                                                        uint8_t *__restrict__ out, int32_t *__restrict__ status,
+                                                        int64_t B, int N, uint32_t inv, int canonical) {
+  constexpr int kRounds = 2;   // 2 planes + misalignment <= 47 vectors
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[2 * kRounds * 512];
+  __shared__ __attribute__((aligned(16))) uint32_t meta[kWave];
+  const Half hf = make_half(threadIdx.x, N, inv);
+  __shared__ uint2 lut[256];
+  load_cw_table<R>(lds, hf.lane);
+  load_spread_lut(lut, hf.lane);
+  const int S = 6 * hf.P;
+  const int64_t npairs = (B + 1) >> 1;
+  const int64_t G = gridDim.x;
+  const uint32_t stage_lds = lds_addr(stage), meta_lds = lds_addr(meta);
+  const uint8_t *sh = stage + hf.h * (kRounds * 512);
+  uint32_t *work = lds + hf.h * 128;   // emit_store_h scratch (free outside the analysis)
+
+  auto board_of = [&](int64_t p) -> int64_t { const int64_t b0 = 2 * p + hf.h; return b0 < B ? b0 : B - 1; };
+  auto flag_off = [&](int a) -> int {   // byte offset inside the board of this lane's flag byte (lanes 0-3)
+    const bool pt = a >= 0 && a < hf.P;
+    return hf.hl == 0 ? 2 * hf.P : hf.hl == 1 ? 3 * hf.P + (pt ? a : 0) : hf.hl == 2 ? 4 * hf.P : 5 * hf.P;
+  };
+  auto issue = [&](int64_t p, int a) {   // everything pair p needs + the action of pair p + 2 G
+    const uint8_t *gi = in + board_of(p) * (int64_t)S;
+    dma_stage_h<kRounds>(gi, 2 * hf.P, stage_lds, hf);
+    const int64_t p2 = p + G;
+    const uint8_t *fa = gi + flag_off(a);
+    const void *src = hf.hl == 4 ? (const void *)(actions + board_of(p2 < npairs ? p2 : p))
+                                 : (const void *)(fa - ((uintptr_t)fa & 3u));
+    if (hf.hl < 5) dma4(src, meta_lds);
+  };
+
+  int64_t p = blockIdx.x;
+  if (p >= npairs) return;
+  int a = actions[board_of(p)];
+  issue(p, a);
+  bool have_prev = false;
+  uint32_t pb = 0, pw = 0, pi = 0, pm = 0;   // previous pair's result rows + {turn, passed, done, illegal} bits
+  for (;;) {
+    dma_wait();
+    WAVE_SYNC();
+    const int64_t b0 = 2 * p + hf.h;
+    const bool on = b0 < B;
+    const int64_t b = on ? b0 : B - 1;
+    const uint8_t *gi = in + b * (int64_t)S;
+    const uint32_t mi = (uint32_t)((uintptr_t)gi & 15u);
+    uint32_t black = plane_to_row<R>(sh + mi, N, hf.hl);
+    uint32_t white = plane_to_row<R>(sh + mi + hf.P, N, hf.hl);
+    const uint32_t mw = meta[hf.lane];
+    const uint32_t fsh = 8u * (uint32_t)((uintptr_t)(gi + flag_off(a)) & 3u);
+    const uint32_t flags = half_of(__ballot(hf.hl < 4 && ((mw >> fsh) & 0xFFu) != 0), hf.h) & 0xFu;
+    const int a_next = __shfl((int)mw, (hf.lane & 32) + 4);
+    lds_drain();
+    WAVE_SYNC();
+    const int64_t pn = p + G;
+    if (pn < npairs) issue(pn, a_next);
+    if (have_prev) {   // stores of the previous pair fly during this pair's analysis
+      const int64_t q0 = 2 * (p - G) + hf.h;
+      const bool qon = q0 < B;
+      const int64_t q = qon ? q0 : B - 1;
+      const bool ill = (pm >> 3) & 1u;
+      if (__ballot(!ill))
+        emit_store_h<R>(out + q * (int64_t)S, pb, pw, pi, pm & 1u, (pm >> 1) & 1u, (pm >> 2) & 1u, hf, work, lut, qon && !ill);
+      if (ill) copy_row_h(in + q * (int64_t)S, out + q * (int64_t)S, S, hf.hl, qon);  // rare: row passes through
+      if (status && qon && hf.hl == 0) status[q] = ill ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
+    }
+    const bool in_range = a >= 0 && a <= hf.P;
+    const bool is_pass = a == hf.P;
+    const bool illegal = !in_range || (!is_pass && (flags & 2u));
+    const int pl = flags & 1u;
+    uint32_t invalid = 0;
+    if (__ballot(!illegal)) {
+      uint32_t mine = pl ? white : black, opp = pl ? black : white;
+      // an illegal half still runs the (wave-wide) analysis on a harmless pass, its result is discarded
+      uint32_t atari_unused;
+      invalid = step_core2<R, false>(mine, opp, illegal ? hf.P : a, hf, lds, 0u, false, atari_unused);
+      black = pl ? opp : mine;
+      white = pl ? mine : opp;
+    }
+    const uint32_t passed = is_pass ? 1 : 0;
+    const uint32_t done = ((flags & 8u) || (is_pass && (flags & 4u))) ? 1 : 0;
+    int nturn = 1 - pl;
+    if (canonical && nturn == 1) {
+      uint32_t t = black; black = white; white = t;
+      nturn = 0;
+    }
+    pb = black; pw = white; pi = invalid;
+    pm = (uint32_t)nturn | (passed << 1) | (done << 2) | ((illegal ? 1u : 0u) << 3);
+    have_prev = true;
+    a = a_next;
+    if (pn >= npairs) break;
+    p = pn;
+  }
+  {
+    const int64_t q0 = 2 * p + hf.h;
+    const bool qon = q0 < B;
+    const int64_t q = qon ? q0 : B - 1;
+    const bool ill = (pm >> 3) & 1u;
+    WAVE_SYNC();
+    if (__ballot(!ill))
+      emit_store_h<R>(out + q * (int64_t)S, pb, pw, pi, pm & 1u, (pm >> 1) & 1u, (pm >> 2) & 1u, hf, work, lut, qon && !ill);
+    if (ill) copy_row_h(in + q * (int64_t)S, out + q * (int64_t)S, S, hf.hl, qon);
+    if (status && qon && hf.hl == 0) status[q] = ill ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
   }
 }
 
 // PERPLY = instantiation for 1-2 plies per launch: the board I/O dominates there and the kernel runs best spill-free
 // at 3 waves per SIMD; the fused instantiation keeps its hot ply loop spill-free at 4 waves per SIMD.
 template <int R, bool PERPLY>
-__global__ __launch_bounds__(kWave, PERPLY ? 3 : 4) void k_rollout2(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+__global__ __launch_bounds__(kWave, PERPLY ? GG_LB_PLY : 4) void k_rollout2(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                     int32_t *__restrict__ last_actions,
                                                     int64_t *__restrict__ steps_done, int64_t B, int N, uint32_t inv,
                                                     int plies, int auto_reset) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv);
+  __shared__ uint2 lut[256];
   load_cw_table<R>(lds, hf.lane);
+  load_spread_lut(lut, hf.lane);
   const int S = 6 * hf.P;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
@@ -516,12 +696,107 @@ __global__ __launch_bounds__(kWave, PERPLY ? 3 : 4) void k_rollout2(uint8_t *__r
     }
     if (__ballot(played != 0)) {
       emit_store_h<R>(gs, black, white, invalid, (uint32_t)turn, (uint32_t)passed, (uint32_t)done, hf,
-                      reinterpret_cast<uint32_t *>(io), on && played != 0);
+                      reinterpret_cast<uint32_t *>(io), lut, on && played != 0);
     }
     if (on && hf.hl == 0) {
       rng[b] = hf.h ? xb : xa;
       if (last_actions) last_actions[b] = last;
       if (steps_done) steps_done[b] += played;
+    }
+  }
+}
+
+// One GoEnv.step for every game of a batched env, in place, one launch (gym_go/envs/go_env.py:49-76):
+// auto-reset of finished games (:40-47), the action (given, or drawn like uniform_random_action :78-81), the legality
+// check (gogame.py:59), next_state, game_ended and GoEnv.reward (:128-149; Tromp-Taylor areas gogame.py:275-300).
+// The two area floods of the post-move position ride in the idle flood lanes of the liberty analysis.
+template <int R>
+__global__ __launch_bounds__(kWave, GG_LB_PLY) void k_env_step2(uint8_t *__restrict__ states, const int32_t *__restrict__ actions,
+                                                        uint64_t *__restrict__ rng, float *__restrict__ rewards,
+                                                        uint8_t *__restrict__ dones, int32_t *__restrict__ status,
+                                                        int32_t *__restrict__ taken, int64_t B, int N, uint32_t inv,
+                                                        float komi, int heuristic, int auto_reset) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
+  const Half hf = make_half(threadIdx.x, N, inv, true);
+  __shared__ uint2 lut[256];
+  load_cw_table<R>(lds, hf.lane);
+  load_spread_lut(lut, hf.lane);
+  const int S = 6 * hf.P;
+  uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
+  const int64_t npairs = (B + 1) >> 1;
+  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+    const int64_t bA = 2 * p, bB = (2 * p + 1 < B) ? 2 * p + 1 : B - 1;
+    const bool on = 2 * p + hf.h < B;
+    const int64_t b = hf.h ? bB : bA;
+    uint8_t *gs = states + b * (int64_t)S;
+    uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
+    WAVE_SYNC();
+    const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
+    WAVE_SYNC();
+    uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
+    uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+    uint32_t invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
+    int turn = flags & 1u, passed = (flags >> 2) & 1u, done = (flags >> 3) & 1u;
+    bool wr = false;               // the stored state changes
+    const bool frozen = done && !auto_reset;   // go_env.py:53 "assert not self.done"
+    if (done && auto_reset) {
+      black = white = invalid = 0;
+      turn = passed = done = 0;
+      wr = true;
+    }
+    int a;
+    if (actions) {
+      a = actions[b];
+    } else {
+      uint64_t xa = uniform64(rng[bA]), xb = uniform64(rng[bB]);
+      const uint32_t valid = hf.full_l1 & ~invalid;
+      const uint32_t incl = half_scan((uint32_t)__popc(valid));
+      const uint32_t cnt_a = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+      const uint32_t cnt_b = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      const uint64_t ua = splitmix_next(xa), ub = splitmix_next(xb);
+      const uint32_t ka = (uint32_t)(((ua >> 32) * (uint64_t)(cnt_a + 1)) >> 32);
+      const uint32_t kb = (uint32_t)(((ub >> 32) * (uint64_t)(cnt_b + 1)) >> 32);
+      a = pick_action2(valid, incl, hf.h ? kb : ka, hf);
+      if (on && !frozen && hf.hl == 0) rng[b] = hf.h ? xb : xa;
+    }
+    const bool in_range = a >= 0 && a <= hf.P;
+    bool bad = !in_range || frozen;
+    if (in_range && a < hf.P) {
+      int ar, ac;
+      split_action(a, N, hf.inv, ar, ac);
+      const uint32_t row = (uint32_t)__shfl((int)invalid, (hf.lane & 32) + ar);
+      bad = bad || ((row >> ac) & 1u);
+    }
+    uint32_t mine = turn ? white : black, opp = turn ? black : white;
+    uint32_t atari_unused, reach[2];
+    // a refused half still runs the (wave-wide) analysis on a harmless pass: it yields the areas of its position
+    const uint32_t ninv = step_core2<R, false, true>(mine, opp, bad ? hf.P : a, hf, lds, 0u, false, atari_unused, reach);
+    if (!bad) {
+      invalid = ninv;
+      black = turn ? opp : mine;
+      white = turn ? mine : opp;
+      if (a == hf.P) { if (passed) done = 1; passed = 1; } else passed = 0;
+      turn ^= 1;
+      wr = true;
+    }
+    // analyze2 saw (c0, c1) = (opp, mine) of the mover: reach[0] = empties touching opp's colour, reach[1] = mine's
+    const bool mover_white = bad ? turn : !turn;   // turn was flipped on commit
+    const uint32_t rb = mover_white ? reach[0] : reach[1], rw = mover_white ? reach[1] : reach[0];
+    const uint32_t ab = half_scan((uint32_t)(__popc(black) + __popc(rb & ~rw)));
+    const uint32_t aw = half_scan((uint32_t)(__popc(white) + __popc(rw & ~rb)));
+    if (__ballot(wr)) {
+      emit_store_h<R>(gs, black, white, invalid, (uint32_t)turn, (uint32_t)passed, (uint32_t)done, hf,
+                      reinterpret_cast<uint32_t *>(io), lut, on && wr);
+    }
+    if (on && hf.hl == 31) {
+      const float margin = (float)((int)ab - (int)aw) - komi;
+      float rwd;
+      if (heuristic) rwd = done ? (margin > 0.f ? 1.f : -1.f) * (float)hf.P : margin;
+      else rwd = done ? (margin > 0.f ? 1.f : margin < 0.f ? -1.f : 0.f) : 0.f;
+      if (rewards) rewards[b] = rwd;
+      if (dones) dones[b] = (uint8_t)done;
+      if (status) status[b] = bad ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
+      if (taken) taken[b] = a;
     }
   }
 }
@@ -555,7 +830,9 @@ __global__ __launch_bounds__(kWave, 4) void k_children2(const uint8_t *__restric
                                                         uint32_t inv, int canonical, int chunks) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv);
+  __shared__ uint2 lut[256];
   load_cw_table<R>(lds, hf.lane);
+  load_spread_lut(lut, hf.lane);
   const int S = 6 * hf.P;
   const int A = hf.P + 1;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
@@ -616,7 +893,7 @@ __global__ __launch_bounds__(kWave, 4) void k_children2(const uint8_t *__restric
         nturn = 0;
       }
       uint8_t *go = gc + (int64_t)a * S;
-      emit_store_h<R>(go, nb, nw, invalid, (uint32_t)nturn, passed, done, hf, reinterpret_cast<uint32_t *>(io), on);
+      emit_store_h<R>(go, nb, nw, invalid, (uint32_t)nturn, passed, done, hf, reinterpret_cast<uint32_t *>(io), lut, on);
       for (int t = 0; t < q && az < p1; ++t, az += 2) zero_step(az);
     }
     for (; az < p1; az += 2) zero_step(az);
@@ -675,7 +952,7 @@ __global__ __launch_bounds__(kWave) void k_areas2(const uint8_t *__restrict__ st
   const int S = 6 * hf.P;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   uint32_t *sc = lds;
-  uint32_t *my5 = lds + Lds2<R>::kRows5 + hf.h * 160;
+  uint32_t *my5 = lds + Lds2<R>::kRows5 + hf.h * kRowBuf;
   const int64_t npairs = (B + 1) >> 1;
   for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
     const bool on = 2 * p + hf.h < B;
@@ -770,7 +1047,9 @@ template <int R>
 __global__ __launch_bounds__(kWave) void k_unpack(const uint32_t *__restrict__ packed, uint8_t *__restrict__ states,
                                                   int64_t B, int N) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[2 * (Cfg<R>::kIoBytes / 4)];
+  __shared__ uint2 lut[256];
   const Half hf = make_half(threadIdx.x, N, 0);
+  load_spread_lut(lut, hf.lane);
   const int S = 6 * hf.P, W = 3 * N + 1;
   uint32_t *work = lds + hf.h * (Cfg<R>::kIoBytes / 4);
   const int64_t npairs = (B + 1) >> 1;
@@ -786,7 +1065,7 @@ __global__ __launch_bounds__(kWave) void k_unpack(const uint32_t *__restrict__ p
       invalid = gp[2 * N + hf.hl] & full;
     }
     const uint32_t fl = gp[3 * N];
-    emit_store_h<R>(states + b * (int64_t)S, black, white, invalid, fl & 1u, (fl >> 1) & 1u, (fl >> 2) & 1u, hf, work,
+    emit_store_h<R>(states + b * (int64_t)S, black, white, invalid, fl & 1u, (fl >> 1) & 1u, (fl >> 2) & 1u, hf, work, lut,
                     on);
   }
 }

@@ -42,8 +42,22 @@ class GoVecEnv:
         """Uniform over valid actions incl. pass, per game, on the device."""
         return gogame.batch_sample_actions(self.states, self.rng)
 
-    def step(self, actions, check=False):
-        """-> (states, rewards, dones, status).  Finished games are reset first when auto_reset."""
+    def step(self, actions=None, check=False):
+        """One GoEnv.step per game in ONE launch -> (states, rewards, dones, status).  actions=None draws a
+        uniform-random valid action per game on the device (it is left in self.last_actions).  Finished games are
+        reset first when auto_reset; rewards are float32, black's perspective (gym_go/envs/go_env.py:128-149)."""
+        if actions is not None:
+            actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        rewards, dones, status, taken = gogame.batch_env_step(self.states, actions, self.rng, self.komi,
+                                                              self.reward_method, self.auto_reset)
+        if check and bool((status != 0).any()):
+            raise AssertionError('illegal move in batch')
+        self.last_actions = taken
+        self.steps_done += (status == 0)
+        return self.states, rewards, dones, status
+
+    def step_unfused(self, actions, check=False):
+        """The same step as separate launches (reset, next_states, areas + torch reward arithmetic); float64 rewards."""
         if self.auto_reset:
             gogame.batch_reset_finished(self.states)
         actions = actions.to(device=self.device, dtype=torch.int32)

@@ -98,6 +98,26 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
                          int32_t N, int32_t plies, int32_t auto_reset, void *hip_stream);
 
 /*
+ * GoEnv.step for every game of a batched env, IN PLACE, one launch            gym_go/envs/go_env.py:49-76
+ *   1. auto_reset != 0: a finished game (plane 5 set) is reset first (GoEnv.reset, :40-47); auto_reset == 0: it
+ *      is refused (status 1, row untouched; the reference asserts `not self.done`, :53).
+ *   2. the action: actions[b] (0 .. N*N, N*N = pass) or, when actions == NULL, drawn uniformly over the valid
+ *      actions with rng[b] exactly like gg_batch_rollout / gg_batch_sample_actions (uniform_random_action, :78-81).
+ *   3. legality (gogame.py:59): out of range or on a set point of plane 3 -> status 1, row untouched.
+ *   4. state = gogame.next_state(state, action)  (:34-87), dones[b] = game_ended (:189-196).
+ *   5. rewards[b] = GoEnv.reward() (:128-149) from black's perspective with Tromp-Taylor areas (gogame.py:275-300)
+ *      of the resulting position: GG_REWARD_REAL  done ? sign(black - white - komi) : 0;
+ *      GG_REWARD_HEURISTIC  done ? (margin > 0 ? +N*N : -N*N) : margin.
+ * rng: uint64 [B], required when actions == NULL (advanced once per game that draws).  rewards float32 [B], dones
+ * uint8 [B], status int32 [B], taken_actions int32 [B] (the action used): each nullable.
+ */
+#define GG_REWARD_REAL 0
+#define GG_REWARD_HEURISTIC 1
+int32_t gg_batch_env_step(uint8_t *states, const int32_t *actions, uint64_t *rng, float *rewards, uint8_t *dones,
+                          int32_t *status, int32_t *taken_actions, int64_t B, int32_t N, float komi,
+                          int32_t reward_method, int32_t auto_reset, void *hip_stream);
+
+/*
  * One sampling pass only (no step): actions[b] ~ Uniform{valid actions of states[b] incl. pass},
  * same generator as gg_batch_rollout (advances rng[b] once).  Finished games: reset is NOT applied;
  * every action counts as valid there (gogame.invalid_moves returns zeros once ended, :155-156).

@@ -97,3 +97,82 @@ def test_vecenv_step_and_rollout_agree_with_oracle():
     want, rng, _ = c_oracle.batch_rollout(want, rng, 33, True)
     assert np.array_equal(env.states.cpu().numpy(), want)
     assert int(env.steps_done.min()) == 153
+
+
+def _ref_reward(states, komi, method, N):
+    from oracle import c_oracle
+    b, w = c_oracle.batch_areas(states)
+    margin = b.astype(np.float64) - w - komi
+    over = states[:, 5, 0, 0] == 1
+    if method == 'real':
+        return np.where(over, np.sign(margin), 0.0)
+    return np.where(over, np.where(margin > 0, 1.0, -1.0) * N * N, margin)
+
+
+@pytest.mark.parametrize('N,B,method,komi', [(19, 257, 'heuristic', 7.5), (9, 300, 'real', 0.0), (5, 64, 'real', 2.0),
+                                             (13, 33, 'heuristic', 0.0), (2, 17, 'real', 0.0)])
+def test_fused_env_step_sampled_matches_oracle(N, B, method, komi):
+    """gg_batch_env_step with on-device sampling: states, drawn actions, dones and GoEnv.reward vs the oracle
+    (gym_go/envs/go_env.py:49-76, :128-149) over many plies incl. game ends and auto-resets."""
+    from gymgo_amd.envs import GoVecEnv
+    from oracle import c_oracle
+    env = GoVecEnv(B, N, komi=komi, reward_method=method, seed=4242)
+    want = np.zeros((B, 6, N, N), np.uint8)
+    rng = c_oracle.rng_seed(4242, B)
+    seen_done = 0
+    for t in range(40 if N == 19 else 150):
+        states, rewards, dones, status = env.step()
+        want, rng, last = c_oracle.batch_rollout(want, rng, 1, True)
+        assert np.array_equal(env.last_actions.cpu().numpy(), last), t
+        assert np.array_equal(states.cpu().numpy(), want), t
+        assert np.array_equal(dones.cpu().numpy(), want[:, 5, 0, 0])
+        assert np.array_equal(rewards.cpu().numpy().astype(np.float64), _ref_reward(want, komi, method, N)), t
+        assert int(status.sum()) == 0
+        seen_done += int(dones.sum())
+    assert np.array_equal(env.rng.cpu().numpy().view(np.uint64), rng)
+    if N <= 9:
+        assert seen_done > 0   # the reset + terminal-reward branches were exercised
+
+
+def test_fused_env_step_refuses_illegal_and_frozen():
+    from gymgo_amd import gogame
+    from gymgo_amd.envs import GoVecEnv
+    from oracle import c_oracle
+    B, N = 203, 9
+    env = GoVecEnv(B, N, komi=0.5, reward_method='heuristic', seed=5, auto_reset=False)
+    env.rollout(40)
+    before = env.states.clone()
+    host = before.cpu().numpy()
+    gen = np.random.default_rng(0)
+    acts = gen.integers(-3, N * N + 4, size=B).astype(np.int32)
+    over = host[:, 5, 0, 0] == 1
+    inval = host[:, 3].reshape(B, -1)
+    in_range = (acts >= 0) & (acts <= N * N)
+    bad = ~in_range | over
+    for i in range(B):
+        if in_range[i] and acts[i] < N * N and inval[i, acts[i]]:
+            bad[i] = True
+    assert bad.any() and (~bad).any()
+    states, rewards, dones, status = env.step(torch.from_numpy(acts).cuda())
+    want = host.copy()
+    ok = np.flatnonzero(~bad)
+    want[ok] = c_oracle.batch_next_states(host[ok], acts[ok])[0]
+    assert np.array_equal(status.cpu().numpy(), bad.astype(np.int32))
+    assert np.array_equal(states.cpu().numpy(), want)
+    assert np.array_equal(dones.cpu().numpy(), want[:, 5, 0, 0])
+    assert np.array_equal(rewards.cpu().numpy().astype(np.float64), _ref_reward(want, 0.5, 'heuristic', N))
+    # the separate-launch form of the same step agrees
+    env2 = GoVecEnv(B, N, komi=0.5, reward_method='heuristic', seed=5, auto_reset=False)
+    env2.states = before.clone()
+    legal = torch.from_numpy(np.where(bad, N * N, acts).astype(np.int32)).cuda()
+    s2, r2, d2, st2 = env2.step_unfused(legal)
+    live = torch.from_numpy(~over).cuda()
+    env3 = GoVecEnv(B, N, komi=0.5, reward_method='heuristic', seed=5, auto_reset=False)
+    env3.states = before.clone()
+    s3, r3, d3, st3 = env3.step(legal)
+    assert torch.equal(s2[live], s3[live]) and torch.equal(r2[live].float(), r3[live])
+    # null outputs / bad arguments
+    with pytest.raises(ValueError):
+        gogame.batch_env_step(env.states)
+    with pytest.raises(KeyError):
+        gogame.batch_env_step(env.states, legal, reward_method='nope')

@@ -54,8 +54,12 @@ def main():
         for method in ('real', 'heuristic'):
             env = GoVecEnv(B, N, komi=7.5, reward_method=method)
             env.rollout(plies)
-            t = timed(lambda: env.step(env.sample_actions()), 30)
-            out['GoVecEnv_step_%s_reward_%dx%d_B%d' % (method, N, N, B)] = {'steps_per_s': B / t, 'note': 'sample + auto-reset + step + areas + rewards + dones'}
+            t = timed(lambda: env.step(), 50)
+            out['GoVecEnv_step_%s_reward_%dx%d_B%d' % (method, N, N, B)] = {
+                'steps_per_s': B / t, 'algorithmic_GBps': B * (2 * S + 29) / t / 1e9, 'roofline_frac': B * (2 * S + 29) / t / PEAK,
+                'note': 'gg_batch_env_step: sample + auto-reset + step + areas + rewards + dones, ONE launch, in place'}
+            t = timed(lambda: env.step_unfused(env.sample_actions()), 30)
+            out['GoVecEnv_step_unfused_%s_reward_%dx%d_B%d' % (method, N, N, B)] = {'steps_per_s': B / t, 'note': 'same step as separate launches'}
         st2, _ = midgame(B, N, plies, 5)
         acts = gogame.batch_sample_actions(st2, gogame.rng_seed(B, 9))
         t = timed(lambda: gogame.batch_next_states(st2, acts, check=False), 50)
