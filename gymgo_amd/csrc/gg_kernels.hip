@@ -54,6 +54,13 @@ int grid_resident(int64_t work, int waves_per_simd) {
   return (int)(work < cap ? (work > 0 ? work : 1) : cap);
 }
 
+// GG_CHILDREN_FULL=1 selects the children kernel that re-analyses every child from scratch (k_children2) - A/B only
+bool children_full() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("GG_CHILDREN_FULL"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
 // GG_SYNC_IO=1 selects the non-pipelined (load, analyse, store) per-ply kernels - A/B measurements only
 bool sync_io() {
   static int v = -1;
@@ -172,7 +179,18 @@ int32_t gg_batch_children(const uint8_t *states, uint8_t *children, int64_t B, i
   if (chunks < 1) chunks = 1;
   if (chunks > A) chunks = A;
   int grid = grid_for(B * chunks);
-  if (variant() == 2) {
+  if (variant() == 2 && !children_full()) {
+    // incremental kernel: the per-parent analysis (4 flood batches at 19x19) is repeated by every chunk, so chunks only
+    // serve to fill the machine and to even out the tail (8 192 parents: 2 chunks each, measured best of 1..12)
+    want = (int64_t)cus * 64;
+    chunks = (int)((want + B - 1) / B);
+    if (chunks < 1) chunks = 1;
+    if (chunks > A) chunks = A;
+    grid = grid_for(B * chunks);
+    GG_DISPATCH(N, (k_children3<9><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
+                (k_children3<13><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
+                (k_children3<19><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)));
+  } else if (variant() == 2) {
     GG_DISPATCH(N, (k_children2<9><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
                 (k_children2<13><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
                 (k_children2<19><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)));

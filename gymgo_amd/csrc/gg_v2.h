@@ -37,6 +37,9 @@ constexpr CwTable make_cw_table() {
 }
 __constant__ CwTable kCw = make_cw_table();
 
+#ifndef GG_LB_CH3
+#define GG_LB_CH3 3   // waves per SIMD k_children3 is compiled for
+#endif
 #ifndef GG_LB_PLY
 #define GG_LB_PLY 3   // waves per SIMD the per-ply kernels are compiled for
 #endif
@@ -897,6 +900,316 @@ __global__ __launch_bounds__(kWave, 4) void k_children2(const uint8_t *__restric
       for (int t = 0; t < q && az < p1; ++t, az += 2) zero_step(az);
     }
     for (; az < p1; az += 2) zero_step(az);
+  }
+}
+
+// gogame.children (gym_go/gogame.py:175-186), INCREMENTAL: one parent per wave, analysed once, every child derived from it.
+//
+// k_children2 re-analyses every child from scratch (~950 VALU per pair of children, which makes the kernel VALU-bound
+// at half of the HBM-write roofline).  But a child differs from its parent by one stone plus its captures, and only
+// the groups adjacent to the new stone q (and, rarely, to a captured group) change their liberty count:
+//   * opponent groups adjacent to q lose exactly the liberty q: count 1 -> captured, 2 -> atari, >= 3 -> still >= 2;
+//   * the mover's groups adjacent to q merge with the new stone into G, whose liberties are dilate(G) & empty';
+//   * a mover's group in atari next to a captured group gains a liberty (rare; finished by a short L1 flood).
+// What this needs from the parent is (a) for every stone the EXACT liberty count of its group, saturated at 3, and
+// (b) for every empty point q the stones of each colour whose group has q as a liberty.  Both come out of the same
+// floods: lane (h, l) floods colour h (0 = mover, 1 = opponent) from the stones adjacent to the l-th empty point of
+// the batch - 32 empty points x 2 colours per wave flood.  Pass 1 runs them for all empty points and counts, per
+// stone, how many floods reach it (three OR-AND ops per flood in L1: ge1, ge2, ge3).  Pass 2 runs them again for the
+// points of this work item's chunk (the 5 KB transpose buffer holds one batch; when the board has <= 32 empty points
+// pass 1's batch is reused) and derives two children per L1 pass, one per half, with ~70 VALU ops + the emitter.
+template <int R>
+__global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *__restrict__ states,
+                                                        uint8_t *__restrict__ children, int64_t B, int N,
+                                                        uint32_t inv, int canonical, int chunks) {
+  constexpr int RS = Cfg<R>::kRowStride;
+  constexpr int RV = (R + 3) / 4;
+  constexpr uint32_t kRingWords = 512, kRingBits = 32 * kRingWords, kBlk = 1024;   // 16 blocks of 1 KB output
+  constexpr int kScWords = kWave * RS > 2 * Cfg<R>::kIoBytes / 4 ? kWave * RS : 2 * Cfg<R>::kIoBytes / 4;
+  __shared__ __attribute__((aligned(16))) uint32_t sc[kScWords];   // flood results; the parent is staged here first
+  __shared__ __attribute__((aligned(16))) uint32_t planes[4 * 32]; // rows: mover, opponent, both bit-reversed
+  __shared__ __attribute__((aligned(16))) uint32_t ring[kRingWords];  // output bit-stream window (1 bit per output byte)
+  __shared__ uint16_t elist[R * R + 2];                            // action index of the t-th empty point
+  __shared__ uint2 lut[256];
+  const Half hf = make_half(threadIdx.x, N, inv);
+  load_spread_lut(lut, hf.lane);
+  const int S = 6 * hf.P;
+  const int A = hf.P + 1;
+  uint8_t *io = reinterpret_cast<uint8_t *>(sc) + hf.h * Cfg<R>::kIoBytes;
+  for (int i = hf.lane; i < (int)kRingWords; i += kWave) ring[i] = 0;   // every flushed block is zeroed again
+  const int per = (A + chunks - 1) / chunks;
+  for (int64_t w = blockIdx.x; w < B * chunks; w += gridDim.x) {
+    const int64_t b = w / chunks;
+    const int ch = (int)(w - b * chunks);
+    const uint8_t *gi = states + b * (int64_t)S;
+    uint8_t *gc = children + b * A * (int64_t)S;
+    const uint32_t flags = load_flags_h(gi, hf.P, 0, hf);
+    WAVE_SYNC();
+    const uint32_t mi = stage_in_h(gi, 4 * hf.P, io, hf.hl);  // both halves hold the same parent
+    WAVE_SYNC();
+    const uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
+    const uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+    const uint32_t invd = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
+    const int pl = flags & 1u;
+    const uint32_t mine = pl ? white : black, opp = pl ? black : white;
+    const uint32_t e = hf.full_l1 & ~(mine | opp);
+    const int a0 = ch * per, a1 = min(A, a0 + per);
+    if (a0 >= A) continue;         // trailing chunk with nothing in it
+    const int p1 = min(a1, hf.P);  // points of the chunk: [a0, p1); the pass slot is in the chunk iff a1 == A
+    const int base = hf.hl * N;
+    const int lo = max(0, min(N, a0 - base)), hi = max(0, min(N, p1 - base));
+    const uint32_t below_lo = (1u << lo) - 1u, below_hi = (1u << hi) - 1u;
+    // empty points: total, list, and the index range [t0, t1) of those inside the chunk
+    const uint32_t ecnt = (uint32_t)__popc(e);
+    const uint32_t eincl = half_scan(ecnt);
+    const int E = __builtin_amdgcn_readlane((int)eincl, 31);
+    const int t0 = __builtin_amdgcn_readlane((int)half_scan((uint32_t)__popc(e & below_lo)), 31);
+    const int t1 = __builtin_amdgcn_readlane((int)half_scan((uint32_t)__popc(e & below_hi)), 31);
+    WAVE_SYNC();  // staging buffer read out
+    if (hf.h == 0) {
+      planes[hf.hl] = mine;
+      planes[32 + hf.hl] = opp;
+      planes[64 + hf.hl] = __brev(mine);
+      planes[96 + hf.hl] = __brev(opp);
+      if (hf.hl < N) {
+        const uint32_t off = eincl - ecnt;
+#pragma unroll
+        for (int c = 0; c < R; ++c)
+          if (c < N && ((e >> c) & 1u)) elist[off + (uint32_t)__popc(e & ((1u << c) - 1u))] = (uint16_t)(base + c);
+      }
+    }
+    WAVE_SYNC();
+
+    // lane (h, l): flood colour h from the stones adjacent to empty point #(tbase + l); result -> sc[lane][row].
+    // Returns the lane's point (action index), -1 if there is none.
+    auto flood_batch = [&](int tbase) -> int {
+      uint32_t m[R], mrev[R], f[R];
+      const int t = tbase + hf.hl;
+      const bool have = t < E;
+      const int x = have ? (int)elist[t] : 0;
+      int xr, xc;
+      split_action(x, N, hf.inv, xr, xc);
+      const uint32_t bit = have ? (1u << xc) : 0u, hb = (bit << 1) | (bit >> 1);
+      {
+        uint32_t mt[RV * 4], rt[RV * 4];
+        const uint4 *pm = reinterpret_cast<const uint4 *>(planes + (hf.h ? 32 : 0));
+        const uint4 *pr = reinterpret_cast<const uint4 *>(planes + 64 + (hf.h ? 32 : 0));
+#pragma unroll
+        for (int i = 0; i < RV; ++i) {
+          const uint4 a = pm[i], c = pr[i];
+          mt[4 * i] = a.x; mt[4 * i + 1] = a.y; mt[4 * i + 2] = a.z; mt[4 * i + 3] = a.w;
+          rt[4 * i] = c.x; rt[4 * i + 1] = c.y; rt[4 * i + 2] = c.z; rt[4 * i + 3] = c.w;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          m[r] = mt[r];
+          mrev[r] = rt[r];
+          const uint32_t sd = (r == xr) ? hb : ((r == xr - 1 || r == xr + 1) ? bit : 0u);
+          f[r] = m[r] & sd;
+        }
+      }
+      WAVE_SYNC();  // earlier readers of sc are done
+      flood2_serial<R>(m, mrev, f, sc + hf.lane * RS);
+      WAVE_SYNC();
+      return have ? x : -1;
+    };
+
+    // pass 1: exact liberty counts (saturated at 3) - half 0 counts for the mover's stones, half 1 for the opponent's
+    uint32_t ge1 = 0, ge2 = 0, ge3 = 0;
+    const int nbatch = (E + 31) >> 5;
+#pragma unroll 1
+    for (int i = 0; i < nbatch; ++i) {
+      flood_batch(32 * i);
+      const int cnt = min(32, E - 32 * i);
+      if (hf.hl < R) {
+        const uint32_t *col = sc + (32 * hf.h) * RS + hf.hl;
+#pragma unroll 4
+        for (int t = 0; t < cnt; ++t) {
+          const uint32_t x = col[t * RS];
+          ge3 = B3(ge2, x, ge3, T_ANDOR);
+          ge2 = B3(ge1, x, ge2, T_ANDOR);
+          ge1 |= x;
+        }
+      }
+    }
+    const uint32_t o2 = (uint32_t)__shfl((int)ge2, hf.lane ^ 32), o3 = (uint32_t)__shfl((int)ge3, hf.lane ^ 32);
+    const uint32_t Mm = hf.h ? o2 : ge2;    // mover's stones with >= 2 liberties
+    const uint32_t Mo = hf.h ? ge2 : o2;    // opponent's stones with >= 2 liberties
+    const uint32_t T3o = hf.h ? ge3 : o3;   // ... with >= 3
+
+    // Streaming emitter.  The slots [a0, a1) of this parent are one contiguous byte range; it is written strictly in
+    // address order as ALIGNED 1 KB blocks (64 lanes x 16 B, the store pattern that reaches memset-like bandwidth:
+    // tools/ubench/write_patterns.hip).  `ring` is a sliding window of the output as a bit-string (bit i = byte
+    // origin[i]); a child ORs its 6 N^2 bits into it, a block leaves through the spread table once every child
+    // overlapping it has been emitted, and the all-zero slots of the illegal actions cost nothing but zero stores.
+    uint8_t *const cstart = gc + (int64_t)a0 * S;
+    const uint32_t start_bit = (uint32_t)((uintptr_t)cstart & (kBlk - 1u));
+    uint8_t *const origin = cstart - start_bit;
+    const uint32_t end_bit = start_bit + (uint32_t)(a1 - a0) * (uint32_t)S;
+    uint32_t sbase = 0, dirty_end = 0;   // wave-uniform: window start (multiple of kBlk); no bit set at or above dirty_end
+    auto flush_until = [&](uint32_t target) {
+#pragma unroll 1
+      while (sbase < target) {
+        const uint32_t off = sbase + 16u * (uint32_t)hf.lane;   // this lane's vector = bytes [off, off + 16)
+        const bool dirty = sbase < dirty_end;
+        V16a o = {{0u, 0u, 0u, 0u}};
+        if (dirty) {
+          const uint8_t *bb = reinterpret_cast<const uint8_t *>(ring) + ((sbase >> 3) & (4u * kRingWords - 1u));
+          const uint2 lo = lut[bb[2 * hf.lane]], hi = lut[bb[2 * hf.lane + 1]];
+          o.w[0] = lo.x; o.w[1] = lo.y; o.w[2] = hi.x; o.w[3] = hi.y;
+        }
+        if (off >= start_bit && off + 16u <= end_bit) {
+          *reinterpret_cast<V16a *>(origin + off) = o;
+        } else if (off + 16u > start_bit && off < end_bit) {   // the ragged vector at either end of the chunk: bytes
+#pragma unroll
+          for (int t = 0; t < 16; ++t)
+            if (off + t >= start_bit && off + t < end_bit) origin[off + t] = (uint8_t)(o.w[t >> 2] >> (8 * (t & 3)));
+        }
+        asm volatile("" ::: "memory");
+        if (dirty && hf.lane < 32) ring[((sbase >> 5) & (kRingWords - 1u)) + hf.lane] = 0;
+        sbase += kBlk;
+      }
+    };
+    auto or_bits = [&](uint32_t p, uint32_t b0, uint32_t b1, uint32_t b3, uint32_t turn, uint32_t passed,
+                       uint32_t done, bool wr) {
+      if (wr && hf.hl < hf.N) {
+        const uint32_t rows[6] = {b0, b1, turn ? hf.full_l1 : 0u, b3, passed ? hf.full_l1 : 0u, done ? hf.full_l1 : 0u};
+        const uint32_t q0 = p + (uint32_t)(hf.hl * hf.N);
+#pragma unroll
+        for (int pn = 0; pn < 6; ++pn) {
+          if (rows[pn]) {
+            const uint32_t q = q0 + (uint32_t)(pn * hf.P);
+            const uint64_t x = (uint64_t)rows[pn] << (q & 31u);
+            const uint32_t wi = (q >> 5) & (kRingWords - 1u);
+            atomicOr(&ring[wi], (uint32_t)x);
+            if ((uint32_t)(x >> 32)) atomicOr(&ring[(wi + 1u) & (kRingWords - 1u)], (uint32_t)(x >> 32));
+          }
+        }
+      }
+    };
+    // one child per half: `a` = its action, `tj` = flood lane of its point inside the current batch (-1: pass)
+    auto child = [&](int a, int tj, bool on) {
+      const bool is_pass = tj < 0;
+      uint32_t nmine = mine, nopp = opp, invalid;
+      if (__ballot(on && !is_pass) == 0) {
+        invalid = invalid_from2(opp, mine, Mo, Mm, hf);
+      } else {
+        const int tl = is_pass ? 0 : tj;
+        uint32_t Rm = 0, Ro = 0;
+        if (hf.hl < R && !is_pass) {
+          Rm = sc[tl * RS + hf.hl];
+          Ro = sc[(32 + tl) * RS + hf.hl];
+        }
+        int ra, ca;
+        split_action(is_pass ? 0 : a, N, hf.inv, ra, ca);
+        const uint32_t bit = is_pass ? 0u : (1u << ca);
+        const uint32_t qrow = hf.hl == ra ? bit : 0u;
+        uint32_t nbm = hf.hl == ra ? ((bit << 1) | (bit >> 1)) : ((hf.hl == ra - 1 || hf.hl == ra + 1) ? bit : 0u);
+        nbm &= hf.full_l1;
+        const bool boxed = half_of(__ballot((nbm & ~opp) != 0), hf.h) == 0;
+        const uint32_t cap = Ro & ~Mo;               // adjacent opponent groups whose only liberty was q
+        nopp = opp & ~cap;
+        nmine = mine | qrow;
+        const uint32_t G = Rm | qrow;
+        const uint32_t e2 = hf.full_l1 & ~(nmine | nopp);
+        const uint32_t dil = B3(shl1(G), G >> 1, dpp0<0x138>(G), T_OR3) | dpp0<0x130>(G);
+        const uint32_t libs = dil & e2;
+        const uint32_t nz = half_of(__ballot(libs != 0), hf.h);
+        const uint32_t many = half_of(__ballot(__popc(libs) > 1), hf.h);
+        const bool multiG = ((nz & (nz - 1u)) | many) != 0;
+        uint32_t Mm2 = (Mm & ~Rm) | (multiG ? G : 0u);
+        if (__ballot(cap != 0)) {
+          // gogame.py:72-75: ko iff exactly one stone died and the new stone is boxed in
+          const uint32_t dm = half_of(__ballot(cap != 0), hf.h);
+          const uint32_t manyc = half_of(__ballot(__popc(cap) > 1), hf.h);
+          int ko_r = -1, ko_c = 0;
+          if (dm && boxed && manyc == 0 && (dm & (dm - 1u)) == 0) {
+            ko_r = __ffs(dm) - 1;
+            ko_c = __ffs(__shfl(cap, (hf.lane & 32) + ko_r)) - 1;
+          }
+          // mover's groups in atari next to a captured group (and not merged into G) now have >= 2 liberties
+          const uint32_t atari_m = mine & ~Mm;
+          const uint32_t dcap = B3(shl1(cap), cap >> 1, dpp0<0x138>(cap), T_OR3) | dpp0<0x130>(cap);
+          uint32_t f = dcap & atari_m & ~G;
+          if (__ballot(f != 0)) {
+#pragma unroll 1
+            for (int it = 0; it < R * R; ++it) {
+              const uint32_t grow = B3(shl1(f), f >> 1, dpp0<0x138>(f), T_OR3) | dpp0<0x130>(f);
+              const uint32_t g = B3(grow, atari_m, f, T_ANDOR);
+              const bool chg = g != f;
+              f = g;
+              if (__ballot(chg) == 0) break;
+            }
+            Mm2 |= f;
+          }
+          const uint32_t Mo2 = (Mo & ~Ro) | (Ro & T3o);
+          invalid = invalid_from2(nopp, nmine, Mo2, Mm2, hf);
+          if (hf.hl == ko_r) invalid |= 1u << ko_c;
+        } else {
+          const uint32_t Mo2 = (Mo & ~Ro) | (Ro & T3o);
+          invalid = invalid_from2(nopp, nmine, Mo2, Mm2, hf);
+        }
+      }
+      uint32_t nb = pl ? nopp : nmine, nw = pl ? nmine : nopp;
+      const uint32_t passed = is_pass ? 1 : 0;
+      const uint32_t done = ((flags & 8u) || (is_pass && (flags & 4u))) ? 1 : 0;
+      int nturn = 1 - pl;
+      if (canonical && nturn == 1) {
+        const uint32_t t = nb; nb = nw; nw = t;
+        nturn = 0;
+      }
+      // both children are emitted in slot order; the window is advanced up to the block the next child starts in
+      const uint32_t pbit = start_bit + (uint32_t)(a - a0) * (uint32_t)S;
+      const uint32_t pA = (uint32_t)__builtin_amdgcn_readlane((int)pbit, 0), pB = (uint32_t)__builtin_amdgcn_readlane((int)pbit, 32);
+      const bool onB = (__ballot(on) >> 32) != 0;
+      WAVE_SYNC();
+      flush_until(pA & ~(kBlk - 1u));
+      WAVE_SYNC();
+      if (!onB || pB + (uint32_t)S <= sbase + kRingBits) {
+        or_bits(pbit, nb, nw, invalid, (uint32_t)nturn, passed, done, on);
+        dirty_end = onB ? pB + (uint32_t)S : pA + (uint32_t)S;
+      } else {
+        or_bits(pbit, nb, nw, invalid, (uint32_t)nturn, passed, done, on && hf.h == 0);
+        dirty_end = pA + (uint32_t)S;
+        WAVE_SYNC();
+        flush_until(pB & ~(kBlk - 1u));
+        WAVE_SYNC();
+        or_bits(pbit, nb, nw, invalid, (uint32_t)nturn, passed, done, on && hf.h == 1);
+        dirty_end = pB + (uint32_t)S;
+      }
+    };
+
+    // pass 2: the chunk's empty points, 32 per flood batch, two legal children per L1 pass
+#pragma unroll 1
+    for (int tb = t0; tb < t1; tb += 32) {
+      int x;
+      if (nbatch == 1 && tb == 0) {   // pass 1's only batch is still in sc
+        const int t = hf.hl;
+        x = t < E ? (int)elist[t] : -1;
+      } else {
+        x = flood_batch(tb);
+      }
+      int xr, xc;
+      split_action(x < 0 ? 0 : x, N, hf.inv, xr, xc);
+      const uint32_t irow = __shfl(invd, xr);   // every lane executes the exchange (a masked-off source lane reads as 0)
+      const bool legal = x >= 0 && tb + hf.hl < t1 && ((irow >> xc) & 1u) == 0;
+      uint32_t lm = (uint32_t)__ballot(legal);   // low half: lanes 0-31 carry the 32 points of the batch
+#pragma unroll 1
+      while (lm) {
+        const int j0 = __ffs(lm) - 1;
+        lm &= lm - 1u;
+        const int j1 = lm ? __ffs(lm) - 1 : -1;
+        lm &= lm - 1u;
+        const int tj = hf.h ? j1 : j0;
+        const bool on = tj >= 0;
+        const int a = __shfl(x, on ? tj : j0);
+        child(a, on ? tj : j0, on);
+      }
+    }
+    if (a1 == A) child(hf.P, -1, hf.h == 0);
+    WAVE_SYNC();
+    flush_until((end_bit + kBlk - 1u) & ~(kBlk - 1u));
+    WAVE_SYNC();
   }
 }
 

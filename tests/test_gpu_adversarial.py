@@ -165,3 +165,43 @@ def test_full_size_properties_and_shard_invariance():
     rng_np = np.array([c_oracle.lib().gg_oracle_rng_seed(seed, int(i)) for i in idx], dtype=np.uint64)
     want, _, _ = c_oracle.batch_rollout(np.zeros((len(idx), 6, N, N), np.uint8), rng_np, plies, True)
     assert np.array_equal(s[torch.as_tensor(idx, device='cuda')].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('N,B,plies', [(19, 96, (30, 120, 250, 330)), (13, 64, (20, 90, 150)), (9, 128, (10, 40, 70)),
+                                        (5, 64, (6, 14, 22)), (3, 32, (3, 7)), (2, 16, (1, 3))])
+def test_children_many_positions(N, B, plies):
+    """gg_batch_children (incremental kernel: per-parent liberty counts + per-point group floods) on positions of
+    every game phase - captures, ko, snapbacks, merges - both canonical settings, against the oracle
+    (gym_go/gogame.py:175-186)."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, 1234 + N)
+    done = 0
+    for p in plies:
+        gogame.batch_rollout(st, rng, p - done, auto_reset=False)
+        done = p
+        host = st.cpu().numpy()
+        live = host[:, 5, 0, 0] == 0      # gogame.children of a finished game is undefined in the reference
+        if not live.any():
+            continue
+        d = st[torch.from_numpy(live).cuda()].contiguous()
+        for canon in (False, True):
+            kids = gogame.batch_children(d, canonical=canon).cpu().numpy()
+            want = c_oracle.batch_children(host[live], canon)
+            assert np.array_equal(kids, want), (N, p, canon, np.argwhere((kids != want).reshape(len(kids), N * N + 1, -1).any(-1))[:5])
+
+
+def test_children_single_chunk_path():
+    """B large enough that every wave expands all N*N+1 slots of its parent (chunks == 1)."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    B, N = 4608, 9
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, 99)
+    gogame.batch_rollout(st, rng, 45, auto_reset=True)
+    host = st.cpu().numpy()
+    live = host[:, 5, 0, 0] == 0
+    d = st[torch.from_numpy(live).cuda()].contiguous()
+    kids = gogame.batch_children(d, canonical=False).cpu().numpy()
+    assert np.array_equal(kids, c_oracle.batch_children(host[live], False))
