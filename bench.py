@@ -86,7 +86,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from gymgo_amd import gogame
+    from gymgo_amd import _lib, gogame
     from gymgo_amd.envs.vec_env import shard
 
     local_rank %= max(1, torch.cuda.device_count())
@@ -157,7 +157,22 @@ def main():
         acts = gogame.batch_sample_actions(states, rng)
         also['gg_batch_next_states_steps_per_s'] = round(
             rate(lambda: gogame.batch_next_states(states, acts, check=False), 16), 1)
-        also['note'] = 'same resident batch; kernel-event time of 1-ply launches / of the out-of-place step API'
+        also['gg_batch_env_step_steps_per_s'] = round(
+            rate(lambda: gogame.batch_env_step(states, None, rng, 7.5, 'real', True), 16), 1)
+        if args.size == 19 and count >= 8192:   # BASELINE config 5: 8 192 mid-game parents, padded 362-slot expansion
+            parents = states[:8192]
+            kids = torch.empty((8192, args.size ** 2 + 1, 6, args.size, args.size), dtype=torch.uint8, device=dev)
+            lib, n = _lib.lib(), args.size
+
+            def expand():
+                _lib.check(lib.gg_batch_children(_lib.dev_ptr(parents, torch.uint8, 'states'), _lib.dev_ptr(kids, torch.uint8, 'children'),
+                                                 8192, n, 0, _lib.stream_ptr(dev)), 'gg_batch_children')
+            per_s = rate(expand, 8) * 8192 / count
+            also['gg_batch_children_parents_per_s'] = round(per_s, 1)
+            also['gg_batch_children_write_roofline_frac'] = round(per_s * 786258 / 8e12, 4)
+            del kids
+        also['note'] = ('same resident batch; kernel-event time of 1-ply launches / of the out-of-place step API / of the fused '
+                        'GoEnv.step (sample + step + areas + reward) / of the 362-slot children expansion of 8 192 parents')
 
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if world > 1:

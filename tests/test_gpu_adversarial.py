@@ -205,3 +205,52 @@ def test_children_single_chunk_path():
     d = st[torch.from_numpy(live).cuda()].contiguous()
     kids = gogame.batch_children(d, canonical=False).cpu().numpy()
     assert np.array_equal(kids, c_oracle.batch_children(host[live], False))
+
+
+def test_children_config5_size_matches_step_kernel():
+    """BASELINE config 5 size (8 192 mid-game 19x19 parents, 362 padded slots each = 6.4 GB): every legal slot of
+    gg_batch_children (incremental kernel) equals gg_batch_next_states of the parent (an independent kernel that
+    analyses the child from scratch), every illegal slot is all zero - checked slice by slice on the device."""
+    from gymgo_amd import gogame
+    B, N = 8192, 19
+    A = N * N + 1
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, 20260927)
+    for g in range(4):   # de-synchronised phases: 60 ... 330 plies
+        gogame.batch_rollout(st[g * 2048:(g + 1) * 2048], rng[g * 2048:(g + 1) * 2048], 60 + 90 * g, auto_reset=False)
+    st = st[st[:, 5, 0, 0] == 0].contiguous()
+    kids = gogame.batch_children(st, canonical=False)
+    assert kids.shape == (len(st), A, 6, N, N)
+    valid = torch.cat([st[:, 3].reshape(len(st), -1) == 0, torch.ones(len(st), 1, dtype=torch.bool, device='cuda')], 1)
+    assert not bool(kids[~valid].any())
+    acts = torch.arange(A, dtype=torch.int32, device='cuda')
+    for lo in range(0, len(st), 512):
+        par = st[lo:lo + 512]
+        v = valid[lo:lo + 512]
+        idx = v.nonzero()
+        rep = par[idx[:, 0]].contiguous()
+        out, status = gogame.batch_next_states(rep, acts[idx[:, 1]].contiguous(), check=False)
+        assert int(status.sum()) == 0
+        assert torch.equal(kids[lo:lo + 512][v], out), lo
+
+
+def test_env_step_config3_size_matches_fused_rollout():
+    """65 536 x 19x19 (BASELINE config 3): K fused GoEnv.step launches with on-device sampling walk exactly the
+    trajectory of one K-ply gg_batch_rollout launch (same generator), rewards/dones consistent with the states."""
+    from gymgo_amd import gogame
+    from gymgo_amd.envs import GoVecEnv
+    B, N, K = 65536, 19, 24
+    env = GoVecEnv(B, N, komi=7.5, reward_method='heuristic', seed=11)
+    env.rollout(200)
+    ref = env.states.clone()
+    ref_rng = env.rng.clone()
+    for _ in range(K):
+        states, rewards, dones, status = env.step()
+        assert int(status.sum()) == 0
+    gogame.batch_rollout(ref, ref_rng, K, True)
+    assert torch.equal(states, ref) and torch.equal(env.rng, ref_rng)
+    b, w = gogame.batch_areas(states)
+    margin = (b - w).float() - 7.5
+    over = states[:, 5, 0, 0] == 1
+    want = torch.where(over, torch.where(margin > 0, 361.0, -361.0), margin)
+    assert torch.equal(rewards, want) and torch.equal(dones, states[:, 5, 0, 0])
