@@ -13,4 +13,7 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- $SHORT > $O/pmc_write.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_inst -o p -- $SHORT > $O/pmc_inst.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_act -o p -- $SHORT > $O/pmc_act.log 2>&1
+# the per-ply / children / areas entry points: throughput table + kernel stats of the same script
+timeout 300 python $R/tools/bench_ops.py > $O/ops.json 2> $O/ops.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_ops -o kt -- python $R/tools/bench_ops.py > $O/kt_ops.log 2>&1
 cat $O/bench.json

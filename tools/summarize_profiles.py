@@ -23,10 +23,12 @@ stats = list(csv.DictReader(open(os.path.join(src, 'kt', 'kt_kernel_stats.csv'))
 
 
 def counters(sub, want='rollout'):
+    """Per-dispatch counters of the full-batch launches (the de-synchronising burn-in launches run on 1/16 slices)."""
     rows = list(csv.DictReader(open(os.path.join(src, sub, 'p_counter_collection.csv'))))
+    full = max(int(r['Grid_Size']) for r in rows if want in r['Kernel_Name'])
     per = collections.defaultdict(dict)
     for r in rows:
-        if want in r['Kernel_Name']:
+        if want in r['Kernel_Name'] and int(r['Grid_Size']) == full:
             d = per[int(r['Dispatch_Id'])]
             d[r['Counter_Name']] = float(r['Counter_Value'])
             d['_vgpr'], d['_sgpr'], d['_lds'] = r.get('VGPR_Count'), r.get('SGPR_Count'), r.get('LDS_Block_Size')
@@ -43,9 +45,14 @@ md.append('| kernel | calls | avg ns | total % |\n|---|---|---|---|')
 for r in stats[:4]:
     md.append('| `%s` | %s | %.0f | %s |' % (r['Name'][:70], r['Calls'], float(r['AverageNs']), r['Percentage']))
 roll = [r for r in stats if 'k_rollout' in r['Name']][0]
-md.append('\nbench.py live launch_ms = %.4f; rocprofv3 average of the same kernel = %.4f ms over %s launches (burn-in, '
-          'warm-up and timed launches all have the same shape: %d plies)'
-          % (bench['roofline']['launch_ms'], float(roll['AverageNs']) / 1e6, roll['Calls'], F))
+trace = [r for r in csv.DictReader(open(os.path.join(src, 'kt', 'kt_kernel_trace.csv'))) if 'k_rollout' in r['Kernel_Name']]
+full = max(int(r['Grid_Size_X']) for r in trace)
+durs = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in trace if int(r['Grid_Size_X']) == full]
+md.append('\nbench.py live launch_ms = %.4f; rocprofv3 average of the %d full-batch launches of the same kernel (burn-in, warm-up, '
+          'timed: %d plies each) = %.4f ms.  The stats row above averages %s launches: %d of them are the de-synchronising '
+          'burn-in launches on 1/16 slices of the batch (kt_kernel_trace: grid %d vs %d threads).'
+          % (bench['roofline']['launch_ms'], len(durs), F, sum(durs) / len(durs) / 1e6, roll['Calls'],
+             int(roll['Calls']) - len(durs), min(int(r['Grid_Size_X']) for r in trace), full))
 
 steps = games * F
 traffic = {}
@@ -74,5 +81,13 @@ for sub in ('pmc_inst', 'pmc_act'):
     md.append('  (LDS %s B per 64-thread workgroup)' % c[0]['_lds'])
 md.append('\nSQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles. The kernel is VALU-issue / dependency-latency bound, '
           'not HBM-bound: per-op issue costs (2 or 4 cycles per wave64) are in profiles/r01_ubench_valu_rates.txt.')
+ops_stats = os.path.join(src, 'kt_ops', 'kt_kernel_stats.csv')
+if os.path.exists(ops_stats):
+    shutil.copy(ops_stats, os.path.join(dst, tag + '_ops_kernel_stats.csv'))
+    shutil.copy(os.path.join(src, 'ops.json'), os.path.join(dst, tag + '_ops.json'))
+    md.append('\n## the other entry points (`tools/bench_ops.py`, rocprofv3 --kernel-trace --stats; %s_ops.json has the rates)\n' % tag)
+    md.append('| kernel | calls | avg ns |\n|---|---|---|')
+    for r in list(csv.DictReader(open(ops_stats)))[:14]:
+        md.append('| `%s` | %s | %.0f |' % (r['Name'][:80], r['Calls'], float(r['AverageNs'])))
 open(os.path.join(dst, tag + '_summary.md'), 'w').write('\n'.join(md) + '\n')
 print('\n'.join(md))
