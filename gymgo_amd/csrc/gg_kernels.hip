@@ -242,10 +242,15 @@ int32_t gg_batch_env_step(uint8_t *states, const int32_t *actions, uint64_t *rng
   if (!inv) return GG_E_BADSIZE;
   hipStream_t s = (hipStream_t)hip_stream;
   const int grid = grid_for((B + 1) / 2);
-  const int heur = reward_method == GG_REWARD_HEURISTIC;
-  GG_DISPATCH(N, (k_env_step2<9><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, heur, auto_reset)),
-              (k_env_step2<13><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, heur, auto_reset)),
-              (k_env_step2<19><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, heur, auto_reset)));
+  if (reward_method == GG_REWARD_HEURISTIC) {
+    GG_DISPATCH(N, (k_env_step2<9, true><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
+                (k_env_step2<13, true><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
+                (k_env_step2<19, true><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)));
+  } else {
+    GG_DISPATCH(N, (k_env_step2<9, false><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
+                (k_env_step2<13, false><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
+                (k_env_step2<19, false><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)));
+  }
   return (int32_t)hipGetLastError();
 }
 

@@ -98,7 +98,8 @@ struct Lds2 {
 // stone (needs make_half(..., areas = true)).
 template <int R, bool DUAL, bool AREAS = false>
 __device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, const Half &hf, uint32_t *lds,
-                                         uint32_t &multi0, uint32_t &alive0, uint32_t &multi1, uint32_t *reach = nullptr) {
+                                         uint32_t &multi0, uint32_t &alive0, uint32_t &multi1, uint32_t *reach = nullptr,
+                                         uint32_t *alive1_out = nullptr) {
   constexpr int RS = Cfg<R>::kRowStride;
   constexpr int RV = (R + 3) / 4;
   uint32_t *sc = lds;
@@ -146,6 +147,7 @@ __device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, c
   else flood2_serial<R>(m, mrev, f, sc + hf.lane * RS);
   WAVE_SYNC();
   multi0 = 0; multi1 = 0; alive0 = 0;
+  if (alive1_out) *alive1_out = 0;
   if (AREAS) { reach[0] = 0; reach[1] = 0; }
   if (hf.hl < R) {
     const uint32_t *base = sc + (hf.h * 32) * RS + hf.hl;
@@ -158,6 +160,7 @@ __device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, c
     uint32_t alive1;
     classify11(w0, alive0, multi0);
     classify11(w1, alive1, multi1);
+    if (alive1_out) *alive1_out = alive1;
     if (AREAS) {
       reach[0] = base[kCwLanes * RS];
       reach[1] = base[(kCwLanes + 1) * RS];
@@ -229,18 +232,43 @@ __device__ __forceinline__ uint32_t step_core2(uint32_t &mine, uint32_t &opp, in
     uint32_t e = hf.full_l1 & ~(mine | opp);
     analyze2<R, DUAL, AREAS>(opp, mine, e, hf, lds, multi_opp, alive_opp, multi_mine, reach);
   } else {
+    uint32_t e = hf.full_l1 & ~(mine | opp);
+    uint32_t alive_mine;
+    analyze2<R, DUAL, AREAS>(opp, mine, e, hf, lds, multi_opp, alive_opp, multi_mine, reach, &alive_mine);
+    const uint32_t dead = is_pass ? 0u : (opp & ~alive_opp);
+    if (__ballot(dead != 0)) {   // some board of the wave captured
+      capture(dead);
+      if (AREAS) {
+        // the territory floods saw the captured stones: analyse the final position again
+        e = hf.full_l1 & ~(mine | opp);
+        analyze2<R, DUAL, AREAS>(opp, mine, e, hf, lds, multi_opp, alive_opp, multi_mine, reach);
+      } else {
+        // No second analysis: removing `dead` only gives liberties to the mover's groups next to it.
+        //  * the group of the new stone, if it had none (G0 = every mover's stone without a liberty): its liberties
+        //    are exactly the captured points next to it;
+        //  * a group in atari next to a captured stone now has >= 2 (its old liberty was an empty point, the new ones
+        //    were stones) - completed by an L1 flood through the atari set;  groups with >= 2 keep >= 2.
+        // The opponent's surviving groups touch no captured point (they would be the same group).
+        const uint32_t G0 = mine & ~alive_mine;
+        const uint32_t dG = B3(shl1(G0), G0 >> 1, dpp0<0x138>(G0), T_OR3) | dpp0<0x130>(G0);
+        const uint32_t l0 = dG & dead;
+        const uint32_t nz = half_of(__ballot(l0 != 0), hf.h), many = half_of(__ballot(__popc(l0) > 1), hf.h);
+        const bool multi0 = ((nz & (nz - 1u)) | many) != 0;
+        const uint32_t atari_m = mine & alive_mine & ~multi_mine;
+        const uint32_t dd = B3(shl1(dead), dead >> 1, dpp0<0x138>(dead), T_OR3) | dpp0<0x130>(dead);
+        uint32_t f = dd & atari_m;
+        if (__ballot(f != 0)) {
 #pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-      uint32_t e = hf.full_l1 & ~(mine | opp);
-      analyze2<R, DUAL, AREAS>(opp, mine, e, hf, lds, multi_opp, alive_opp, multi_mine, reach);
-      if (pass == 0) {
-        uint32_t dead = is_pass ? 0u : (opp & ~alive_opp);
-        if (__ballot(dead != 0)) {  // some board of the wave captured: fix it up, analyse both again
-          capture(dead);
-          continue;
+          for (int it = 0; it < R * R; ++it) {
+            const uint32_t grow = B3(shl1(f), f >> 1, dpp0<0x138>(f), T_OR3) | dpp0<0x130>(f);
+            const uint32_t g = B3(grow, atari_m, f, T_ANDOR);
+            const bool ch = g != f;
+            f = g;
+            if (__ballot(ch) == 0) break;
+          }
         }
+        multi_mine |= f | (multi0 ? G0 : 0u);
       }
-      break;
     }
   }
   atari_out = mine & ~multi_mine;
@@ -712,15 +740,19 @@ __global__ __launch_bounds__(kWave, PERPLY ? GG_LB_PLY : 4) void k_rollout2(uint
 // One GoEnv.step for every game of a batched env, in place, one launch (gym_go/envs/go_env.py:49-76):
 // auto-reset of finished games (:40-47), the action (given, or drawn like uniform_random_action :78-81), the legality
 // check (gogame.py:59), next_state, game_ended and GoEnv.reward (:128-149; Tromp-Taylor areas gogame.py:275-300).
-// The two area floods of the post-move position ride in the idle flood lanes of the liberty analysis.
-template <int R>
+// HEUR (reward_method heuristic: the area margin is the reward of every ply): the two area floods of the post-move
+// position ride in the idle flood lanes of the liberty analysis.  !HEUR (reward_method real): the areas only matter
+// when a game ends, so the step runs the plain analysis and a wave whose pair just finished a game (two passes: no
+// stone moved, the liberty classes are not needed again) runs one more analysis for the territory.
+template <int R, bool HEUR>
 __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_env_step2(uint8_t *__restrict__ states, const int32_t *__restrict__ actions,
                                                         uint64_t *__restrict__ rng, float *__restrict__ rewards,
                                                         uint8_t *__restrict__ dones, int32_t *__restrict__ status,
                                                         int32_t *__restrict__ taken, int64_t B, int N, uint32_t inv,
-                                                        float komi, int heuristic, int auto_reset) {
+                                                        float komi, int auto_reset) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
-  const Half hf = make_half(threadIdx.x, N, inv, true);
+  const Half hf = make_half(threadIdx.x, N, inv, HEUR);
+  const Half hfa = make_half(threadIdx.x, N, inv, true);   // lanes 22 / 23 of each half flood the empty points
   __shared__ uint2 lut[256];
   load_cw_table<R>(lds, hf.lane);
   load_spread_lut(lut, hf.lane);
@@ -771,9 +803,9 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_env_step2(uint8_t *__restr
       bad = bad || ((row >> ac) & 1u);
     }
     uint32_t mine = turn ? white : black, opp = turn ? black : white;
-    uint32_t atari_unused, reach[2];
+    uint32_t atari_unused, reach[2] = {0u, 0u};
     // a refused half still runs the (wave-wide) analysis on a harmless pass: it yields the areas of its position
-    const uint32_t ninv = step_core2<R, false, true>(mine, opp, bad ? hf.P : a, hf, lds, 0u, false, atari_unused, reach);
+    const uint32_t ninv = step_core2<R, false, HEUR>(mine, opp, bad ? hf.P : a, hf, lds, 0u, false, atari_unused, reach);
     if (!bad) {
       invalid = ninv;
       black = turn ? opp : mine;
@@ -781,6 +813,10 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_env_step2(uint8_t *__restr
       if (a == hf.P) { if (passed) done = 1; passed = 1; } else passed = 0;
       turn ^= 1;
       wr = true;
+    }
+    if (!HEUR && __ballot(on && done)) {   // a game of the pair is over (or was refused as over): score it
+      uint32_t m0, a0, m1;
+      analyze2<R, false, true>(opp, mine, hf.full_l1 & ~(mine | opp), hfa, lds, m0, a0, m1, reach);
     }
     // analyze2 saw (c0, c1) = (opp, mine) of the mover: reach[0] = empties touching opp's colour, reach[1] = mine's
     const bool mover_white = bad ? turn : !turn;   // turn was flipped on commit
@@ -794,7 +830,7 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_env_step2(uint8_t *__restr
     if (on && hf.hl == 31) {
       const float margin = (float)((int)ab - (int)aw) - komi;
       float rwd;
-      if (heuristic) rwd = done ? (margin > 0.f ? 1.f : -1.f) * (float)hf.P : margin;
+      if (HEUR) rwd = done ? (margin > 0.f ? 1.f : -1.f) * (float)hf.P : margin;
       else rwd = done ? (margin > 0.f ? 1.f : margin < 0.f ? -1.f : 0.f) : 0.f;
       if (rewards) rewards[b] = rwd;
       if (dones) dones[b] = (uint8_t)done;
