@@ -27,6 +27,11 @@ class GoVecEnv:
         self.rng = gogame.rng_seed(batch_size, seed, first_game, self.device)
         self.steps_done = torch.zeros(batch_size, dtype=torch.int64, device=self.device)
         self.last_actions = torch.full((batch_size,), -1, dtype=torch.int32, device=self.device)
+        # step() outputs live in fixed buffers (rewards, dones, status; the action taken goes to last_actions): no
+        # allocation per step, and the step can be captured in a hipGraph.  They are overwritten by the next step.
+        self._step_out = (torch.empty(batch_size, dtype=torch.float32, device=self.device),
+                          torch.empty(batch_size, dtype=torch.uint8, device=self.device),
+                          torch.empty(batch_size, dtype=torch.int32, device=self.device), self.last_actions)
 
     def reset(self, mask=None):
         if mask is None:
@@ -45,14 +50,14 @@ class GoVecEnv:
     def step(self, actions=None, check=False):
         """One GoEnv.step per game in ONE launch -> (states, rewards, dones, status).  actions=None draws a
         uniform-random valid action per game on the device (it is left in self.last_actions).  Finished games are
-        reset first when auto_reset; rewards are float32, black's perspective (gym_go/envs/go_env.py:128-149)."""
+        reset first when auto_reset; rewards are float32, black's perspective (gym_go/envs/go_env.py:128-149).
+        The returned rewards / dones / status are views of fixed buffers, overwritten by the next step()."""
         if actions is not None:
             actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
         rewards, dones, status, taken = gogame.batch_env_step(self.states, actions, self.rng, self.komi,
-                                                              self.reward_method, self.auto_reset)
+                                                              self.reward_method, self.auto_reset, out=self._step_out)
         if check and bool((status != 0).any()):
             raise AssertionError('illegal move in batch')
-        self.last_actions = taken
         self.steps_done += (status == 0)
         return self.states, rewards, dones, status
 
@@ -64,7 +69,7 @@ class GoVecEnv:
         self.states, status = gogame.batch_next_states(self.states, actions, check=False)
         if check and bool((status != 0).any()):
             raise AssertionError('illegal move in batch')
-        self.last_actions = actions
+        self.last_actions.copy_(actions)
         self.steps_done += (status == 0).to(torch.int64)
         dones = self.states[:, govars.DONE_CHNL, 0, 0]   # planes 2/4/5 are uniform: one byte per game
         return self.states, self.rewards(dones), dones, status

@@ -429,25 +429,26 @@ def batch_rollout(batch_states, rng, plies, auto_reset=True, last_actions=None, 
 REWARD_METHODS = {'real': 0, 'heuristic': 1}   # GG_REWARD_* of include/gymgo_amd.h (gym_go/envs/go_env.py:11-17)
 
 
-def batch_env_step(batch_states, actions=None, rng=None, komi=0.0, reward_method='real', auto_reset=True):
+def batch_env_step(batch_states, actions=None, rng=None, komi=0.0, reward_method='real', auto_reset=True, out=None):
     """IN PLACE GoEnv.step (gym_go/envs/go_env.py:49-76) of every game in ONE launch (gg_batch_env_step): auto-reset,
     the action (`actions`, or drawn uniformly with `rng` when None), legality, next_state, game_ended and
-    GoEnv.reward (:128-149).  -> (rewards float32 [B], dones uint8 [B], status int32 [B], taken int32 [B])."""
+    GoEnv.reward (:128-149).  -> (rewards float32 [B], dones uint8 [B], status int32 [B], taken int32 [B]);
+    `out` = such a 4-tuple to write into (no allocation: the call is then capturable in a hipGraph as is)."""
     B, C, N, _ = batch_states.shape
     dev = batch_states.device
     if actions is None and rng is None:
         raise ValueError('batch_env_step needs actions or an rng state to draw them with')
-    rewards = torch.empty(B, dtype=torch.float32, device=dev)
-    dones = torch.empty(B, dtype=_U8, device=dev)
-    status = torch.empty(B, dtype=_I32, device=dev)
-    taken = torch.empty(B, dtype=_I32, device=dev)
+    if out is None:
+        out = (torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=_U8, device=dev),
+               torch.empty(B, dtype=_I32, device=dev), torch.empty(B, dtype=_I32, device=dev))
+    rewards, dones, status, taken = out
     code = _lib.lib().gg_batch_env_step(
         _lib.dev_ptr(batch_states, _U8, 'states'), _lib.dev_ptr(actions, _I32, 'actions'),
         _lib.dev_ptr(rng, _I64, 'rng'), _lib.dev_ptr(rewards, torch.float32, 'rewards'),
         _lib.dev_ptr(dones, _U8, 'dones'), _lib.dev_ptr(status, _I32, 'status'), _lib.dev_ptr(taken, _I32, 'taken'),
         B, N, float(komi), REWARD_METHODS[reward_method], int(bool(auto_reset)), _lib.stream_ptr(dev))
     _lib.check(code, 'gg_batch_env_step')
-    return rewards, dones, status, taken
+    return out
 
 
 def batch_sample_actions(batch_states, rng):

@@ -176,3 +176,36 @@ def test_fused_env_step_refuses_illegal_and_frozen():
         gogame.batch_env_step(env.states)
     with pytest.raises(KeyError):
         gogame.batch_env_step(env.states, legal, reward_method='nope')
+
+
+def test_vecenv_step_captured_in_hipgraph():
+    """GoVecEnv.step() allocates nothing (fixed output buffers), so K steps with on-device sampling can be captured
+    in a hipGraph; a replay walks the same trajectory as the fused rollout and leaves the last step's rewards."""
+    from gymgo_amd import gogame
+    from gymgo_amd.envs import GoVecEnv
+    B, N, K = 2048, 9, 10
+    env = GoVecEnv(B, N, komi=0.5, reward_method='heuristic', seed=3)
+    env.rollout(25)
+    s0, r0, n0 = env.states.clone(), env.rng.clone(), env.steps_done.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        env.step()
+    torch.cuda.current_stream().wait_stream(side)
+    env.states.copy_(s0); env.rng.copy_(r0); env.steps_done.copy_(n0)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(K):
+            states, rewards, dones, status = env.step()
+    env.states.copy_(s0); env.rng.copy_(r0); env.steps_done.copy_(n0)
+    graph.replay()
+    torch.cuda.synchronize()
+    want, wr = s0.clone(), r0.clone()
+    gogame.batch_rollout(want, wr, K, True)
+    assert torch.equal(env.states, want) and torch.equal(env.rng, wr)
+    assert int((env.steps_done - n0).min()) == K and int(status.sum()) == 0
+    b, w = gogame.batch_areas(want)
+    margin = (b - w).float() - 0.5
+    over = want[:, 5, 0, 0] == 1
+    assert torch.equal(rewards, torch.where(over, torch.where(margin > 0, 81.0, -81.0), margin))
+    assert torch.equal(dones, want[:, 5, 0, 0])
