@@ -320,6 +320,86 @@ int32_t gg_batch_unpack_states(const uint32_t *packed, uint8_t *states, int64_t 
   return (int32_t)hipGetLastError();
 }
 
+// ---- the same operations on packed boards (uint32 [B][3 N + 1], see gg_batch_pack_states): no byte-plane conversions
+int32_t gg_batch_next_states_packed(const uint32_t *in, const int32_t *actions, uint32_t *out, int32_t *status, int64_t B,
+                                    int32_t N, int32_t canonical, void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (B == 0) return 0;
+  if (!in || !actions || !out) return GG_E_NULLPTR;
+  const uint32_t inv = recip16(N);
+  if (!inv) return GG_E_BADSIZE;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int grid = grid_for((B + 1) / 2);
+  GG_DISPATCH(N, (k_next_states_p<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+              (k_next_states_p<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+              (k_next_states_p<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_rollout_packed(uint32_t *packed, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B,
+                                int32_t N, int32_t plies, int32_t auto_reset, void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (plies < 0) return GG_E_BADARG;
+  if (B == 0 || plies == 0) return 0;
+  if (!packed || !rng) return GG_E_NULLPTR;
+  const uint32_t inv = recip16(N);
+  if (!inv) return GG_E_BADSIZE;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int grid = grid_for((B + 1) / 2);
+  uint8_t *st = reinterpret_cast<uint8_t *>(packed);
+  GG_DISPATCH(N, (k_rollout2<9, false, true><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
+              (k_rollout2<13, false, true><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
+              (k_rollout2<19, false, true><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_env_step_packed(uint32_t *packed, const int32_t *actions, uint64_t *rng, float *rewards, uint8_t *dones,
+                                 int32_t *status, int32_t *taken_actions, int64_t B, int32_t N, float komi,
+                                 int32_t reward_method, int32_t auto_reset, void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (reward_method != GG_REWARD_REAL && reward_method != GG_REWARD_HEURISTIC) return GG_E_BADARG;
+  if (B == 0) return 0;
+  if (!packed || (!actions && !rng)) return GG_E_NULLPTR;
+  const uint32_t inv = recip16(N);
+  if (!inv) return GG_E_BADSIZE;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int grid = grid_for((B + 1) / 2);
+  uint8_t *st = reinterpret_cast<uint8_t *>(packed);
+  if (reward_method == GG_REWARD_HEURISTIC) {
+    GG_DISPATCH(N, (k_env_step2<9, true, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
+                (k_env_step2<13, true, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
+                (k_env_step2<19, true, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)));
+  } else {
+    GG_DISPATCH(N, (k_env_step2<9, false, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
+                (k_env_step2<13, false, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
+                (k_env_step2<19, false, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)));
+  }
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_children_packed(const uint32_t *packed, uint32_t *children, int64_t B, int32_t N, int32_t canonical,
+                                 void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (B == 0) return 0;
+  if (!packed || !children) return GG_E_NULLPTR;
+  const uint32_t inv = recip16(N);
+  if (!inv) return GG_E_BADSIZE;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int A = N * N + 1;
+  int cus = device_cus();
+  if (cus <= 0) cus = 256;
+  int chunks = (int)(((int64_t)cus * 64 + B - 1) / B);
+  if (chunks < 1) chunks = 1;
+  if (chunks > A) chunks = A;
+  const int grid = grid_for(B * chunks);
+  const uint8_t *st = reinterpret_cast<const uint8_t *>(packed);
+  uint8_t *ch = reinterpret_cast<uint8_t *>(children);
+  GG_DISPATCH(N, (k_children3<9, true><<<grid, kWave, 0, s>>>(st, ch, B, N, inv, canonical, chunks)),
+              (k_children3<13, true><<<grid, kWave, 0, s>>>(st, ch, B, N, inv, canonical, chunks)),
+              (k_children3<19, true><<<grid, kWave, 0, s>>>(st, ch, B, N, inv, canonical, chunks)));
+  return (int32_t)hipGetLastError();
+}
+
 int32_t gg_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B, void *hip_stream) {
   if (B < 0) return GG_E_BADSIZE;
   if (B == 0) return 0;

@@ -455,6 +455,80 @@ __device__ __forceinline__ int pick_action2(uint32_t valid, uint32_t incl, uint3
   return hit ? r * hf.N + c : hf.P;
 }
 
+// ---------------------------------------------------------------- packed boards (3 N + 1 words, see k_pack) as kernel I/O
+// The L1 rows ARE the packed format, so the PACKED instantiations of the step kernels skip the byte-plane
+// conversions altogether: a board is 232 B instead of 2 166 B and costs no VALU work to read or write.
+// fw: bit 0 turn, bit 1 previous move was a pass, bit 2 game over.
+__device__ __forceinline__ void load_packed_h(const uint32_t *gp, int N, const Half &hf, uint32_t &black, uint32_t &white,
+                                              uint32_t &invalid, uint32_t &fw) {
+  black = white = invalid = 0;
+  if (hf.hl < N) {
+    black = gp[hf.hl];
+    white = gp[N + hf.hl];
+    invalid = gp[2 * N + hf.hl];
+  }
+  fw = gp[3 * N];
+}
+__device__ __forceinline__ void store_packed_h(uint32_t *gp, int N, const Half &hf, uint32_t black, uint32_t white,
+                                               uint32_t invalid, uint32_t turn, uint32_t passed, uint32_t done, bool wr) {
+  if (wr && hf.hl < N) {
+    gp[hf.hl] = black;
+    gp[N + hf.hl] = white;
+    gp[2 * N + hf.hl] = invalid;
+  }
+  if (wr && hf.hl == 31) gp[3 * N] = turn | (passed << 1) | (done << 2);
+}
+
+// gogame.batch_next_states on packed boards (out of place), two boards per wave
+template <int R>
+__global__ __launch_bounds__(kWave, 4) void k_next_states_p(const uint32_t *__restrict__ in, const int32_t *__restrict__ actions,
+                                                            uint32_t *__restrict__ out, int32_t *__restrict__ status,
+                                                            int64_t B, int N, uint32_t inv, int canonical) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
+  const Half hf = make_half(threadIdx.x, N, inv);
+  load_cw_table<R>(lds, hf.lane);
+  const int W = 3 * N + 1;
+  const int64_t npairs = (B + 1) >> 1;
+  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+    const int64_t b0 = 2 * p + hf.h;
+    const bool on = b0 < B;
+    const int64_t b = on ? b0 : B - 1;
+    uint32_t black, white, invalid, fw;
+    load_packed_h(in + b * (int64_t)W, N, hf, black, white, invalid, fw);
+    const int a = actions[b];
+    const bool in_range = a >= 0 && a <= hf.P;
+    const bool is_pass = a == hf.P;
+    bool illegal = !in_range;
+    if (in_range && !is_pass) {
+      int ar, ac;
+      split_action(a, N, hf.inv, ar, ac);
+      illegal = (((uint32_t)__shfl((int)invalid, (hf.lane & 32) + ar) >> ac) & 1u) != 0;
+    }
+    const int pl = fw & 1u;
+    uint32_t nb = black, nw = white, ninv = invalid, nturn = pl, passed = (fw >> 1) & 1u, done = (fw >> 2) & 1u;
+    if (__ballot(!illegal)) {
+      uint32_t mine = pl ? white : black, opp = pl ? black : white;
+      uint32_t atari_unused;
+      // an illegal half still runs the (wave-wide) analysis on a harmless pass, its result is discarded
+      const uint32_t iv = step_core2<R, false>(mine, opp, illegal ? hf.P : a, hf, lds, 0u, false, atari_unused);
+      if (!illegal) {
+        ninv = iv;
+        nb = pl ? opp : mine;
+        nw = pl ? mine : opp;
+        done = (done || (is_pass && passed)) ? 1u : 0u;
+        passed = is_pass ? 1u : 0u;
+        nturn = 1u - (uint32_t)pl;
+        if (canonical && nturn == 1u) {
+          const uint32_t t = nb; nb = nw; nw = t;
+          nturn = 0u;
+        }
+      }
+    }
+    store_packed_h(out + b * (int64_t)W, N, hf, nb, nw, ninv, nturn, passed, done, on);  // illegal: row passes through
+    if (status && on && hf.hl == 0) status[b] = illegal ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
+  }
+}
+
 template <int R>
 __global__ __launch_bounds__(kWave, 3) void k_next_states2s(const uint8_t *__restrict__ in,
                                                         const int32_t *__restrict__ actions,
@@ -659,8 +733,9 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_next_states2(const uint8_t
 
 // PERPLY = instantiation for 1-2 plies per launch: the board I/O dominates there and the kernel runs best spill-free
 // at 3 waves per SIMD; the fused instantiation keeps its hot ply loop spill-free at 4 waves per SIMD.
-template <int R, bool PERPLY>
-__global__ __launch_bounds__(kWave, PERPLY ? GG_LB_PLY : 4) void k_rollout2(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+// PACKED: `states` holds packed boards (uint32 [B][3 N + 1]).
+template <int R, bool PERPLY, bool PACKED = false>
+__global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_rollout2(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                     int32_t *__restrict__ last_actions,
                                                     int64_t *__restrict__ steps_done, int64_t B, int N, uint32_t inv,
                                                     int plies, int auto_reset) {
@@ -677,14 +752,23 @@ __global__ __launch_bounds__(kWave, PERPLY ? GG_LB_PLY : 4) void k_rollout2(uint
     const bool on = 2 * p + hf.h < B;
     const int64_t b = hf.h ? bB : bA;
     uint8_t *gs = states + b * (int64_t)S;
-    uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
-    WAVE_SYNC();
-    const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
-    WAVE_SYNC();
-    uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
-    uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
-    uint32_t invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
-    int turn = flags & 1u, passed = (flags >> 2) & 1u, done = (flags >> 3) & 1u;
+    uint32_t *gp = reinterpret_cast<uint32_t *>(states) + b * (int64_t)(3 * N + 1);
+    uint32_t black, white, invalid;
+    int turn, passed, done;
+    if (PACKED) {
+      uint32_t fw;
+      load_packed_h(gp, N, hf, black, white, invalid, fw);
+      turn = fw & 1u; passed = (fw >> 1) & 1u; done = (fw >> 2) & 1u;
+    } else {
+      const uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
+      WAVE_SYNC();
+      const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
+      WAVE_SYNC();
+      black = plane_to_row<R>(io + mi, N, hf.hl);
+      white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+      invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
+      turn = flags & 1u; passed = (flags >> 2) & 1u; done = (flags >> 3) & 1u;
+    }
     uint64_t xa = uniform64(rng[bA]), xb = uniform64(rng[bB]);  // generator states live in SGPRs
     int last = -1, played = 0;
     uint32_t atari = 0;   // next mover's opponents in atari, known from the previous ply of this launch
@@ -725,7 +809,9 @@ __global__ __launch_bounds__(kWave, PERPLY ? GG_LB_PLY : 4) void k_rollout2(uint
         ++played;
       }
     }
-    if (__ballot(played != 0)) {
+    if (PACKED) {
+      store_packed_h(gp, N, hf, black, white, invalid, (uint32_t)turn, (uint32_t)passed, (uint32_t)done, on && played != 0);
+    } else if (__ballot(played != 0)) {
       emit_store_h<R>(gs, black, white, invalid, (uint32_t)turn, (uint32_t)passed, (uint32_t)done, hf,
                       reinterpret_cast<uint32_t *>(io), lut, on && played != 0);
     }
@@ -744,8 +830,8 @@ __global__ __launch_bounds__(kWave, PERPLY ? GG_LB_PLY : 4) void k_rollout2(uint
 // position ride in the idle flood lanes of the liberty analysis.  !HEUR (reward_method real): the areas only matter
 // when a game ends, so the step runs the plain analysis and a wave whose pair just finished a game (two passes: no
 // stone moved, the liberty classes are not needed again) runs one more analysis for the territory.
-template <int R, bool HEUR>
-__global__ __launch_bounds__(kWave, GG_LB_PLY) void k_env_step2(uint8_t *__restrict__ states, const int32_t *__restrict__ actions,
+template <int R, bool HEUR, bool PACKED = false>
+__global__ __launch_bounds__(kWave, PACKED ? 4 : GG_LB_PLY) void k_env_step2(uint8_t *__restrict__ states, const int32_t *__restrict__ actions,
                                                         uint64_t *__restrict__ rng, float *__restrict__ rewards,
                                                         uint8_t *__restrict__ dones, int32_t *__restrict__ status,
                                                         int32_t *__restrict__ taken, int64_t B, int N, uint32_t inv,
@@ -764,14 +850,23 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_env_step2(uint8_t *__restr
     const bool on = 2 * p + hf.h < B;
     const int64_t b = hf.h ? bB : bA;
     uint8_t *gs = states + b * (int64_t)S;
-    uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
-    WAVE_SYNC();
-    const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
-    WAVE_SYNC();
-    uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
-    uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
-    uint32_t invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
-    int turn = flags & 1u, passed = (flags >> 2) & 1u, done = (flags >> 3) & 1u;
+    uint32_t *gp = reinterpret_cast<uint32_t *>(states) + b * (int64_t)(3 * N + 1);
+    uint32_t black, white, invalid;
+    int turn, passed, done;
+    if (PACKED) {
+      uint32_t fw;
+      load_packed_h(gp, N, hf, black, white, invalid, fw);
+      turn = fw & 1u; passed = (fw >> 1) & 1u; done = (fw >> 2) & 1u;
+    } else {
+      const uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
+      WAVE_SYNC();
+      const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
+      WAVE_SYNC();
+      black = plane_to_row<R>(io + mi, N, hf.hl);
+      white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+      invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
+      turn = flags & 1u; passed = (flags >> 2) & 1u; done = (flags >> 3) & 1u;
+    }
     bool wr = false;               // the stored state changes
     const bool frozen = done && !auto_reset;   // go_env.py:53 "assert not self.done"
     if (done && auto_reset) {
@@ -823,7 +918,9 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_env_step2(uint8_t *__restr
     const uint32_t rb = mover_white ? reach[0] : reach[1], rw = mover_white ? reach[1] : reach[0];
     const uint32_t ab = half_scan((uint32_t)(__popc(black) + __popc(rb & ~rw)));
     const uint32_t aw = half_scan((uint32_t)(__popc(white) + __popc(rw & ~rb)));
-    if (__ballot(wr)) {
+    if (PACKED) {
+      store_packed_h(gp, N, hf, black, white, invalid, (uint32_t)turn, (uint32_t)passed, (uint32_t)done, on && wr);
+    } else if (__ballot(wr)) {
       emit_store_h<R>(gs, black, white, invalid, (uint32_t)turn, (uint32_t)passed, (uint32_t)done, hf,
                       reinterpret_cast<uint32_t *>(io), lut, on && wr);
     }
@@ -954,7 +1051,8 @@ __global__ __launch_bounds__(kWave, 4) void k_children2(const uint8_t *__restric
 // stone, how many floods reach it (three OR-AND ops per flood in L1: ge1, ge2, ge3).  Pass 2 runs them again for the
 // points of this work item's chunk (the 5 KB transpose buffer holds one batch; when the board has <= 32 empty points
 // pass 1's batch is reused) and derives two children per L1 pass, one per half, with ~70 VALU ops + the emitter.
-template <int R>
+// PACKED: parents and children are packed boards (uint32 [3 N + 1] each): 84 KB instead of 786 KB per 19x19 parent.
+template <int R, bool PACKED = false>
 __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *__restrict__ states,
                                                         uint8_t *__restrict__ children, int64_t B, int N,
                                                         uint32_t inv, int canonical, int chunks) {
@@ -979,13 +1077,23 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
     const int ch = (int)(w - b * chunks);
     const uint8_t *gi = states + b * (int64_t)S;
     uint8_t *gc = children + b * A * (int64_t)S;
-    const uint32_t flags = load_flags_h(gi, hf.P, 0, hf);
-    WAVE_SYNC();
-    const uint32_t mi = stage_in_h(gi, 4 * hf.P, io, hf.hl);  // both halves hold the same parent
-    WAVE_SYNC();
-    const uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
-    const uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
-    const uint32_t invd = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
+    const int W = 3 * N + 1;
+    uint32_t *gcp = reinterpret_cast<uint32_t *>(children) + b * A * (int64_t)W;   // PACKED: this parent's child slots
+    uint32_t flags, black, white, invd;   // flags: bit 0 turn, bit 2 passed, bit 3 done
+    if (PACKED) {
+      uint32_t fw;
+      load_packed_h(reinterpret_cast<const uint32_t *>(states) + b * (int64_t)W, N, hf, black, white, invd, fw);
+      flags = (fw & 1u) | ((fw & 6u) << 1);
+      WAVE_SYNC();
+    } else {
+      flags = load_flags_h(gi, hf.P, 0, hf);
+      WAVE_SYNC();
+      const uint32_t mi = stage_in_h(gi, 4 * hf.P, io, hf.hl);  // both halves hold the same parent
+      WAVE_SYNC();
+      black = plane_to_row<R>(io + mi, N, hf.hl);
+      white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+      invd = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
+    }
     const int pl = flags & 1u;
     const uint32_t mine = pl ? white : black, opp = pl ? black : white;
     const uint32_t e = hf.full_l1 & ~(mine | opp);
@@ -1123,6 +1231,14 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
         }
       }
     };
+    if (PACKED) {
+      // packed slots: zero the chunk's slots with coalesced stores, wait for them, then overwrite the legal ones
+      uint32_t *z = gcp + (int64_t)a0 * W;
+      const int nz = (a1 - a0) * W;
+      for (int i = hf.lane; i < nz; i += kWave) z[i] = 0u;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WAVE_SYNC();
+    }
     // one child per half: `a` = its action, `tj` = flood lane of its point inside the current batch (-1: pass)
     auto child = [&](int a, int tj, bool on) {
       const bool is_pass = tj < 0;
@@ -1194,6 +1310,10 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
         const uint32_t t = nb; nb = nw; nw = t;
         nturn = 0;
       }
+      if (PACKED) {
+        store_packed_h(gcp + (int64_t)a * W, N, hf, nb, nw, invalid, (uint32_t)nturn, passed, done, on);
+        return;
+      }
       // both children are emitted in slot order; the window is advanced up to the block the next child starts in
       const uint32_t pbit = start_bit + (uint32_t)(a - a0) * (uint32_t)S;
       const uint32_t pA = (uint32_t)__builtin_amdgcn_readlane((int)pbit, 0), pB = (uint32_t)__builtin_amdgcn_readlane((int)pbit, 32);
@@ -1243,9 +1363,11 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
       }
     }
     if (a1 == A) child(hf.P, -1, hf.h == 0);
-    WAVE_SYNC();
-    flush_until((end_bit + kBlk - 1u) & ~(kBlk - 1u));
-    WAVE_SYNC();
+    if (!PACKED) {
+      WAVE_SYNC();
+      flush_until((end_bit + kBlk - 1u) & ~(kBlk - 1u));
+      WAVE_SYNC();
+    }
   }
 }
 

@@ -498,3 +498,72 @@ def batch_unpack(packed, board_size):
                                              B, board_size, _lib.stream_ptr(packed.device))
     _lib.check(code, 'gg_batch_unpack_states')
     return states
+
+
+# ---------------------------------------------------------------- the step path on packed boards
+# Same operations as above on [B, 3N+1] int32 packed boards (batch_pack): 232 B per 19x19 board instead of 2 166 B and no
+# byte <-> bit conversion inside the kernels - for search trees / replay buffers that unpack only what a network reads.
+
+def _packed_size(packed):
+    W = packed.shape[-1]
+    if packed.dtype != _I32 or (W - 1) % 3 or not 2 <= (W - 1) // 3 <= 19:
+        raise ValueError('packed boards are int32 [..., 3N+1] (got %s %s)' % (packed.dtype, tuple(packed.shape)))
+    return (W - 1) // 3
+
+
+def batch_next_states_packed(packed, batch_action1d, canonical=False, check=True):
+    """gogame.batch_next_states (gym_go/gogame.py:90-150) on packed boards -> (packed_out, status int32 [B])."""
+    N = _packed_size(packed)
+    B = packed.shape[0]
+    actions = _actions_tensor(batch_action1d, B, packed.device)
+    out = torch.empty_like(packed)
+    status = torch.empty(B, dtype=_I32, device=packed.device)
+    code = _lib.lib().gg_batch_next_states_packed(
+        _lib.dev_ptr(packed, _I32, 'packed'), _lib.dev_ptr(actions, _I32, 'actions'), _lib.dev_ptr(out, _I32, 'out'),
+        _lib.dev_ptr(status, _I32, 'status'), B, N, int(bool(canonical)), _lib.stream_ptr(packed.device))
+    _lib.check(code, 'gg_batch_next_states_packed')
+    if check and bool((status != 0).any()):
+        raise AssertionError('invalid move in batch (gym_go/gogame.py:117)')
+    return out, status
+
+
+def batch_rollout_packed(packed, rng, plies, auto_reset=True, last_actions=None, steps_done=None):
+    """IN PLACE batch_rollout on packed boards (gg_batch_rollout_packed)."""
+    N = _packed_size(packed)
+    B = packed.shape[0]
+    code = _lib.lib().gg_batch_rollout_packed(
+        _lib.dev_ptr(packed, _I32, 'packed'), _lib.dev_ptr(rng, _I64, 'rng'), _lib.dev_ptr(last_actions, _I32, 'last_actions'),
+        _lib.dev_ptr(steps_done, _I64, 'steps_done'), B, N, int(plies), int(bool(auto_reset)), _lib.stream_ptr(packed.device))
+    _lib.check(code, 'gg_batch_rollout_packed')
+    return packed
+
+
+def batch_env_step_packed(packed, actions=None, rng=None, komi=0.0, reward_method='real', auto_reset=True, out=None):
+    """IN PLACE batch_env_step on packed boards -> (rewards, dones, status, taken)."""
+    N = _packed_size(packed)
+    B = packed.shape[0]
+    dev = packed.device
+    if actions is None and rng is None:
+        raise ValueError('batch_env_step_packed needs actions or an rng state to draw them with')
+    if out is None:
+        out = (torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=_U8, device=dev),
+               torch.empty(B, dtype=_I32, device=dev), torch.empty(B, dtype=_I32, device=dev))
+    rewards, dones, status, taken = out
+    code = _lib.lib().gg_batch_env_step_packed(
+        _lib.dev_ptr(packed, _I32, 'packed'), _lib.dev_ptr(actions, _I32, 'actions'), _lib.dev_ptr(rng, _I64, 'rng'),
+        _lib.dev_ptr(rewards, torch.float32, 'rewards'), _lib.dev_ptr(dones, _U8, 'dones'), _lib.dev_ptr(status, _I32, 'status'),
+        _lib.dev_ptr(taken, _I32, 'taken'), B, N, float(komi), REWARD_METHODS[reward_method], int(bool(auto_reset)),
+        _lib.stream_ptr(dev))
+    _lib.check(code, 'gg_batch_env_step_packed')
+    return out
+
+
+def batch_children_packed(packed, canonical=False):
+    """gogame.children (gym_go/gogame.py:175-186) of every packed parent -> int32 [B, N*N+1, 3N+1], invalid slots zero."""
+    N = _packed_size(packed)
+    B = packed.shape[0]
+    kids = torch.empty((B, N * N + 1, packed_words(N)), dtype=_I32, device=packed.device)
+    code = _lib.lib().gg_batch_children_packed(_lib.dev_ptr(packed, _I32, 'packed'), _lib.dev_ptr(kids, _I32, 'children'),
+                                               B, N, int(bool(canonical)), _lib.stream_ptr(packed.device))
+    _lib.check(code, 'gg_batch_children_packed')
+    return kids

@@ -150,6 +150,27 @@ int32_t gg_packed_words(int32_t N);
 int32_t gg_batch_pack_states(const uint8_t *states, uint32_t *packed, int64_t B, int32_t N, void *hip_stream);
 int32_t gg_batch_unpack_states(const uint32_t *packed, uint8_t *states, int64_t B, int32_t N, void *hip_stream);
 
+/*
+ * The step path on PACKED boards (uint32 [B][gg_packed_words(N)], the format of gg_batch_pack_states): same semantics,
+ * arguments and error behaviour as the byte-plane entry points of the same name, with `packed` in place of `states`.
+ * A board is 232 B instead of 2 166 B at 19x19 and the kernels skip the byte <-> bit conversions - for search trees and
+ * replay buffers that keep states packed and unpack only what goes to a network.
+ *   gg_batch_next_states_packed   gogame.batch_next_states         gym_go/gogame.py:90-150   (in / out must not overlap)
+ *   gg_batch_rollout_packed       loop of uniform_random_action + step  gym_go/envs/go_env.py:49-81   (in place)
+ *   gg_batch_env_step_packed      GoEnv.step + reward + reset      gym_go/envs/go_env.py:40-76, :128-149   (in place)
+ *   gg_batch_children_packed      gogame.children per state        gym_go/gogame.py:175-186
+ *                                 children: uint32 [B][N*N+1][gg_packed_words(N)], slots of invalid actions all zero
+ */
+int32_t gg_batch_next_states_packed(const uint32_t *in, const int32_t *actions, uint32_t *out, int32_t *status, int64_t B,
+                                    int32_t N, int32_t canonical, void *hip_stream);
+int32_t gg_batch_rollout_packed(uint32_t *packed, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B,
+                                int32_t N, int32_t plies, int32_t auto_reset, void *hip_stream);
+int32_t gg_batch_env_step_packed(uint32_t *packed, const int32_t *actions, uint64_t *rng, float *rewards, uint8_t *dones,
+                                 int32_t *status, int32_t *taken_actions, int64_t B, int32_t N, float komi,
+                                 int32_t reward_method, int32_t auto_reset, void *hip_stream);
+int32_t gg_batch_children_packed(const uint32_t *packed, uint32_t *children, int64_t B, int32_t N, int32_t canonical,
+                                 void *hip_stream);
+
 /* rng[b] = initial generator state for (base_seed, game index first_game + b). */
 int32_t gg_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B, void *hip_stream);
 

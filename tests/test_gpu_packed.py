@@ -1,0 +1,108 @@
+"""-m gpu: the step path on packed boards (gg_batch_*_packed) against the oracle and against the byte-plane kernels."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+def _mid(B, N, plies, seed=5, auto_reset=True):
+    from gymgo_amd import gogame
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, seed)
+    gogame.batch_rollout(st, rng, plies, auto_reset)
+    return st, rng
+
+
+@pytest.mark.parametrize('N,B,plies', [(19, 301, 200), (13, 128, 90), (9, 257, 40), (5, 64, 12), (2, 9, 2)])
+def test_packed_next_states_matches_oracle(N, B, plies):
+    """gogame.batch_next_states (gym_go/gogame.py:90-150) on packed boards: legal, illegal and out-of-range actions."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    st, rng = _mid(B, N, plies, auto_reset=False)
+    host = st.cpu().numpy()
+    gen = np.random.default_rng(N)
+    acts = gogame.batch_sample_actions(st, rng).cpu().numpy()
+    wild = gen.random(B) < 0.25
+    acts[wild] = gen.integers(-2, N * N + 3, size=int(wild.sum()))
+    in_range = (acts >= 0) & (acts <= N * N)
+    bad = ~in_range
+    inval = host[:, 3].reshape(B, -1)
+    for i in range(B):
+        if in_range[i] and acts[i] < N * N and inval[i, acts[i]]:
+            bad[i] = True
+    packed = gogame.batch_pack(st)
+    for canon in (False, True):
+        out, status = gogame.batch_next_states_packed(packed, torch.from_numpy(acts).cuda(), canonical=canon, check=False)
+        assert np.array_equal(status.cpu().numpy(), bad.astype(np.int32))
+        want = host.copy()
+        ok = np.flatnonzero(~bad)
+        want[ok] = c_oracle.batch_next_states(host[ok], acts[ok], canon)[0]
+        assert np.array_equal(gogame.batch_unpack(out, N).cpu().numpy(), want), (N, canon)
+    assert torch.equal(packed, gogame.batch_pack(st))   # the input is untouched
+    with pytest.raises(AssertionError):
+        gogame.batch_next_states_packed(packed, torch.full((B,), -5, dtype=torch.int32).cuda())
+
+
+@pytest.mark.parametrize('N,B', [(19, 513), (9, 1000), (7, 33), (3, 17)])
+def test_packed_rollout_and_env_step_match_byte_plane_kernels(N, B):
+    """Same generator, same trajectory: the packed fused rollout and the packed fused env step walk the states of
+    gg_batch_rollout / gg_batch_env_step (which are pinned to the oracle elsewhere), rewards and dones included."""
+    from gymgo_amd import gogame
+    st, rng = _mid(B, N, 17)
+    packed = gogame.batch_pack(st)
+    prng = rng.clone()
+    la, lb = (torch.full((B,), -7, dtype=torch.int32, device='cuda') for _ in range(2))
+    sa, sb = (torch.zeros(B, dtype=torch.int64, device='cuda') for _ in range(2))
+    gogame.batch_rollout(st, rng, 37, True, la, sa)
+    gogame.batch_rollout_packed(packed, prng, 37, True, lb, sb)
+    assert torch.equal(gogame.batch_unpack(packed, N), st) and torch.equal(rng, prng)
+    assert torch.equal(la, lb) and torch.equal(sa, sb)
+    for method in ('real', 'heuristic'):
+        for _ in range(30 if N > 9 else 120):
+            r1 = gogame.batch_env_step(st, None, rng, 2.5, method, True)
+            r2 = gogame.batch_env_step_packed(packed, None, prng, 2.5, method, True)
+            for x, y in zip(r1, r2):
+                assert torch.equal(x, y)
+        assert torch.equal(gogame.batch_unpack(packed, N), st) and torch.equal(rng, prng)
+    # given actions incl. illegal ones, frozen games (auto_reset off)
+    gen = np.random.default_rng(1)
+    acts = torch.from_numpy(gen.integers(-1, N * N + 2, size=B).astype(np.int32)).cuda()
+    r1 = gogame.batch_env_step(st, acts, None, 0.0, 'heuristic', False)
+    r2 = gogame.batch_env_step_packed(packed, acts, None, 0.0, 'heuristic', False)
+    for x, y in zip(r1, r2):
+        assert torch.equal(x, y)
+    assert torch.equal(gogame.batch_unpack(packed, N), st)
+    assert int(r1[2].sum()) > 0
+
+
+@pytest.mark.parametrize('N,B,plies', [(19, 64, 240), (19, 40, 30), (9, 96, 45), (5, 48, 15)])
+def test_packed_children_match_oracle(N, B, plies):
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    st, _ = _mid(B, N, plies, auto_reset=False)
+    st = st[st[:, 5, 0, 0] == 0].contiguous()
+    host = st.cpu().numpy()
+    packed = gogame.batch_pack(st)
+    for canon in (False, True):
+        kids = gogame.batch_children_packed(packed, canonical=canon)
+        assert kids.shape == (len(st), N * N + 1, 3 * N + 1)
+        flat = gogame.batch_unpack(kids.reshape(-1, 3 * N + 1), N).cpu().numpy().reshape(len(st), N * N + 1, 6, N, N)
+        want = c_oracle.batch_children(host, canon)
+        valid = np.concatenate([host[:, 3].reshape(len(st), -1) == 0, np.ones((len(st), 1), bool)], 1)
+        assert np.array_equal(flat[valid], want[valid])
+        assert not kids.cpu().numpy()[~valid].any()      # invalid slots: all words zero (turn bit included)
+
+
+def test_packed_children_single_chunk_and_bad_arguments():
+    from gymgo_amd import _lib, gogame
+    st, _ = _mid(4352, 9, 40)
+    st = st[st[:, 5, 0, 0] == 0].contiguous()
+    packed = gogame.batch_pack(st)
+    kids = gogame.batch_children_packed(packed)
+    full = gogame.batch_children(st)
+    assert torch.equal(gogame.batch_unpack(kids.reshape(-1, 28), 9).reshape(full.shape)[:, :, :2], full[:, :, :2])
+    with pytest.raises(ValueError):
+        gogame.batch_children_packed(packed[:, :27])
+    with pytest.raises(_lib.GymGoNativeError):
+        gogame.batch_rollout_packed(packed.cpu(), gogame.rng_seed(len(packed), 1), 3)

@@ -86,6 +86,31 @@ def main():
         out['gg_batch_children_19x19_B8192%s' % ('_canonical' if canon else '')] = {
             'parents_per_s': B / t, 'child_states_per_s': B * (N * N + 1) / t, 'ms_per_batch': t * 1e3,
             'algorithmic_GBps': nbytes / t / 1e9, 'roofline_frac': nbytes / t / PEAK, 'mean_valid_children': valid}
+    # the same parents as packed boards: 362 x 232 B per parent
+    pk = gogame.batch_pack(st)
+    t = timed(lambda: gogame.batch_children_packed(pk), 10)
+    out['gg_batch_children_packed_19x19_B8192'] = {
+        'parents_per_s': B / t, 'child_states_per_s': B * (N * N + 1) / t, 'ms_per_batch': t * 1e3,
+        'bytes_per_parent': (N * N + 2) * (3 * N + 1) * 4, 'moved_GBps': B * (N * N + 2) * (3 * N + 1) * 4 / t / 1e9}
+    # packed step path, 65 536 games
+    B2 = 65536
+    st2, rng2 = midgame(B2, N, 250, 5)
+    pk2 = gogame.batch_pack(st2)
+    acts = gogame.batch_sample_actions(st2, rng2)
+    PB = (3 * N + 1) * 4
+    t = timed(lambda: gogame.batch_next_states_packed(pk2, acts, check=False), 50)
+    out['gg_batch_next_states_packed_19x19_B65536'] = {'steps_per_s': B2 / t, 'moved_GBps': B2 * (2 * PB + 4) / t / 1e9}
+    buf = None
+
+    def pstep(method):
+        nonlocal buf
+        buf = gogame.batch_env_step_packed(pk2, None, rng2, 7.5, method, True, out=buf)
+    for method in ('real', 'heuristic'):
+        t = timed(lambda: pstep(method), 50)
+        out['gg_batch_env_step_packed_%s_19x19_B65536' % method] = {'steps_per_s': B2 / t}
+    for F in (1, 64):
+        t = timed(lambda: gogame.batch_rollout_packed(pk2, rng2, F, True), 20 if F == 1 else 5)
+        out['gg_batch_rollout_packed_F%d_19x19_B65536' % F] = {'steps_per_s': B2 * F / t}
     # single-state latency (GoEnv.children / next_state path)
     one = st[0]
     t0 = time.perf_counter()
