@@ -106,3 +106,23 @@ def test_packed_children_single_chunk_and_bad_arguments():
         gogame.batch_children_packed(packed[:, :27])
     with pytest.raises(_lib.GymGoNativeError):
         gogame.batch_rollout_packed(packed.cpu(), gogame.rng_seed(len(packed), 1), 3)
+
+
+def test_packed_vecenv_walks_the_same_games():
+    from gymgo_amd.envs import GoVecEnv
+    B, N = 777, 9
+    a = GoVecEnv(B, N, komi=1.5, reward_method='real', seed=8)
+    b = GoVecEnv(B, N, komi=1.5, reward_method='real', seed=8, packed=True)
+    a.rollout(21); b.rollout(21)
+    for t in range(90):
+        sa, ra, da, xa = a.step()
+        sb, rb, db, xb = b.step()
+        assert torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(xa, xb)
+    assert sb.shape == (B, 3 * N + 1) and torch.equal(b.states, a.states)
+    assert torch.equal(a.last_actions, b.last_actions) and torch.equal(a.steps_done, b.steps_done)
+    acts = a.sample_actions()
+    assert torch.equal(acts, b.sample_actions())
+    a.step(acts); b.step(acts)
+    assert torch.equal(b.states, a.states) and torch.equal(a.rewards(), b.rewards())
+    b.reset()
+    assert int(b.states.sum()) == 0
