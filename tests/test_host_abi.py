@@ -38,6 +38,13 @@ def test_argument_validation_without_device(built):
     assert L.gg_batch_next_states(None, None, None, None, 2, 9, 0, None) == -2
     assert L.gg_batch_rollout(None, None, None, None, 2, 9, -1, 1, None) == -3
     assert L.gg_batch_children(None, None, 0, 19, 0, None) == 0
+    assert L.gg_batch_env_step(None, None, None, None, None, None, None, 2, 9, 0.0, 0, 1, None) == -2
+    assert L.gg_batch_env_step(None, None, None, None, None, None, None, 2, 9, 0.0, 7, 1, None) == -3
+    assert L.gg_batch_env_step_packed(None, None, None, None, None, None, None, 2, 9, 0.0, 1, 1, None) == -2
+    assert L.gg_batch_next_states_packed(None, None, None, None, 2, 1, 0, None) == -1
+    assert L.gg_batch_rollout_packed(None, None, None, None, 2, 9, -4, 1, None) == -3
+    assert L.gg_batch_children_packed(None, None, 3, 9, 0, None) == -2
+    assert L.gg_packed_words(19) == 58 and L.gg_packed_words(1) == -1
 
 
 def test_no_cpu_fallback(built):
