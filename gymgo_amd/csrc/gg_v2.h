@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(kWave, 4) void k_invalid_mask2(const uint8_t *__res
     const int nx = flags & 1u;  // side to move
     const uint32_t nxs = nx ? white : black, pls = nx ? black : white;
     uint32_t multi_nx, alive_nx, multi_pl;
-    analyze2<R, true>(nxs, pls, hf.full_l1 & ~(black | white), hf, lds, multi_nx, alive_nx, multi_pl);
+    analyze2<R, false>(nxs, pls, hf.full_l1 & ~(black | white), hf, lds, multi_nx, alive_nx, multi_pl);
     uint32_t invalid = invalid_from2(nxs, pls, multi_nx, multi_pl, hf);
     if (k >= 0 && k < hf.P) {
       const int kr = (int)(((uint32_t)k * inv) >> 16), kc = k - kr * N;
