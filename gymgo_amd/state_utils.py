@@ -13,6 +13,14 @@ from gymgo_amd.gogame import _Box, _invalid_mask_dev
 
 neighbor_deltas = np.array([[-1, 0], [1, 0], [0, -1], [0, 1]])  # gym_go/state_utils.py:21
 
+# The reference's scipy.ndimage structuring elements (gym_go/state_utils.py:7-19), kept as module constants for callers
+# that import them; the kernels encode the same 4-connectivity in their shifts.
+surround_struct = np.zeros((3, 3), dtype=np.int64)
+surround_struct[tuple((neighbor_deltas + 1).T)] = 1          # the four neighbours of the centre
+group_struct = np.zeros((3, 3, 3), dtype=np.int64)
+group_struct[1] = surround_struct
+group_struct[1, 1, 1] = 1                                    # 4-connected inside a board, boards not connected
+
 
 def _ko_tensor(batch_ko, B, N, device):
     if batch_ko is None:
