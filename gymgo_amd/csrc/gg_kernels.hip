@@ -400,6 +400,39 @@ int32_t gg_batch_children_packed(const uint32_t *packed, uint32_t *children, int
   return (int32_t)hipGetLastError();
 }
 
+int32_t gg_batch_play_moves(uint8_t *states, const int32_t *moves, int32_t *played, int64_t B, int32_t N, int32_t T,
+                            void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (T < 0) return GG_E_BADARG;
+  if (B == 0) return 0;
+  if (!states || (T > 0 && !moves)) return GG_E_NULLPTR;
+  const uint32_t inv = recip16(N);
+  if (!inv) return GG_E_BADSIZE;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int grid = grid_for((B + 1) / 2);
+  GG_DISPATCH(N, (k_play_moves2<9, false><<<grid, kWave, 0, s>>>(states, moves, played, B, N, inv, T)),
+              (k_play_moves2<13, false><<<grid, kWave, 0, s>>>(states, moves, played, B, N, inv, T)),
+              (k_play_moves2<19, false><<<grid, kWave, 0, s>>>(states, moves, played, B, N, inv, T)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_play_moves_packed(uint32_t *packed, const int32_t *moves, int32_t *played, int64_t B, int32_t N, int32_t T,
+                                   void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (T < 0) return GG_E_BADARG;
+  if (B == 0) return 0;
+  if (!packed || (T > 0 && !moves)) return GG_E_NULLPTR;
+  const uint32_t inv = recip16(N);
+  if (!inv) return GG_E_BADSIZE;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int grid = grid_for((B + 1) / 2);
+  uint8_t *st = reinterpret_cast<uint8_t *>(packed);
+  GG_DISPATCH(N, (k_play_moves2<9, true><<<grid, kWave, 0, s>>>(st, moves, played, B, N, inv, T)),
+              (k_play_moves2<13, true><<<grid, kWave, 0, s>>>(st, moves, played, B, N, inv, T)),
+              (k_play_moves2<19, true><<<grid, kWave, 0, s>>>(st, moves, played, B, N, inv, T)));
+  return (int32_t)hipGetLastError();
+}
+
 int32_t gg_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B, void *hip_stream) {
   if (B < 0) return GG_E_BADSIZE;
   if (B == 0) return 0;

@@ -823,6 +823,90 @@ __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_
   }
 }
 
+// Replay of given move sequences with the boards resident on-chip: state = next_state(state, moves[b][t]) for
+// t = 0 .. T-1 (a loop of gogame.next_state / GoEnv.step: gym_go/gogame.py:34-87, gym_go/envs/go_env.py:49-76) in ONE
+// launch.  A game stops at its first move that is out of range, on an invalid point (gogame.py:59) or made after the game
+// has ended (go_env.py:53); played[b] = number of moves applied = index of that move, or T.  moves: int32 [B][T].
+template <int R, bool PACKED>
+__global__ __launch_bounds__(kWave, 4) void k_play_moves2(uint8_t *__restrict__ states, const int32_t *__restrict__ moves,
+                                                          int32_t *__restrict__ played_out, int64_t B, int N, uint32_t inv,
+                                                          int T) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
+  const Half hf = make_half(threadIdx.x, N, inv);
+  __shared__ uint2 lut[256];
+  load_cw_table<R>(lds, hf.lane);
+  load_spread_lut(lut, hf.lane);
+  const int S = 6 * hf.P;
+  uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
+  const int64_t npairs = (B + 1) >> 1;
+  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+    const bool on = 2 * p + hf.h < B;
+    const int64_t b = on ? 2 * p + hf.h : B - 1;
+    uint8_t *gs = states + b * (int64_t)S;
+    uint32_t *gp = reinterpret_cast<uint32_t *>(states) + b * (int64_t)(3 * N + 1);
+    uint32_t black, white, invalid;
+    int turn, passed, done;
+    if (PACKED) {
+      uint32_t fw;
+      load_packed_h(gp, N, hf, black, white, invalid, fw);
+      turn = fw & 1u; passed = (fw >> 1) & 1u; done = (fw >> 2) & 1u;
+    } else {
+      const uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
+      WAVE_SYNC();
+      const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
+      WAVE_SYNC();
+      black = plane_to_row<R>(io + mi, N, hf.hl);
+      white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+      invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
+      turn = flags & 1u; passed = (flags >> 2) & 1u; done = (flags >> 3) & 1u;
+    }
+    int played = 0;
+    bool live = on;
+    uint32_t atari = 0;
+    bool have_atari = false;
+    const int32_t *mv_row = moves + b * (int64_t)T;
+#pragma unroll 1
+    for (int t0 = 0; t0 < T && __ballot(live); t0 += 32) {
+      const int mv = (t0 + hf.hl < T) ? mv_row[t0 + hf.hl] : -1;   // lane l of a half holds move t0 + l of its game
+      const int nt = T - t0 < 32 ? T - t0 : 32;
+#pragma unroll 1
+      for (int i = 0; i < nt; ++i) {
+        if (__ballot(live) == 0) break;
+        const int a = __shfl(mv, (hf.lane & 32) + i);
+        bool legal = live && !done && a >= 0 && a <= hf.P;
+        if (legal && a < hf.P) {
+          int ar, ac;
+          split_action(a, N, hf.inv, ar, ac);
+          // (the condition is uniform inside a half and the source lane is in the same half, hence active)
+          legal = (((uint32_t)__shfl((int)invalid, (hf.lane & 32) + ar) >> ac) & 1u) == 0;
+        }
+        live = legal;
+        uint32_t mine = turn ? white : black, opp = turn ? black : white;
+        uint32_t natari;
+        // a stopped half still runs the (wave-wide) analysis on a harmless pass, its result is discarded
+        const uint32_t ninv = step_core2<R, false>(mine, opp, legal ? a : hf.P, hf, lds, atari, have_atari, natari);
+        have_atari = true;
+        if (legal) {
+          atari = natari;
+          invalid = ninv;
+          black = turn ? opp : mine;
+          white = turn ? mine : opp;
+          if (a == hf.P) { if (passed) done = 1; passed = 1; } else passed = 0;
+          turn ^= 1;
+          ++played;
+        }
+      }
+    }
+    if (PACKED) {
+      store_packed_h(gp, N, hf, black, white, invalid, (uint32_t)turn, (uint32_t)passed, (uint32_t)done, on && played != 0);
+    } else if (__ballot(played != 0)) {
+      emit_store_h<R>(gs, black, white, invalid, (uint32_t)turn, (uint32_t)passed, (uint32_t)done, hf,
+                      reinterpret_cast<uint32_t *>(io), lut, on && played != 0);
+    }
+    if (played_out && on && hf.hl == 0) played_out[b] = played;
+  }
+}
+
 // One GoEnv.step for every game of a batched env, in place, one launch (gym_go/envs/go_env.py:49-76):
 // auto-reset of finished games (:40-47), the action (given, or drawn like uniform_random_action :78-81), the legality
 // check (gogame.py:59), next_state, game_ended and GoEnv.reward (:128-149; Tromp-Taylor areas gogame.py:275-300).

@@ -567,3 +567,21 @@ def batch_children_packed(packed, canonical=False):
                                                B, N, int(bool(canonical)), _lib.stream_ptr(packed.device))
     _lib.check(code, 'gg_batch_children_packed')
     return kids
+
+
+def batch_play_moves(batch_states, moves):
+    """IN PLACE: state[b] = next_state(state[b], moves[b, t]) for t = 0 .. T-1 in one launch (gg_batch_play_moves; a loop
+    of gym_go/gogame.py:34-87).  `batch_states`: uint8 [B,6,N,N] or packed int32 [B,3N+1]; moves: int [B, T].
+    -> played int32 [B]: moves applied per game (a game stops at its first illegal move or when it has ended)."""
+    packed = batch_states.dim() == 2
+    N = _packed_size(batch_states) if packed else batch_states.shape[-1]
+    B = batch_states.shape[0]
+    moves = moves.to(device=batch_states.device, dtype=_I32).contiguous()
+    if moves.dim() != 2 or moves.shape[0] != B:
+        raise ValueError('moves must be [B, T]')
+    played = torch.empty(B, dtype=_I32, device=batch_states.device)
+    fn = _lib.lib().gg_batch_play_moves_packed if packed else _lib.lib().gg_batch_play_moves
+    code = fn(_lib.dev_ptr(batch_states, _I32 if packed else _U8, 'states'), _lib.dev_ptr(moves, _I32, 'moves'),
+              _lib.dev_ptr(played, _I32, 'played'), B, N, moves.shape[1], _lib.stream_ptr(batch_states.device))
+    _lib.check(code, 'gg_batch_play_moves')
+    return played

@@ -171,6 +171,19 @@ int32_t gg_batch_env_step_packed(uint32_t *packed, const int32_t *actions, uint6
 int32_t gg_batch_children_packed(const uint32_t *packed, uint32_t *children, int64_t B, int32_t N, int32_t canonical,
                                  void *hip_stream);
 
+/*
+ * Replay of given move sequences, IN PLACE, the boards resident on-chip for all T moves (one launch instead of T):
+ * for t = 0 .. T-1: states[b] = gogame.next_state(states[b], moves[b][t])      gym_go/gogame.py:34-87
+ * i.e. a loop of GoEnv.step (gym_go/envs/go_env.py:49-76) over recorded games, search lines or a policy's action buffer.
+ * moves: int32 [B][T] (N*N = pass).  A game stops at its first move that is out of range, on an invalid point
+ * (gogame.py:59) or made after the game has ended (go_env.py:53) and keeps the state before that move;
+ * played (nullable): int32 [B] = number of moves applied (T if all were).  _packed: the same on packed boards.
+ */
+int32_t gg_batch_play_moves(uint8_t *states, const int32_t *moves, int32_t *played, int64_t B, int32_t N, int32_t T,
+                            void *hip_stream);
+int32_t gg_batch_play_moves_packed(uint32_t *packed, const int32_t *moves, int32_t *played, int64_t B, int32_t N, int32_t T,
+                                   void *hip_stream);
+
 /* rng[b] = initial generator state for (base_seed, game index first_game + b). */
 int32_t gg_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B, void *hip_stream);
 

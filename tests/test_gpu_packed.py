@@ -126,3 +126,44 @@ def test_packed_vecenv_walks_the_same_games():
     assert torch.equal(b.states, a.states) and torch.equal(a.rewards(), b.rewards())
     b.reset()
     assert int(b.states.sum()) == 0
+
+
+@pytest.mark.parametrize('N,B,T', [(19, 200, 70), (9, 333, 100), (5, 65, 33), (13, 64, 1)])
+def test_play_moves_replays_recorded_and_corrupted_games(N, B, T):
+    """gg_batch_play_moves / _packed: T given moves per game in one launch == the oracle stepping move by move
+    (gym_go/gogame.py:34-87), stopping at the first illegal move or at the end of the game."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    st, rng = _mid(B, N, 11, auto_reset=False)
+    start = st.clone()
+    rec = torch.empty((B, T), dtype=torch.int32, device='cuda')
+    la = torch.empty(B, dtype=torch.int32, device='cuda')
+    for t in range(T):                       # record a legal continuation (auto-reset off: finished games yield -1)
+        gogame.batch_rollout(st, rng, 1, False, la, None)
+        rec[:, t] = la
+    moves = rec.clone().cpu().numpy()
+    gen = np.random.default_rng(N + T)
+    for i in gen.choice(B, B // 3, replace=False):    # corrupt one move of every third game
+        moves[i, gen.integers(0, T)] = gen.integers(-2, N * N + 2)
+    # expected: step game by game on the host with the oracle
+    host = start.cpu().numpy()
+    want = host.copy()
+    played = np.zeros(B, np.int32)
+    for i in range(B):
+        s = host[i]
+        for t in range(T):
+            a = int(moves[i, t])
+            if s[5, 0, 0] or a < 0 or a > N * N or (a < N * N and s[3].reshape(-1)[a]):
+                break
+            s = c_oracle.next_state(s, a)
+            played[i] += 1
+        want[i] = s
+    mv = torch.from_numpy(moves).cuda()
+    a = start.clone()
+    got = gogame.batch_play_moves(a, mv)
+    assert np.array_equal(got.cpu().numpy(), played)
+    assert np.array_equal(a.cpu().numpy(), want)
+    pk = gogame.batch_pack(start)
+    got2 = gogame.batch_play_moves(pk, mv)
+    assert torch.equal(got2, got) and torch.equal(gogame.batch_unpack(pk, N), a)
+    assert played.min() < T <= played.max() or T == 1

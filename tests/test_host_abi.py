@@ -45,6 +45,8 @@ def test_argument_validation_without_device(built):
     assert L.gg_batch_rollout_packed(None, None, None, None, 2, 9, -4, 1, None) == -3
     assert L.gg_batch_children_packed(None, None, 3, 9, 0, None) == -2
     assert L.gg_packed_words(19) == 58 and L.gg_packed_words(1) == -1
+    assert L.gg_batch_play_moves(None, None, None, 2, 9, -1, None) == -3
+    assert L.gg_batch_play_moves_packed(None, None, None, 2, 9, 5, None) == -2
 
 
 def test_no_cpu_fallback(built):

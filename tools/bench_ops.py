@@ -111,6 +111,24 @@ def main():
     for F in (1, 64):
         t = timed(lambda: gogame.batch_rollout_packed(pk2, rng2, F, True), 20 if F == 1 else 5)
         out['gg_batch_rollout_packed_F%d_19x19_B65536' % F] = {'steps_per_s': B2 * F / t}
+    # replay of recorded move sequences (64 moves per game in one launch)
+    T = 64
+    rec = torch.empty((B2, T), dtype=torch.int32, device='cuda')
+    la = torch.empty(B2, dtype=torch.int32, device='cuda')
+    base = st2.clone()
+    r3 = gogame.rng_seed(B2, 21)
+    tmp = st2.clone()
+    for tt in range(T):
+        gogame.batch_rollout(tmp, r3, 1, False, la, None)
+        rec[:, tt] = la
+    work = base.clone()
+
+    def replay():
+        work.copy_(base)
+        gogame.batch_play_moves(work, rec)
+    t_copy = timed(lambda: work.copy_(base), 20)
+    t = timed(replay, 10) - t_copy
+    out['gg_batch_play_moves_T64_19x19_B65536'] = {'moves_per_s': B2 * float(gogame.batch_play_moves(base.clone(), rec).float().mean()) / t}
     # single-state latency (GoEnv.children / next_state path)
     one = st[0]
     t0 = time.perf_counter()
