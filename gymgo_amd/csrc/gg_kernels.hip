@@ -8,6 +8,7 @@
 #include "gg_common.h"
 #include "gg_v1.h"
 #include "gg_v2.h"
+#include "gg_v3.h"
 #include "gymgo_amd.h"
 
 namespace {
@@ -59,6 +60,19 @@ bool children_full() {
   static int v = -1;
   if (v < 0) { const char *e = getenv("GG_CHILDREN_FULL"); v = (e && e[0] == '1') ? 1 : 0; }
   return v == 1;
+}
+
+// GG_ROLLOUT_V2=1 keeps the fused rollout on the v2 kernel (full analysis per ply, 2 boards per wave) - A/B only
+bool rollout_v2() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("GG_ROLLOUT_V2"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
+int v3_min_plies() {
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("GG_V3_MIN"); v = e ? atoi(e) : 8; }
+  return v;
 }
 
 // GG_SYNC_IO=1 selects the non-pipelined (load, analyse, store) per-ply kernels - A/B measurements only
@@ -212,6 +226,13 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
   if (!inv) return GG_E_BADSIZE;
   hipStream_t s = (hipStream_t)hip_stream;
   int grid = grid_for(B);
+  if (variant() == 2 && plies >= v3_min_plies() && !rollout_v2()) {   // incremental classes, 12 boards per wave
+    grid = grid_for((B + kNB3 - 1) / kNB3);
+    GG_DISPATCH(N, (k_rollout3<9, false><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
+                (k_rollout3<13, false><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
+                (k_rollout3<19, false><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)));
+    return (int32_t)hipGetLastError();
+  }
   if (variant() == 2) {
     grid = grid_for((B + 1) / 2);
     if (plies <= 2) {

@@ -1,0 +1,350 @@
+// gg_v3.h - fused uniform-random rollout, TWELVE BOARDS PER WAVEFRONT, incremental liberty classes.
+#pragma once
+#include "gg_v2.h"
+
+namespace gg {
+
+// ===================================================================== v3: incremental analysis, 12 boards per wave
+// The v2 rollout re-derives every group's liberty class each ply with 22 floods per board (2 boards per wave).  The cost
+// of a flood batch does not depend on how many of the wave's 64 lanes carry a flood, so the lever is floods per board:
+// a move at q only changes the groups ADJACENT to q (and, rarely, to a captured group).  The kernel therefore keeps, per
+// board, the stones of either colour whose group has >= 2 liberties (every other stone is in atari: a legal position
+// has no liberty-less group) and updates them per ply from FIVE floods:
+//   lane 0 of a board: the mover's group G that the new stone joins (flood from q through the mover's stones + q);
+//   lanes 1-4:         the opponent's group at the upper / lower / left / right neighbour of q (empty otherwise).
+// In L1 (one board per half, six passes per ply):
+//   * an opponent group g_j adjacent to q is recounted exactly: dilate(g_j) & empty' -> 0 liberties: captured,
+//     1: atari, >= 2: still "multi" (two ballots classify a point set as empty / single / more);
+//   * G is recounted on the position after the captures;
+//   * a mover's group in atari next to a captured stone gains a liberty -> multi (rare; L1 flood through the atari set);
+//   * every other group keeps its class.  The invalid-move mask follows from the classes exactly as in v2.
+// 12 boards x 5 lanes = 60 lanes per flood batch: the floods cost a sixth per board, the L1 work (sampling, the class
+// patch, the mask) is what remains - about 160 VALU ops per board and ply against 346.
+// Board state lives in LDS between the passes (5 rows per board: black, white, invalid, multi_black, multi_white).
+constexpr int kNB3 = 12;
+
+template <int R>
+struct Lds3 {
+  static constexpr int RS = Cfg<R>::kRowStride;
+  static constexpr int kState = 0;                               // [5][kNB3][RS]
+  static constexpr int kMeta = kState + 5 * kNB3 * RS;           // flags[16], act[16], last[16], played[16], rng[32]
+  static constexpr int kUnion = kMeta + 96;
+  // ply loop: flood input planes [4][kNB3][RS] (mover + new stone, opponent, both bit-reversed) + transpose buffer
+  static constexpr int kPlanes = kUnion;
+  static constexpr int kSc = kPlanes + 4 * kNB3 * RS;
+  static constexpr int kLoopEnd = kSc + kWave * RS;
+  // load / store: the v2 analysis scratch (first classes of a board); at store time its region 0 holds the emitter's
+  // scratch (2 x 128 words) and the spread table (uint2[256])
+  static constexpr int kV2 = kUnion;
+  static constexpr int kLut = kV2 + 256;
+  static constexpr int kIoEnd = kV2 + Lds2<R>::kTotal;
+  static_assert(Lds2<R>::kRegion0 >= 256 + 512, "region 0 holds the emitter scratch and the spread table");
+  static constexpr int kTotal = kLoopEnd > kIoEnd ? kLoopEnd : kIoEnd;
+};
+
+// is the point set x (L1 rows of this half) non-empty / larger than one point?
+__device__ __forceinline__ void set_size(uint32_t x, const Half &hf, bool &any, bool &two) {
+  const uint32_t nz = half_of(__ballot(x != 0), hf.h), many = half_of(__ballot(__popc(x) > 1), hf.h);
+  any = nz != 0;
+  two = ((nz & (nz - 1u)) | many) != 0;
+}
+__device__ __forceinline__ uint32_t dilate_l1(uint32_t x) {
+  return B3(shl1(x), x >> 1, dpp0<0x138>(x), T_OR3) | dpp0<0x130>(x);
+}
+
+template <int R, bool PACKED>
+__global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+                                                       int32_t *__restrict__ last_actions, int64_t *__restrict__ steps_done,
+                                                       int64_t B, int N, uint32_t inv, int plies, int auto_reset) {
+  constexpr int RS = Lds3<R>::RS;
+  constexpr int RV = (R + 3) / 4;
+  constexpr int PL = kNB3 * RS;   // words per plane of all boards
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds3<R>::kTotal];
+  const Half hf = make_half(threadIdx.x, N, inv);
+  uint32_t *st = lds + Lds3<R>::kState;     // st[p * PL + s * RS + row]
+  uint32_t *flagsv = lds + Lds3<R>::kMeta;  // bit 0 turn, 1 passed, 2 done, 3 on
+  int *actv = reinterpret_cast<int *>(lds + Lds3<R>::kMeta + 16);
+  int *lastv = reinterpret_cast<int *>(lds + Lds3<R>::kMeta + 32);
+  int *playedv = reinterpret_cast<int *>(lds + Lds3<R>::kMeta + 48);
+  uint32_t *rngv = lds + Lds3<R>::kMeta + 64;   // [2 * s], [2 * s + 1]
+  uint32_t *planes = lds + Lds3<R>::kPlanes;
+  uint32_t *sc = lds + Lds3<R>::kSc;
+  uint32_t *v2 = lds + Lds3<R>::kV2;
+  uint2 *lut = reinterpret_cast<uint2 *>(lds + Lds3<R>::kLut);
+  const int S = 6 * hf.P, W = 3 * N + 1;
+  const bool row = hf.hl < RS;
+  const int64_t ngroups = (B + kNB3 - 1) / kNB3;
+
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t b_first = g * kNB3;
+    // ---------------------------------------------------------------- load: 6 pairs, first classes by the v2 analysis
+    WAVE_SYNC();
+    load_cw_table<R>(v2, hf.lane);
+#pragma unroll 1
+    for (int i = 0; i < kNB3 / 2; ++i) {
+      const int s = 2 * i + hf.h;
+      const bool on = b_first + s < B;
+      const int64_t b = on ? b_first + s : B - 1;
+      uint32_t black, white, invalid;
+      int turn, passed, done;
+      if (PACKED) {
+        uint32_t fw;
+        load_packed_h(reinterpret_cast<const uint32_t *>(states) + b * (int64_t)W, N, hf, black, white, invalid, fw);
+        turn = fw & 1u; passed = (fw >> 1) & 1u; done = (fw >> 2) & 1u;
+      } else {
+        const uint8_t *gs = states + b * (int64_t)S;
+        uint8_t *io = reinterpret_cast<uint8_t *>(v2) + hf.h * Cfg<R>::kIoBytes;
+        const uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
+        WAVE_SYNC();
+        const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
+        WAVE_SYNC();
+        black = plane_to_row<R>(io + mi, N, hf.hl);
+        white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+        invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
+        turn = flags & 1u; passed = (flags >> 2) & 1u; done = (flags >> 3) & 1u;
+      }
+      uint32_t mb, ab, mw;
+      analyze2<R, false>(black, white, hf.full_l1 & ~(black | white), hf, v2, mb, ab, mw);
+      if (row) {
+        st[0 * PL + s * RS + hf.hl] = black;
+        st[1 * PL + s * RS + hf.hl] = white;
+        st[2 * PL + s * RS + hf.hl] = invalid;
+        st[3 * PL + s * RS + hf.hl] = mb;
+        st[4 * PL + s * RS + hf.hl] = mw;
+      }
+      if (hf.hl == 0) {
+        flagsv[s] = (uint32_t)turn | ((uint32_t)passed << 1) | ((uint32_t)done << 2) | (on ? 8u : 0u);
+        lastv[s] = -1;
+        playedv[s] = 0;
+        const uint64_t x = rng[b];
+        rngv[2 * s] = (uint32_t)x;
+        rngv[2 * s + 1] = (uint32_t)(x >> 32);
+      }
+      WAVE_SYNC();
+    }
+
+    // ---------------------------------------------------------------- the plies
+#pragma unroll 1
+    for (int t = 0; t < plies; ++t) {
+      // phase A: per board sample the move, place the stone, publish the flood inputs
+      uint64_t anylive = 0;
+#pragma unroll 1
+      for (int i = 0; i < kNB3 / 2; ++i) {
+        const int s = 2 * i + hf.h;
+        const uint32_t fl = flagsv[s];
+        int turn = fl & 1u, done = (fl >> 2) & 1u;
+        const bool on = (fl >> 3) & 1u;
+        const bool live = on && !(done && !auto_reset);
+        uint32_t black = 0, white = 0, invalid = 0;
+        if (row) {
+          black = st[0 * PL + s * RS + hf.hl];
+          white = st[1 * PL + s * RS + hf.hl];
+          invalid = st[2 * PL + s * RS + hf.hl];
+        }
+        if (done && live) {   // auto-reset: init_state
+          black = white = invalid = 0;
+          turn = 0;
+          if (row) {
+            st[0 * PL + s * RS + hf.hl] = 0; st[1 * PL + s * RS + hf.hl] = 0; st[2 * PL + s * RS + hf.hl] = 0;
+            st[3 * PL + s * RS + hf.hl] = 0; st[4 * PL + s * RS + hf.hl] = 0;
+          }
+          if (hf.hl == 0) flagsv[s] = 8u;
+        }
+        const uint32_t valid = hf.full_l1 & ~invalid;
+        const uint32_t incl = half_scan((uint32_t)__popc(valid));
+        const uint32_t cnt_a = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+        const uint32_t cnt_b = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint64_t xa = uniform64(((uint64_t)rngv[4 * i + 1] << 32) | rngv[4 * i]);
+        uint64_t xb = uniform64(((uint64_t)rngv[4 * i + 3] << 32) | rngv[4 * i + 2]);
+        const uint64_t ua = splitmix_next(xa), ub = splitmix_next(xb);
+        const uint32_t ka = (uint32_t)(((ua >> 32) * (uint64_t)(cnt_a + 1)) >> 32);
+        const uint32_t kb = (uint32_t)(((ub >> 32) * (uint64_t)(cnt_b + 1)) >> 32);
+        int a = pick_action2(valid, incl, hf.h ? kb : ka, hf);
+        if (!live) a = hf.P;
+        if (live && hf.hl == 0) {
+          const uint64_t x = hf.h ? xb : xa;
+          rngv[2 * s] = (uint32_t)x;
+          rngv[2 * s + 1] = (uint32_t)(x >> 32);
+        }
+        anylive |= __ballot(live);
+        uint32_t mine = turn ? white : black;
+        const uint32_t opp = turn ? black : white;
+        if (a < hf.P) {
+          int ar, ac;
+          split_action(a, N, hf.inv, ar, ac);
+          if (hf.hl == ar) mine |= 1u << ac;
+        }
+        if (row) {
+          planes[0 * PL + s * RS + hf.hl] = mine;
+          planes[1 * PL + s * RS + hf.hl] = opp;
+          planes[2 * PL + s * RS + hf.hl] = __brev(mine);
+          planes[3 * PL + s * RS + hf.hl] = __brev(opp);
+        }
+        if (hf.hl == 0) actv[s] = live ? a : -1;   // -1: the board does not move this ply
+      }
+      if (anylive == 0) break;
+      WAVE_SYNC();
+
+      // flood batch: lane -> (board s, role j); role 0 floods the mover's stones from q, roles 1-4 the opponent's from
+      // the four neighbours of q
+      {
+        const int s = (hf.lane * 13) >> 6, j = hf.lane - 5 * s;
+        const bool used = hf.lane < 5 * kNB3;
+        const int a = used ? actv[s] : -1;
+        uint32_t m[R], mrev[R], f[R];
+        int sr = -1;
+        uint32_t sbit = 0;
+        if (a >= 0 && a < hf.P) {
+          int ar, ac;
+          split_action(a, N, hf.inv, ar, ac);
+          sr = ar + (j == 1 ? -1 : (j == 2 ? 1 : 0));
+          sbit = j == 3 ? ((1u << ac) >> 1) : (j == 4 ? (1u << ac) << 1 : (1u << ac));
+        }
+        {
+          uint32_t mt[RV * 4], rt[RV * 4];
+          const int ss = used ? s : 0;
+          const uint4 *pm = reinterpret_cast<const uint4 *>(planes + (j == 0 ? 0 : 1) * PL + ss * RS);
+          const uint4 *pr = reinterpret_cast<const uint4 *>(planes + (j == 0 ? 2 : 3) * PL + ss * RS);
+#pragma unroll
+          for (int i = 0; i < RV; ++i) {
+            const uint4 x = pm[i], y = pr[i];
+            mt[4 * i] = x.x; mt[4 * i + 1] = x.y; mt[4 * i + 2] = x.z; mt[4 * i + 3] = x.w;
+            rt[4 * i] = y.x; rt[4 * i + 1] = y.y; rt[4 * i + 2] = y.z; rt[4 * i + 3] = y.w;
+          }
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            m[r] = mt[r];
+            mrev[r] = rt[r];
+            f[r] = (r == sr) ? (m[r] & sbit) : 0u;
+          }
+        }
+        flood2_serial<R>(m, mrev, f, sc + hf.lane * RS);
+      }
+      WAVE_SYNC();
+
+      // phase B: per board patch the classes, resolve captures and ko, build the next mover's mask
+#pragma unroll 1
+      for (int i = 0; i < kNB3 / 2; ++i) {
+        const int s = 2 * i + hf.h;
+        const int a = actv[s];
+        const bool moves = a >= 0;
+        const uint32_t fl = flagsv[s];
+        int turn = fl & 1u, passed = (fl >> 1) & 1u, done = (fl >> 2) & 1u;
+        uint32_t black = 0, white = 0, mbk = 0, mwh = 0, g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0;
+        if (row) {
+          black = st[0 * PL + s * RS + hf.hl];
+          white = st[1 * PL + s * RS + hf.hl];
+          mbk = st[3 * PL + s * RS + hf.hl];
+          mwh = st[4 * PL + s * RS + hf.hl];
+        }
+        if (hf.hl < R) {   // the floods write rows 0 .. R-1 of their blocks only
+          const uint32_t *gr = sc + (5 * s) * RS + hf.hl;
+          g0 = gr[0]; g1 = gr[RS]; g2 = gr[2 * RS]; g3 = gr[3 * RS]; g4 = gr[4 * RS];
+        }
+        const bool is_pass = a == hf.P;
+        const uint32_t mine0 = turn ? white : black, opp0 = turn ? black : white;
+        uint32_t Mm = turn ? mwh : mbk, Mo = turn ? mbk : mwh;
+        int ar = 0, ac = 0;
+        split_action((moves && !is_pass) ? a : 0, N, hf.inv, ar, ac);
+        const uint32_t bit = (moves && !is_pass) ? (1u << ac) : 0u;
+        const uint32_t qrow = hf.hl == ar ? bit : 0u;
+        uint32_t nbm = hf.hl == ar ? ((bit << 1) | (bit >> 1)) : ((hf.hl == ar - 1 || hf.hl == ar + 1) ? bit : 0u);
+        nbm &= hf.full_l1;
+        const bool boxed = half_of(__ballot((nbm & ~opp0) != 0), hf.h) == 0;
+        const uint32_t mine1 = mine0 | qrow;
+        const uint32_t e1 = hf.full_l1 & ~(mine1 | opp0);
+        // the opponent's groups at the four neighbours: recount
+        bool any, two;
+        uint32_t cap = 0, keep = 0;
+        set_size(dilate_l1(g1) & e1, hf, any, two); cap |= any ? 0u : g1; keep |= two ? g1 : 0u;
+        set_size(dilate_l1(g2) & e1, hf, any, two); cap |= any ? 0u : g2; keep |= two ? g2 : 0u;
+        set_size(dilate_l1(g3) & e1, hf, any, two); cap |= any ? 0u : g3; keep |= two ? g3 : 0u;
+        set_size(dilate_l1(g4) & e1, hf, any, two); cap |= any ? 0u : g4; keep |= two ? g4 : 0u;
+        const uint32_t gall = g1 | g2 | g3 | g4;
+        uint32_t Mo2 = (Mo & ~gall) | keep;
+        const uint32_t opp1 = opp0 & ~cap;
+        const uint32_t e2 = e1 | cap;
+        set_size(dilate_l1(g0) & e2, hf, any, two);
+        uint32_t Mm2 = (Mm & ~g0) | (two ? g0 : 0u);
+        int ko_r = -1, ko_c = 0;
+        if (__ballot(cap != 0)) {
+          // gogame.py:72-75: ko iff exactly one stone died and the new stone is boxed in
+          const uint32_t dm = half_of(__ballot(cap != 0), hf.h);
+          const uint32_t manyc = half_of(__ballot(__popc(cap) > 1), hf.h);
+          if (dm && boxed && manyc == 0 && (dm & (dm - 1u)) == 0) {
+            ko_r = __ffs(dm) - 1;
+            ko_c = __ffs(__shfl(cap, (hf.lane & 32) + ko_r)) - 1;
+          }
+          // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties
+          const uint32_t atari_m = mine0 & ~Mm & ~g0;
+          uint32_t f = dilate_l1(cap) & atari_m;
+          if (__ballot(f != 0)) {
+#pragma unroll 1
+            for (int it = 0; it < R * R; ++it) {
+              const uint32_t gnew = B3(dilate_l1(f), atari_m, f, T_ANDOR);
+              const bool chg = gnew != f;
+              f = gnew;
+              if (__ballot(chg) == 0) break;
+            }
+            Mm2 |= f;
+          }
+        }
+        uint32_t invalid = invalid_from2(opp1, mine1, Mo2, Mm2, hf);
+        if (hf.hl == ko_r) invalid |= 1u << ko_c;
+        if (moves) {
+          if (is_pass) { if (passed) done = 1; passed = 1; } else passed = 0;
+          const uint32_t nb = turn ? opp1 : mine1, nw = turn ? mine1 : opp1;
+          const uint32_t nmb = turn ? Mo2 : Mm2, nmw = turn ? Mm2 : Mo2;
+          turn ^= 1;
+          if (row) {
+            st[0 * PL + s * RS + hf.hl] = nb;
+            st[1 * PL + s * RS + hf.hl] = nw;
+            st[2 * PL + s * RS + hf.hl] = invalid;
+            st[3 * PL + s * RS + hf.hl] = nmb;
+            st[4 * PL + s * RS + hf.hl] = nmw;
+          }
+          if (hf.hl == 0) {
+            flagsv[s] = (uint32_t)turn | ((uint32_t)passed << 1) | ((uint32_t)done << 2) | 8u;
+            lastv[s] = a;
+            playedv[s] += 1;
+          }
+        }
+      }
+      WAVE_SYNC();
+    }
+
+    // ---------------------------------------------------------------- store
+    WAVE_SYNC();
+    if (!PACKED) load_spread_lut(lut, hf.lane);
+#pragma unroll 1
+    for (int i = 0; i < kNB3 / 2; ++i) {
+      const int s = 2 * i + hf.h;
+      const uint32_t fl = flagsv[s];
+      const bool on = (fl >> 3) & 1u;
+      const int64_t b = on ? b_first + s : B - 1;
+      const int played = playedv[s];
+      uint32_t black = 0, white = 0, invalid = 0;
+      if (row) {
+        black = st[0 * PL + s * RS + hf.hl];
+        white = st[1 * PL + s * RS + hf.hl];
+        invalid = st[2 * PL + s * RS + hf.hl];
+      }
+      const bool wr = on && played != 0;
+      if (PACKED) {
+        store_packed_h(reinterpret_cast<uint32_t *>(states) + b * (int64_t)W, N, hf, black, white, invalid, fl & 1u,
+                       (fl >> 1) & 1u, (fl >> 2) & 1u, wr);
+      } else if (__ballot(wr)) {
+        emit_store_h<R>(states + b * (int64_t)S, black, white, invalid, fl & 1u, (fl >> 1) & 1u, (fl >> 2) & 1u, hf,
+                        v2 + hf.h * 128, lut, wr);
+      }
+      if (on && hf.hl == 0) {
+        rng[b] = ((uint64_t)rngv[2 * s + 1] << 32) | rngv[2 * s];
+        if (last_actions) last_actions[b] = lastv[s];
+        if (steps_done) steps_done[b] += played;
+      }
+      WAVE_SYNC();
+    }
+  }
+}
+
+}  // namespace gg
