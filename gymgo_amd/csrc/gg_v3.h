@@ -21,6 +21,12 @@ namespace gg {
 // 12 boards x 5 lanes = 60 lanes per flood batch: the floods cost a sixth per board, the L1 work (sampling, the class
 // patch, the mask) is what remains - about 160 VALU ops per board and ply against 346.
 // Board state lives in LDS between the passes (5 rows per board: black, white, invalid, multi_black, multi_white).
+#ifndef GG_V3_UA
+#define GG_V3_UA 1
+#endif
+#ifndef GG_V3_UB
+#define GG_V3_UB 1
+#endif
 constexpr int kNB3 = 12;
 
 template <int R>
@@ -29,9 +35,9 @@ struct Lds3 {
   static constexpr int kState = 0;                               // [5][kNB3][RS]
   static constexpr int kMeta = kState + 5 * kNB3 * RS;           // flags[16], act[16], last[16], played[16], rng[32]
   static constexpr int kUnion = kMeta + 96;
-  // ply loop: flood input planes [4][kNB3][RS] (mover + new stone, opponent, both bit-reversed) + transpose buffer
-  static constexpr int kPlanes = kUnion;
-  static constexpr int kSc = kPlanes + 4 * kNB3 * RS;
+  // ply loop: per flood lane its result word (liberty class, size, ...) + the transpose buffer of the group masks
+  static constexpr int kCls = kUnion;
+  static constexpr int kSc = kCls + kWave;
   static constexpr int kLoopEnd = kSc + kWave * RS;
   // load / store: the v2 analysis scratch (first classes of a board); at store time its region 0 holds the emitter's
   // scratch (2 x 128 words) and the spread table (uint2[256])
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
   int *lastv = reinterpret_cast<int *>(lds + Lds3<R>::kMeta + 32);
   int *playedv = reinterpret_cast<int *>(lds + Lds3<R>::kMeta + 48);
   uint32_t *rngv = lds + Lds3<R>::kMeta + 64;   // [2 * s], [2 * s + 1]
-  uint32_t *planes = lds + Lds3<R>::kPlanes;
+  uint32_t *clsv = lds + Lds3<R>::kCls;
   uint32_t *sc = lds + Lds3<R>::kSc;
   uint32_t *v2 = lds + Lds3<R>::kV2;
   uint2 *lut = reinterpret_cast<uint2 *>(lds + Lds3<R>::kLut);
@@ -126,110 +132,138 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
     // ---------------------------------------------------------------- the plies
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
-      // phase A: per board sample the move, place the stone, publish the flood inputs
-      uint64_t anylive = 0;
-#pragma unroll 1
-      for (int i = 0; i < kNB3 / 2; ++i) {
-        const int s = 2 * i + hf.h;
-        const uint32_t fl = flagsv[s];
-        int turn = fl & 1u, done = (fl >> 2) & 1u;
-        const bool on = (fl >> 3) & 1u;
+      // phase 1 - one LANE per board (lanes 0-11): liveness, the generator, the k-th valid point
+      uint64_t resetm;
+      {
+        const bool bl = hf.lane < kNB3;
+        const int sb = bl ? hf.lane : 0;
+        const uint32_t fl = flagsv[sb];
+        const bool on = bl && ((fl >> 3) & 1u);
+        const bool done = (fl >> 2) & 1u;
         const bool live = on && !(done && !auto_reset);
-        uint32_t black = 0, white = 0, invalid = 0;
-        if (row) {
-          black = st[0 * PL + s * RS + hf.hl];
-          white = st[1 * PL + s * RS + hf.hl];
-          invalid = st[2 * PL + s * RS + hf.hl];
+        const bool reset = live && done;           // auto-reset: the board is init_state from now on
+        const uint32_t fullrow = (1u << N) - 1u;
+        uint32_t vrows[R];
+        uint32_t n = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint32_t iv = st[2 * PL + sb * RS + r];
+          const uint32_t v = r < N ? (reset ? fullrow : (fullrow & ~iv)) : 0u;
+          vrows[r] = v;
+          n += (uint32_t)__popc(v);
         }
-        if (done && live) {   // auto-reset: init_state
-          black = white = invalid = 0;
-          turn = 0;
-          if (row) {
-            st[0 * PL + s * RS + hf.hl] = 0; st[1 * PL + s * RS + hf.hl] = 0; st[2 * PL + s * RS + hf.hl] = 0;
-            st[3 * PL + s * RS + hf.hl] = 0; st[4 * PL + s * RS + hf.hl] = 0;
-          }
-          if (hf.hl == 0) flagsv[s] = 8u;
+        uint64_t x = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
+        const uint64_t u = splitmix_next(x);
+        uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(n + 1)) >> 32);
+        int rr = -1;
+        uint32_t acc = 0, tt = 0, vr = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint32_t c = (uint32_t)__popc(vrows[r]);
+          const bool hit = rr < 0 && k < acc + c;
+          if (hit) { rr = r; tt = k - acc; vr = vrows[r]; }
+          acc += c;
         }
-        const uint32_t valid = hf.full_l1 & ~invalid;
-        const uint32_t incl = half_scan((uint32_t)__popc(valid));
-        const uint32_t cnt_a = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
-        const uint32_t cnt_b = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        uint64_t xa = uniform64(((uint64_t)rngv[4 * i + 1] << 32) | rngv[4 * i]);
-        uint64_t xb = uniform64(((uint64_t)rngv[4 * i + 3] << 32) | rngv[4 * i + 2]);
-        const uint64_t ua = splitmix_next(xa), ub = splitmix_next(xb);
-        const uint32_t ka = (uint32_t)(((ua >> 32) * (uint64_t)(cnt_a + 1)) >> 32);
-        const uint32_t kb = (uint32_t)(((ub >> 32) * (uint64_t)(cnt_b + 1)) >> 32);
-        int a = pick_action2(valid, incl, hf.h ? kb : ka, hf);
-        if (!live) a = hf.P;
-        if (live && hf.hl == 0) {
-          const uint64_t x = hf.h ? xb : xa;
-          rngv[2 * s] = (uint32_t)x;
-          rngv[2 * s + 1] = (uint32_t)(x >> 32);
+        uint32_t pos = 0;   // the tt-th set bit of vr
+#pragma unroll
+        for (int sh = 16; sh >= 1; sh >>= 1) {
+          const uint32_t c = (uint32_t)__popc((vr >> pos) & ((1u << sh) - 1u));
+          if (tt >= c) { tt -= c; pos += sh; }
         }
-        anylive |= __ballot(live);
-        uint32_t mine = turn ? white : black;
-        const uint32_t opp = turn ? black : white;
-        if (a < hf.P) {
-          int ar, ac;
-          split_action(a, N, hf.inv, ar, ac);
-          if (hf.hl == ar) mine |= 1u << ac;
+        const int a = !live ? -1 : (rr >= 0 ? rr * N + (int)pos : hf.P);   // -1: the board does not move this ply
+        if (bl) {
+          actv[sb] = a;
+          if (live) { rngv[2 * sb] = (uint32_t)x; rngv[2 * sb + 1] = (uint32_t)(x >> 32); }
         }
-        if (row) {
-          planes[0 * PL + s * RS + hf.hl] = mine;
-          planes[1 * PL + s * RS + hf.hl] = opp;
-          planes[2 * PL + s * RS + hf.hl] = __brev(mine);
-          planes[3 * PL + s * RS + hf.hl] = __brev(opp);
-        }
-        if (hf.hl == 0) actv[s] = live ? a : -1;   // -1: the board does not move this ply
+        if (__ballot(live) == 0) break;
+        resetm = __ballot(reset);
       }
-      if (anylive == 0) break;
+      while (resetm) {   // rare
+        const int s = __ffsll((unsigned long long)resetm) - 1;
+        resetm &= resetm - 1;
+        for (int i = hf.lane; i < 5 * RS; i += kWave) st[(i / RS) * PL + s * RS + (i % RS)] = 0;
+        if (hf.lane == 0) flagsv[s] = 8u;
+      }
       WAVE_SYNC();
 
-      // flood batch: lane -> (board s, role j); role 0 floods the mover's stones from q, roles 1-4 the opponent's from
-      // the four neighbours of q
+      // phase 2 - one lane per (board, role): role 0 floods the mover's stones from the new stone q, roles 1-4 the
+      // opponent's from the four neighbours of q; then every lane counts the liberties of its own group
       {
         const int s = (hf.lane * 13) >> 6, j = hf.lane - 5 * s;
         const bool used = hf.lane < 5 * kNB3;
-        const int a = used ? actv[s] : -1;
-        uint32_t m[R], mrev[R], f[R];
-        int sr = -1;
-        uint32_t sbit = 0;
-        if (a >= 0 && a < hf.P) {
-          int ar, ac;
-          split_action(a, N, hf.inv, ar, ac);
-          sr = ar + (j == 1 ? -1 : (j == 2 ? 1 : 0));
-          sbit = j == 3 ? ((1u << ac) >> 1) : (j == 4 ? (1u << ac) << 1 : (1u << ac));
-        }
+        const int ss = used ? s : 0;
+        const int a = used ? actv[ss] : -1;
+        const int turn = flagsv[ss] & 1u;
+        const bool moving = a >= 0 && a < hf.P;
+        int ar = -9, ac = 0;
+        if (moving) split_action(a, N, hf.inv, ar, ac);
+        const uint32_t bit = moving ? (1u << ac) : 0u;
+        const uint32_t *own = st + ((j == 0) ? turn : 1 - turn) * PL + ss * RS;   // the colour this lane floods
+        const uint32_t *oth = st + ((j == 0) ? 1 - turn : turn) * PL + ss * RS;
+        const int sr = ar + (j == 1 ? -1 : (j == 2 ? 1 : 0));
+        const uint32_t sbit = j == 3 ? (bit >> 1) : (j == 4 ? (bit << 1) : bit);
+        uint32_t seedrow = 0;
         {
-          uint32_t mt[RV * 4], rt[RV * 4];
-          const int ss = used ? s : 0;
-          const uint4 *pm = reinterpret_cast<const uint4 *>(planes + (j == 0 ? 0 : 1) * PL + ss * RS);
-          const uint4 *pr = reinterpret_cast<const uint4 *>(planes + (j == 0 ? 2 : 3) * PL + ss * RS);
+          uint32_t m[R], mrev[R], f[R];
+          uint32_t mt[RV * 4];
+          const uint4 *pm = reinterpret_cast<const uint4 *>(own);
 #pragma unroll
           for (int i = 0; i < RV; ++i) {
-            const uint4 x = pm[i], y = pr[i];
+            const uint4 x = pm[i];
             mt[4 * i] = x.x; mt[4 * i + 1] = x.y; mt[4 * i + 2] = x.z; mt[4 * i + 3] = x.w;
-            rt[4 * i] = y.x; rt[4 * i + 1] = y.y; rt[4 * i + 2] = y.z; rt[4 * i + 3] = y.w;
           }
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            m[r] = mt[r];
-            mrev[r] = rt[r];
+            m[r] = mt[r] | ((j == 0 && r == ar) ? bit : 0u);
+            mrev[r] = __brev(m[r]);
             f[r] = (r == sr) ? (m[r] & sbit) : 0u;
+            seedrow |= f[r];
+          }
+          flood2_serial<R>(m, mrev, f, sc + hf.lane * RS);
+        }
+        // liberties of this lane's group on the position with the new stone (captures not yet removed)
+        uint32_t cnt = 0, sz = 0;
+        {
+          uint32_t gt[RV * 4], ot[RV * 4], wt[RV * 4];
+          const uint4 *pg = reinterpret_cast<const uint4 *>(sc + hf.lane * RS);
+          const uint4 *po = reinterpret_cast<const uint4 *>(oth);
+          const uint4 *pw = reinterpret_cast<const uint4 *>(own);
+#pragma unroll
+          for (int i = 0; i < RV; ++i) {
+            const uint4 x = pg[i], y = po[i], z = pw[i];
+            gt[4 * i] = x.x; gt[4 * i + 1] = x.y; gt[4 * i + 2] = x.z; gt[4 * i + 3] = x.w;
+            ot[4 * i] = y.x; ot[4 * i + 1] = y.y; ot[4 * i + 2] = y.z; ot[4 * i + 3] = y.w;
+            wt[4 * i] = z.x; wt[4 * i + 1] = z.y; wt[4 * i + 2] = z.z; wt[4 * i + 3] = z.w;
+          }
+          const uint32_t fullrow = (1u << N) - 1u;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const uint32_t occ = ot[r] | wt[r] | (r == ar ? bit : 0u);
+            const uint32_t e = r < N ? (fullrow & ~occ) : 0u;
+            const uint32_t up = r > 0 ? gt[r - 1] : 0u, dn = r + 1 < R ? gt[r + 1] : 0u;   // rows >= R are not written
+            const uint32_t d = B3(shl1(gt[r]), gt[r] >> 1, up, T_OR3) | dn;
+            const uint32_t l = d & e;
+            const uint32_t c = (uint32_t)__popc(l);
+            cnt += c < 2u ? c : 2u;
+            sz += (uint32_t)__popc(gt[r]);
           }
         }
-        flood2_serial<R>(m, mrev, f, sc + hf.lane * RS);
+        // roles 1-4: is this neighbour of q off the board or an opponent stone?  (all four: the new stone is boxed in)
+        const bool off = j == 1 ? ar == 0 : (j == 2 ? ar == N - 1 : (j == 3 ? ac == 0 : ac == N - 1));
+        const bool okbox = off || seedrow != 0;
+        clsv[hf.lane] = (cnt < 2u ? cnt : 2u) | (sz == 1u ? 4u : 0u) | (sz != 0u ? 8u : 0u) | (okbox ? 16u : 0u);
       }
       WAVE_SYNC();
 
-      // phase B: per board patch the classes, resolve captures and ko, build the next mover's mask
-#pragma unroll 1
+      // phase 3 - one board per half, six passes: patch the classes, resolve captures and ko, the next mover's mask
+#pragma unroll GG_V3_UB
       for (int i = 0; i < kNB3 / 2; ++i) {
         const int s = 2 * i + hf.h;
         const int a = actv[s];
         const bool moves = a >= 0;
         const uint32_t fl = flagsv[s];
         int turn = fl & 1u, passed = (fl >> 1) & 1u, done = (fl >> 2) & 1u;
+        const uint32_t c0 = clsv[5 * s], c1 = clsv[5 * s + 1], c2 = clsv[5 * s + 2], c3 = clsv[5 * s + 3], c4 = clsv[5 * s + 4];
         uint32_t black = 0, white = 0, mbk = 0, mwh = 0, g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0;
         if (row) {
           black = st[0 * PL + s * RS + hf.hl];
@@ -243,37 +277,36 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
         }
         const bool is_pass = a == hf.P;
         const uint32_t mine0 = turn ? white : black, opp0 = turn ? black : white;
-        uint32_t Mm = turn ? mwh : mbk, Mo = turn ? mbk : mwh;
+        const uint32_t Mm = turn ? mwh : mbk, Mo = turn ? mbk : mwh;
         int ar = 0, ac = 0;
         split_action((moves && !is_pass) ? a : 0, N, hf.inv, ar, ac);
         const uint32_t bit = (moves && !is_pass) ? (1u << ac) : 0u;
         const uint32_t qrow = hf.hl == ar ? bit : 0u;
-        uint32_t nbm = hf.hl == ar ? ((bit << 1) | (bit >> 1)) : ((hf.hl == ar - 1 || hf.hl == ar + 1) ? bit : 0u);
-        nbm &= hf.full_l1;
-        const bool boxed = half_of(__ballot((nbm & ~opp0) != 0), hf.h) == 0;
         const uint32_t mine1 = mine0 | qrow;
-        const uint32_t e1 = hf.full_l1 & ~(mine1 | opp0);
-        // the opponent's groups at the four neighbours: recount
-        bool any, two;
-        uint32_t cap = 0, keep = 0;
-        set_size(dilate_l1(g1) & e1, hf, any, two); cap |= any ? 0u : g1; keep |= two ? g1 : 0u;
-        set_size(dilate_l1(g2) & e1, hf, any, two); cap |= any ? 0u : g2; keep |= two ? g2 : 0u;
-        set_size(dilate_l1(g3) & e1, hf, any, two); cap |= any ? 0u : g3; keep |= two ? g3 : 0u;
-        set_size(dilate_l1(g4) & e1, hf, any, two); cap |= any ? 0u : g4; keep |= two ? g4 : 0u;
+        // an opponent group at a neighbour of q: 0 liberties left -> captured, 1 -> atari, >= 2 -> multi
+        const bool k1 = (c1 & 11u) == 8u, k2 = (c2 & 11u) == 8u, k3 = (c3 & 11u) == 8u, k4 = (c4 & 11u) == 8u;
+        const uint32_t cap = (k1 ? g1 : 0u) | (k2 ? g2 : 0u) | (k3 ? g3 : 0u) | (k4 ? g4 : 0u);
+        const uint32_t keep = ((c1 & 3u) == 2u ? g1 : 0u) | ((c2 & 3u) == 2u ? g2 : 0u) | ((c3 & 3u) == 2u ? g3 : 0u) |
+                              ((c4 & 3u) == 2u ? g4 : 0u);
         const uint32_t gall = g1 | g2 | g3 | g4;
-        uint32_t Mo2 = (Mo & ~gall) | keep;
+        const uint32_t Mo2 = (Mo & ~gall) | keep;
         const uint32_t opp1 = opp0 & ~cap;
-        const uint32_t e2 = e1 | cap;
-        set_size(dilate_l1(g0) & e2, hf, any, two);
-        uint32_t Mm2 = (Mm & ~g0) | (two ? g0 : 0u);
+        uint32_t libsG = c0 & 3u;               // liberties of G among the empty points (saturated at 2)
+        uint32_t Mm_fix = 0;
         int ko_r = -1, ko_c = 0;
         if (__ballot(cap != 0)) {
+          // captured stones next to G are liberties of G too
+          bool any, two;
+          set_size(dilate_l1(g0) & cap, hf, any, two);
+          libsG += two ? 2u : (any ? 1u : 0u);
           // gogame.py:72-75: ko iff exactly one stone died and the new stone is boxed in
-          const uint32_t dm = half_of(__ballot(cap != 0), hf.h);
-          const uint32_t manyc = half_of(__ballot(__popc(cap) > 1), hf.h);
-          if (dm && boxed && manyc == 0 && (dm & (dm - 1u)) == 0) {
-            ko_r = __ffs(dm) - 1;
-            ko_c = __ffs(__shfl(cap, (hf.lane & 32) + ko_r)) - 1;
+          const uint32_t ncap1 = (k1 && (c1 & 4u) ? 1u : 0u) + (k2 && (c2 & 4u) ? 1u : 0u) + (k3 && (c3 & 4u) ? 1u : 0u) +
+                                 (k4 && (c4 & 4u) ? 1u : 0u);
+          const uint32_t ncapn = (k1 ? 1u : 0u) + (k2 ? 1u : 0u) + (k3 ? 1u : 0u) + (k4 ? 1u : 0u);
+          const bool boxed = (c1 & c2 & c3 & c4 & 16u) != 0;
+          if (boxed && ncapn == 1u && ncap1 == 1u) {
+            ko_r = ar + (k1 ? -1 : (k2 ? 1 : 0));
+            ko_c = ac + (k3 ? -1 : (k4 ? 1 : 0));
           }
           // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties
           const uint32_t atari_m = mine0 & ~Mm & ~g0;
@@ -286,9 +319,10 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
               f = gnew;
               if (__ballot(chg) == 0) break;
             }
-            Mm2 |= f;
+            Mm_fix = f;
           }
         }
+        const uint32_t Mm2 = (Mm & ~g0) | (libsG >= 2u ? g0 : 0u) | Mm_fix;
         uint32_t invalid = invalid_from2(opp1, mine1, Mo2, Mm2, hf);
         if (hf.hl == ko_r) invalid |= 1u << ko_c;
         if (moves) {
