@@ -177,12 +177,18 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
         }
         if (__ballot(live) == 0) break;
         resetm = __ballot(reset);
-      }
-      while (resetm) {   // rare
-        const int s = __ffsll((unsigned long long)resetm) - 1;
-        resetm &= resetm - 1;
-        for (int i = hf.lane; i < 5 * RS; i += kWave) st[(i / RS) * PL + s * RS + (i % RS)] = 0;
-        if (hf.lane == 0) flagsv[s] = 8u;
+        while (resetm) {   // rare
+          const int s = __ffsll((unsigned long long)resetm) - 1;
+          resetm &= resetm - 1;
+          for (int i = hf.lane; i < 5 * RS; i += kWave) st[(i / RS) * PL + s * RS + (i % RS)] = 0;
+          if (hf.lane == 0) flagsv[s] = 8u;
+        }
+        WAVE_SYNC();
+        // the new stone goes into the mover's plane right away: every later phase sees the position with it
+        if (bl && a >= 0 && a < hf.P) {
+          const int turn = reset ? 0 : (int)(fl & 1u);
+          st[turn * PL + sb * RS + rr] |= 1u << pos;
+        }
       }
       WAVE_SYNC();
 
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
           }
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            m[r] = mt[r] | ((j == 0 && r == ar) ? bit : 0u);
+            m[r] = mt[r];
             mrev[r] = __brev(m[r]);
             f[r] = (r == sr) ? (m[r] & sbit) : 0u;
             seedrow |= f[r];
@@ -238,8 +244,7 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
           const uint32_t fullrow = (1u << N) - 1u;
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const uint32_t occ = ot[r] | wt[r] | (r == ar ? bit : 0u);
-            const uint32_t e = r < N ? (fullrow & ~occ) : 0u;
+            const uint32_t e = r < N ? (fullrow & ~(ot[r] | wt[r])) : 0u;
             const uint32_t up = r > 0 ? gt[r - 1] : 0u, dn = r + 1 < R ? gt[r + 1] : 0u;   // rows >= R are not written
             const uint32_t d = B3(shl1(gt[r]), gt[r] >> 1, up, T_OR3) | dn;
             const uint32_t l = d & e;
@@ -252,6 +257,12 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
         const bool off = j == 1 ? ar == 0 : (j == 2 ? ar == N - 1 : (j == 3 ? ac == 0 : ac == N - 1));
         const bool okbox = off || seedrow != 0;
         clsv[hf.lane] = (cnt < 2u ? cnt : 2u) | (sz == 1u ? 4u : 0u) | (sz != 0u ? 8u : 0u) | (okbox ? 16u : 0u);
+        // an opponent group that keeps >= 2 liberties keeps its class: phase 3 must not see it
+        if (j != 0 && cnt >= 2u) {
+          uint4 *pz = reinterpret_cast<uint4 *>(sc + hf.lane * RS);
+#pragma unroll
+          for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
       }
       WAVE_SYNC();
 
@@ -264,37 +275,25 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
         const uint32_t fl = flagsv[s];
         int turn = fl & 1u, passed = (fl >> 1) & 1u, done = (fl >> 2) & 1u;
         const uint32_t c0 = clsv[5 * s], c1 = clsv[5 * s + 1], c2 = clsv[5 * s + 2], c3 = clsv[5 * s + 3], c4 = clsv[5 * s + 4];
-        uint32_t black = 0, white = 0, mbk = 0, mwh = 0, g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0;
-        if (row) {
-          black = st[0 * PL + s * RS + hf.hl];
-          white = st[1 * PL + s * RS + hf.hl];
-          mbk = st[3 * PL + s * RS + hf.hl];
-          mwh = st[4 * PL + s * RS + hf.hl];
-        }
+        // planes by role, not by colour: the mover's stones / classes are plane `turn` / 3 + `turn`
+        uint32_t *pmine = st + turn * PL + s * RS + hf.hl, *popp = st + (1 - turn) * PL + s * RS + hf.hl;
+        uint32_t *pMm = st + (3 + turn) * PL + s * RS + hf.hl, *pMo = st + (4 - turn) * PL + s * RS + hf.hl;
+        uint32_t mine1 = 0, opp0 = 0, Mm = 0, Mo = 0, g0 = 0, gch = 0;
+        if (row) { mine1 = *pmine; opp0 = *popp; Mm = *pMm; Mo = *pMo; }
         if (hf.hl < R) {   // the floods write rows 0 .. R-1 of their blocks only
           const uint32_t *gr = sc + (5 * s) * RS + hf.hl;
-          g0 = gr[0]; g1 = gr[RS]; g2 = gr[2 * RS]; g3 = gr[3 * RS]; g4 = gr[4 * RS];
+          g0 = gr[0];
+          gch = gr[RS] | gr[2 * RS] | gr[3 * RS] | gr[4 * RS];   // the opponent groups whose class changes
         }
         const bool is_pass = a == hf.P;
-        const uint32_t mine0 = turn ? white : black, opp0 = turn ? black : white;
-        const uint32_t Mm = turn ? mwh : mbk, Mo = turn ? mbk : mwh;
-        int ar = 0, ac = 0;
-        split_action((moves && !is_pass) ? a : 0, N, hf.inv, ar, ac);
-        const uint32_t bit = (moves && !is_pass) ? (1u << ac) : 0u;
-        const uint32_t qrow = hf.hl == ar ? bit : 0u;
-        const uint32_t mine1 = mine0 | qrow;
-        // an opponent group at a neighbour of q: 0 liberties left -> captured, 1 -> atari, >= 2 -> multi
         const bool k1 = (c1 & 11u) == 8u, k2 = (c2 & 11u) == 8u, k3 = (c3 & 11u) == 8u, k4 = (c4 & 11u) == 8u;
-        const uint32_t cap = (k1 ? g1 : 0u) | (k2 ? g2 : 0u) | (k3 ? g3 : 0u) | (k4 ? g4 : 0u);
-        const uint32_t keep = ((c1 & 3u) == 2u ? g1 : 0u) | ((c2 & 3u) == 2u ? g2 : 0u) | ((c3 & 3u) == 2u ? g3 : 0u) |
-                              ((c4 & 3u) == 2u ? g4 : 0u);
-        const uint32_t gall = g1 | g2 | g3 | g4;
-        const uint32_t Mo2 = (Mo & ~gall) | keep;
-        const uint32_t opp1 = opp0 & ~cap;
-        uint32_t libsG = c0 & 3u;               // liberties of G among the empty points (saturated at 2)
-        uint32_t Mm_fix = 0;
+        uint32_t cap = 0, Mm_fix = 0, libsG = c0 & 3u;   // libsG: liberties of G among the empty points (saturated at 2)
         int ko_r = -1, ko_c = 0;
-        if (__ballot(cap != 0)) {
+        if (__ballot(moves && (k1 || k2 || k3 || k4))) {   // a capture on some board of the pair (~ 20 % of the passes)
+          if (hf.hl < R) {
+            const uint32_t *gr = sc + (5 * s) * RS + hf.hl;
+            cap = (k1 ? gr[RS] : 0u) | (k2 ? gr[2 * RS] : 0u) | (k3 ? gr[3 * RS] : 0u) | (k4 ? gr[4 * RS] : 0u);
+          }
           // captured stones next to G are liberties of G too
           bool any, two;
           set_size(dilate_l1(g0) & cap, hf, any, two);
@@ -305,11 +304,13 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
           const uint32_t ncapn = (k1 ? 1u : 0u) + (k2 ? 1u : 0u) + (k3 ? 1u : 0u) + (k4 ? 1u : 0u);
           const bool boxed = (c1 & c2 & c3 & c4 & 16u) != 0;
           if (boxed && ncapn == 1u && ncap1 == 1u) {
+            int ar, ac;
+            split_action(a, N, hf.inv, ar, ac);
             ko_r = ar + (k1 ? -1 : (k2 ? 1 : 0));
             ko_c = ac + (k3 ? -1 : (k4 ? 1 : 0));
           }
           // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties
-          const uint32_t atari_m = mine0 & ~Mm & ~g0;
+          const uint32_t atari_m = mine1 & ~Mm & ~g0;
           uint32_t f = dilate_l1(cap) & atari_m;
           if (__ballot(f != 0)) {
 #pragma unroll 1
@@ -322,20 +323,19 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
             Mm_fix = f;
           }
         }
+        const uint32_t Mo2 = Mo & ~gch;
+        const uint32_t opp1 = opp0 & ~cap;
         const uint32_t Mm2 = (Mm & ~g0) | (libsG >= 2u ? g0 : 0u) | Mm_fix;
         uint32_t invalid = invalid_from2(opp1, mine1, Mo2, Mm2, hf);
         if (hf.hl == ko_r) invalid |= 1u << ko_c;
         if (moves) {
           if (is_pass) { if (passed) done = 1; passed = 1; } else passed = 0;
-          const uint32_t nb = turn ? opp1 : mine1, nw = turn ? mine1 : opp1;
-          const uint32_t nmb = turn ? Mo2 : Mm2, nmw = turn ? Mm2 : Mo2;
           turn ^= 1;
           if (row) {
-            st[0 * PL + s * RS + hf.hl] = nb;
-            st[1 * PL + s * RS + hf.hl] = nw;
+            *popp = opp1;
             st[2 * PL + s * RS + hf.hl] = invalid;
-            st[3 * PL + s * RS + hf.hl] = nmb;
-            st[4 * PL + s * RS + hf.hl] = nmw;
+            *pMm = Mm2;
+            *pMo = Mo2;
           }
           if (hf.hl == 0) {
             flagsv[s] = (uint32_t)turn | ((uint32_t)passed << 1) | ((uint32_t)done << 2) | 8u;
