@@ -194,8 +194,12 @@ def main():
             except Exception:
                 traffic = None
         rcap = 9 if N <= 9 else 13 if N <= 13 else 19
-        kernel_name = ('k_rollout<%d>' % rcap if os.environ.get('GG_KERNEL_VARIANT') == '1'
-                       else 'k_rollout2<%d, %s>' % (rcap, 'true' if F <= 2 else 'false'))
+        if os.environ.get('GG_KERNEL_VARIANT') == '1':
+            kernel_name = 'k_rollout<%d>' % rcap
+        elif F >= int(os.environ.get('GG_V3_MIN', '8')) and os.environ.get('GG_ROLLOUT_V2') != '1':
+            kernel_name = 'k_rollout3<%d, false>' % rcap        # 12 boards per wave, liberty classes carried across plies
+        else:
+            kernel_name = 'k_rollout2<%d, %s, false>' % (rcap, 'true' if F <= 2 else 'false')
         line = {
             'metric': 'env steps/sec across batched games, 19x19 uniform-random rollouts',
             'value': round(value, 1), 'unit': 'env steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
@@ -213,6 +217,10 @@ def main():
                 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                 'algorithmic_bytes_per_step': algo, 'steps_per_launch': count * F,
                 'launch_ms': round(launch_ms, 5),
+                'note': ('achieved = algorithmic bytes of the per-ply path (read + write one board + action per step) / '
+                         'launch time; the fused kernel keeps the boards on-chip for all plies of a launch, so it can '
+                         'exceed what any per-ply streaming implementation could reach (frac > 1); `traffic` is the '
+                         'HBM traffic it really causes per launch'),
             },
         }
         if cpu is not None:

@@ -25,7 +25,7 @@ namespace gg {
 #define GG_V3_UA 1
 #endif
 #ifndef GG_V3_UB
-#define GG_V3_UB 1
+#define GG_V3_UB 2
 #endif
 constexpr int kNB3 = 12;
 
