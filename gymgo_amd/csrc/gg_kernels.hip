@@ -366,8 +366,15 @@ int32_t gg_batch_rollout_packed(uint32_t *packed, uint64_t *rng, int32_t *last_a
   const uint32_t inv = recip16(N);
   if (!inv) return GG_E_BADSIZE;
   hipStream_t s = (hipStream_t)hip_stream;
-  const int grid = grid_for((B + 1) / 2);
   uint8_t *st = reinterpret_cast<uint8_t *>(packed);
+  if (plies >= v3_min_plies() && !rollout_v2()) {
+    const int grid3 = grid_for((B + kNB3 - 1) / kNB3);
+    GG_DISPATCH(N, (k_rollout3<9, true><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
+                (k_rollout3<13, true><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
+                (k_rollout3<19, true><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)));
+    return (int32_t)hipGetLastError();
+  }
+  const int grid = grid_for((B + 1) / 2);
   GG_DISPATCH(N, (k_rollout2<9, false, true><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
               (k_rollout2<13, false, true><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
               (k_rollout2<19, false, true><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)));
