@@ -99,12 +99,15 @@ struct Lds2 {
 template <int R, bool DUAL, bool AREAS = false>
 __device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, const Half &hf, uint32_t *lds,
                                          uint32_t &multi0, uint32_t &alive0, uint32_t &multi1, uint32_t *reach = nullptr,
-                                         uint32_t *alive1_out = nullptr) {
+                                         uint32_t *alive1_out = nullptr, bool compact = false) {
   constexpr int RS = Cfg<R>::kRowStride;
   constexpr int RV = (R + 3) / 4;
   uint32_t *sc = lds;
-  uint32_t *my5 = lds + Lds2<R>::kRows5 + hf.h * kRowBuf;
-  const uint32_t *cwt = lds + Lds2<R>::kCwt;
+  // compact (LDS-tight callers): the row planes alias the transpose buffer - they are read into registers before the
+  // flood and the flood's first store to the buffer comes sweeps later (DS operations of a wave execute in order) -
+  // and the class table is read from constant memory instead of its LDS copy: the scratch is region 0 alone.
+  uint32_t *my5 = compact ? lds + hf.h * kRowBuf : lds + Lds2<R>::kRows5 + hf.h * kRowBuf;
+  const uint32_t *cwt = compact ? &kCw.m[0][0] : lds + Lds2<R>::kCwt;
   WAVE_SYNC();
   my5[hf.hl] = c0;
   my5[32 + hf.hl] = c1;

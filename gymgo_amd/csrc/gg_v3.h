@@ -33,18 +33,18 @@ template <int R>
 struct Lds3 {
   static constexpr int RS = Cfg<R>::kRowStride;
   static constexpr int kState = 0;                               // [5][kNB3][RS]
-  static constexpr int kMeta = kState + 5 * kNB3 * RS;           // flags[16], act[16], last[16], played[16], rng[32]
-  static constexpr int kUnion = kMeta + 96;
+  static constexpr int kMeta = kState + 5 * kNB3 * RS;           // flags[12], act[12], last[12], played[12], rng[24]
+  static constexpr int kUnion = kMeta + 72;
   // ply loop: per flood lane its result word (liberty class, size, ...) + the transpose buffer of the group masks
+  // (60 flood lanes + one shared dummy block for the four idle lanes, whose floods are empty)
   static constexpr int kCls = kUnion;
   static constexpr int kSc = kCls + kWave;
-  static constexpr int kLoopEnd = kSc + kWave * RS;
-  // load / store: the v2 analysis scratch (first classes of a board); at store time its region 0 holds the emitter's
-  // scratch (2 x 128 words) and the spread table (uint2[256])
+  static constexpr int kLoopEnd = kSc + (5 * kNB3 + 1) * RS;
+  // load / store: the v2 analysis in its compact form (region 0 only: staging / transpose buffer); at store time the
+  // emitter's scratch (2 x 128 words) and the spread table (uint2[256])
   static constexpr int kV2 = kUnion;
   static constexpr int kLut = kV2 + 256;
-  static constexpr int kIoEnd = kV2 + Lds2<R>::kTotal;
-  static_assert(Lds2<R>::kRegion0 >= 256 + 512, "region 0 holds the emitter scratch and the spread table");
+  static constexpr int kIoEnd = kV2 + (Lds2<R>::kRegion0 > 768 ? Lds2<R>::kRegion0 : 768);
   static constexpr int kTotal = kLoopEnd > kIoEnd ? kLoopEnd : kIoEnd;
 };
 
@@ -59,7 +59,7 @@ __device__ __forceinline__ uint32_t dilate_l1(uint32_t x) {
 }
 
 template <int R, bool PACKED>
-__global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+__global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                        int32_t *__restrict__ last_actions, int64_t *__restrict__ steps_done,
                                                        int64_t B, int N, uint32_t inv, int plies, int auto_reset) {
   constexpr int RS = Lds3<R>::RS;
@@ -69,10 +69,10 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
   const Half hf = make_half(threadIdx.x, N, inv);
   uint32_t *st = lds + Lds3<R>::kState;     // st[p * PL + s * RS + row]
   uint32_t *flagsv = lds + Lds3<R>::kMeta;  // bit 0 turn, 1 passed, 2 done, 3 on
-  int *actv = reinterpret_cast<int *>(lds + Lds3<R>::kMeta + 16);
-  int *lastv = reinterpret_cast<int *>(lds + Lds3<R>::kMeta + 32);
-  int *playedv = reinterpret_cast<int *>(lds + Lds3<R>::kMeta + 48);
-  uint32_t *rngv = lds + Lds3<R>::kMeta + 64;   // [2 * s], [2 * s + 1]
+  int *actv = reinterpret_cast<int *>(lds + Lds3<R>::kMeta + 12);
+  int *lastv = reinterpret_cast<int *>(lds + Lds3<R>::kMeta + 24);
+  int *playedv = reinterpret_cast<int *>(lds + Lds3<R>::kMeta + 36);
+  uint32_t *rngv = lds + Lds3<R>::kMeta + 48;   // [2 * s], [2 * s + 1]
   uint32_t *clsv = lds + Lds3<R>::kCls;
   uint32_t *sc = lds + Lds3<R>::kSc;
   uint32_t *v2 = lds + Lds3<R>::kV2;
@@ -85,7 +85,6 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
     const int64_t b_first = g * kNB3;
     // ---------------------------------------------------------------- load: 6 pairs, first classes by the v2 analysis
     WAVE_SYNC();
-    load_cw_table<R>(v2, hf.lane);
 #pragma unroll 1
     for (int i = 0; i < kNB3 / 2; ++i) {
       const int s = 2 * i + hf.h;
@@ -110,7 +109,7 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
         turn = flags & 1u; passed = (flags >> 2) & 1u; done = (flags >> 3) & 1u;
       }
       uint32_t mb, ab, mw;
-      analyze2<R, false>(black, white, hf.full_l1 & ~(black | white), hf, v2, mb, ab, mw);
+      analyze2<R, false>(black, white, hf.full_l1 & ~(black | white), hf, v2, mb, ab, mw, nullptr, nullptr, true);
       if (row) {
         st[0 * PL + s * RS + hf.hl] = black;
         st[1 * PL + s * RS + hf.hl] = white;
@@ -225,13 +224,13 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
             f[r] = (r == sr) ? (m[r] & sbit) : 0u;
             seedrow |= f[r];
           }
-          flood2_serial<R>(m, mrev, f, sc + hf.lane * RS);
+          flood2_serial<R>(m, mrev, f, sc + (used ? hf.lane : 5 * kNB3) * RS);
         }
         // liberties of this lane's group on the position with the new stone (captures not yet removed)
         uint32_t cnt = 0, sz = 0;
         {
           uint32_t gt[RV * 4], ot[RV * 4], wt[RV * 4];
-          const uint4 *pg = reinterpret_cast<const uint4 *>(sc + hf.lane * RS);
+          const uint4 *pg = reinterpret_cast<const uint4 *>(sc + (used ? hf.lane : 5 * kNB3) * RS);
           const uint4 *po = reinterpret_cast<const uint4 *>(oth);
           const uint4 *pw = reinterpret_cast<const uint4 *>(own);
 #pragma unroll
@@ -259,7 +258,7 @@ __global__ __launch_bounds__(kWave, 3) void k_rollout3(uint8_t *__restrict__ sta
         clsv[hf.lane] = (cnt < 2u ? cnt : 2u) | (sz == 1u ? 4u : 0u) | (sz != 0u ? 8u : 0u) | (okbox ? 16u : 0u);
         // an opponent group that keeps >= 2 liberties keeps its class: phase 3 must not see it
         if (j != 0 && cnt >= 2u) {
-          uint4 *pz = reinterpret_cast<uint4 *>(sc + hf.lane * RS);
+          uint4 *pz = reinterpret_cast<uint4 *>(sc + (used ? hf.lane : 5 * kNB3) * RS);
 #pragma unroll
           for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
         }
