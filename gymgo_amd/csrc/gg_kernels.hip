@@ -437,6 +437,13 @@ int32_t gg_batch_play_moves(uint8_t *states, const int32_t *moves, int32_t *play
   const uint32_t inv = recip16(N);
   if (!inv) return GG_E_BADSIZE;
   hipStream_t s = (hipStream_t)hip_stream;
+  if (T >= v3_min_plies() && !rollout_v2()) {
+    const int grid3 = grid_for((B + kNB3 - 1) / kNB3);
+    GG_DISPATCH(N, (k_rollout3<9, false, true><<<grid3, kWave, 0, s>>>(states, nullptr, nullptr, nullptr, B, N, inv, T, 0, moves, played)),
+                (k_rollout3<13, false, true><<<grid3, kWave, 0, s>>>(states, nullptr, nullptr, nullptr, B, N, inv, T, 0, moves, played)),
+                (k_rollout3<19, false, true><<<grid3, kWave, 0, s>>>(states, nullptr, nullptr, nullptr, B, N, inv, T, 0, moves, played)));
+    return (int32_t)hipGetLastError();
+  }
   const int grid = grid_for((B + 1) / 2);
   GG_DISPATCH(N, (k_play_moves2<9, false><<<grid, kWave, 0, s>>>(states, moves, played, B, N, inv, T)),
               (k_play_moves2<13, false><<<grid, kWave, 0, s>>>(states, moves, played, B, N, inv, T)),
@@ -453,8 +460,15 @@ int32_t gg_batch_play_moves_packed(uint32_t *packed, const int32_t *moves, int32
   const uint32_t inv = recip16(N);
   if (!inv) return GG_E_BADSIZE;
   hipStream_t s = (hipStream_t)hip_stream;
-  const int grid = grid_for((B + 1) / 2);
   uint8_t *st = reinterpret_cast<uint8_t *>(packed);
+  if (T >= v3_min_plies() && !rollout_v2()) {
+    const int grid3 = grid_for((B + kNB3 - 1) / kNB3);
+    GG_DISPATCH(N, (k_rollout3<9, true, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, moves, played)),
+                (k_rollout3<13, true, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, moves, played)),
+                (k_rollout3<19, true, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, moves, played)));
+    return (int32_t)hipGetLastError();
+  }
+  const int grid = grid_for((B + 1) / 2);
   GG_DISPATCH(N, (k_play_moves2<9, true><<<grid, kWave, 0, s>>>(st, moves, played, B, N, inv, T)),
               (k_play_moves2<13, true><<<grid, kWave, 0, s>>>(st, moves, played, B, N, inv, T)),
               (k_play_moves2<19, true><<<grid, kWave, 0, s>>>(st, moves, played, B, N, inv, T)));

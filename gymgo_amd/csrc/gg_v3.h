@@ -58,10 +58,14 @@ __device__ __forceinline__ uint32_t dilate_l1(uint32_t x) {
   return B3(shl1(x), x >> 1, dpp0<0x138>(x), T_OR3) | dpp0<0x130>(x);
 }
 
-template <int R, bool PACKED>
+// MOVES: the moves are given (moves: int32 [B][plies], gg_batch_play_moves) instead of drawn: a game stops at its first
+// move that is out of range, on an invalid point or made after the game has ended; played_out[b] = moves applied.
+template <int R, bool PACKED, bool MOVES = false>
 __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                        int32_t *__restrict__ last_actions, int64_t *__restrict__ steps_done,
-                                                       int64_t B, int N, uint32_t inv, int plies, int auto_reset) {
+                                                       int64_t B, int N, uint32_t inv, int plies, int auto_reset,
+                                                       const int32_t *__restrict__ moves = nullptr,
+                                                       int32_t *__restrict__ played_out = nullptr) {
   constexpr int RS = Lds3<R>::RS;
   constexpr int RV = (R + 3) / 4;
   constexpr int PL = kNB3 * RS;   // words per plane of all boards
@@ -121,17 +125,20 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
         flagsv[s] = (uint32_t)turn | ((uint32_t)passed << 1) | ((uint32_t)done << 2) | (on ? 8u : 0u);
         lastv[s] = -1;
         playedv[s] = 0;
-        const uint64_t x = rng[b];
-        rngv[2 * s] = (uint32_t)x;
-        rngv[2 * s + 1] = (uint32_t)(x >> 32);
+        if (!MOVES) {
+          const uint64_t x = rng[b];
+          rngv[2 * s] = (uint32_t)x;
+          rngv[2 * s + 1] = (uint32_t)(x >> 32);
+        }
       }
       WAVE_SYNC();
     }
 
     // ---------------------------------------------------------------- the plies
+    int mv_next = 0;
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
-      // phase 1 - one LANE per board (lanes 0-11): liveness, the generator, the k-th valid point
+      // phase 1 - one LANE per board (lanes 0-11): liveness, the generator, the k-th valid point (or the given move)
       uint64_t resetm;
       {
         const bool bl = hf.lane < kNB3;
@@ -139,40 +146,61 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
         const uint32_t fl = flagsv[sb];
         const bool on = bl && ((fl >> 3) & 1u);
         const bool done = (fl >> 2) & 1u;
-        const bool live = on && !(done && !auto_reset);
-        const bool reset = live && done;           // auto-reset: the board is init_state from now on
-        const uint32_t fullrow = (1u << N) - 1u;
-        uint32_t vrows[R];
-        uint32_t n = 0;
+        bool live, reset;
+        int rr = -1, a;
+        uint32_t pos = 0;
+        uint64_t x = 0;
+        if (MOVES) {
+          // the move of this ply was fetched during the previous one (mv_next), the next one is requested now
+          const int64_t bm = (b_first + sb < B) ? b_first + sb : B - 1;
+          const int mv = t == 0 ? moves[bm * (int64_t)plies] : mv_next;
+          if (t + 1 < plies) mv_next = moves[bm * (int64_t)plies + t + 1];
+          reset = false;
+          live = on && !done && !((fl >> 4) & 1u) && mv >= 0 && mv <= hf.P;
+          a = hf.P;
+          if (live && mv < hf.P) {
+            int ar, ac;
+            split_action(mv, N, hf.inv, ar, ac);
+            live = ((st[2 * PL + sb * RS + ar] >> ac) & 1u) == 0;
+            rr = ar; pos = (uint32_t)ac;
+            a = mv;
+          }
+          if (on && !live && bl) flagsv[sb] = fl | 16u;   // stopped for good
+          if (!live) a = -1;
+        } else {
+          live = on && !(done && !auto_reset);
+          reset = live && done;           // auto-reset: the board is init_state from now on
+          const uint32_t fullrow = (1u << N) - 1u;
+          uint32_t vrows[R];
+          uint32_t n = 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const uint32_t iv = st[2 * PL + sb * RS + r];
-          const uint32_t v = r < N ? (reset ? fullrow : (fullrow & ~iv)) : 0u;
-          vrows[r] = v;
-          n += (uint32_t)__popc(v);
-        }
-        uint64_t x = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
-        const uint64_t u = splitmix_next(x);
-        uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(n + 1)) >> 32);
-        int rr = -1;
-        uint32_t acc = 0, tt = 0, vr = 0;
+          for (int r = 0; r < R; ++r) {
+            const uint32_t iv = st[2 * PL + sb * RS + r];
+            const uint32_t v = r < N ? (reset ? fullrow : (fullrow & ~iv)) : 0u;
+            vrows[r] = v;
+            n += (uint32_t)__popc(v);
+          }
+          x = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
+          const uint64_t u = splitmix_next(x);
+          uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(n + 1)) >> 32);
+          uint32_t acc = 0, tt = 0, vr = 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const uint32_t c = (uint32_t)__popc(vrows[r]);
-          const bool hit = rr < 0 && k < acc + c;
-          if (hit) { rr = r; tt = k - acc; vr = vrows[r]; }
-          acc += c;
-        }
-        uint32_t pos = 0;   // the tt-th set bit of vr
+          for (int r = 0; r < R; ++r) {
+            const uint32_t c = (uint32_t)__popc(vrows[r]);
+            const bool hit = rr < 0 && k < acc + c;
+            if (hit) { rr = r; tt = k - acc; vr = vrows[r]; }
+            acc += c;
+          }
 #pragma unroll
-        for (int sh = 16; sh >= 1; sh >>= 1) {
-          const uint32_t c = (uint32_t)__popc((vr >> pos) & ((1u << sh) - 1u));
-          if (tt >= c) { tt -= c; pos += sh; }
+          for (int sh = 16; sh >= 1; sh >>= 1) {   // the tt-th set bit of vr
+            const uint32_t c = (uint32_t)__popc((vr >> pos) & ((1u << sh) - 1u));
+            if (tt >= c) { tt -= c; pos += sh; }
+          }
+          a = !live ? -1 : (rr >= 0 ? rr * N + (int)pos : hf.P);   // -1: the board does not move this ply
         }
-        const int a = !live ? -1 : (rr >= 0 ? rr * N + (int)pos : hf.P);   // -1: the board does not move this ply
         if (bl) {
           actv[sb] = a;
-          if (live) { rngv[2 * sb] = (uint32_t)x; rngv[2 * sb + 1] = (uint32_t)(x >> 32); }
+          if (!MOVES && live) { rngv[2 * sb] = (uint32_t)x; rngv[2 * sb + 1] = (uint32_t)(x >> 32); }
         }
         if (__ballot(live) == 0) break;
         resetm = __ballot(reset);
@@ -371,9 +399,10 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
                         v2 + hf.h * 128, lut, wr);
       }
       if (on && hf.hl == 0) {
-        rng[b] = ((uint64_t)rngv[2 * s + 1] << 32) | rngv[2 * s];
+        if (!MOVES) rng[b] = ((uint64_t)rngv[2 * s + 1] << 32) | rngv[2 * s];
         if (last_actions) last_actions[b] = lastv[s];
         if (steps_done) steps_done[b] += played;
+        if (MOVES && played_out) played_out[b] = played;
       }
       WAVE_SYNC();
     }
