@@ -25,7 +25,7 @@ namespace gg {
 #define GG_V3_UA 1
 #endif
 #ifndef GG_V3_UB
-#define GG_V3_UB 2
+#define GG_V3_UB 1
 #endif
 constexpr int kNB3 = 12;
 
@@ -64,7 +64,7 @@ template <int R, bool PACKED, bool MOVES = false>
 __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                        int32_t *__restrict__ last_actions, int64_t *__restrict__ steps_done,
                                                        int64_t B, int N, uint32_t inv, int plies, int auto_reset,
-                                                       const int32_t *__restrict__ moves = nullptr,
+                                                       int nb, const int32_t *__restrict__ moves = nullptr,
                                                        int32_t *__restrict__ played_out = nullptr) {
   constexpr int RS = Lds3<R>::RS;
   constexpr int RV = (R + 3) / 4;
@@ -83,14 +83,15 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
   uint2 *lut = reinterpret_cast<uint2 *>(lds + Lds3<R>::kLut);
   const int S = 6 * hf.P, W = 3 * N + 1;
   const bool row = hf.hl < RS;
-  const int64_t ngroups = (B + kNB3 - 1) / kNB3;
+  // nb (even, <= kNB3) boards per wave: the host picks it so that the groups fill the resident waves evenly
+  const int64_t ngroups = (B + nb - 1) / nb;
 
   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-    const int64_t b_first = g * kNB3;
+    const int64_t b_first = g * nb;
     // ---------------------------------------------------------------- load: 6 pairs, first classes by the v2 analysis
     WAVE_SYNC();
 #pragma unroll 1
-    for (int i = 0; i < kNB3 / 2; ++i) {
+    for (int i = 0; i < nb / 2; ++i) {
       const int s = 2 * i + hf.h;
       const bool on = b_first + s < B;
       const int64_t b = on ? b_first + s : B - 1;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
       // phase 1 - one LANE per board (lanes 0-11): liveness, the generator, the k-th valid point (or the given move)
       uint64_t resetm;
       {
-        const bool bl = hf.lane < kNB3;
+        const bool bl = hf.lane < nb;
         const int sb = bl ? hf.lane : 0;
         const uint32_t fl = flagsv[sb];
         const bool on = bl && ((fl >> 3) & 1u);
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
       // opponent's from the four neighbours of q; then every lane counts the liberties of its own group
       {
         const int s = (hf.lane * 13) >> 6, j = hf.lane - 5 * s;
-        const bool used = hf.lane < 5 * kNB3;
+        const bool used = hf.lane < 5 * nb;
         const int ss = used ? s : 0;
         const int a = used ? actv[ss] : -1;
         const int turn = flagsv[ss] & 1u;
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
 
       // phase 3 - one board per half, six passes: patch the classes, resolve captures and ko, the next mover's mask
 #pragma unroll GG_V3_UB
-      for (int i = 0; i < kNB3 / 2; ++i) {
+      for (int i = 0; i < nb / 2; ++i) {
         const int s = 2 * i + hf.h;
         const int a = actv[s];
         const bool moves = a >= 0;
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
     WAVE_SYNC();
     if (!PACKED) load_spread_lut(lut, hf.lane);
 #pragma unroll 1
-    for (int i = 0; i < kNB3 / 2; ++i) {
+    for (int i = 0; i < nb / 2; ++i) {
       const int s = 2 * i + hf.h;
       const uint32_t fl = flagsv[s];
       const bool on = (fl >> 3) & 1u;

@@ -89,7 +89,7 @@ int32_t gg_batch_children(const uint8_t *states, uint8_t *children, int64_t B, i
  * state = next_state(state, a).  A finished game (plane 5 set) is reset to zeros first when
  * auto_reset != 0, otherwise it is left frozen and draws nothing.
  * rng: uint64 [B] per-game generator state (see gg_rng_seed), advanced once per ply played.
- * last_actions (nullable): int32 [B], last action played (-1 if frozen).
+ * last_actions (nullable): int32 [B], the last action applied during this call (-1 if the game was frozen throughout).
  * steps_done (nullable): int64 [B], incremented by the number of plies actually played.
  * Sampler (build-defined, mirrored by oracle/gg_oracle.c): x += 0x9E3779B97F4A7C15;
  * u = splitmix64_finalise(x); k = ((u >> 32) * n_valid) >> 32; action = k-th valid action ascending.

@@ -361,11 +361,14 @@ void gg_oracle_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actio
                              int32_t plies, int32_t auto_reset)
 {
     size_t S = (size_t)NUM_CHNLS * N * N;
-    for (int64_t b = 0; b < B; ++b)
+    for (int64_t b = 0; b < B; ++b) {
+        int32_t last = -1; /* the last action applied in this call; -1 if the game was frozen throughout */
         for (int t = 0; t < plies; ++t) {
             int32_t a = gg_oracle_rollout_ply(states + b * S, rng + b, N, auto_reset);
-            if (last_actions) last_actions[b] = a;
+            if (a >= 0) last = a;
         }
+        if (last_actions) last_actions[b] = last;
+    }
 }
 
 int32_t gg_oracle_version(void) { return 1; }

@@ -262,6 +262,67 @@ print("variant1 ok")
     assert r.returncode == 0 and 'variant1 ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize('nb', [12, 6, 2])
+def test_v3_rollout_kernel_forced_in_subprocess(oracle, nb):
+    """The incremental-class fused kernel (k_rollout3: liberty classes carried across plies, `nb` boards per wave) is
+    normally used from 8 192 games up; GG_V3_NB forces it for any batch so that the small oracle-checked batches run
+    through it: rollouts from the empty board and from mid-game, auto-reset on and off, every row capacity, odd batch
+    sizes, the packed form and the given-moves form."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from gymgo_amd import gogame
+from oracle import c_oracle
+for N, B in ((19, 131), (13, 77), (9, 250), (6, 40), (2, 13)):
+    for auto in (True, False):
+        rng = gogame.rng_seed(B, 7 + N); rng_np = c_oracle.rng_seed(7 + N, B)
+        st = torch.zeros((B, 6, N, N), dtype=torch.uint8, device="cuda"); want = np.zeros((B, 6, N, N), np.uint8)
+        pk = gogame.batch_pack(st); prng = rng.clone()
+        la = torch.empty(B, dtype=torch.int32, device="cuda"); sd = torch.zeros(B, dtype=torch.int64, device="cuda")
+        total = 0
+        for plies in (8, 9, 33, 64, 150 if N > 6 else 40):
+            gogame.batch_rollout(st, rng, plies, auto, la, sd)
+            gogame.batch_rollout_packed(pk, prng, plies, auto)
+            want, rng_np, wl = c_oracle.batch_rollout(want, rng_np, plies, auto)
+            total += plies
+            assert np.array_equal(st.cpu().numpy(), want), ("rollout", N, auto, total)
+            assert np.array_equal(rng.cpu().numpy().view(np.uint64), rng_np), ("rng", N, auto, total)
+            assert np.array_equal(la.cpu().numpy(), wl), ("last", N, auto, total)
+            assert torch.equal(gogame.batch_unpack(pk, N), st) and torch.equal(prng, rng), ("packed", N, auto, total)
+        if auto:
+            assert int(sd.min()) == total
+    # given moves: record a continuation ply by ply, corrupt a third of the games, replay in one launch
+    T = 40
+    rec = torch.empty((B, T), dtype=torch.int32, device="cuda")
+    start = st.clone(); tmp = st.clone(); r2 = gogame.rng_seed(B, 99)
+    for t in range(T):
+        gogame.batch_rollout(tmp, r2, 1, False, la, None)
+        rec[:, t] = la
+    moves = rec.cpu().numpy().copy()
+    gen = np.random.default_rng(N)
+    for i in gen.choice(B, max(1, B // 3), replace=False):
+        moves[i, gen.integers(0, T)] = gen.integers(-2, N * N + 2)
+    host = start.cpu().numpy(); exp = host.copy(); played = np.zeros(B, np.int32)
+    for i in range(B):
+        s = host[i]
+        for t in range(T):
+            a = int(moves[i, t])
+            if s[5, 0, 0] or a < 0 or a > N * N or (a < N * N and s[3].reshape(-1)[a]):
+                break
+            s = c_oracle.next_state(s, a); played[i] += 1
+        exp[i] = s
+    got = gogame.batch_play_moves(start, torch.from_numpy(moves).cuda())
+    assert np.array_equal(got.cpu().numpy(), played) and np.array_equal(start.cpu().numpy(), exp), ("play_moves", N)
+print("v3 ok")
+'''
+    env = dict(os.environ, GG_V3_NB=str(nb))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'v3 ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_update_pieces_standalone(gg, oracle):
     """state_utils.update_pieces / batch_update_pieces (gg_batch_update_pieces): stones after capture resolution equal
     planes 0/1 of the oracle's next_state; killed groups are reported per group in raster order."""
