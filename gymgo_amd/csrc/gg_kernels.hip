@@ -253,9 +253,9 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
   int grid = grid_for(B);
   if (use_v3(B, plies)) {   // incremental classes, 12 boards per wave
     const int nb = v3_boards_per_wave(B, grid);
-    GG_DISPATCH(N, (k_rollout3<9, false><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
-                (k_rollout3<13, false><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
-                (k_rollout3<19, false><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)));
+    GG_DISPATCH(N, (k_rollout3<9, 0><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
+                (k_rollout3<13, 0><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
+                (k_rollout3<19, 0><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)));
     return (int32_t)hipGetLastError();
   }
   if (variant() == 2) {
@@ -360,9 +360,9 @@ int32_t gg_batch_unpack_states(const uint32_t *packed, uint8_t *states, int64_t 
   if (!states || !packed) return GG_E_NULLPTR;
   hipStream_t s = (hipStream_t)hip_stream;
   int grid = grid_for((B + 1) / 2);
-  GG_DISPATCH(N, (k_unpack<9><<<grid, kWave, 0, s>>>(packed, states, B, N)),
-              (k_unpack<13><<<grid, kWave, 0, s>>>(packed, states, B, N)),
-              (k_unpack<19><<<grid, kWave, 0, s>>>(packed, states, B, N)));
+  GG_DISPATCH(N, (k_unpack<9><<<grid, kWave, 0, s>>>(packed, states, B, N, 3)),
+              (k_unpack<13><<<grid, kWave, 0, s>>>(packed, states, B, N, 3)),
+              (k_unpack<19><<<grid, kWave, 0, s>>>(packed, states, B, N, 3)));
   return (int32_t)hipGetLastError();
 }
 
@@ -395,9 +395,9 @@ int32_t gg_batch_rollout_packed(uint32_t *packed, uint64_t *rng, int32_t *last_a
   if (use_v3(B, plies)) {
     int grid3;
     const int nb = v3_boards_per_wave(B, grid3);
-    GG_DISPATCH(N, (k_rollout3<9, true><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
-                (k_rollout3<13, true><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
-                (k_rollout3<19, true><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)));
+    GG_DISPATCH(N, (k_rollout3<9, 1><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
+                (k_rollout3<13, 1><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
+                (k_rollout3<19, 1><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)));
     return (int32_t)hipGetLastError();
   }
   const int grid = grid_for((B + 1) / 2);
@@ -466,9 +466,9 @@ int32_t gg_batch_play_moves(uint8_t *states, const int32_t *moves, int32_t *play
   if (use_v3(B, T)) {
     int grid3;
     const int nb = v3_boards_per_wave(B, grid3);
-    GG_DISPATCH(N, (k_rollout3<9, false, true><<<grid3, kWave, 0, s>>>(states, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
-                (k_rollout3<13, false, true><<<grid3, kWave, 0, s>>>(states, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
-                (k_rollout3<19, false, true><<<grid3, kWave, 0, s>>>(states, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)));
+    GG_DISPATCH(N, (k_rollout3<9, 0, true><<<grid3, kWave, 0, s>>>(states, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
+                (k_rollout3<13, 0, true><<<grid3, kWave, 0, s>>>(states, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
+                (k_rollout3<19, 0, true><<<grid3, kWave, 0, s>>>(states, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)));
     return (int32_t)hipGetLastError();
   }
   const int grid = grid_for((B + 1) / 2);
@@ -491,15 +491,80 @@ int32_t gg_batch_play_moves_packed(uint32_t *packed, const int32_t *moves, int32
   if (use_v3(B, T)) {
     int grid3;
     const int nb = v3_boards_per_wave(B, grid3);
-    GG_DISPATCH(N, (k_rollout3<9, true, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
-                (k_rollout3<13, true, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
-                (k_rollout3<19, true, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)));
+    GG_DISPATCH(N, (k_rollout3<9, 1, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
+                (k_rollout3<13, 1, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
+                (k_rollout3<19, 1, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)));
     return (int32_t)hipGetLastError();
   }
   const int grid = grid_for((B + 1) / 2);
   GG_DISPATCH(N, (k_play_moves2<9, true><<<grid, kWave, 0, s>>>(st, moves, played, B, N, inv, T)),
               (k_play_moves2<13, true><<<grid, kWave, 0, s>>>(st, moves, played, B, N, inv, T)),
               (k_play_moves2<19, true><<<grid, kWave, 0, s>>>(st, moves, played, B, N, inv, T)));
+  return (int32_t)hipGetLastError();
+}
+
+// ---- tracked boards (uint32 [B][5 N + 1]): packed boards that carry their liberty classes (see gg_v3.h)
+int32_t gg_tracked_words(int32_t N) { return (N < 2 || N > GG_MAX_BOARD) ? GG_E_BADSIZE : 5 * N + 1; }
+
+int32_t gg_batch_track_states(const uint8_t *states, uint32_t *tracked, int64_t B, int32_t N, void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (B == 0) return 0;
+  if (!states || !tracked) return GG_E_NULLPTR;
+  const uint32_t inv = recip16(N);
+  if (!inv) return GG_E_BADSIZE;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int grid = grid_for((B + 1) / 2);
+  GG_DISPATCH(N, (k_track<9><<<grid, kWave, 0, s>>>(states, tracked, B, N, inv)),
+              (k_track<13><<<grid, kWave, 0, s>>>(states, tracked, B, N, inv)),
+              (k_track<19><<<grid, kWave, 0, s>>>(states, tracked, B, N, inv)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_untrack_states(const uint32_t *tracked, uint8_t *states, int64_t B, int32_t N, void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (B == 0) return 0;
+  if (!states || !tracked) return GG_E_NULLPTR;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int grid = grid_for((B + 1) / 2);
+  GG_DISPATCH(N, (k_unpack<9><<<grid, kWave, 0, s>>>(tracked, states, B, N, 5)),
+              (k_unpack<13><<<grid, kWave, 0, s>>>(tracked, states, B, N, 5)),
+              (k_unpack<19><<<grid, kWave, 0, s>>>(tracked, states, B, N, 5)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_rollout_tracked(uint32_t *tracked, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B,
+                                 int32_t N, int32_t plies, int32_t auto_reset, void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (plies < 0) return GG_E_BADARG;
+  if (B == 0 || plies == 0) return 0;
+  if (!tracked || !rng) return GG_E_NULLPTR;
+  const uint32_t inv = recip16(N);
+  if (!inv) return GG_E_BADSIZE;
+  hipStream_t s = (hipStream_t)hip_stream;
+  uint8_t *st = reinterpret_cast<uint8_t *>(tracked);
+  int grid3;
+  const int nb = v3_boards_per_wave(B, grid3);
+  GG_DISPATCH(N, (k_rollout3<9, 2><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
+              (k_rollout3<13, 2><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
+              (k_rollout3<19, 2><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_play_moves_tracked(uint32_t *tracked, const int32_t *moves, int32_t *played, int64_t B, int32_t N, int32_t T,
+                                    void *hip_stream) {
+  if (int32_t e = check(B, N)) return e;
+  if (T < 0) return GG_E_BADARG;
+  if (B == 0) return 0;
+  if (!tracked || (T > 0 && !moves)) return GG_E_NULLPTR;
+  const uint32_t inv = recip16(N);
+  if (!inv) return GG_E_BADSIZE;
+  hipStream_t s = (hipStream_t)hip_stream;
+  uint8_t *st = reinterpret_cast<uint8_t *>(tracked);
+  int grid3;
+  const int nb = v3_boards_per_wave(B, grid3);
+  GG_DISPATCH(N, (k_rollout3<9, 2, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
+              (k_rollout3<13, 2, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
+              (k_rollout3<19, 2, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)));
   return (int32_t)hipGetLastError();
 }
 

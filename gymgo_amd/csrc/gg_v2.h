@@ -1603,12 +1603,12 @@ __global__ __launch_bounds__(kWave) void k_pack(const uint8_t *__restrict__ stat
 
 template <int R>
 __global__ __launch_bounds__(kWave) void k_unpack(const uint32_t *__restrict__ packed, uint8_t *__restrict__ states,
-                                                  int64_t B, int N) {
+                                                  int64_t B, int N, int planes) {   // planes: 3 packed, 5 tracked
   __shared__ __attribute__((aligned(16))) uint32_t lds[2 * (Cfg<R>::kIoBytes / 4)];
   __shared__ uint2 lut[256];
   const Half hf = make_half(threadIdx.x, N, 0);
   load_spread_lut(lut, hf.lane);
-  const int S = 6 * hf.P, W = 3 * N + 1;
+  const int S = 6 * hf.P, W = planes * N + 1;
   uint32_t *work = lds + hf.h * (Cfg<R>::kIoBytes / 4);
   const int64_t npairs = (B + 1) >> 1;
   for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
@@ -1622,7 +1622,7 @@ __global__ __launch_bounds__(kWave) void k_unpack(const uint32_t *__restrict__ p
       white = gp[N + hf.hl] & full;
       invalid = gp[2 * N + hf.hl] & full;
     }
-    const uint32_t fl = gp[3 * N];
+    const uint32_t fl = gp[planes * N];
     emit_store_h<R>(states + b * (int64_t)S, black, white, invalid, fl & 1u, (fl >> 1) & 1u, (fl >> 2) & 1u, hf, work, lut,
                     on);
   }

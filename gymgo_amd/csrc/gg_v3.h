@@ -60,7 +60,10 @@ __device__ __forceinline__ uint32_t dilate_l1(uint32_t x) {
 
 // MOVES: the moves are given (moves: int32 [B][plies], gg_batch_play_moves) instead of drawn: a game stops at its first
 // move that is out of range, on an invalid point or made after the game has ended; played_out[b] = moves applied.
-template <int R, bool PACKED, bool MOVES = false>
+// IO: 0 = byte planes (uint8 [B][6][N][N]), 1 = packed boards (uint32 [B][3N+1]), 2 = TRACKED boards (uint32 [B][5N+1]:
+// the rows of black, white, invalid, multi_black, multi_white + the flag word - a packed board that carries its
+// liberty classes, so that a launch needs no first analysis: per-ply stepping at the fused kernel's rate).
+template <int R, int IO, bool MOVES = false>
 __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                        int32_t *__restrict__ last_actions, int64_t *__restrict__ steps_done,
                                                        int64_t B, int N, uint32_t inv, int plies, int auto_reset,
@@ -81,7 +84,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
   uint32_t *sc = lds + Lds3<R>::kSc;
   uint32_t *v2 = lds + Lds3<R>::kV2;
   uint2 *lut = reinterpret_cast<uint2 *>(lds + Lds3<R>::kLut);
-  const int S = 6 * hf.P, W = 3 * N + 1;
+  constexpr bool PACKED = IO == 1, TRACKED = IO == 2;
+  const int S = 6 * hf.P, W = (TRACKED ? 5 : 3) * N + 1;
   const bool row = hf.hl < RS;
   // nb (even, <= kNB3) boards per wave: the host picks it so that the groups fill the resident waves evenly
   const int64_t ngroups = (B + nb - 1) / nb;
@@ -95,9 +99,18 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
       const int s = 2 * i + hf.h;
       const bool on = b_first + s < B;
       const int64_t b = on ? b_first + s : B - 1;
-      uint32_t black, white, invalid;
+      uint32_t black, white, invalid, mb = 0, mw = 0;
       int turn, passed, done;
-      if (PACKED) {
+      if (TRACKED) {
+        const uint32_t *gp = reinterpret_cast<const uint32_t *>(states) + b * (int64_t)W;
+        black = white = invalid = 0;
+        if (hf.hl < N) {
+          black = gp[hf.hl]; white = gp[N + hf.hl]; invalid = gp[2 * N + hf.hl];
+          mb = gp[3 * N + hf.hl]; mw = gp[4 * N + hf.hl];
+        }
+        const uint32_t fw = gp[5 * N];
+        turn = fw & 1u; passed = (fw >> 1) & 1u; done = (fw >> 2) & 1u;
+      } else if (PACKED) {
         uint32_t fw;
         load_packed_h(reinterpret_cast<const uint32_t *>(states) + b * (int64_t)W, N, hf, black, white, invalid, fw);
         turn = fw & 1u; passed = (fw >> 1) & 1u; done = (fw >> 2) & 1u;
@@ -113,8 +126,10 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
         invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
         turn = flags & 1u; passed = (flags >> 2) & 1u; done = (flags >> 3) & 1u;
       }
-      uint32_t mb, ab, mw;
-      analyze2<R, false>(black, white, hf.full_l1 & ~(black | white), hf, v2, mb, ab, mw, nullptr, nullptr, true);
+      if (!TRACKED) {
+        uint32_t ab;
+        analyze2<R, false>(black, white, hf.full_l1 & ~(black | white), hf, v2, mb, ab, mw, nullptr, nullptr, true);
+      }
       if (row) {
         st[0 * PL + s * RS + hf.hl] = black;
         st[1 * PL + s * RS + hf.hl] = white;
@@ -377,7 +392,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
 
     // ---------------------------------------------------------------- store
     WAVE_SYNC();
-    if (!PACKED) load_spread_lut(lut, hf.lane);
+    if (IO == 0) load_spread_lut(lut, hf.lane);
 #pragma unroll 1
     for (int i = 0; i < nb / 2; ++i) {
       const int s = 2 * i + hf.h;
@@ -392,7 +407,15 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
         invalid = st[2 * PL + s * RS + hf.hl];
       }
       const bool wr = on && played != 0;
-      if (PACKED) {
+      if (TRACKED) {
+        uint32_t *gp = reinterpret_cast<uint32_t *>(states) + b * (int64_t)W;
+        if (wr && hf.hl < N) {
+          gp[hf.hl] = black; gp[N + hf.hl] = white; gp[2 * N + hf.hl] = invalid;
+          gp[3 * N + hf.hl] = st[3 * PL + s * RS + hf.hl];
+          gp[4 * N + hf.hl] = st[4 * PL + s * RS + hf.hl];
+        }
+        if (wr && hf.hl == 31) gp[5 * N] = fl & 7u;
+      } else if (PACKED) {
         store_packed_h(reinterpret_cast<uint32_t *>(states) + b * (int64_t)W, N, hf, black, white, invalid, fl & 1u,
                        (fl >> 1) & 1u, (fl >> 2) & 1u, wr);
       } else if (__ballot(wr)) {
@@ -407,6 +430,38 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
       }
       WAVE_SYNC();
     }
+  }
+}
+
+// byte planes -> tracked boards: the rows of planes 0 / 1 / 3 and the liberty classes of one v2 analysis
+template <int R>
+__global__ __launch_bounds__(kWave, 4) void k_track(const uint8_t *__restrict__ states, uint32_t *__restrict__ tracked,
+                                                     int64_t B, int N, uint32_t inv) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
+  const Half hf = make_half(threadIdx.x, N, inv);
+  load_cw_table<R>(lds, hf.lane);
+  const int S = 6 * hf.P, W = 5 * N + 1;
+  uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
+  const int64_t npairs = (B + 1) >> 1;
+  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+    const bool on = 2 * p + hf.h < B;
+    const int64_t b = on ? 2 * p + hf.h : B - 1;
+    const uint8_t *gs = states + b * (int64_t)S;
+    const uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
+    WAVE_SYNC();
+    const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
+    WAVE_SYNC();
+    const uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
+    const uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+    const uint32_t invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
+    uint32_t mb, ab, mw;
+    analyze2<R, false>(black, white, hf.full_l1 & ~(black | white), hf, lds, mb, ab, mw);
+    uint32_t *gp = tracked + b * (int64_t)W;
+    if (on && hf.hl < N) {
+      gp[hf.hl] = black; gp[N + hf.hl] = white; gp[2 * N + hf.hl] = invalid;
+      gp[3 * N + hf.hl] = mb; gp[4 * N + hf.hl] = mw;
+    }
+    if (on && hf.hl == 31) gp[5 * N] = (flags & 1u) | ((flags >> 1) & 6u);
   }
 }
 

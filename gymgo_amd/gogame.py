@@ -585,3 +585,63 @@ def batch_play_moves(batch_states, moves):
               _lib.dev_ptr(played, _I32, 'played'), B, N, moves.shape[1], _lib.stream_ptr(batch_states.device))
     _lib.check(code, 'gg_batch_play_moves')
     return played
+
+
+# ---------------------------------------------------------------- tracked boards: packed boards + their liberty classes
+def tracked_words(board_size):
+    """uint32 words per tracked board (5 N + 1): rows of black, white, invalid, multi_black, multi_white + flags."""
+    return 5 * board_size + 1
+
+
+def _tracked_size(tracked):
+    W = tracked.shape[-1]
+    if tracked.dtype != _I32 or (W - 1) % 5 or not 2 <= (W - 1) // 5 <= 19:
+        raise ValueError('tracked boards are int32 [..., 5N+1] (got %s %s)' % (tracked.dtype, tuple(tracked.shape)))
+    return (W - 1) // 5
+
+
+def batch_track(batch_states):
+    """uint8 [B,6,N,N] -> tracked int32 [B, 5N+1] (gg_batch_track_states): the packed board plus the stones of either
+    colour whose group has >= 2 liberties.  Tracked boards step at the fused kernel's rate even one ply per launch."""
+    B, C, N, _ = batch_states.shape
+    tracked = torch.empty((B, tracked_words(N)), dtype=_I32, device=batch_states.device)
+    code = _lib.lib().gg_batch_track_states(_lib.dev_ptr(batch_states, _U8, 'states'), _lib.dev_ptr(tracked, _I32, 'tracked'),
+                                            B, N, _lib.stream_ptr(batch_states.device))
+    _lib.check(code, 'gg_batch_track_states')
+    return tracked
+
+
+def batch_untrack(tracked):
+    """tracked int32 [B, 5N+1] -> uint8 [B,6,N,N] (gg_batch_untrack_states)."""
+    N = _tracked_size(tracked)
+    B = tracked.shape[0]
+    states = torch.empty((B, govars.NUM_CHNLS, N, N), dtype=_U8, device=tracked.device)
+    code = _lib.lib().gg_batch_untrack_states(_lib.dev_ptr(tracked, _I32, 'tracked'), _lib.dev_ptr(states, _U8, 'states'),
+                                              B, N, _lib.stream_ptr(tracked.device))
+    _lib.check(code, 'gg_batch_untrack_states')
+    return states
+
+
+def batch_rollout_tracked(tracked, rng, plies, auto_reset=True, last_actions=None, steps_done=None):
+    """IN PLACE batch_rollout on tracked boards (gg_batch_rollout_tracked)."""
+    N = _tracked_size(tracked)
+    B = tracked.shape[0]
+    code = _lib.lib().gg_batch_rollout_tracked(
+        _lib.dev_ptr(tracked, _I32, 'tracked'), _lib.dev_ptr(rng, _I64, 'rng'), _lib.dev_ptr(last_actions, _I32, 'last_actions'),
+        _lib.dev_ptr(steps_done, _I64, 'steps_done'), B, N, int(plies), int(bool(auto_reset)), _lib.stream_ptr(tracked.device))
+    _lib.check(code, 'gg_batch_rollout_tracked')
+    return tracked
+
+
+def batch_play_moves_tracked(tracked, moves, played=None):
+    """IN PLACE batch_play_moves on tracked boards; moves [B, T] (T = 1: one GoEnv.step per game) -> played int32 [B]."""
+    N = _tracked_size(tracked)
+    B = tracked.shape[0]
+    moves = moves.to(device=tracked.device, dtype=_I32).reshape(B, -1).contiguous()
+    if played is None:
+        played = torch.empty(B, dtype=_I32, device=tracked.device)
+    code = _lib.lib().gg_batch_play_moves_tracked(_lib.dev_ptr(tracked, _I32, 'tracked'), _lib.dev_ptr(moves, _I32, 'moves'),
+                                                  _lib.dev_ptr(played, _I32, 'played'), B, N, moves.shape[1],
+                                                  _lib.stream_ptr(tracked.device))
+    _lib.check(code, 'gg_batch_play_moves_tracked')
+    return played

@@ -184,6 +184,25 @@ int32_t gg_batch_play_moves(uint8_t *states, const int32_t *moves, int32_t *play
 int32_t gg_batch_play_moves_packed(uint32_t *packed, const int32_t *moves, int32_t *played, int64_t B, int32_t N, int32_t T,
                                    void *hip_stream);
 
+/*
+ * TRACKED boards: uint32 [B][gg_tracked_words(N) = 5 N + 1] = the packed board (rows of planes 0 / 1 / 3) + two more
+ * row sets - the black / the white stones whose group has >= 2 liberties - + the flag word (bit 0 turn, bit 1 previous
+ * move was a pass, bit 2 game over).  A board that carries its liberty classes needs no analysis when a launch starts,
+ * so stepping it ONE ply per launch (a policy network choosing every move) runs at the fused kernel's rate.
+ *   gg_batch_track_states       uint8 [B][6][N][N] -> tracked (classes by one analysis)
+ *   gg_batch_untrack_states     tracked -> uint8 [B][6][N][N]
+ *   gg_batch_rollout_tracked    as gg_batch_rollout, in place on tracked boards
+ *   gg_batch_play_moves_tracked as gg_batch_play_moves, in place on tracked boards (T = 1: one GoEnv.step per game)
+ * The class rows must belong to the position: boards edited by the caller go through untrack / track again.
+ */
+int32_t gg_tracked_words(int32_t N);
+int32_t gg_batch_track_states(const uint8_t *states, uint32_t *tracked, int64_t B, int32_t N, void *hip_stream);
+int32_t gg_batch_untrack_states(const uint32_t *tracked, uint8_t *states, int64_t B, int32_t N, void *hip_stream);
+int32_t gg_batch_rollout_tracked(uint32_t *tracked, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B,
+                                 int32_t N, int32_t plies, int32_t auto_reset, void *hip_stream);
+int32_t gg_batch_play_moves_tracked(uint32_t *tracked, const int32_t *moves, int32_t *played, int64_t B, int32_t N, int32_t T,
+                                    void *hip_stream);
+
 /* rng[b] = initial generator state for (base_seed, game index first_game + b). */
 int32_t gg_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B, void *hip_stream);
 

@@ -167,3 +167,42 @@ def test_play_moves_replays_recorded_and_corrupted_games(N, B, T):
     got2 = gogame.batch_play_moves(pk, mv)
     assert torch.equal(got2, got) and torch.equal(gogame.batch_unpack(pk, N), a)
     assert played.min() < T <= played.max() or T == 1
+
+
+@pytest.mark.parametrize('N,B', [(19, 150), (13, 97), (9, 700), (5, 66), (2, 11)])
+def test_tracked_boards_step_like_the_oracle(N, B):
+    """Tracked boards (packed + liberty classes): track/untrack round trip, fused rollouts, and ONE given move per
+    launch (the policy-driven step) against the oracle - including illegal moves, passes and finished games."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    st, rng = _mid(B, N, 9, auto_reset=False)
+    tr = gogame.batch_track(st)
+    assert tr.shape == (B, 5 * N + 1) and torch.equal(gogame.batch_untrack(tr), st)
+    assert torch.equal(tr[:, :3 * N], gogame.batch_pack(st)[:, :3 * N])
+    want = st.cpu().numpy()
+    wrng = rng.cpu().numpy().view(np.uint64).copy()
+    # fused rollouts on tracked boards (no first analysis inside the launch)
+    for plies, auto in ((1, True), (3, False), (20, True), (64, True)):
+        gogame.batch_rollout_tracked(tr, rng, plies, auto)
+        want, wrng, _ = c_oracle.batch_rollout(want, wrng, plies, auto)
+        assert np.array_equal(gogame.batch_untrack(tr).cpu().numpy(), want), (N, plies)
+        assert torch.equal(tr, gogame.batch_track(gogame.batch_untrack(tr))), ('classes', N, plies)   # classes stay exact
+    # one given move per launch: sampled legal moves with some corrupted
+    gen = np.random.default_rng(N)
+    for t in range(30):
+        cur = gogame.batch_untrack(tr)
+        acts = gogame.batch_sample_actions(cur, rng).cpu().numpy()
+        wild = gen.random(B) < 0.1
+        acts[wild] = gen.integers(-1, N * N + 2, size=int(wild.sum()))
+        host = cur.cpu().numpy()
+        ok = (acts >= 0) & (acts <= N * N) & (host[:, 5, 0, 0] == 0)
+        for i in np.flatnonzero(ok):
+            if acts[i] < N * N and host[i, 3].reshape(-1)[acts[i]]:
+                ok[i] = False
+        exp = host.copy()
+        idx = np.flatnonzero(ok)
+        exp[idx] = c_oracle.batch_next_states(host[idx], acts[idx])[0]
+        played = gogame.batch_play_moves_tracked(tr, torch.from_numpy(acts).cuda())
+        assert np.array_equal(played.cpu().numpy(), ok.astype(np.int32)), (N, t)
+        assert np.array_equal(gogame.batch_untrack(tr).cpu().numpy(), exp), (N, t)
+    assert torch.equal(tr, gogame.batch_track(gogame.batch_untrack(tr)))

@@ -111,6 +111,24 @@ def main():
     for F in (1, 64):
         t = timed(lambda: gogame.batch_rollout_packed(pk2, rng2, F, True), 20 if F == 1 else 5)
         out['gg_batch_rollout_packed_F%d_19x19_B65536' % F] = {'steps_per_s': B2 * F / t}
+    # tracked boards (packed + liberty classes): one ply per launch at the fused kernel's rate
+    tr = gogame.batch_track(st2)
+    rt = gogame.rng_seed(B2, 31)
+    played = torch.empty(B2, dtype=torch.int32, device='cuda')
+    for F in (1, 64):
+        t = timed(lambda: gogame.batch_rollout_tracked(tr, rt, F, True), 50 if F == 1 else 5)
+        out['gg_batch_rollout_tracked_F%d_19x19_B65536' % F] = {'steps_per_s': B2 * F / t}
+
+    def policy_step():   # the policy-driven step: on-device sampler standing in for a network, then one move per game
+        a = gogame.batch_sample_actions(gogame.batch_untrack(tr), rt)
+        gogame.batch_play_moves_tracked(tr, a, played)
+    one = gogame.batch_sample_actions(gogame.batch_untrack(tr), rt)
+    t = timed(lambda: gogame.batch_play_moves_tracked(tr, torch.full_like(one, N * N), played), 50)
+    out['gg_batch_play_moves_tracked_T1_19x19_B65536'] = {'steps_per_s': B2 / t, 'note': 'one given move (a pass) per game per launch'}
+    t = timed(lambda: gogame.batch_track(st2), 20)
+    out['gg_batch_track_states_19x19_B65536'] = {'boards_per_s': B2 / t}
+    t = timed(lambda: gogame.batch_untrack(tr), 20)
+    out['gg_batch_untrack_states_19x19_B65536'] = {'boards_per_s': B2 / t}
     # replay of recorded move sequences (64 moves per game in one launch)
     T = 64
     rec = torch.empty((B2, T), dtype=torch.int32, device='cuda')
