@@ -44,15 +44,17 @@ md.append('## rocprofv3 --kernel-trace --stats (same command)\n')
 md.append('| kernel | calls | avg ns | total % |\n|---|---|---|---|')
 for r in stats[:4]:
     md.append('| `%s` | %s | %.0f | %s |' % (r['Name'][:70], r['Calls'], float(r['AverageNs']), r['Percentage']))
-roll = [r for r in stats if 'k_rollout' in r['Name']][0]
 trace = [r for r in csv.DictReader(open(os.path.join(src, 'kt', 'kt_kernel_trace.csv'))) if 'k_rollout' in r['Kernel_Name']]
 full = max(int(r['Grid_Size_X']) for r in trace)
-durs = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in trace if int(r['Grid_Size_X']) == full]
-md.append('\nbench.py live launch_ms = %.4f; rocprofv3 average of the %d full-batch launches of the same kernel (burn-in, warm-up, '
-          'timed: %d plies each) = %.4f ms.  The stats row above averages %s launches: %d of them are the de-synchronising '
-          'burn-in launches on 1/16 slices of the batch (kt_kernel_trace: grid %d vs %d threads).'
-          % (bench['roofline']['launch_ms'], len(durs), F, sum(durs) / len(durs) / 1e6, roll['Calls'],
-             int(roll['Calls']) - len(durs), min(int(r['Grid_Size_X']) for r in trace), full))
+fullrows = [r for r in trace if int(r['Grid_Size_X']) == full]
+kname = fullrows[0]['Kernel_Name']
+durs = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in fullrows]
+other = [r for r in trace if int(r['Grid_Size_X']) != full]
+md.append('\nbench.py live launch_ms = %.4f; rocprofv3 average of the %d full-batch launches of `%s` (burn-in, warm-up, '
+          'timed: %d plies each) = %.4f ms.  The other %d rollout launches of the trace are the de-synchronising burn-in '
+          'launches on 1/16 slices of the batch (4 096 games each: below 8 192 games `gg_batch_rollout` uses the v2 kernel).'
+          % (bench['roofline']['launch_ms'], len(durs), kname.split('(')[0].replace('void gg::', ''), F,
+             sum(durs) / len(durs) / 1e6, len(other)))
 
 steps = games * F
 traffic = {}
