@@ -323,6 +323,36 @@ print("v3 ok")
     assert r.returncode == 0 and 'v3 ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_ab_kernels_in_subprocess(oracle):
+    """The A/B kernels kept behind switches - gg_batch_next_states without the LDS-DMA pipeline (GG_SYNC_IO=1) and
+    gg_batch_children re-analysing every child (GG_CHILDREN_FULL=1) - stay bit-exact with the oracle."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from gymgo_amd import gogame
+from oracle import c_oracle
+for N, B, plies in ((19, 199, 150), (9, 130, 50), (4, 31, 9)):
+    rng = gogame.rng_seed(B, 3); st = torch.zeros((B, 6, N, N), dtype=torch.uint8, device="cuda")
+    gogame.batch_rollout(st, rng, plies, False)
+    host = st.cpu().numpy()
+    acts = gogame.batch_sample_actions(st, rng)
+    for canon in (False, True):
+        nxt, status = gogame.batch_next_states(st, acts, canonical=canon, check=False)
+        w, ws = c_oracle.batch_next_states(host, acts.cpu().numpy(), canon)
+        assert np.array_equal(nxt.cpu().numpy(), w) and np.array_equal(status.cpu().numpy(), ws), ("next", N, canon)
+    live = host[:, 5, 0, 0] == 0
+    kids = gogame.batch_children(st[torch.from_numpy(live).cuda()][:24].contiguous(), False).cpu().numpy()
+    assert np.array_equal(kids, c_oracle.batch_children(host[live][:24], False)), ("children", N)
+print("ab ok")
+'''
+    env = dict(os.environ, GG_SYNC_IO='1', GG_CHILDREN_FULL='1')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'ab ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_update_pieces_standalone(gg, oracle):
     """state_utils.update_pieces / batch_update_pieces (gg_batch_update_pieces): stones after capture resolution equal
     planes 0/1 of the oracle's next_state; killed groups are reported per group in raster order."""
