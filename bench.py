@@ -196,7 +196,7 @@ def main():
         rcap = 9 if N <= 9 else 13 if N <= 13 else 19
         if os.environ.get('GG_KERNEL_VARIANT') == '1':
             kernel_name = 'k_rollout<%d>' % rcap
-        elif (F >= int(os.environ.get('GG_V3_MIN', '8')) and os.environ.get('GG_ROLLOUT_V2') != '1'
+        elif (F >= int(os.environ.get('GG_V3_MIN', '6')) and os.environ.get('GG_ROLLOUT_V2') != '1'
               and (count >= 32 * torch.cuda.get_device_properties(dev).multi_processor_count or os.environ.get('GG_V3_NB'))):
             kernel_name = 'k_rollout3<%d, false>' % rcap        # 12 boards per wave, liberty classes carried across plies
         else:

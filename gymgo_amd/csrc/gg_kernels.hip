@@ -90,7 +90,7 @@ bool use_v3(int64_t B, int plies);
 
 int v3_min_plies() {
   static int v = -1;
-  if (v < 0) { const char *e = getenv("GG_V3_MIN"); v = e ? atoi(e) : 8; }
+  if (v < 0) { const char *e = getenv("GG_V3_MIN"); v = e ? atoi(e) : 6; }
   return v;
 }
 
