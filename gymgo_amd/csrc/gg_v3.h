@@ -293,13 +293,13 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
             const uint32_t l = d & e;
             const uint32_t c = (uint32_t)__popc(l);
             cnt += c < 2u ? c : 2u;
-            sz += (uint32_t)__popc(gt[r]);
+            sz += gt[r];   // sum of the row words: equals the seed bit iff the group is the seed stone alone
           }
         }
         // roles 1-4: is this neighbour of q off the board or an opponent stone?  (all four: the new stone is boxed in)
         const bool off = j == 1 ? ar == 0 : (j == 2 ? ar == N - 1 : (j == 3 ? ac == 0 : ac == N - 1));
         const bool okbox = off || seedrow != 0;
-        clsv[hf.lane] = (cnt < 2u ? cnt : 2u) | (sz == 1u ? 4u : 0u) | (sz != 0u ? 8u : 0u) | (okbox ? 16u : 0u);
+        clsv[hf.lane] = (cnt < 2u ? cnt : 2u) | ((sz != 0u && sz == sbit) ? 4u : 0u) | (sz != 0u ? 8u : 0u) | (okbox ? 16u : 0u);
         // an opponent group that keeps >= 2 liberties keeps its class: phase 3 must not see it
         if (j != 0 && cnt >= 2u) {
           uint4 *pz = reinterpret_cast<uint4 *>(sc + (used ? hf.lane : 5 * kNB3) * RS);
