@@ -117,6 +117,17 @@ uint32_t recip16(int32_t N) {
   return inv;
 }
 
+// v3 kernels: the instantiation with compile-time N when the board fills its row capacity (9, 13, 19)
+#define GG_DISPATCH3(N, IO, MOVES, GRID, ...)                                                          \
+  do {                                                                                                  \
+    if ((N) == 9) { k_rollout3<9, IO, MOVES, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }        \
+    else if ((N) < 9) { k_rollout3<9, IO, MOVES, false><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }   \
+    else if ((N) == 13) { k_rollout3<13, IO, MOVES, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
+    else if ((N) < 13) { k_rollout3<13, IO, MOVES, false><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
+    else if ((N) == 19) { k_rollout3<19, IO, MOVES, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
+    else { k_rollout3<19, IO, MOVES, false><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }               \
+  } while (0)
+
 #define GG_DISPATCH(N, CALL9, CALL13, CALL19) \
   do {                                        \
     if ((N) <= 9) { CALL9; }                  \
@@ -253,9 +264,7 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
   int grid = grid_for(B);
   if (use_v3(B, plies)) {   // incremental classes, 12 boards per wave
     const int nb = v3_boards_per_wave(B, grid);
-    GG_DISPATCH(N, (k_rollout3<9, 0><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
-                (k_rollout3<13, 0><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
-                (k_rollout3<19, 0><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)));
+    GG_DISPATCH3(N, 0, false, grid, states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
     return (int32_t)hipGetLastError();
   }
   if (variant() == 2) {
@@ -395,9 +404,7 @@ int32_t gg_batch_rollout_packed(uint32_t *packed, uint64_t *rng, int32_t *last_a
   if (use_v3(B, plies)) {
     int grid3;
     const int nb = v3_boards_per_wave(B, grid3);
-    GG_DISPATCH(N, (k_rollout3<9, 1><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
-                (k_rollout3<13, 1><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
-                (k_rollout3<19, 1><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)));
+    GG_DISPATCH3(N, 1, false, grid3, st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
     return (int32_t)hipGetLastError();
   }
   const int grid = grid_for((B + 1) / 2);
@@ -466,9 +473,7 @@ int32_t gg_batch_play_moves(uint8_t *states, const int32_t *moves, int32_t *play
   if (use_v3(B, T)) {
     int grid3;
     const int nb = v3_boards_per_wave(B, grid3);
-    GG_DISPATCH(N, (k_rollout3<9, 0, true><<<grid3, kWave, 0, s>>>(states, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
-                (k_rollout3<13, 0, true><<<grid3, kWave, 0, s>>>(states, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
-                (k_rollout3<19, 0, true><<<grid3, kWave, 0, s>>>(states, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)));
+    GG_DISPATCH3(N, 0, true, grid3, states, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played);
     return (int32_t)hipGetLastError();
   }
   const int grid = grid_for((B + 1) / 2);
@@ -491,9 +496,7 @@ int32_t gg_batch_play_moves_packed(uint32_t *packed, const int32_t *moves, int32
   if (use_v3(B, T)) {
     int grid3;
     const int nb = v3_boards_per_wave(B, grid3);
-    GG_DISPATCH(N, (k_rollout3<9, 1, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
-                (k_rollout3<13, 1, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
-                (k_rollout3<19, 1, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)));
+    GG_DISPATCH3(N, 1, true, grid3, st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played);
     return (int32_t)hipGetLastError();
   }
   const int grid = grid_for((B + 1) / 2);
@@ -544,9 +547,7 @@ int32_t gg_batch_rollout_tracked(uint32_t *tracked, uint64_t *rng, int32_t *last
   uint8_t *st = reinterpret_cast<uint8_t *>(tracked);
   int grid3;
   const int nb = v3_boards_per_wave(B, grid3);
-  GG_DISPATCH(N, (k_rollout3<9, 2><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
-              (k_rollout3<13, 2><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)),
-              (k_rollout3<19, 2><<<grid3, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb)));
+  GG_DISPATCH3(N, 2, false, grid3, st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
   return (int32_t)hipGetLastError();
 }
 
@@ -562,9 +563,7 @@ int32_t gg_batch_play_moves_tracked(uint32_t *tracked, const int32_t *moves, int
   uint8_t *st = reinterpret_cast<uint8_t *>(tracked);
   int grid3;
   const int nb = v3_boards_per_wave(B, grid3);
-  GG_DISPATCH(N, (k_rollout3<9, 2, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
-              (k_rollout3<13, 2, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)),
-              (k_rollout3<19, 2, true><<<grid3, kWave, 0, s>>>(st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played)));
+  GG_DISPATCH3(N, 2, true, grid3, st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played);
   return (int32_t)hipGetLastError();
 }
 

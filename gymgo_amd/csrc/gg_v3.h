@@ -63,7 +63,9 @@ __device__ __forceinline__ uint32_t dilate_l1(uint32_t x) {
 // IO: 0 = byte planes (uint8 [B][6][N][N]), 1 = packed boards (uint32 [B][3N+1]), 2 = TRACKED boards (uint32 [B][5N+1]:
 // the rows of black, white, invalid, multi_black, multi_white + the flag word - a packed board that carries its
 // liberty classes, so that a launch needs no first analysis: per-ply stepping at the fused kernel's rate).
-template <int R, int IO, bool MOVES = false>
+// FULLN: the board fills the row capacity (N == R: 9, 13, 19) - the per-row "r < N" guards of the lane-per-board code
+// fold away at compile time (they cost one v_cndmask each otherwise).
+template <int R, int IO, bool MOVES = false, bool FULLN = false>
 __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                        int32_t *__restrict__ last_actions, int64_t *__restrict__ steps_done,
                                                        int64_t B, int N, uint32_t inv, int plies, int auto_reset,
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const uint32_t iv = st[2 * PL + sb * RS + r];
-            const uint32_t v = r < N ? (reset ? fullrow : (fullrow & ~iv)) : 0u;
+            const uint32_t v = (FULLN || r < N) ? (reset ? fullrow : (fullrow & ~iv)) : 0u;
             vrows[r] = v;
             n += (uint32_t)__popc(v);
           }
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
           const uint32_t fullrow = (1u << N) - 1u;
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const uint32_t e = r < N ? (fullrow & ~(ot[r] | wt[r])) : 0u;
+            const uint32_t e = (FULLN || r < N) ? (fullrow & ~(ot[r] | wt[r])) : 0u;
             const uint32_t up = r > 0 ? gt[r - 1] : 0u, dn = r + 1 < R ? gt[r + 1] : 0u;   // rows >= R are not written
             const uint32_t d = B3(shl1(gt[r]), gt[r] >> 1, up, T_OR3) | dn;
             const uint32_t l = d & e;
