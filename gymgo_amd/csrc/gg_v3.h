@@ -54,6 +54,8 @@ __device__ __forceinline__ void set_size(uint32_t x, const Half &hf, bool &any, 
   any = nz != 0;
   two = ((nz & (nz - 1u)) | many) != 0;
 }
+// the 21 ballot bits of board k of a three-boards-per-wave pass
+__device__ __forceinline__ uint32_t third_of(uint64_t ballot, int k) { return (uint32_t)(ballot >> (21 * k)) & 0x1FFFFFu; }
 __device__ __forceinline__ uint32_t dilate_l1(uint32_t x) {
   return B3(shl1(x), x >> 1, dpp0<0x138>(x), T_OR3) | dpp0<0x130>(x);
 }
@@ -153,6 +155,9 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
     }
 
     // ---------------------------------------------------------------- the plies
+    const int tk = (hf.lane * 49) >> 10, tl = hf.lane - 21 * tk;   // phase 3: board-of-the-pass and row of this lane
+    Half ht = hf;
+    ht.full_l1 = (tk < 3 && tl < N) ? (1u << N) - 1u : 0u;
     int mv_next = 0;
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
@@ -311,22 +316,29 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
       }
       WAVE_SYNC();
 
-      // phase 3 - one board per half, six passes: patch the classes, resolve captures and ko, the next mover's mask
-#pragma unroll GG_V3_UB
-      for (int i = 0; i < nb / 2; ++i) {
-        const int s = 2 * i + hf.h;
-        const int a = actv[s];
+      // phase 3 - THREE boards per pass (lane -> board k = lane / 21, row tl = lane % 21: 19 rows + 2 idle lanes per
+      // board keep the one-lane DPP shifts of neighbouring boards apart), four passes: patch the classes, resolve
+      // captures and ko, the next mover's mask
+#pragma unroll 1
+      for (int i = 0; 3 * i < nb; ++i) {
+        const int s = 3 * i + tk;
+        const bool act = tk < 3 && s < nb;
+        const int sa = act ? s : 0;
+        const int a = act ? actv[sa] : -1;
         const bool moves = a >= 0;
-        const uint32_t fl = flagsv[s];
+        const uint32_t fl = flagsv[sa];
         int turn = fl & 1u, passed = (fl >> 1) & 1u, done = (fl >> 2) & 1u;
-        const uint32_t c0 = clsv[5 * s], c1 = clsv[5 * s + 1], c2 = clsv[5 * s + 2], c3 = clsv[5 * s + 3], c4 = clsv[5 * s + 4];
+        const uint32_t c0 = clsv[5 * sa], c1 = clsv[5 * sa + 1], c2 = clsv[5 * sa + 2], c3 = clsv[5 * sa + 3],
+                       c4 = clsv[5 * sa + 4];
         // planes by role, not by colour: the mover's stones / classes are plane `turn` / 3 + `turn`
-        uint32_t *pmine = st + turn * PL + s * RS + hf.hl, *popp = st + (1 - turn) * PL + s * RS + hf.hl;
-        uint32_t *pMm = st + (3 + turn) * PL + s * RS + hf.hl, *pMo = st + (4 - turn) * PL + s * RS + hf.hl;
+        const int tr = tl < R ? tl : 0;
+        uint32_t *pmine = st + turn * PL + sa * RS + tr, *popp = st + (1 - turn) * PL + sa * RS + tr;
+        uint32_t *pMm = st + (3 + turn) * PL + sa * RS + tr, *pMo = st + (4 - turn) * PL + sa * RS + tr;
+        const bool rowt = act && tl < R;   // the floods write rows 0 .. R-1 of their blocks only
         uint32_t mine1 = 0, opp0 = 0, Mm = 0, Mo = 0, g0 = 0, gch = 0;
-        if (row) { mine1 = *pmine; opp0 = *popp; Mm = *pMm; Mo = *pMo; }
-        if (hf.hl < R) {   // the floods write rows 0 .. R-1 of their blocks only
-          const uint32_t *gr = sc + (5 * s) * RS + hf.hl;
+        if (rowt) {
+          mine1 = *pmine; opp0 = *popp; Mm = *pMm; Mo = *pMo;
+          const uint32_t *gr = sc + (5 * sa) * RS + tr;
           g0 = gr[0];
           gch = gr[RS] | gr[2 * RS] | gr[3 * RS] | gr[4 * RS];   // the opponent groups whose class changes
         }
@@ -334,21 +346,23 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
         const bool k1 = (c1 & 11u) == 8u, k2 = (c2 & 11u) == 8u, k3 = (c3 & 11u) == 8u, k4 = (c4 & 11u) == 8u;
         uint32_t cap = 0, Mm_fix = 0, libsG = c0 & 3u;   // libsG: liberties of G among the empty points (saturated at 2)
         int ko_r = -1, ko_c = 0;
-        if (__ballot(moves && (k1 || k2 || k3 || k4))) {   // a capture on some board of the pair (~ 20 % of the passes)
-          if (hf.hl < R) {
-            const uint32_t *gr = sc + (5 * s) * RS + hf.hl;
+        if (__ballot(moves && (k1 || k2 || k3 || k4))) {   // a capture on some board of the pass
+          if (rowt) {
+            const uint32_t *gr = sc + (5 * sa) * RS + tr;
             cap = (k1 ? gr[RS] : 0u) | (k2 ? gr[2 * RS] : 0u) | (k3 ? gr[3 * RS] : 0u) | (k4 ? gr[4 * RS] : 0u);
           }
           // captured stones next to G are liberties of G too
-          bool any, two;
-          set_size(dilate_l1(g0) & cap, hf, any, two);
-          libsG += two ? 2u : (any ? 1u : 0u);
+          {
+            const uint32_t x = dilate_l1(g0) & cap;
+            const uint32_t nz = third_of(__ballot(x != 0), tk), many = third_of(__ballot(__popc(x) > 1), tk);
+            libsG += ((nz & (nz - 1u)) | many) ? 2u : (nz ? 1u : 0u);
+          }
           // gogame.py:72-75: ko iff exactly one stone died and the new stone is boxed in
           const uint32_t ncap1 = (k1 && (c1 & 4u) ? 1u : 0u) + (k2 && (c2 & 4u) ? 1u : 0u) + (k3 && (c3 & 4u) ? 1u : 0u) +
                                  (k4 && (c4 & 4u) ? 1u : 0u);
           const uint32_t ncapn = (k1 ? 1u : 0u) + (k2 ? 1u : 0u) + (k3 ? 1u : 0u) + (k4 ? 1u : 0u);
           const bool boxed = (c1 & c2 & c3 & c4 & 16u) != 0;
-          if (boxed && ncapn == 1u && ncap1 == 1u) {
+          if (moves && boxed && ncapn == 1u && ncap1 == 1u) {
             int ar, ac;
             split_action(a, N, hf.inv, ar, ac);
             ko_r = ar + (k1 ? -1 : (k2 ? 1 : 0));
@@ -371,21 +385,21 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
         const uint32_t Mo2 = Mo & ~gch;
         const uint32_t opp1 = opp0 & ~cap;
         const uint32_t Mm2 = (Mm & ~g0) | (libsG >= 2u ? g0 : 0u) | Mm_fix;
-        uint32_t invalid = invalid_from2(opp1, mine1, Mo2, Mm2, hf);
-        if (hf.hl == ko_r) invalid |= 1u << ko_c;
+        uint32_t invalid = invalid_from2(opp1, mine1, Mo2, Mm2, ht);
+        if (tl == ko_r) invalid |= 1u << ko_c;
         if (moves) {
           if (is_pass) { if (passed) done = 1; passed = 1; } else passed = 0;
           turn ^= 1;
-          if (row) {
+          if (rowt) {
             *popp = opp1;
-            st[2 * PL + s * RS + hf.hl] = invalid;
+            st[2 * PL + sa * RS + tr] = invalid;
             *pMm = Mm2;
             *pMo = Mo2;
           }
-          if (hf.hl == 0) {
-            flagsv[s] = (uint32_t)turn | ((uint32_t)passed << 1) | ((uint32_t)done << 2) | 8u;
-            lastv[s] = a;
-            playedv[s] += 1;
+          if (tl == 0) {
+            flagsv[sa] = (uint32_t)turn | ((uint32_t)passed << 1) | ((uint32_t)done << 2) | 8u;
+            lastv[sa] = a;
+            playedv[sa] += 1;
           }
         }
       }
