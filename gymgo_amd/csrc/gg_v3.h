@@ -258,43 +258,42 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
         const uint32_t *oth = st + ((j == 0) ? 1 - turn : turn) * PL + ss * RS;
         const int sr = ar + (j == 1 ? -1 : (j == 2 ? 1 : 0));
         const uint32_t sbit = j == 3 ? (bit >> 1) : (j == 4 ? (bit << 1) : bit);
-        uint32_t seedrow = 0;
+        uint32_t seedrow = 0, cnt = 0, sz = 0;
         {
-          uint32_t m[R], mrev[R], f[R];
-          uint32_t mt[RV * 4];
-          const uint4 *pm = reinterpret_cast<const uint4 *>(own);
+          uint32_t m[R];
+          {
+            uint32_t mrev[R], f[R];
+            uint32_t mt[RV * 4];
+            const uint4 *pm = reinterpret_cast<const uint4 *>(own);
 #pragma unroll
-          for (int i = 0; i < RV; ++i) {
-            const uint4 x = pm[i];
-            mt[4 * i] = x.x; mt[4 * i + 1] = x.y; mt[4 * i + 2] = x.z; mt[4 * i + 3] = x.w;
-          }
+            for (int i = 0; i < RV; ++i) {
+              const uint4 x = pm[i];
+              mt[4 * i] = x.x; mt[4 * i + 1] = x.y; mt[4 * i + 2] = x.z; mt[4 * i + 3] = x.w;
+            }
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            m[r] = mt[r];
-            mrev[r] = __brev(m[r]);
-            f[r] = (r == sr) ? (m[r] & sbit) : 0u;
-            seedrow |= f[r];
+            for (int r = 0; r < R; ++r) {
+              m[r] = mt[r];
+              mrev[r] = __brev(m[r]);
+              f[r] = (r == sr) ? (m[r] & sbit) : 0u;
+              seedrow |= f[r];
+            }
+            flood2_serial<R>(m, mrev, f, sc + (used ? hf.lane : 5 * kNB3) * RS);
           }
-          flood2_serial<R>(m, mrev, f, sc + (used ? hf.lane : 5 * kNB3) * RS);
-        }
-        // liberties of this lane's group on the position with the new stone (captures not yet removed)
-        uint32_t cnt = 0, sz = 0;
-        {
-          uint32_t gt[RV * 4], ot[RV * 4], wt[RV * 4];
+          // liberties of this lane's group on the position with the new stone (captures not yet removed); m[] still
+          // holds the flooded colour's rows
+          uint32_t gt[RV * 4], ot[RV * 4];
           const uint4 *pg = reinterpret_cast<const uint4 *>(sc + (used ? hf.lane : 5 * kNB3) * RS);
           const uint4 *po = reinterpret_cast<const uint4 *>(oth);
-          const uint4 *pw = reinterpret_cast<const uint4 *>(own);
 #pragma unroll
           for (int i = 0; i < RV; ++i) {
-            const uint4 x = pg[i], y = po[i], z = pw[i];
+            const uint4 x = pg[i], y = po[i];
             gt[4 * i] = x.x; gt[4 * i + 1] = x.y; gt[4 * i + 2] = x.z; gt[4 * i + 3] = x.w;
             ot[4 * i] = y.x; ot[4 * i + 1] = y.y; ot[4 * i + 2] = y.z; ot[4 * i + 3] = y.w;
-            wt[4 * i] = z.x; wt[4 * i + 1] = z.y; wt[4 * i + 2] = z.z; wt[4 * i + 3] = z.w;
           }
           const uint32_t fullrow = (1u << N) - 1u;
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const uint32_t e = (FULLN || r < N) ? (fullrow & ~(ot[r] | wt[r])) : 0u;
+            const uint32_t e = (FULLN || r < N) ? (fullrow & ~(ot[r] | m[r])) : 0u;
             const uint32_t up = r > 0 ? gt[r - 1] : 0u, dn = r + 1 < R ? gt[r + 1] : 0u;   // rows >= R are not written
             const uint32_t d = B3(shl1(gt[r]), gt[r] >> 1, up, T_OR3) | dn;
             const uint32_t l = d & e;
