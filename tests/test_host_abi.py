@@ -145,3 +145,27 @@ def test_killed_group_listing_and_point_inference():
     assert sorted(map(tuple, adj)) == [(0, 1), (1, 0)] and state_utils._point_of(s, adj, 1) == 0
     s[0, 0, 1] = s[0, 1, 0] = 1
     assert state_utils.adj_data(s, (0, 0), 1)[1] is True
+
+
+def test_host_side_argument_checks_without_device(built):
+    """Shape / dtype / argument validation of the Python wrappers happens before any device work."""
+    import torch
+    from gymgo_amd import gogame
+    with pytest.raises(ValueError):
+        gogame._packed_size(torch.zeros((4, 57), dtype=torch.int32))      # 3N+1 with N=19 is 58
+    with pytest.raises(ValueError):
+        gogame._packed_size(torch.zeros((4, 58), dtype=torch.int64))
+    assert gogame._packed_size(torch.zeros((4, 58), dtype=torch.int32)) == 19
+    assert gogame._tracked_size(torch.zeros((2, 96), dtype=torch.int32)) == 19
+    with pytest.raises(ValueError):
+        gogame._tracked_size(torch.zeros((2, 58), dtype=torch.int32))
+    assert gogame.packed_words(9) == 28 and gogame.tracked_words(9) == 46
+    with pytest.raises(ValueError):
+        gogame.batch_env_step(torch.zeros((2, 6, 5, 5), dtype=torch.uint8))              # neither actions nor rng
+    with pytest.raises(KeyError):
+        gogame.REWARD_METHODS['nope']
+    if not torch.cuda.is_available():
+        with pytest.raises(built.GymGoNativeError):                                         # host tensors never compute
+            gogame.batch_rollout_packed(torch.zeros((2, 28), dtype=torch.int32), torch.zeros(2, dtype=torch.int64), 3)
+        with pytest.raises(built.GymGoNativeError):
+            gogame.batch_track(torch.zeros((2, 6, 9, 9), dtype=torch.uint8))
