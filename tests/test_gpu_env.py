@@ -209,3 +209,40 @@ def test_vecenv_step_captured_in_hipgraph():
     over = want[:, 5, 0, 0] == 1
     assert torch.equal(rewards, torch.where(over, torch.where(margin > 0, 81.0, -81.0), margin))
     assert torch.equal(dones, want[:, 5, 0, 0])
+
+
+def test_symmetries_and_helpers_on_device_tensors():
+    """all_symmetries / random_symmetry (gym_go/gogame.py:338-382: h-flip bit 0, v-flip bit 1, rot90 bit 2) on device
+    tensors against the same NumPy operations; liberties / num_liberties / areas helpers on a played position."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    N = 7
+    st = gogame.batch_init_state(1, N, device='cuda')
+    rng = gogame.rng_seed(1, 12)
+    gogame.batch_rollout(st, rng, 23, False)
+    img = st[0]
+    host = img.cpu().numpy()
+    syms = gogame.all_symmetries(img)
+    assert len(syms) == 8
+    for i, x in enumerate(syms):
+        want = host
+        if (i >> 0) % 2:
+            want = np.flip(want, 2)
+        if (i >> 1) % 2:
+            want = np.flip(want, 1)
+        if (i >> 2) % 2:
+            want = np.rot90(want, axes=(1, 2))
+        assert np.array_equal(x.cpu().numpy(), want), i
+    r = gogame.random_symmetry(img).cpu().numpy()
+    assert any(np.array_equal(r, s.cpu().numpy()) for s in syms)
+    # areas of every symmetry equal the areas of the position (scoring is symmetric)
+    b0, w0 = gogame.areas(img)
+    for x in syms:
+        assert gogame.areas(x.contiguous()) == (b0, w0)
+    ob, ow = c_oracle.batch_areas(host[None])
+    assert (int(b0), int(w0)) == (int(ob[0]), int(ow[0]))
+    libs_b, libs_w = gogame.liberties(host)
+    nb, nw = gogame.num_liberties(host)
+    assert int(libs_b.sum()) == int(nb) and int(libs_w.sum()) == int(nw)
+    empties = (host[0] + host[1]) == 0
+    assert not (libs_b & ~empties).any() and not (libs_w & ~empties).any()
