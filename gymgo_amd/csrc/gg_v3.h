@@ -25,7 +25,7 @@ namespace gg {
 #define GG_V3_UA 1
 #endif
 #ifndef GG_V3_UB
-#define GG_V3_UB 1
+#define GG_V3_UB 2
 #endif
 constexpr int kNB3 = 12;
 
@@ -318,8 +318,9 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
       // phase 3 - THREE boards per pass (lane -> board k = lane / 21, row tl = lane % 21: 19 rows + 2 idle lanes per
       // board keep the one-lane DPP shifts of neighbouring boards apart), four passes: patch the classes, resolve
       // captures and ko, the next mover's mask
-#pragma unroll 1
-      for (int i = 0; 3 * i < nb; ++i) {
+#pragma unroll GG_V3_UB
+      for (int i = 0; i < kNB3 / 3; ++i) {
+        if (3 * i >= nb) continue;
         const int s = 3 * i + tk;
         const bool act = tk < 3 && s < nb;
         const int sa = act ? s : 0;
