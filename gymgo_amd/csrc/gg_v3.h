@@ -96,10 +96,43 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
 
   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const int64_t b_first = g * nb;
-    // ---------------------------------------------------------------- load: 6 pairs, first classes by the v2 analysis
+    // ---------------------------------------------------------------- load
     WAVE_SYNC();
+    if (TRACKED) {
+      // the group's boards are ONE contiguous block of nb x (5 N + 1) words: a flat, fully coalesced copy into the LDS
+      // planes (all loads in flight at once), instead of six dependent per-pair passes
+      const int64_t nbrd = (B - b_first) < nb ? (B - b_first) : nb;
+      const int nw = (int)nbrd * W;
+      const uint32_t *gp = reinterpret_cast<const uint32_t *>(states) + b_first * (int64_t)W;
+      for (int i = hf.lane; i < 5 * PL; i += kWave) st[i] = 0;      // rows N .. RS-1 and absent boards read as zero
+      const uint32_t invW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;   // i / W exactly for i < 12 * 96
+      WAVE_SYNC();
+      for (int i = hf.lane; i < nw; i += kWave) {
+        const uint32_t v = gp[i];
+        const int sb = (int)(((uint32_t)i * invW) >> 20), w = i - sb * W;
+        if (w == 5 * N) {
+          flagsv[sb] = (v & 7u) | 8u;
+        } else {
+          const int pl = (int)(((uint32_t)w * hf.inv) >> 16), rw = w - pl * N;
+          st[pl * PL + sb * RS + rw] = v;
+        }
+      }
+      if (hf.lane < nb) {
+        const int sb = hf.lane;
+        const bool on = b_first + sb < B;
+        if (!on) flagsv[sb] = 0;
+        lastv[sb] = -1;
+        playedv[sb] = 0;
+        if (!MOVES) {
+          const uint64_t x = rng[on ? b_first + sb : B - 1];
+          rngv[2 * sb] = (uint32_t)x;
+          rngv[2 * sb + 1] = (uint32_t)(x >> 32);
+        }
+      }
+      WAVE_SYNC();
+    }
 #pragma unroll 1
-    for (int i = 0; i < nb / 2; ++i) {
+    for (int i = 0; i < (TRACKED ? 0 : nb / 2); ++i) {   // byte planes / packed boards: 6 pairs, first classes by the v2 analysis
       const int s = 2 * i + hf.h;
       const bool on = b_first + s < B;
       const int64_t b = on ? b_first + s : B - 1;
@@ -408,9 +441,37 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
 
     // ---------------------------------------------------------------- store
     WAVE_SYNC();
+    if (TRACKED) {
+      const int64_t nbrd = (B - b_first) < nb ? (B - b_first) : nb;
+      const int nw = (int)nbrd * W;
+      uint32_t *gp = reinterpret_cast<uint32_t *>(states) + b_first * (int64_t)W;
+      const uint32_t invW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;   // i / W exactly for i < 12 * 96
+      for (int i = hf.lane; i < nw; i += kWave) {
+        const int sb = (int)(((uint32_t)i * invW) >> 20), w = i - sb * W;
+        if (playedv[sb] == 0) continue;                 // untouched boards are not rewritten
+        uint32_t v;
+        if (w == 5 * N) {
+          v = flagsv[sb] & 7u;
+        } else {
+          const int pl = (int)(((uint32_t)w * hf.inv) >> 16), rw = w - pl * N;
+          v = st[pl * PL + sb * RS + rw];
+        }
+        gp[i] = v;
+      }
+      if (hf.lane < nb && b_first + hf.lane < B) {
+        const int sb = hf.lane;
+        const int64_t b = b_first + sb;
+        const int played = playedv[sb];
+        if (!MOVES) rng[b] = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
+        if (last_actions) last_actions[b] = lastv[sb];
+        if (steps_done) steps_done[b] += played;
+        if (MOVES && played_out) played_out[b] = played;
+      }
+      WAVE_SYNC();
+    }
     if (IO == 0) load_spread_lut(lut, hf.lane);
 #pragma unroll 1
-    for (int i = 0; i < nb / 2; ++i) {
+    for (int i = 0; i < (TRACKED ? 0 : nb / 2); ++i) {
       const int s = 2 * i + hf.h;
       const uint32_t fl = flagsv[s];
       const bool on = (fl >> 3) & 1u;
