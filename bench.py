@@ -63,7 +63,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=128)
     ap.add_argument('--size', type=int, default=19)
     ap.add_argument('--games-per-gpu', type=int, default=0, help='0 = 65536 at 1 GPU, 131072 per GPU otherwise')
-    ap.add_argument('--fuse', type=int, default=int(os.environ.get('GG_BENCH_FUSE', '64')),
+    ap.add_argument('--fuse', type=int, default=int(os.environ.get('GG_BENCH_FUSE', '256')),
                     help='plies per kernel launch')
     ap.add_argument('--burn-in', type=int, default=256, help='untimed plies before warmup (stationary board mix)')
     ap.add_argument('--desync', type=int, default=640, help='spread of extra burn-in plies across the batch (0 = lock-step)')
@@ -100,8 +100,14 @@ def main():
     total_games = per_gpu * world
     first, count = shard(total_games, rank, world)
     N, F = args.size, max(1, args.fuse)
-    K = (args.steps + F - 1) // F * F
-    W = (args.warmup + F - 1) // F * F
+    K, W = max(1, args.steps), max(0, args.warmup)    # EXACTLY K timed and W warm-up steps: full launches of F plies + a remainder
+    F = min(F, K)
+
+    def run_plies(n):
+        for _ in range(n // F):
+            gogame.batch_rollout(states, rng, F, True, None, steps_done)
+        if n % F:
+            gogame.batch_rollout(states, rng, n % F, True, None, steps_done)
 
     states = gogame.batch_init_state(count, N, device=dev)
     rng = gogame.rng_seed(count, 20260927, first, dev)
@@ -117,8 +123,7 @@ def main():
                 gogame.batch_rollout(states[lo:hi], rng[lo:hi], gslice * args.desync // 16, True)
     for _ in range((args.burn_in + F - 1) // F):   # same launch shape as the timed ones (rocprof averages then agree)
         gogame.batch_rollout(states, rng, F, True, None, steps_done)
-    for _ in range(W // F):
-        gogame.batch_rollout(states, rng, F, True, None, steps_done)
+    run_plies(W)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -131,8 +136,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     ev0.record()            # launches go to torch's current stream (gymgo_amd/_lib.py: stream_ptr)
-    for _ in range(K // F):
-        gogame.batch_rollout(states, rng, F, True, None, steps_done)
+    run_plies(K)
     ev1.record()
     fence()
     wall = time.perf_counter() - t0
@@ -180,9 +184,8 @@ def main():
     wall_max = float(t[0])
     if rank == 0:
         value = K * total_games / wall_max
-        launches = K // F
         algo = ALGO_BYTES_PER_STEP.get(N, 12 * N * N + 4)
-        launch_ms = kernel_ms / launches
+        launch_ms = kernel_ms * F / K     # per F plies (K is a multiple of F by default: then the average launch time)
         achieved = algo * count * F / (launch_ms * 1e-3) / 1e9
         traffic = None
         tj = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')

@@ -2,13 +2,13 @@
 # Runs ON THE GPU BOX (via gpurun): bench + rocprofv3 passes for the round's profile evidence.
 #   tools/profile_round.sh <tag> [fuse]
 # kernel-trace/stats and each PMC group are separate runs (never --pmc together with sys/hip traces).
-TAG=${1:-r01}; F=${2:-16}
+TAG=${1:-r01}; F=${2:-256}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 256 --warmup 64 --fuse $F"
+BENCH="python $R/bench.py --steps 1024 --warmup 256 --fuse $F"
 timeout 600 $BENCH > $O/bench.json 2> $O/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $BENCH --no-cpu-baseline --no-also > $O/kt.log 2>&1
-SHORT="python $R/bench.py --steps 32 --warmup 0 --burn-in 256 --fuse $F --no-cpu-baseline --no-also"
+SHORT="python $R/bench.py --steps 768 --warmup 0 --burn-in 256 --fuse $F --no-cpu-baseline --no-also"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- $SHORT > $O/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- $SHORT > $O/pmc_write.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_inst -o p -- $SHORT > $O/pmc_inst.log 2>&1
