@@ -201,7 +201,8 @@ def main():
             kernel_name = 'k_rollout<%d>' % rcap
         elif (F >= int(os.environ.get('GG_V3_MIN', '6')) and os.environ.get('GG_ROLLOUT_V2') != '1'
               and (count >= 32 * torch.cuda.get_device_properties(dev).multi_processor_count or os.environ.get('GG_V3_NB'))):
-            kernel_name = 'k_rollout3<%d, false>' % rcap        # 12 boards per wave, liberty classes carried across plies
+            # 12 boards per wave, liberty classes carried across plies; <row capacity, byte-plane I/O, drawn moves, N == capacity>
+            kernel_name = 'k_rollout3<%d, 0, false, %s>' % (rcap, 'true' if N == rcap else 'false')
         else:
             kernel_name = 'k_rollout2<%d, %s, false>' % (rcap, 'true' if F <= 2 else 'false')
         line = {
