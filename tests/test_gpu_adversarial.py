@@ -254,3 +254,35 @@ def test_env_step_config3_size_matches_fused_rollout():
     over = states[:, 5, 0, 0] == 1
     want = torch.where(over, torch.where(margin > 0, 361.0, -361.0), margin)
     assert torch.equal(rewards, want) and torch.equal(dones, states[:, 5, 0, 0])
+
+
+def test_v3_and_v2_rollout_kernels_agree_at_config3_size():
+    """65 536 x 19x19 games, 700 plies in launches of 256 / 64 / 7 / 300 / 73 plies: the incremental-class kernel
+    (k_rollout3, the default at this size) and the per-ply-analysis kernel (k_rollout2, GG_ROLLOUT_V2=1, pinned to the
+    oracle by the small-batch tests) must leave bit-identical states, generator states, last actions and step counts."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, torch
+from gymgo_amd import gogame
+B, N = 65536, 19
+st = gogame.batch_init_state(B, N, device="cuda"); rng = gogame.rng_seed(B, 20260927)
+la = torch.empty(B, dtype=torch.int32, device="cuda"); sd = torch.zeros(B, dtype=torch.int64, device="cuda")
+h = hashlib.sha256()
+for plies in (256, 64, 7, 300, 73):
+    gogame.batch_rollout(st, rng, plies, True, la, sd)
+    for t in (st, rng, la, sd):
+        h.update(t.cpu().numpy().tobytes())
+print("digest", h.hexdigest(), int(sd.sum()))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for v2 in ('0', '1'):
+        env = dict(os.environ, GG_ROLLOUT_V2=v2)
+        env.pop('GG_V3_NB', None)
+        r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and 'digest' in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+        out.append(r.stdout.strip().splitlines()[-1])
+    assert out[0] == out[1], out
+    assert out[0].endswith(str(65536 * 700))
