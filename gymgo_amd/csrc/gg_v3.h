@@ -21,11 +21,8 @@ namespace gg {
 // 12 boards x 5 lanes = 60 lanes per flood batch: the floods cost a sixth per board, the L1 work (sampling, the class
 // patch, the mask) is what remains - about 160 VALU ops per board and ply against 346.
 // Board state lives in LDS between the passes (5 rows per board: black, white, invalid, multi_black, multi_white).
-#ifndef GG_V3_UA
-#define GG_V3_UA 1
-#endif
 #ifndef GG_V3_UB
-#define GG_V3_UB 2
+#define GG_V3_UB 2   // unroll of the class-patch passes (1: 3.63e9, 2: 3.72e9, 4: spills, 1.98e9)
 #endif
 constexpr int kNB3 = 12;
 
