@@ -12,15 +12,21 @@ namespace gg {
 // has no liberty-less group) and updates them per ply from FIVE floods:
 //   lane 0 of a board: the mover's group G that the new stone joins (flood from q through the mover's stones + q);
 //   lanes 1-4:         the opponent's group at the upper / lower / left / right neighbour of q (empty otherwise).
-// In L1 (one board per half, six passes per ply):
-//   * an opponent group g_j adjacent to q is recounted exactly: dilate(g_j) & empty' -> 0 liberties: captured,
-//     1: atari, >= 2: still "multi" (two ballots classify a point set as empty / single / more);
-//   * G is recounted on the position after the captures;
-//   * a mover's group in atari next to a captured stone gains a liberty -> multi (rare; L1 flood through the atari set);
-//   * every other group keeps its class.  The invalid-move mask follows from the classes exactly as in v2.
-// 12 boards x 5 lanes = 60 lanes per flood batch: the floods cost a sixth per board, the L1 work (sampling, the class
-// patch, the mask) is what remains - about 160 VALU ops per board and ply against 346.
-// Board state lives in LDS between the passes (5 rows per board: black, white, invalid, multi_black, multi_white).
+// A ply is three phases, each with its own lane assignment:
+//   1. one LANE per board (12 lanes): liveness, the generator, the k-th valid point of the stored mask (row prefix sums
+//      over its 19 rows), the stone ORed into the mover's plane; auto-reset on a rare path;
+//   2. one lane per (board, role): the flood, then the liberties (dilate & empty, saturated at 2) and the size of the
+//      lane's own group, 19 rows in registers; an opponent group that keeps >= 2 liberties zeroes its result;
+//   3. THREE boards per pass in the row-per-lane layout (lane -> board lane / 21, row lane % 21), four passes:
+//        * an opponent group next to q with no liberty left is captured, with one left it leaves the class plane;
+//        * G takes the class of its own count (+ the captured points next to it);
+//        * a mover's group in atari next to a captured stone gains a liberty -> multi (rare; a flood through the atari
+//          set in this layout);
+//        * every other group keeps its class.  The invalid-move mask follows from the classes exactly as in v2.
+// 12 boards x 5 lanes = 60 lanes per flood batch: the floods cost a sixth per board - about 120 VALU ops per board and
+// ply against 346 (PMC, profiles/r01_summary.md).
+// Board state lives in LDS between the phases (5 rows per board: black, white, invalid, multi_black, multi_white);
+// 10 224 B per wave, 128 VGPRs: four waves per SIMD.
 #ifndef GG_V3_UB
 #define GG_V3_UB 2   // unroll of the class-patch passes (1: 3.63e9, 2: 3.72e9, 4: spills, 1.98e9)
 #endif
