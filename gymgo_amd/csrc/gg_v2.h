@@ -598,13 +598,17 @@ __global__ __launch_bounds__(kWave, 3) void k_next_states2s(const uint8_t *__res
 __device__ __forceinline__ uint32_t lds_addr(const void *p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
-// lane L's 16 (4) bytes at g land at LDS address m0 + 16 L (m0 + 4 L); m0 must be wave-uniform
+// lane L's 16 (4) bytes at g land at LDS address m0 + 16 L (m0 + 4 L); m0 must be wave-uniform.  M0 is written and
+// consumed inside one asm statement and declared clobbered (clang warns that M0 is a reserved register: silenced here).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void dma16(const void *g, uint32_t m0) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0), "v"(g) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0), "v"(g) : "memory", "m0");
 }
 __device__ __forceinline__ void dma4(const void *g, uint32_t m0) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0), "v"(g) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0), "v"(g) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
