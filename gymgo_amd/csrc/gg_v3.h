@@ -191,17 +191,21 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
     }
 
     // ---------------------------------------------------------------- the plies
-    const int tk = (hf.lane * 49) >> 10, tl = hf.lane - 21 * tk;   // phase 3: board-of-the-pass and row of this lane
     Half ht = hf;
-    ht.full_l1 = (tk < 3 && tl < N) ? (1u << N) - 1u : 0u;
     int mv_next = 0;
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
+      // the lane-derived indices of the three phases are recomputed every ply (a few VALU ops) instead of being hoisted
+      // out of the loop, where they end up in scratch: a reload is a vector-memory round trip at the top of each phase
+      int ln = hf.lane;
+      asm volatile("" : "+v"(ln));
+      const int tk = (ln * 49) >> 10, tl = ln - 21 * tk;   // phase 3: board-of-the-pass and row of this lane
+      ht.full_l1 = (tk < 3 && tl < N) ? (1u << N) - 1u : 0u;
       // phase 1 - one LANE per board (lanes 0-11): liveness, the generator, the k-th valid point (or the given move)
       uint64_t resetm;
       {
-        const bool bl = hf.lane < nb;
-        const int sb = bl ? hf.lane : 0;
+        const bool bl = ln < nb;
+        const int sb = bl ? ln : 0;
         const uint32_t fl = flagsv[sb];
         const bool on = bl && ((fl >> 3) & 1u);
         const bool done = (fl >> 2) & 1u;
@@ -281,8 +285,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
       // phase 2 - one lane per (board, role): role 0 floods the mover's stones from the new stone q, roles 1-4 the
       // opponent's from the four neighbours of q; then every lane counts the liberties of its own group
       {
-        const int s = (hf.lane * 13) >> 6, j = hf.lane - 5 * s;
-        const bool used = hf.lane < 5 * nb;
+        const int s = (ln * 13) >> 6, j = ln - 5 * s;
+        const bool used = ln < 5 * nb;
         const int ss = used ? s : 0;
         const int a = used ? actv[ss] : -1;
         const int turn = flagsv[ss] & 1u;
@@ -313,12 +317,12 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
               f[r] = (r == sr) ? (m[r] & sbit) : 0u;
               seedrow |= f[r];
             }
-            flood2_serial<R>(m, mrev, f, sc + (used ? hf.lane : 5 * kNB3) * RS);
+            flood2_serial<R>(m, mrev, f, sc + (used ? ln : 5 * kNB3) * RS);
           }
           // liberties of this lane's group on the position with the new stone (captures not yet removed); m[] still
           // holds the flooded colour's rows
           uint32_t gt[RV * 4], ot[RV * 4];
-          const uint4 *pg = reinterpret_cast<const uint4 *>(sc + (used ? hf.lane : 5 * kNB3) * RS);
+          const uint4 *pg = reinterpret_cast<const uint4 *>(sc + (used ? ln : 5 * kNB3) * RS);
           const uint4 *po = reinterpret_cast<const uint4 *>(oth);
 #pragma unroll
           for (int i = 0; i < RV; ++i) {
@@ -341,10 +345,10 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
         // roles 1-4: is this neighbour of q off the board or an opponent stone?  (all four: the new stone is boxed in)
         const bool off = j == 1 ? ar == 0 : (j == 2 ? ar == N - 1 : (j == 3 ? ac == 0 : ac == N - 1));
         const bool okbox = off || seedrow != 0;
-        clsv[hf.lane] = (cnt < 2u ? cnt : 2u) | ((sz != 0u && sz == sbit) ? 4u : 0u) | (sz != 0u ? 8u : 0u) | (okbox ? 16u : 0u);
+        clsv[ln] = (cnt < 2u ? cnt : 2u) | ((sz != 0u && sz == sbit) ? 4u : 0u) | (sz != 0u ? 8u : 0u) | (okbox ? 16u : 0u);
         // an opponent group that keeps >= 2 liberties keeps its class: phase 3 must not see it
         if (j != 0 && cnt >= 2u) {
-          uint4 *pz = reinterpret_cast<uint4 *>(sc + (used ? hf.lane : 5 * kNB3) * RS);
+          uint4 *pz = reinterpret_cast<uint4 *>(sc + (used ? ln : 5 * kNB3) * RS);
 #pragma unroll
           for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
         }
