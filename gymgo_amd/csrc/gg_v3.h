@@ -197,8 +197,9 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
     for (int t = 0; t < plies; ++t) {
       // the lane-derived indices of the three phases are recomputed every ply (a few VALU ops) instead of being hoisted
       // out of the loop, where they end up in scratch: a reload is a vector-memory round trip at the top of each phase
-      int ln = hf.lane;
-      asm volatile("" : "+v"(ln));
+      // (volatile asm: neither hoisted nor merged)
+      int ln;   // = hf.lane (one wave per workgroup), straight from the hardware
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
       const int tk = (ln * 49) >> 10, tl = ln - 21 * tk;   // phase 3: board-of-the-pass and row of this lane
       ht.full_l1 = (tk < 3 && tl < N) ? (1u << N) - 1u : 0u;
       // phase 1 - one LANE per board (lanes 0-11): liveness, the generator, the k-th valid point (or the given move)
@@ -236,23 +237,37 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
           const uint32_t fullrow = (1u << N) - 1u;
           uint32_t vrows[R];
           uint32_t n = 0;
+          {
+            // the rows come in as RV unconditional 16-byte reads: a per-row `reset ? ... : load` turns into 19 predicated
+            // single-word reads, each waited for on its own
+            uint32_t ivt[RV * 4];
+            const uint4 *pi = reinterpret_cast<const uint4 *>(st + 2 * PL + sb * RS);
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const uint32_t iv = st[2 * PL + sb * RS + r];
-            const uint32_t v = (FULLN || r < N) ? (reset ? fullrow : (fullrow & ~iv)) : 0u;
-            vrows[r] = v;
-            n += (uint32_t)__popc(v);
+            for (int i = 0; i < RV; ++i) {
+              const uint4 q = pi[i];
+              ivt[4 * i] = q.x; ivt[4 * i + 1] = q.y; ivt[4 * i + 2] = q.z; ivt[4 * i + 3] = q.w;
+            }
+            const uint32_t rm = reset ? ~0u : 0u;   // a board being reset plays on the empty board
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const uint32_t v = (FULLN || r < N) ? B3(fullrow, rm, ivt[r], TA & (TB | (~TC & 0xFF))) : 0u;
+              vrows[r] = v;
+              n += (uint32_t)__popc(v);
+            }
           }
           x = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
           const uint64_t u = splitmix_next(x);
           uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(n + 1)) >> 32);
-          uint32_t acc = 0, tt = 0, vr = 0;
+          // the row of the k-th valid point: the running counts are non-decreasing, so walking the rows downwards the
+          // last row with k < count(rows 0..r) is the first such row - one compare feeds the three selects
+          uint32_t tt = 0, vr = 0;
+          uint32_t pre[R + 1];
+          pre[0] = 0;
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const uint32_t c = (uint32_t)__popc(vrows[r]);
-            const bool hit = rr < 0 && k < acc + c;
-            if (hit) { rr = r; tt = k - acc; vr = vrows[r]; }
-            acc += c;
+          for (int r = 0; r < R; ++r) pre[r + 1] = pre[r] + (uint32_t)__popc(vrows[r]);
+#pragma unroll
+          for (int r = R - 1; r >= 0; --r) {
+            if (k < pre[r + 1]) { rr = r; tt = k - pre[r]; vr = vrows[r]; }
           }
 #pragma unroll
           for (int sh = 16; sh >= 1; sh >>= 1) {   // the tt-th set bit of vr

@@ -27,7 +27,14 @@
 #define I_LSHL64(d, x, y) "v_lshlrev_b32 %" #d ", %" #x ", %" #y "\n"
 #define I_LSHR_V(d, x, y) "v_lshrrev_b32 %" #d ", %" #x ", %" #y "\n"
 #define I_BFE_V(d, x, y) "v_bfe_u32 %" #d ", %" #x ", %" #y ", 1\n"
-#define I_SAVEEXEC(d, x, y) "s_and_saveexec_b64 s[22:23], s[20:21]\n v_xor_b32 %" #d ", %" #x ", %" #y "\n s_or_b64 exec, exec, s[22:23]\n"
+#define CND3_VCC(d, x, y) "v_cndmask_b32 %" #d ", %" #x ", %" #y ", vcc\n v_cndmask_b32 %" #x ", %" #y ", %" #d ", vcc\n v_cndmask_b32 %" #y ", %" #d ", %" #x ", vcc\n"
+#define CND3_SGPR(d, x, y) "v_cndmask_b32_e64 %" #d ", %" #x ", %" #y ", s[22:23]\n v_cndmask_b32_e64 %" #x ", %" #y ", %" #d ", s[22:23]\n v_cndmask_b32_e64 %" #y ", %" #d ", %" #x ", s[22:23]\n"
+#define I_SMOV_CND3(d, x, y) "s_mov_b64 vcc, s[20:21]\n s_nop 1\n" CND3_VCC(d, x, y)
+#define I_SAND_CND3(d, x, y) "s_and_b64 vcc, vcc, s[20:21]\n s_nop 1\n" CND3_VCC(d, x, y)
+#define I_SAND_CND3_SGPR(d, x, y) "s_and_b64 s[22:23], s[20:21], s[20:21]\n s_nop 1\n" CND3_SGPR(d, x, y)
+#define I_VCMP_CND3(d, x, y) "v_cmp_lt_u32 vcc, %" #x ", %" #y "\n s_nop 1\n" CND3_VCC(d, x, y)
+#define I_VCMP_CND3_SGPR(d, x, y) "v_cmp_lt_u32_e64 s[22:23], %" #x ", %" #y "\n s_nop 1\n" CND3_SGPR(d, x, y)
+#define I_VCMP_SAND_CND3(d, x, y) "v_cmp_lt_u32 vcc, %" #x ", %" #y "\n s_and_b64 vcc, vcc, s[20:21]\n s_nop 1\n" CND3_VCC(d, x, y)
 
 #define KERNEL(NAME, INS)                                                 \
   __global__ void NAME(uint32_t *out, uint32_t seed, int iters) {         \
@@ -45,7 +52,9 @@ KERNEL(k_xor, I_XOR) KERNEL(k_cnd_vcc, I_CND_VCC) KERNEL(k_cnd_sgpr, I_CND_SGPR)
 KERNEL(k_cmp_vcc, I_CMP_VCC) KERNEL(k_cmp_sgpr, I_CMP_SGPR) KERNEL(k_cmp_cnd, I_CMP_CND) KERNEL(k_cmp_cnd_e64, I_CMP_CND_E64)
 KERNEL(k_min, I_MIN) KERNEL(k_mullo, I_MULLO) KERNEL(k_mulhi, I_MULHI) KERNEL(k_mad24, I_MAD24) KERNEL(k_dpp, I_DPP)
 KERNEL(k_dpp_wave, I_DPP_WAVE) KERNEL(k_xor_dpp, I_XOR_DPP) KERNEL(k_subb, I_SUBB) KERNEL(k_addc, I_ADDC)
-KERNEL(k_lshl_v, I_LSHL64) KERNEL(k_lshr_v, I_LSHR_V) KERNEL(k_bfe_v, I_BFE_V) KERNEL(k_saveexec, I_SAVEEXEC)
+KERNEL(k_smov_cnd3, I_SMOV_CND3) KERNEL(k_sand_cnd3, I_SAND_CND3) KERNEL(k_sand_cnd3_sgpr, I_SAND_CND3_SGPR)
+KERNEL(k_vcmp_cnd3, I_VCMP_CND3) KERNEL(k_vcmp_cnd3_sgpr, I_VCMP_CND3_SGPR) KERNEL(k_vcmp_sand_cnd3, I_VCMP_SAND_CND3)
+KERNEL(k_lshl_v, I_LSHL64) KERNEL(k_lshr_v, I_LSHR_V) KERNEL(k_bfe_v, I_BFE_V)
 
 typedef void (*kern_t)(uint32_t *, uint32_t, int);
 double base_ns = 0;
@@ -77,6 +86,8 @@ int main() {
   run("v_mov_b32_dpp row_shr:1", k_dpp, 1); run("v_mov_b32_dpp wave_shr:1", k_dpp_wave, 1); run("v_xor_b32_dpp row_shr:1", k_xor_dpp, 1);
   run("v_sub_co_u32 -> vcc", k_subb, 1); run("v_addc_co_u32 vcc -> vcc", k_addc, 1);
   run("v_lshlrev_b32 v, v", k_lshl_v, 1); run("v_lshrrev_b32 v, v", k_lshr_v, 1); run("v_bfe_u32 v, v, 1", k_bfe_v, 1);
-  run("saveexec + v_xor + restore", k_saveexec, 3);
+  run("s_mov vcc + 3 v_cndmask (vcc)", k_smov_cnd3, 4); run("s_and vcc + 3 v_cndmask (vcc)", k_sand_cnd3, 4);
+  run("s_and sgpr + 3 v_cndmask_e64", k_sand_cnd3_sgpr, 4); run("v_cmp vcc + 3 v_cndmask (vcc)", k_vcmp_cnd3, 4);
+  run("v_cmp_e64 sgpr + 3 v_cndmask_e64", k_vcmp_cnd3_sgpr, 4); run("v_cmp vcc + s_and vcc + 3 v_cndmask", k_vcmp_sand_cnd3, 5);
   return 0;
 }
