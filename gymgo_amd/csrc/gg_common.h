@@ -139,11 +139,14 @@ __device__ __forceinline__ void flood2_dual(const uint32_t (&m)[R], const uint32
 
 // `out` = this lane's row of the L2 -> L1 transpose buffer: the converged fill is stored there in normal bit order
 // (the normal-order copy made for the closure test is the result, so it never has to stay live across sweeps).
-template <int R>
+// PREREV: the caller hands the odd rows of the seeds over bit-reversed already
+template <int R, bool PREREV = false>
 __device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R],
                                               uint32_t *out) {
+  if (!PREREV) {
 #pragma unroll
-  for (int r = 1; r < R; r += 2) f[r] = __brev(f[r]);  // seeds arrive in normal order
+    for (int r = 1; r < R; r += 2) f[r] = __brev(f[r]);  // seeds arrive in normal order
+  }
 #pragma unroll 1
   for (int it = 0; it < R * R; ++it) {
 #pragma unroll

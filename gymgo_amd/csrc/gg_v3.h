@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
         const uint32_t *oth = st + ((j == 0) ? 1 - turn : turn) * PL + ss * RS;
         const int sr = ar + (j == 1 ? -1 : (j == 2 ? 1 : 0));
         const uint32_t sbit = j == 3 ? (bit >> 1) : (j == 4 ? (bit << 1) : bit);
-        uint32_t seedrow = 0, cnt = 0, sz = 0;
+        uint32_t cnt = 0, sz = 0;
         {
           uint32_t m[R];
           {
@@ -325,14 +325,18 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
               const uint4 x = pm[i];
               mt[4 * i] = x.x; mt[4 * i + 1] = x.y; mt[4 * i + 2] = x.z; mt[4 * i + 3] = x.w;
             }
+            // the seed is one bit of row sr: a one-hot row selector turns "r == sr" into a sign-extending bit extract
+            // (the flood keeps its odd rows bit-reversed: their seeds are cut out of mrev with the reversed seed bit)
+            const uint32_t onehot = (sr >= 0 && sr < R) ? (1u << sr) : 0u;
+            const uint32_t sbit_rev = __brev(sbit);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
               m[r] = mt[r];
               mrev[r] = __brev(m[r]);
-              f[r] = (r == sr) ? (m[r] & sbit) : 0u;
-              seedrow |= f[r];
+              const uint32_t sel = (uint32_t)__builtin_amdgcn_sbfe((int)onehot, r, 1);   // 0 or ~0
+              f[r] = (r & 1) ? B3(mrev[r], sbit_rev, sel, TA & TB & TC) : B3(m[r], sbit, sel, TA & TB & TC);
             }
-            flood2_serial<R>(m, mrev, f, sc + (used ? ln : 5 * kNB3) * RS);
+            flood2_serial<R, true>(m, mrev, f, sc + (used ? ln : 5 * kNB3) * RS);
           }
           // liberties of this lane's group on the position with the new stone (captures not yet removed); m[] still
           // holds the flooded colour's rows
@@ -348,18 +352,17 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
           const uint32_t fullrow = (1u << N) - 1u;
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const uint32_t e = (FULLN || r < N) ? (fullrow & ~(ot[r] | m[r])) : 0u;
+            const uint32_t e = (FULLN || r < N) ? B3(ot[r], m[r], fullrow, ~(TA | TB) & TC & 0xFF) : 0u;   // empty points
             const uint32_t up = r > 0 ? gt[r - 1] : 0u, dn = r + 1 < R ? gt[r + 1] : 0u;   // rows >= R are not written
-            const uint32_t d = B3(shl1(gt[r]), gt[r] >> 1, up, T_OR3) | dn;
-            const uint32_t l = d & e;
-            const uint32_t c = (uint32_t)__popc(l);
-            cnt += c < 2u ? c : 2u;
+            const uint32_t d = B3(shl1(gt[r]), gt[r] >> 1, up, T_OR3);
+            const uint32_t l = B3(d, dn, e, (TA | TB) & TC);
+            cnt += (uint32_t)__popc(l);   // only min(cnt, 2) is used: one accumulating v_bcnt per row
             sz += gt[r];   // sum of the row words: equals the seed bit iff the group is the seed stone alone
           }
         }
         // roles 1-4: is this neighbour of q off the board or an opponent stone?  (all four: the new stone is boxed in)
         const bool off = j == 1 ? ar == 0 : (j == 2 ? ar == N - 1 : (j == 3 ? ac == 0 : ac == N - 1));
-        const bool okbox = off || seedrow != 0;
+        const bool okbox = off || sz != 0u;   // the flooded group is non-empty iff its seed was a stone
         clsv[ln] = (cnt < 2u ? cnt : 2u) | ((sz != 0u && sz == sbit) ? 4u : 0u) | (sz != 0u ? 8u : 0u) | (okbox ? 16u : 0u);
         // an opponent group that keeps >= 2 liberties keeps its class: phase 3 must not see it
         if (j != 0 && cnt >= 2u) {
