@@ -17,19 +17,18 @@ namespace gg {
 //      over its 19 rows), the stone ORed into the mover's plane; auto-reset on a rare path;
 //   2. one lane per (board, role): the flood, then the liberties (dilate & empty, saturated at 2) and the size of the
 //      lane's own group, 19 rows in registers; an opponent group that keeps >= 2 liberties zeroes its result;
-//   3. THREE boards per pass in the row-per-lane layout (lane -> board lane / 21, row lane % 21), four passes:
+//   3. SIX boards per pass, two adjacent rows per lane (lane -> board lane / 10, rows 2t and 2t+1 with t = lane % 10),
+//      two passes (one row per lane, three boards per pass, four passes: 4.7e9 steps/s against 5.1e9 - the work of a
+//      pass that does not depend on the row is paid per pass):
 //        * an opponent group next to q with no liberty left is captured, with one left it leaves the class plane;
 //        * G takes the class of its own count (+ the captured points next to it);
 //        * a mover's group in atari next to a captured stone gains a liberty -> multi (rare; a flood through the atari
 //          set in this layout);
 //        * every other group keeps its class.  The invalid-move mask follows from the classes exactly as in v2.
-// 12 boards x 5 lanes = 60 lanes per flood batch: the floods cost a sixth per board - about 120 VALU ops per board and
+// 12 boards x 5 lanes = 60 lanes per flood batch: the floods cost a sixth per board - about 100 VALU ops per board and
 // ply against 346 (PMC, profiles/r01_summary.md).
 // Board state lives in LDS between the phases (5 rows per board: black, white, invalid, multi_black, multi_white);
 // 10 224 B per wave, 128 VGPRs: four waves per SIMD.
-#ifndef GG_V3_UB
-#define GG_V3_UB 2   // unroll of the class-patch passes (1: 3.63e9, 2: 3.72e9, 4: spills, 1.98e9)
-#endif
 constexpr int kNB3 = 12;
 
 template <int R>
@@ -57,10 +56,14 @@ __device__ __forceinline__ void set_size(uint32_t x, const Half &hf, bool &any, 
   any = nz != 0;
   two = ((nz & (nz - 1u)) | many) != 0;
 }
-// the 21 ballot bits of board k of a three-boards-per-wave pass
-__device__ __forceinline__ uint32_t third_of(uint64_t ballot, int k) { return (uint32_t)(ballot >> (21 * k)) & 0x1FFFFFu; }
-__device__ __forceinline__ uint32_t dilate_l1(uint32_t x) {
-  return B3(shl1(x), x >> 1, dpp0<0x138>(x), T_OR3) | dpp0<0x130>(x);
+// phase 3 keeps TWO adjacent rows (2t, 2t+1) per lane, ten lanes per board, six boards per pass: the bits of board k
+__device__ __forceinline__ uint32_t sixth_of(uint64_t ballot, int k) { return (uint32_t)(ballot >> (10 * k)) & 0x3FFu; }
+// 4-neighbourhood dilation of the row pair (a = row 2t, b = row 2t+1): the rows above a / below b sit in the
+// neighbouring lanes (a non-existent row 2t+1 = R is zero, so nothing leaks from the previous board; what leaks into
+// such a row from the next board is masked by the caller)
+__device__ __forceinline__ void dilate_pair(uint32_t a, uint32_t b, uint32_t &da, uint32_t &db) {
+  da = B3(shl1(a), a >> 1, dpp0<0x138>(b), T_OR3) | b;
+  db = B3(shl1(b), b >> 1, dpp0<0x130>(a), T_OR3) | a;
 }
 
 // MOVES: the moves are given (moves: int32 [B][plies], gg_batch_play_moves) instead of drawn: a game stops at its first
@@ -191,7 +194,6 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
     }
 
     // ---------------------------------------------------------------- the plies
-    Half ht = hf;
     int mv_next = 0;
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
@@ -200,8 +202,10 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
       // (volatile asm: neither hoisted nor merged)
       int ln;   // = hf.lane (one wave per workgroup), straight from the hardware
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-      const int tk = (ln * 49) >> 10, tl = ln - 21 * tk;   // phase 3: board-of-the-pass and row of this lane
-      ht.full_l1 = (tk < 3 && tl < N) ? (1u << N) - 1u : 0u;
+      const int k6 = (ln * 103) >> 10, t6 = ln - 10 * k6;   // phase 3: board-of-the-pass and row pair of this lane
+      const int k6c = k6 < 6 ? k6 : 0, ra = 2 * t6;
+      const uint32_t fullA = (k6 < 6 && ra < N) ? (1u << N) - 1u : 0u, fullB = (k6 < 6 && ra + 1 < N) ? (1u << N) - 1u : 0u;
+      const uint32_t mB = ra + 1 < R ? ~0u : 0u;
       // phase 1 - one LANE per board (lanes 0-11): liveness, the generator, the k-th valid point (or the given move)
       uint64_t resetm;
       {
@@ -373,46 +377,56 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
       }
       WAVE_SYNC();
 
-      // phase 3 - THREE boards per pass (lane -> board k = lane / 21, row tl = lane % 21: 19 rows + 2 idle lanes per
-      // board keep the one-lane DPP shifts of neighbouring boards apart), four passes: patch the classes, resolve
-      // captures and ko, the next mover's mask
-#pragma unroll GG_V3_UB
-      for (int i = 0; i < kNB3 / 3; ++i) {
-        if (3 * i >= nb) continue;
-        const int s = 3 * i + tk;
-        const bool act = tk < 3 && s < nb;
-        const int sa = act ? s : 0;
-        const int a = act ? actv[sa] : -1;
+      // phase 3 - SIX boards per pass (lane -> board k6 = lane / 10, rows 2t and 2t+1 with t = lane % 10), two passes:
+      // patch the classes, resolve captures and ko, the next mover's mask.  Two rows per lane halve the per-pass work
+      // that does not depend on the row (addresses, class decode, ballots, flags) against one row per lane.
+#pragma unroll 1
+      for (int i = 0; i < kNB3 / 6; ++i) {
+        if (6 * i >= nb) continue;
+        const int sa = 6 * i + k6c;          // lanes 60-63 shadow board 0 of the pass: always a real slot (< kNB3)
+        const bool act = k6 < 6 && sa < nb;
+        const int av = actv[sa];
+        const int a = act ? av : -1;
         const bool moves = a >= 0;
         const uint32_t fl = flagsv[sa];
         int turn = fl & 1u, passed = (fl >> 1) & 1u, done = (fl >> 2) & 1u;
         const uint32_t c0 = clsv[5 * sa], c1 = clsv[5 * sa + 1], c2 = clsv[5 * sa + 2], c3 = clsv[5 * sa + 3],
                        c4 = clsv[5 * sa + 4];
         // planes by role, not by colour: the mover's stones / classes are plane `turn` / 3 + `turn`
-        const int tr = tl < R ? tl : 0;
-        uint32_t *pmine = st + turn * PL + sa * RS + tr, *popp = st + (1 - turn) * PL + sa * RS + tr;
-        uint32_t *pMm = st + (3 + turn) * PL + sa * RS + tr, *pMo = st + (4 - turn) * PL + sa * RS + tr;
-        const bool rowt = act && tl < R;   // the floods write rows 0 .. R-1 of their blocks only
-        uint32_t mine1 = 0, opp0 = 0, Mm = 0, Mo = 0, g0 = 0, gch = 0;
+        uint2 *pmine = reinterpret_cast<uint2 *>(st + turn * PL + sa * RS + ra);
+        uint2 *popp = reinterpret_cast<uint2 *>(st + (1 - turn) * PL + sa * RS + ra);
+        uint2 *pMm = reinterpret_cast<uint2 *>(st + (3 + turn) * PL + sa * RS + ra);
+        uint2 *pMo = reinterpret_cast<uint2 *>(st + (4 - turn) * PL + sa * RS + ra);
+        const uint2 *gr = reinterpret_cast<const uint2 *>(sc + (5 * sa) * RS + ra);
+        const bool rowt = act && ra < R;     // the floods write rows 0 .. R-1 of their blocks only (row R is masked: mB)
+        uint2 mine1 = make_uint2(0u, 0u), opp0 = mine1, Mm = mine1, Mo = mine1, g0 = mine1, gch = mine1;
         if (rowt) {
-          mine1 = *pmine; opp0 = *popp; Mm = *pMm; Mo = *pMo;
-          const uint32_t *gr = sc + (5 * sa) * RS + tr;
+          mine1 = *pmine; opp0 = *popp; Mm = *pMm; Mo = *pMo;     // (rows >= N of the planes are zero)
           g0 = gr[0];
-          gch = gr[RS] | gr[2 * RS] | gr[3 * RS] | gr[4 * RS];   // the opponent groups whose class changes
+          const uint2 g1 = gr[RS / 2], g2 = gr[RS], g3 = gr[3 * RS / 2], g4 = gr[2 * RS];
+          g0.y &= mB;
+          gch.x = g1.x | g2.x | g3.x | g4.x;   // the opponent groups whose class changes
+          gch.y = (g1.y | g2.y | g3.y | g4.y) & mB;
         }
         const bool is_pass = a == hf.P;
         const bool k1 = (c1 & 11u) == 8u, k2 = (c2 & 11u) == 8u, k3 = (c3 & 11u) == 8u, k4 = (c4 & 11u) == 8u;
-        uint32_t cap = 0, Mm_fix = 0, libsG = c0 & 3u;   // libsG: liberties of G among the empty points (saturated at 2)
+        uint2 cap = make_uint2(0u, 0u), Mm_fix = cap;
+        uint32_t libsG = c0 & 3u;   // libsG: liberties of G among the empty points (saturated at 2)
         int ko_r = -1, ko_c = 0;
         if (__ballot(moves && (k1 || k2 || k3 || k4))) {   // a capture on some board of the pass
           if (rowt) {
-            const uint32_t *gr = sc + (5 * sa) * RS + tr;
-            cap = (k1 ? gr[RS] : 0u) | (k2 ? gr[2 * RS] : 0u) | (k3 ? gr[3 * RS] : 0u) | (k4 ? gr[4 * RS] : 0u);
+            const uint2 z = make_uint2(0u, 0u);
+            const uint2 g1 = k1 ? gr[RS / 2] : z, g2 = k2 ? gr[RS] : z, g3 = k3 ? gr[3 * RS / 2] : z, g4 = k4 ? gr[2 * RS] : z;
+            cap.x = g1.x | g2.x | g3.x | g4.x;
+            cap.y = (g1.y | g2.y | g3.y | g4.y) & mB;
           }
           // captured stones next to G are liberties of G too
           {
-            const uint32_t x = dilate_l1(g0) & cap;
-            const uint32_t nz = third_of(__ballot(x != 0), tk), many = third_of(__ballot(__popc(x) > 1), tk);
+            uint32_t da, db;
+            dilate_pair(g0.x, g0.y, da, db);
+            const uint32_t xa = da & cap.x, xb = db & cap.y;
+            const uint32_t nz = sixth_of(__ballot((xa | xb) != 0), k6),
+                           many = sixth_of(__ballot(__popc(xa) + __popc(xb) > 1), k6);
             libsG += ((nz & (nz - 1u)) | many) ? 2u : (nz ? 1u : 0u);
           }
           // gogame.py:72-75: ko iff exactly one stone died and the new stone is boxed in
@@ -427,34 +441,51 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
             ko_c = ac + (k3 ? -1 : (k4 ? 1 : 0));
           }
           // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties
-          const uint32_t atari_m = mine1 & ~Mm & ~g0;
-          uint32_t f = dilate_l1(cap) & atari_m;
-          if (__ballot(f != 0)) {
+          const uint32_t atari_a = mine1.x & ~Mm.x & ~g0.x, atari_b = mine1.y & ~Mm.y & ~g0.y;
+          uint32_t fa, fb;
+          dilate_pair(cap.x, cap.y, fa, fb);
+          fa &= atari_a; fb &= atari_b;
+          if (__ballot((fa | fb) != 0)) {
 #pragma unroll 1
             for (int it = 0; it < R * R; ++it) {
-              const uint32_t gnew = B3(dilate_l1(f), atari_m, f, T_ANDOR);
-              const bool chg = gnew != f;
-              f = gnew;
+              uint32_t da, db;
+              dilate_pair(fa, fb, da, db);
+              const uint32_t na = B3(da, atari_a, fa, T_ANDOR), nbw = B3(db, atari_b, fb, T_ANDOR);
+              const bool chg = ((na ^ fa) | (nbw ^ fb)) != 0;
+              fa = na; fb = nbw;
               if (__ballot(chg) == 0) break;
             }
-            Mm_fix = f;
+            Mm_fix = make_uint2(fa, fb);
           }
         }
-        const uint32_t Mo2 = Mo & ~gch;
-        const uint32_t opp1 = opp0 & ~cap;
-        const uint32_t Mm2 = (Mm & ~g0) | (libsG >= 2u ? g0 : 0u) | Mm_fix;
-        uint32_t invalid = invalid_from2(opp1, mine1, Mo2, Mm2, ht);
-        if (tl == ko_r) invalid |= 1u << ko_c;
+        const uint32_t gsel = libsG >= 2u ? ~0u : 0u;
+        uint2 Mo2, opp1, Mm2, invalid;
+        Mo2.x = Mo.x & ~gch.x; Mo2.y = Mo.y & ~gch.y;
+        opp1.x = opp0.x & ~cap.x; opp1.y = opp0.y & ~cap.y;
+        Mm2.x = (Mm.x & ~g0.x) | (gsel & g0.x) | Mm_fix.x;
+        Mm2.y = (Mm.y & ~g0.y) | (gsel & g0.y) | Mm_fix.y;
+        {
+          // state_utils.compute_invalid_moves on the pair of rows (invalid_from2, two rows per lane)
+          const uint32_t ea = fullA & ~(opp1.x | mine1.x), eb = fullB & ~(opp1.y | mine1.y);
+          const uint32_t xa = B3(ea, opp1.x & Mo2.x, mine1.x & ~Mm2.x, T_OR3), xb = B3(eb, opp1.y & Mo2.y, mine1.y & ~Mm2.y, T_OR3);
+          uint32_t na, nbw;
+          dilate_pair(xa, xb, na, nbw);
+          // (dilate_pair ORs the row itself in through shl / shr only: the centre bit is not set by it)
+          invalid.x = fullA & ~(ea & na);
+          invalid.y = fullB & ~(eb & nbw);
+        }
+        if (ra == ko_r) invalid.x |= 1u << ko_c;
+        if (ra + 1 == ko_r) invalid.y |= 1u << ko_c;
         if (moves) {
           if (is_pass) { if (passed) done = 1; passed = 1; } else passed = 0;
           turn ^= 1;
           if (rowt) {
             *popp = opp1;
-            st[2 * PL + sa * RS + tr] = invalid;
+            *reinterpret_cast<uint2 *>(st + 2 * PL + sa * RS + ra) = invalid;
             *pMm = Mm2;
             *pMo = Mo2;
           }
-          if (tl == 0) {
+          if (t6 == 0) {
             flagsv[sa] = (uint32_t)turn | ((uint32_t)passed << 1) | ((uint32_t)done << 2) | 8u;
             lastv[sa] = a;
             playedv[sa] += 1;
