@@ -56,15 +56,20 @@ __device__ __forceinline__ void set_size(uint32_t x, const Half &hf, bool &any, 
   any = nz != 0;
   two = ((nz & (nz - 1u)) | many) != 0;
 }
-// phase 3 keeps TWO adjacent rows (2t, 2t+1) per lane, ten lanes per board, six boards per pass: the bits of board k
-__device__ __forceinline__ uint32_t sixth_of(uint64_t ballot, int k) { return (uint32_t)(ballot >> (10 * k)) & 0x3FFu; }
-// 4-neighbourhood dilation of the row pair (a = row 2t, b = row 2t+1): the rows above a / below b sit in the
-// neighbouring lanes (a non-existent row 2t+1 = R is zero, so nothing leaks from the previous board; what leaks into
-// such a row from the next board is masked by the caller)
-__device__ __forceinline__ void dilate_pair(uint32_t a, uint32_t b, uint32_t &da, uint32_t &db) {
-  da = B3(shl1(a), a >> 1, dpp0<0x138>(b), T_OR3) | b;
-  db = B3(shl1(b), b >> 1, dpp0<0x130>(a), T_OR3) | a;
+// phase 3 keeps FOUR adjacent rows (4t .. 4t+3) per lane, five lanes per board, all twelve boards in one pass - the lane
+// assignment of the floods (board = lane / 5).  The 5 ballot bits of board k:
+__device__ __forceinline__ uint32_t fifth_of(uint64_t ballot, int k) { return (uint32_t)(ballot >> (5 * k)) & 0x1Fu; }
+// 4-neighbourhood dilation of the four rows of a lane: the row above x[0] / below x[3] sits in the neighbouring lane (a
+// non-existent row >= R is zero, so nothing leaks from the previous board; what leaks into such a row from the next
+// board is masked by the caller).  The centre point is not part of the result.
+__device__ __forceinline__ void dilate_quad(const uint32_t (&x)[4], uint32_t (&d)[4]) {
+  const uint32_t up = dpp0<0x138>(x[3]), dn = dpp0<0x130>(x[0]);
+  d[0] = B3(shl1(x[0]), x[0] >> 1, up, T_OR3) | x[1];
+  d[1] = B3(shl1(x[1]), x[1] >> 1, x[0], T_OR3) | x[2];
+  d[2] = B3(shl1(x[2]), x[2] >> 1, x[1], T_OR3) | x[3];
+  d[3] = B3(shl1(x[3]), x[3] >> 1, x[2], T_OR3) | dn;
 }
+__device__ __forceinline__ void unpack4(const uint4 v, uint32_t (&x)[4]) { x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
 
 // MOVES: the moves are given (moves: int32 [B][plies], gg_batch_play_moves) instead of drawn: a game stops at its first
 // move that is out of range, on an invalid point or made after the game has ended; played_out[b] = moves applied.
@@ -202,10 +207,14 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
       // (volatile asm: neither hoisted nor merged)
       int ln;   // = hf.lane (one wave per workgroup), straight from the hardware
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-      const int k6 = (ln * 103) >> 10, t6 = ln - 10 * k6;   // phase 3: board-of-the-pass and row pair of this lane
-      const int k6c = k6 < 6 ? k6 : 0, ra = 2 * t6;
-      const uint32_t fullA = (k6 < 6 && ra < N) ? (1u << N) - 1u : 0u, fullB = (k6 < 6 && ra + 1 < N) ? (1u << N) - 1u : 0u;
-      const uint32_t mB = ra + 1 < R ? ~0u : 0u;
+      const int s5 = (ln * 13) >> 6, t5 = ln - 5 * s5;   // phases 2 and 3: board and role / row quad of this lane
+      const int s5c = s5 < kNB3 ? s5 : 0, r0 = 4 * t5;
+      uint32_t full4[4], mrow[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        full4[r] = (s5 < kNB3 && r0 + r < N) ? (1u << N) - 1u : 0u;
+        mrow[r] = r0 + r < R ? ~0u : 0u;
+      }
       // phase 1 - one LANE per board (lanes 0-11): liveness, the generator, the k-th valid point (or the given move)
       uint64_t resetm;
       {
@@ -377,14 +386,13 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
       }
       WAVE_SYNC();
 
-      // phase 3 - SIX boards per pass (lane -> board k6 = lane / 10, rows 2t and 2t+1 with t = lane % 10), two passes:
-      // patch the classes, resolve captures and ko, the next mover's mask.  Two rows per lane halve the per-pass work
-      // that does not depend on the row (addresses, class decode, ballots, flags) against one row per lane.
-#pragma unroll 1
-      for (int i = 0; i < kNB3 / 6; ++i) {
-        if (6 * i >= nb) continue;
-        const int sa = 6 * i + k6c;          // lanes 60-63 shadow board 0 of the pass: always a real slot (< kNB3)
-        const bool act = k6 < 6 && sa < nb;
+      // phase 3 - all twelve boards in ONE pass, four adjacent rows per lane (lane -> board s5 = lane / 5, rows 4t .. 4t+3
+      // with t = lane % 5): patch the classes, resolve captures and ko, the next mover's mask.  What does not depend on
+      // the row (addresses, class decode, ballots, flags) is paid once per ply; with one row per lane and three boards per
+      // pass it was paid four times (4.7e9 steps/s), with two rows and six boards twice (5.1e9).
+      {
+        const int sa = s5c;          // lanes 60-63 shadow board 0: always a real slot (< kNB3)
+        const bool act = s5 < nb;    // (nb <= kNB3 = 12: lanes 60-63 have s5 = 12)
         const int av = actv[sa];
         const int a = act ? av : -1;
         const bool moves = a >= 0;
@@ -393,40 +401,47 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
         const uint32_t c0 = clsv[5 * sa], c1 = clsv[5 * sa + 1], c2 = clsv[5 * sa + 2], c3 = clsv[5 * sa + 3],
                        c4 = clsv[5 * sa + 4];
         // planes by role, not by colour: the mover's stones / classes are plane `turn` / 3 + `turn`
-        uint2 *pmine = reinterpret_cast<uint2 *>(st + turn * PL + sa * RS + ra);
-        uint2 *popp = reinterpret_cast<uint2 *>(st + (1 - turn) * PL + sa * RS + ra);
-        uint2 *pMm = reinterpret_cast<uint2 *>(st + (3 + turn) * PL + sa * RS + ra);
-        uint2 *pMo = reinterpret_cast<uint2 *>(st + (4 - turn) * PL + sa * RS + ra);
-        const uint2 *gr = reinterpret_cast<const uint2 *>(sc + (5 * sa) * RS + ra);
-        const bool rowt = act && ra < R;     // the floods write rows 0 .. R-1 of their blocks only (row R is masked: mB)
-        uint2 mine1 = make_uint2(0u, 0u), opp0 = mine1, Mm = mine1, Mo = mine1, g0 = mine1, gch = mine1;
+        uint4 *pmine = reinterpret_cast<uint4 *>(st + turn * PL + sa * RS + r0);
+        uint4 *popp = reinterpret_cast<uint4 *>(st + (1 - turn) * PL + sa * RS + r0);
+        uint4 *pMm = reinterpret_cast<uint4 *>(st + (3 + turn) * PL + sa * RS + r0);
+        uint4 *pMo = reinterpret_cast<uint4 *>(st + (4 - turn) * PL + sa * RS + r0);
+        const uint4 *gr = reinterpret_cast<const uint4 *>(sc + (5 * sa) * RS + r0);   // block j: gr[j * RS / 4]
+        const bool rowt = act && r0 < R;     // the floods write rows 0 .. R-1 of their blocks only (rows >= R: mrow)
+        uint32_t mine1[4] = {0u, 0u, 0u, 0u}, opp0[4] = {0u, 0u, 0u, 0u}, Mm[4] = {0u, 0u, 0u, 0u}, Mo[4] = {0u, 0u, 0u, 0u},
+                 g0[4] = {0u, 0u, 0u, 0u}, gch[4] = {0u, 0u, 0u, 0u};
         if (rowt) {
-          mine1 = *pmine; opp0 = *popp; Mm = *pMm; Mo = *pMo;     // (rows >= N of the planes are zero)
-          g0 = gr[0];
-          const uint2 g1 = gr[RS / 2], g2 = gr[RS], g3 = gr[3 * RS / 2], g4 = gr[2 * RS];
-          g0.y &= mB;
-          gch.x = g1.x | g2.x | g3.x | g4.x;   // the opponent groups whose class changes
-          gch.y = (g1.y | g2.y | g3.y | g4.y) & mB;
+          unpack4(*pmine, mine1); unpack4(*popp, opp0); unpack4(*pMm, Mm); unpack4(*pMo, Mo);   // (rows >= N are zero)
+          uint32_t g1[4], g2[4], g3[4], g4[4];
+          unpack4(gr[0], g0); unpack4(gr[RS / 4], g1); unpack4(gr[2 * RS / 4], g2); unpack4(gr[3 * RS / 4], g3);
+          unpack4(gr[RS], g4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            g0[r] &= mrow[r];
+            gch[r] = (g1[r] | g2[r] | g3[r] | g4[r]) & mrow[r];   // the opponent groups whose class changes
+          }
         }
         const bool is_pass = a == hf.P;
         const bool k1 = (c1 & 11u) == 8u, k2 = (c2 & 11u) == 8u, k3 = (c3 & 11u) == 8u, k4 = (c4 & 11u) == 8u;
-        uint2 cap = make_uint2(0u, 0u), Mm_fix = cap;
+        uint32_t cap[4] = {0u, 0u, 0u, 0u}, Mm_fix[4] = {0u, 0u, 0u, 0u};
         uint32_t libsG = c0 & 3u;   // libsG: liberties of G among the empty points (saturated at 2)
         int ko_r = -1, ko_c = 0;
-        if (__ballot(moves && (k1 || k2 || k3 || k4))) {   // a capture on some board of the pass
+        if (__ballot(moves && (k1 || k2 || k3 || k4))) {   // a capture on some board
           if (rowt) {
-            const uint2 z = make_uint2(0u, 0u);
-            const uint2 g1 = k1 ? gr[RS / 2] : z, g2 = k2 ? gr[RS] : z, g3 = k3 ? gr[3 * RS / 2] : z, g4 = k4 ? gr[2 * RS] : z;
-            cap.x = g1.x | g2.x | g3.x | g4.x;
-            cap.y = (g1.y | g2.y | g3.y | g4.y) & mB;
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            uint32_t g1[4], g2[4], g3[4], g4[4];
+            unpack4(k1 ? gr[RS / 4] : z, g1); unpack4(k2 ? gr[2 * RS / 4] : z, g2); unpack4(k3 ? gr[3 * RS / 4] : z, g3);
+            unpack4(k4 ? gr[RS] : z, g4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cap[r] = (g1[r] | g2[r] | g3[r] | g4[r]) & mrow[r];
           }
           // captured stones next to G are liberties of G too
           {
-            uint32_t da, db;
-            dilate_pair(g0.x, g0.y, da, db);
-            const uint32_t xa = da & cap.x, xb = db & cap.y;
-            const uint32_t nz = sixth_of(__ballot((xa | xb) != 0), k6),
-                           many = sixth_of(__ballot(__popc(xa) + __popc(xb) > 1), k6);
+            uint32_t d[4];
+            dilate_quad(g0, d);
+            uint32_t any = 0, cnt = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const uint32_t x = d[r] & cap[r]; any |= x; cnt += (uint32_t)__popc(x); }
+            const uint32_t nz = fifth_of(__ballot(any != 0), s5), many = fifth_of(__ballot(cnt > 1u), s5);
             libsG += ((nz & (nz - 1u)) | many) ? 2u : (nz ? 1u : 0u);
           }
           // gogame.py:72-75: ko iff exactly one stone died and the new stone is boxed in
@@ -441,51 +456,55 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
             ko_c = ac + (k3 ? -1 : (k4 ? 1 : 0));
           }
           // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties
-          const uint32_t atari_a = mine1.x & ~Mm.x & ~g0.x, atari_b = mine1.y & ~Mm.y & ~g0.y;
-          uint32_t fa, fb;
-          dilate_pair(cap.x, cap.y, fa, fb);
-          fa &= atari_a; fb &= atari_b;
-          if (__ballot((fa | fb) != 0)) {
+          uint32_t atari[4], f[4];
+          dilate_quad(cap, f);
+          uint32_t anyf = 0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { atari[r] = mine1[r] & ~Mm[r] & ~g0[r]; f[r] &= atari[r]; anyf |= f[r]; }
+          if (__ballot(anyf != 0)) {
 #pragma unroll 1
             for (int it = 0; it < R * R; ++it) {
-              uint32_t da, db;
-              dilate_pair(fa, fb, da, db);
-              const uint32_t na = B3(da, atari_a, fa, T_ANDOR), nbw = B3(db, atari_b, fb, T_ANDOR);
-              const bool chg = ((na ^ fa) | (nbw ^ fb)) != 0;
-              fa = na; fb = nbw;
-              if (__ballot(chg) == 0) break;
+              uint32_t d[4], chg = 0;
+              dilate_quad(f, d);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const uint32_t nw = B3(d[r], atari[r], f[r], T_ANDOR);
+                chg |= nw ^ f[r];
+                f[r] = nw;
+              }
+              if (__ballot(chg != 0) == 0) break;
             }
-            Mm_fix = make_uint2(fa, fb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Mm_fix[r] = f[r];
           }
         }
         const uint32_t gsel = libsG >= 2u ? ~0u : 0u;
-        uint2 Mo2, opp1, Mm2, invalid;
-        Mo2.x = Mo.x & ~gch.x; Mo2.y = Mo.y & ~gch.y;
-        opp1.x = opp0.x & ~cap.x; opp1.y = opp0.y & ~cap.y;
-        Mm2.x = (Mm.x & ~g0.x) | (gsel & g0.x) | Mm_fix.x;
-        Mm2.y = (Mm.y & ~g0.y) | (gsel & g0.y) | Mm_fix.y;
-        {
-          // state_utils.compute_invalid_moves on the pair of rows (invalid_from2, two rows per lane)
-          const uint32_t ea = fullA & ~(opp1.x | mine1.x), eb = fullB & ~(opp1.y | mine1.y);
-          const uint32_t xa = B3(ea, opp1.x & Mo2.x, mine1.x & ~Mm2.x, T_OR3), xb = B3(eb, opp1.y & Mo2.y, mine1.y & ~Mm2.y, T_OR3);
-          uint32_t na, nbw;
-          dilate_pair(xa, xb, na, nbw);
-          // (dilate_pair ORs the row itself in through shl / shr only: the centre bit is not set by it)
-          invalid.x = fullA & ~(ea & na);
-          invalid.y = fullB & ~(eb & nbw);
+        uint32_t Mo2[4], opp1[4], Mm2[4], e[4], x[4], nbr[4], invalid[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Mo2[r] = Mo[r] & ~gch[r];
+          opp1[r] = opp0[r] & ~cap[r];
+          Mm2[r] = B3(Mm[r], gsel, g0[r], (TA & ~TC & 0xFF) | (TB & TC)) | Mm_fix[r];   // (Mm & ~g0) | (gsel & g0)
+          // state_utils.compute_invalid_moves on the lane's rows (invalid_from2, four rows per lane)
+          e[r] = full4[r] & ~(opp1[r] | mine1[r]);
+          x[r] = B3(e[r], opp1[r] & Mo2[r], mine1[r] & ~Mm2[r], T_OR3);
         }
-        if (ra == ko_r) invalid.x |= 1u << ko_c;
-        if (ra + 1 == ko_r) invalid.y |= 1u << ko_c;
+        dilate_quad(x, nbr);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          invalid[r] = full4[r] & ~(e[r] & nbr[r]);
+          if (r0 + r == ko_r) invalid[r] |= 1u << ko_c;
+        }
         if (moves) {
           if (is_pass) { if (passed) done = 1; passed = 1; } else passed = 0;
           turn ^= 1;
           if (rowt) {
-            *popp = opp1;
-            *reinterpret_cast<uint2 *>(st + 2 * PL + sa * RS + ra) = invalid;
-            *pMm = Mm2;
-            *pMo = Mo2;
+            *popp = make_uint4(opp1[0], opp1[1], opp1[2], opp1[3]);
+            *reinterpret_cast<uint4 *>(st + 2 * PL + sa * RS + r0) = make_uint4(invalid[0], invalid[1], invalid[2], invalid[3]);
+            *pMm = make_uint4(Mm2[0], Mm2[1], Mm2[2], Mm2[3]);
+            *pMo = make_uint4(Mo2[0], Mo2[1], Mo2[2], Mo2[3]);
           }
-          if (t6 == 0) {
+          if (t5 == 0) {
             flagsv[sa] = (uint32_t)turn | ((uint32_t)passed << 1) | ((uint32_t)done << 2) | 8u;
             lastv[sa] = a;
             playedv[sa] += 1;
