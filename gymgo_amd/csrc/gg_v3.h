@@ -17,9 +17,9 @@ namespace gg {
 //      over its 19 rows), the stone ORed into the mover's plane; auto-reset on a rare path;
 //   2. one lane per (board, role): the flood, then the liberties (dilate & empty, saturated at 2) and the size of the
 //      lane's own group, 19 rows in registers; an opponent group that keeps >= 2 liberties zeroes its result;
-//   3. SIX boards per pass, two adjacent rows per lane (lane -> board lane / 10, rows 2t and 2t+1 with t = lane % 10),
-//      two passes (one row per lane, three boards per pass, four passes: 4.7e9 steps/s against 5.1e9 - the work of a
-//      pass that does not depend on the row is paid per pass):
+//   3. all twelve boards in one pass, four adjacent rows per lane (lane -> board lane / 5 as in phase 2, rows 4t .. 4t+3
+//      with t = lane % 5).  One row per lane, three boards per pass and four passes ran 4.7e9 steps/s, two rows / six
+//      boards / two passes 5.1e9, this 5.25e9: the work of a pass that does not depend on the row is paid per pass:
 //        * an opponent group next to q with no liberty left is captured, with one left it leaves the class plane;
 //        * G takes the class of its own count (+ the captured points next to it);
 //        * a mover's group in atari next to a captured stone gains a liberty -> multi (rare; a flood through the atari
