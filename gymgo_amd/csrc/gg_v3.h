@@ -215,16 +215,19 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
         full4[r] = (s5 < kNB3 && r0 + r < N) ? (1u << N) - 1u : 0u;
         mrow[r] = r0 + r < R ? ~0u : 0u;
       }
-      // phase 1 - one LANE per board (lanes 0-11): liveness, the generator, the k-th valid point (or the given move)
+      // phase 1 - five lanes per board, four rows each (the lane assignment of phases 2 and 3): liveness, the generator
+      // (drawn redundantly by the five lanes), the k-th valid point of the stored mask (or the given move).  With one lane
+      // per board the 19 row counts and the row selection cost 19 steps on 12 useful lanes; here a lane counts its own
+      // four rows, the board's prefix / total come from wave shifts, and only the lane that holds the point selects.
       uint64_t resetm;
       {
-        const bool bl = ln < nb;
-        const int sb = bl ? ln : 0;
+        const bool bl = s5 < nb;
+        const int sb = s5c;
         const uint32_t fl = flagsv[sb];
         const bool on = bl && ((fl >> 3) & 1u);
         const bool done = (fl >> 2) & 1u;
-        bool live, reset;
-        int rr = -1, a;
+        bool live, reset, place = false, wr_act;
+        int rabs = 0, a;
         uint32_t pos = 0;
         uint64_t x = 0;
         if (MOVES) {
@@ -239,73 +242,73 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
             int ar, ac;
             split_action(mv, N, hf.inv, ar, ac);
             live = ((st[2 * PL + sb * RS + ar] >> ac) & 1u) == 0;
-            rr = ar; pos = (uint32_t)ac;
+            rabs = ar; pos = (uint32_t)ac;
             a = mv;
           }
-          if (on && !live && bl) flagsv[sb] = fl | 16u;   // stopped for good
+          wr_act = bl && t5 == 0;
+          if (on && !live && wr_act) flagsv[sb] = fl | 16u;   // stopped for good
           if (!live) a = -1;
+          place = wr_act && a >= 0 && a < hf.P;
         } else {
           live = on && !(done && !auto_reset);
           reset = live && done;           // auto-reset: the board is init_state from now on
-          const uint32_t fullrow = (1u << N) - 1u;
-          uint32_t vrows[R];
-          uint32_t n = 0;
+          uint32_t v[4];
           {
-            // the rows come in as RV unconditional 16-byte reads: a per-row `reset ? ... : load` turns into 19 predicated
-            // single-word reads, each waited for on its own
-            uint32_t ivt[RV * 4];
-            const uint4 *pi = reinterpret_cast<const uint4 *>(st + 2 * PL + sb * RS);
-#pragma unroll
-            for (int i = 0; i < RV; ++i) {
-              const uint4 q = pi[i];
-              ivt[4 * i] = q.x; ivt[4 * i + 1] = q.y; ivt[4 * i + 2] = q.z; ivt[4 * i + 3] = q.w;
-            }
+            uint32_t iv[4];
+            unpack4(*reinterpret_cast<const uint4 *>(st + 2 * PL + sb * RS + (r0 < R ? r0 : 0)), iv);
             const uint32_t rm = reset ? ~0u : 0u;   // a board being reset plays on the empty board
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-              const uint32_t v = (FULLN || r < N) ? B3(fullrow, rm, ivt[r], TA & (TB | (~TC & 0xFF))) : 0u;
-              vrows[r] = v;
-              n += (uint32_t)__popc(v);
-            }
+            for (int r = 0; r < 4; ++r) v[r] = B3(full4[r], rm, iv[r], TA & (TB | (~TC & 0xFF)));   // full4: 0 for rows >= N
           }
+          const uint32_t p1 = (uint32_t)__popc(v[0]), p2 = p1 + (uint32_t)__popc(v[1]), p3 = p2 + (uint32_t)__popc(v[2]),
+                         T = p3 + (uint32_t)__popc(v[3]);
+          // valid points in the board's lanes up to this one (S) and from this one on (Q): four one-lane wave shifts each
+          // way, cut at the board's first / last lane
+          const uint32_t mlo = t5 >= 1 ? ~0u : 0u, mhi = t5 <= 3 ? ~0u : 0u;
+          uint32_t S = T, Q = T;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            S = T + (dpp0<0x138>(S) & mlo);
+            Q = T + (dpp0<0x130>(Q) & mhi);
+          }
+          const uint32_t P = S - T, n = S + Q - T;   // before this lane / on the whole board
           x = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
           const uint64_t u = splitmix_next(x);
-          uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(n + 1)) >> 32);
-          // the row of the k-th valid point: the running counts are non-decreasing, so walking the rows downwards the
-          // last row with k < count(rows 0..r) is the first such row - one compare feeds the three selects
-          uint32_t tt = 0, vr = 0;
-          uint32_t pre[R + 1];
-          pre[0] = 0;
-#pragma unroll
-          for (int r = 0; r < R; ++r) pre[r + 1] = pre[r] + (uint32_t)__popc(vrows[r]);
-#pragma unroll
-          for (int r = R - 1; r >= 0; --r) {
-            if (k < pre[r + 1]) { rr = r; tt = k - pre[r]; vr = vrows[r]; }
-          }
+          const uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(n + 1)) >> 32);   // k == n: the pass
+          const bool hit = k >= P && k < P + T;        // this lane holds the k-th valid point
+          uint32_t tt = k - P, vr = v[0];
+          int rr = 0;
+          if (tt >= p1) { rr = 1; vr = v[1]; }
+          if (tt >= p2) { rr = 2; vr = v[2]; }
+          if (tt >= p3) { rr = 3; vr = v[3]; }
+          tt -= rr == 0 ? 0u : (rr == 1 ? p1 : (rr == 2 ? p2 : p3));
 #pragma unroll
           for (int sh = 16; sh >= 1; sh >>= 1) {   // the tt-th set bit of vr
             const uint32_t c = (uint32_t)__popc((vr >> pos) & ((1u << sh) - 1u));
             if (tt >= c) { tt -= c; pos += sh; }
           }
-          a = !live ? -1 : (rr >= 0 ? rr * N + (int)pos : hf.P);   // -1: the board does not move this ply
+          rabs = r0 + rr;
+          // -1: the board does not move this ply.  The lane with the point announces it; a pass / an idle board is
+          // announced by the board's first lane
+          a = !live ? -1 : (k < n ? rabs * N + (int)pos : hf.P);
+          wr_act = bl && (live && k < n ? hit : t5 == 0);
+          place = bl && live && hit;
         }
-        if (bl) {
-          actv[sb] = a;
-          if (!MOVES && live) { rngv[2 * sb] = (uint32_t)x; rngv[2 * sb + 1] = (uint32_t)(x >> 32); }
-        }
+        if (wr_act) actv[sb] = a;
+        if (!MOVES && bl && t5 == 0 && live) { rngv[2 * sb] = (uint32_t)x; rngv[2 * sb + 1] = (uint32_t)(x >> 32); }
         if (__ballot(live) == 0) break;
-        resetm = __ballot(reset);
+        resetm = __ballot(reset && t5 == 0);
         while (resetm) {   // rare
-          const int s = __ffsll((unsigned long long)resetm) - 1;
+          const int s = ((__ffsll((unsigned long long)resetm) - 1) * 13) >> 6;   // lane 5 s -> board s
           resetm &= resetm - 1;
           for (int i = hf.lane; i < 5 * RS; i += kWave) st[(i / RS) * PL + s * RS + (i % RS)] = 0;
           if (hf.lane == 0) flagsv[s] = 8u;
         }
         WAVE_SYNC();
         // the new stone goes into the mover's plane right away: every later phase sees the position with it
-        if (bl && a >= 0 && a < hf.P) {
+        if (place) {
           const int turn = reset ? 0 : (int)(fl & 1u);
-          st[turn * PL + sb * RS + rr] |= 1u << pos;
+          st[turn * PL + sb * RS + rabs] |= 1u << pos;
         }
       }
       WAVE_SYNC();
