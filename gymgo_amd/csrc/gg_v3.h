@@ -209,11 +209,11 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
       const int s5 = (ln * 13) >> 6, t5 = ln - 5 * s5;   // phases 2 and 3: board and role / row quad of this lane
       const int s5c = s5 < kNB3 ? s5 : 0, r0 = 4 * t5;
-      uint32_t full4[4], mrow[4];
+      uint32_t full4[4];   // the N-bit row mask of the lane's rows that exist (also what keeps the unwritten rows >= R of
+                           // the flood blocks out: flood results only have bits < N)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         full4[r] = (s5 < kNB3 && r0 + r < N) ? (1u << N) - 1u : 0u;
-        mrow[r] = r0 + r < R ? ~0u : 0u;
       }
       // phase 1 - five lanes per board, four rows each (the lane assignment of phases 2 and 3): liveness, the generator
       // (drawn redundantly by the five lanes), the k-th valid point of the stored mask (or the given move).  With one lane
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
         uint4 *pMm = reinterpret_cast<uint4 *>(st + (3 + turn) * PL + sa * RS + r0);
         uint4 *pMo = reinterpret_cast<uint4 *>(st + (4 - turn) * PL + sa * RS + r0);
         const uint4 *gr = reinterpret_cast<const uint4 *>(sc + (5 * sa) * RS + r0);   // block j: gr[j * RS / 4]
-        const bool rowt = act && r0 < R;     // the floods write rows 0 .. R-1 of their blocks only (rows >= R: mrow)
+        const bool rowt = act && r0 < R;     // the floods write rows 0 .. R-1 of their blocks only (rows >= R: full4 == 0)
         uint32_t mine1[4] = {0u, 0u, 0u, 0u}, opp0[4] = {0u, 0u, 0u, 0u}, Mm[4] = {0u, 0u, 0u, 0u}, Mo[4] = {0u, 0u, 0u, 0u},
                  g0[4] = {0u, 0u, 0u, 0u}, gch[4] = {0u, 0u, 0u, 0u};
         if (rowt) {
@@ -419,8 +419,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
           unpack4(gr[RS], g4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            g0[r] &= mrow[r];
-            gch[r] = (g1[r] | g2[r] | g3[r] | g4[r]) & mrow[r];   // the opponent groups whose class changes
+            g0[r] &= full4[r];
+            gch[r] = (g1[r] | g2[r] | g3[r] | g4[r]) & full4[r];   // the opponent groups whose class changes
           }
         }
         const bool is_pass = a == hf.P;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
             unpack4(k1 ? gr[RS / 4] : z, g1); unpack4(k2 ? gr[2 * RS / 4] : z, g2); unpack4(k3 ? gr[3 * RS / 4] : z, g3);
             unpack4(k4 ? gr[RS] : z, g4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cap[r] = (g1[r] | g2[r] | g3[r] | g4[r]) & mrow[r];
+            for (int r = 0; r < 4; ++r) cap[r] = (g1[r] | g2[r] | g3[r] | g4[r]) & full4[r];
           }
           // captured stones next to G are liberties of G too
           {
