@@ -177,6 +177,27 @@ def main():
             del kids
         also['note'] = ('same resident batch; kernel-event time of 1-ply launches / of the out-of-place step API / of the fused '
                         'GoEnv.step (sample + step + areas + reward) / of the 362-slot children expansion of 8 192 parents')
+        if world == 1 and count == 65536 and not args.games_per_gpu:
+            # the per-GPU batch of the N > 1 lines (131 072 games, BASELINE config 4) on ONE GPU: the base for weak-scaling
+            # ratios - 65 536 games fill the resident waves 1.33 times, 131 072 games 2.67 times
+            big = 131072
+            st2 = gogame.batch_init_state(big, N, device=dev)
+            rg2 = gogame.rng_seed(big, 20260927, 0, dev)
+            if args.desync:
+                chunk2 = big // 16
+                for gslice in range(1, 16):
+                    gogame.batch_rollout(st2[gslice * chunk2:(gslice + 1) * chunk2], rg2[gslice * chunk2:(gslice + 1) * chunk2],
+                                         gslice * args.desync // 16, True)
+            gogame.batch_rollout(st2, rg2, F, True)
+            torch.cuda.synchronize(dev)
+            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b0.record()
+            for _ in range(4):
+                gogame.batch_rollout(st2, rg2, F, True)
+            b1.record()
+            torch.cuda.synchronize(dev)
+            also['rollout_131072_games_steps_per_s'] = round(big * 4 * F / (b0.elapsed_time(b1) * 1e-3), 1)
+            del st2, rg2
 
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if world > 1:
