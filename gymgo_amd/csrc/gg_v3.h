@@ -12,9 +12,11 @@ namespace gg {
 // has no liberty-less group) and updates them per ply from FIVE floods:
 //   lane 0 of a board: the mover's group G that the new stone joins (flood from q through the mover's stones + q);
 //   lanes 1-4:         the opponent's group at the upper / lower / left / right neighbour of q (empty otherwise).
-// A ply is three phases, each with its own lane assignment:
-//   1. one LANE per board (12 lanes): liveness, the generator, the k-th valid point of the stored mask (row prefix sums
-//      over its 19 rows), the stone ORed into the mover's plane; auto-reset on a rare path;
+// A ply is three phases, all on ONE lane assignment (board = lane / 5; lanes 60-63 idle):
+//   1. sampling, five lanes per board and four rows each: liveness, the generator (drawn redundantly by the five lanes),
+//      the k-th valid point of the stored mask (a lane counts its own rows, the board's prefix / total come from wave
+//      shifts, the lane that holds the point selects row and bit), the stone ORed into the mover's plane; auto-reset on
+//      a rare path (one lane per board and 19 rows per lane: 5.25e9 steps/s against 5.5e9);
 //   2. one lane per (board, role): the flood, then the liberties (dilate & empty, saturated at 2) and the size of the
 //      lane's own group, 19 rows in registers; an opponent group that keeps >= 2 liberties zeroes its result;
 //   3. all twelve boards in one pass, four adjacent rows per lane (lane -> board lane / 5 as in phase 2, rows 4t .. 4t+3
