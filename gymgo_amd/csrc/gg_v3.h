@@ -90,6 +90,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
   constexpr int RV = (R + 3) / 4;
   constexpr int PL = kNB3 * RS;   // words per plane of all boards
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds3<R>::kTotal];
+  if (FULLN) N = R;   // a compile-time constant from here on: row masks, r * N + c and the "row exists" tests fold
   const Half hf = make_half(threadIdx.x, N, inv);
   uint32_t *st = lds + Lds3<R>::kState;     // st[p * PL + s * RS + row]
   uint32_t *flagsv = lds + Lds3<R>::kMeta;  // bit 0 turn, 1 passed, 2 done, 3 on
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout3(uint8_t *__restrict__ sta
       int ln;   // = hf.lane (one wave per workgroup), straight from the hardware
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
       const int s5 = (ln * 13) >> 6, t5 = ln - 5 * s5;   // phases 2 and 3: board and role / row quad of this lane
+      __builtin_assume(t5 >= 0 && t5 < 5);
       const int s5c = s5 < kNB3 ? s5 : 0, r0 = 4 * t5;
       uint32_t full4[4];   // the N-bit row mask of the lane's rows that exist (also what keeps the unwritten rows >= R of
                            // the flood blocks out: flood results only have bits < N)
