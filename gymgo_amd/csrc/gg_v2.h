@@ -741,11 +741,12 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_next_states2(const uint8_t
 // PERPLY = instantiation for 1-2 plies per launch: the board I/O dominates there and the kernel runs best spill-free
 // at 3 waves per SIMD; the fused instantiation keeps its hot ply loop spill-free at 4 waves per SIMD.
 // PACKED: `states` holds packed boards (uint32 [B][3 N + 1]).
-template <int R, bool PERPLY, bool PACKED = false>
+template <int R, bool PERPLY, bool PACKED = false, bool FULLN = false>
 __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_rollout2(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                     int32_t *__restrict__ last_actions,
                                                     int64_t *__restrict__ steps_done, int64_t B, int N, uint32_t inv,
                                                     int plies, int auto_reset) {
+  if (FULLN) { N = R; inv = (65536u + R - 1u) / R; }   // N == R: compile-time constants (see k_env_step2)
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv);
   __shared__ uint2 lut[256];
@@ -921,12 +922,15 @@ __global__ __launch_bounds__(kWave, 4) void k_play_moves2(uint8_t *__restrict__ 
 // position ride in the idle flood lanes of the liberty analysis.  !HEUR (reward_method real): the areas only matter
 // when a game ends, so the step runs the plain analysis and a wave whose pair just finished a game (two passes: no
 // stone moved, the liberty classes are not needed again) runs one more analysis for the territory.
-template <int R, bool HEUR, bool PACKED = false>
+template <int R, bool HEUR, bool PACKED = false, bool FULLN = false>
 __global__ __launch_bounds__(kWave, PACKED ? 4 : GG_LB_PLY) void k_env_step2(uint8_t *__restrict__ states, const int32_t *__restrict__ actions,
                                                         uint64_t *__restrict__ rng, float *__restrict__ rewards,
                                                         uint8_t *__restrict__ dones, int32_t *__restrict__ status,
                                                         int32_t *__restrict__ taken, int64_t B, int N, uint32_t inv,
                                                         float komi, int auto_reset) {
+  // FULLN: the board fills the row capacity (N == R) - N, N * N and the reciprocal become compile-time constants
+  // (GoVecEnv.step 19x19: 7.9e8 against 7.6e8 steps/s; the same on k_next_states2 costs registers: 7.0e8 against 1.0e9)
+  if (FULLN) { N = R; inv = (65536u + R - 1u) / R; }
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv, HEUR);
   const Half hfa = make_half(threadIdx.x, N, inv, true);   // lanes 22 / 23 of each half flood the empty points
