@@ -185,7 +185,8 @@ int32_t gg_batch_invalid_mask(const uint8_t *states, const int32_t *ko, uint8_t 
     grid = grid_for((B + 1) / 2);
     GG_DISPATCH(N, (k_invalid_mask2<9><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
                 (k_invalid_mask2<13><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
-                (k_invalid_mask2<19><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)));
+                (N == 19 ? k_invalid_mask2<19, true><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)
+                         : k_invalid_mask2<19><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)));
   } else {
     GG_DISPATCH(N, (k_invalid_mask<9><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
                 (k_invalid_mask<13><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
@@ -204,7 +205,8 @@ int32_t gg_batch_areas(const uint8_t *states, int32_t *black, int32_t *white, in
     grid = grid_for((B + 1) / 2);
     GG_DISPATCH(N, (k_areas2<9><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
                 (k_areas2<13><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
-                (k_areas2<19><<<grid, kWave, 0, s>>>(states, black, white, B, N)));
+                (N == 19 ? k_areas2<19, true><<<grid, kWave, 0, s>>>(states, black, white, B, N)
+                         : k_areas2<19><<<grid, kWave, 0, s>>>(states, black, white, B, N)));
   } else {
     GG_DISPATCH(N, (k_areas<9><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
                 (k_areas<13><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
@@ -391,7 +393,8 @@ int32_t gg_batch_next_states_packed(const uint32_t *in, const int32_t *actions, 
   const int grid = grid_for((B + 1) / 2);
   GG_DISPATCH(N, (k_next_states_p<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
               (k_next_states_p<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
-              (k_next_states_p<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
+              (N == 19 ? k_next_states_p<19, true><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)
+                       : k_next_states_p<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
   return (int32_t)hipGetLastError();
 }
 
@@ -414,7 +417,8 @@ int32_t gg_batch_rollout_packed(uint32_t *packed, uint64_t *rng, int32_t *last_a
   const int grid = grid_for((B + 1) / 2);
   GG_DISPATCH(N, (k_rollout2<9, false, true><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
               (k_rollout2<13, false, true><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
-              (k_rollout2<19, false, true><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)));
+              (N == 19 ? k_rollout2<19, false, true, true><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
+                       : k_rollout2<19, false, true><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)));
   return (int32_t)hipGetLastError();
 }
 
@@ -433,11 +437,13 @@ int32_t gg_batch_env_step_packed(uint32_t *packed, const int32_t *actions, uint6
   if (reward_method == GG_REWARD_HEURISTIC) {
     GG_DISPATCH(N, (k_env_step2<9, true, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
                 (k_env_step2<13, true, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
-                (k_env_step2<19, true, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)));
+                (N == 19 ? k_env_step2<19, true, true, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
+                         : k_env_step2<19, true, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)));
   } else {
     GG_DISPATCH(N, (k_env_step2<9, false, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
                 (k_env_step2<13, false, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
-                (k_env_step2<19, false, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)));
+                (N == 19 ? k_env_step2<19, false, true, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
+                         : k_env_step2<19, false, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)));
   }
   return (int32_t)hipGetLastError();
 }

@@ -483,10 +483,11 @@ __device__ __forceinline__ void store_packed_h(uint32_t *gp, int N, const Half &
 }
 
 // gogame.batch_next_states on packed boards (out of place), two boards per wave
-template <int R>
+template <int R, bool FULLN = false>
 __global__ __launch_bounds__(kWave, 4) void k_next_states_p(const uint32_t *__restrict__ in, const int32_t *__restrict__ actions,
                                                             uint32_t *__restrict__ out, int32_t *__restrict__ status,
                                                             int64_t B, int N, uint32_t inv, int canonical) {
+  if (FULLN) { N = R; inv = (65536u + R - 1u) / R; }   // N == R: compile-time constants (see k_env_step2)
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv);
   load_cw_table<R>(lds, hf.lane);
@@ -1468,10 +1469,11 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
 
 // state_utils.batch_compute_invalid_moves (gym_go/state_utils.py:86-156), two boards per wave: plane 3 recomputed from
 // planes 0-2 (+ an optional ko point per game).
-template <int R>
+template <int R, bool FULLN = false>
 __global__ __launch_bounds__(kWave, 4) void k_invalid_mask2(const uint8_t *__restrict__ states,
                                                             const int32_t *__restrict__ ko, uint8_t *__restrict__ mask,
                                                             int64_t B, int N, uint32_t inv) {
+  if (FULLN) { N = R; inv = (65536u + R - 1u) / R; }   // N == R: compile-time constants (see k_env_step2)
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv);
   load_cw_table<R>(lds, hf.lane);
@@ -1508,9 +1510,10 @@ __global__ __launch_bounds__(kWave, 4) void k_invalid_mask2(const uint8_t *__res
 
 // gogame.areas (gym_go/gogame.py:275-300), two boards per wave: in each half lane 0 floods the empty points from
 // those touching black, lane 1 from those touching white; a region reached by exactly one colour belongs to it.
-template <int R>
+template <int R, bool FULLN = false>
 __global__ __launch_bounds__(kWave) void k_areas2(const uint8_t *__restrict__ states, int32_t *__restrict__ black_area,
                                                   int32_t *__restrict__ white_area, int64_t B, int N) {
+  if (FULLN) N = R;   // N == R: a compile-time constant (see k_env_step2)
   constexpr int RS = Cfg<R>::kRowStride;
   constexpr int RV = (R + 3) / 4;
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
