@@ -135,6 +135,18 @@ uint32_t recip16(int32_t N) {
     else { CALL19; }                          \
   } while (0)
 
+// GG_K(R, F) = the launch of the kernel for row capacity R; F: the board fills the capacity (N == R is a compile-time
+// constant in that instantiation)
+#define GG_DISPATCH_N(N)                     \
+  do {                                       \
+    if ((N) == 9) { GG_K(9, true); }         \
+    else if ((N) < 9) { GG_K(9, false); }    \
+    else if ((N) == 13) { GG_K(13, true); }  \
+    else if ((N) < 13) { GG_K(13, false); }  \
+    else if ((N) == 19) { GG_K(19, true); }  \
+    else { GG_K(19, false); }                \
+  } while (0)
+
 }  // namespace
 
 extern "C" {
@@ -183,10 +195,9 @@ int32_t gg_batch_invalid_mask(const uint8_t *states, const int32_t *ko, uint8_t 
   int grid = grid_for(B);
   if (variant() == 2) {
     grid = grid_for((B + 1) / 2);
-    GG_DISPATCH(N, (k_invalid_mask2<9><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
-                (k_invalid_mask2<13><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
-                (N == 19 ? k_invalid_mask2<19, true><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)
-                         : k_invalid_mask2<19><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)));
+#define GG_K(R, F) k_invalid_mask2<R, F><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)
+    GG_DISPATCH_N(N);
+#undef GG_K
   } else {
     GG_DISPATCH(N, (k_invalid_mask<9><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
                 (k_invalid_mask<13><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
@@ -203,10 +214,9 @@ int32_t gg_batch_areas(const uint8_t *states, int32_t *black, int32_t *white, in
   int grid = grid_for(B);
   if (variant() == 2) {
     grid = grid_for((B + 1) / 2);
-    GG_DISPATCH(N, (k_areas2<9><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
-                (k_areas2<13><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
-                (N == 19 ? k_areas2<19, true><<<grid, kWave, 0, s>>>(states, black, white, B, N)
-                         : k_areas2<19><<<grid, kWave, 0, s>>>(states, black, white, B, N)));
+#define GG_K(R, F) k_areas2<R, F><<<grid, kWave, 0, s>>>(states, black, white, B, N)
+    GG_DISPATCH_N(N);
+#undef GG_K
   } else {
     GG_DISPATCH(N, (k_areas<9><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
                 (k_areas<13><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
@@ -272,15 +282,13 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
   if (variant() == 2) {
     grid = grid_for((B + 1) / 2);
     if (plies <= 2) {
-      GG_DISPATCH(N, (k_rollout2<9, true><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
-                  (k_rollout2<13, true><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
-                  (N == 19 ? k_rollout2<19, true, false, true><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
-                           : k_rollout2<19, true><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)));
+#define GG_K(R, F) k_rollout2<R, true, false, F><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
+      GG_DISPATCH_N(N);
+#undef GG_K
     } else {
-      GG_DISPATCH(N, (k_rollout2<9, false><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
-                  (k_rollout2<13, false><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
-                  (N == 19 ? k_rollout2<19, false, false, true><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
-                           : k_rollout2<19, false><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)));
+#define GG_K(R, F) k_rollout2<R, false, false, F><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
+      GG_DISPATCH_N(N);
+#undef GG_K
     }
   } else {
     GG_DISPATCH(N, (k_rollout<9><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
@@ -302,15 +310,13 @@ int32_t gg_batch_env_step(uint8_t *states, const int32_t *actions, uint64_t *rng
   hipStream_t s = (hipStream_t)hip_stream;
   const int grid = grid_for((B + 1) / 2);
   if (reward_method == GG_REWARD_HEURISTIC) {
-    GG_DISPATCH(N, (k_env_step2<9, true><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
-                (k_env_step2<13, true><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
-                (N == 19 ? k_env_step2<19, true, false, true><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
-                         : k_env_step2<19, true><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)));
+#define GG_K(R, F) k_env_step2<R, true, false, F><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
+    GG_DISPATCH_N(N);
+#undef GG_K
   } else {
-    GG_DISPATCH(N, (k_env_step2<9, false><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
-                (k_env_step2<13, false><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
-                (N == 19 ? k_env_step2<19, false, false, true><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
-                         : k_env_step2<19, false><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)));
+#define GG_K(R, F) k_env_step2<R, false, false, F><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
+    GG_DISPATCH_N(N);
+#undef GG_K
   }
   return (int32_t)hipGetLastError();
 }
@@ -391,10 +397,9 @@ int32_t gg_batch_next_states_packed(const uint32_t *in, const int32_t *actions, 
   if (!inv) return GG_E_BADSIZE;
   hipStream_t s = (hipStream_t)hip_stream;
   const int grid = grid_for((B + 1) / 2);
-  GG_DISPATCH(N, (k_next_states_p<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
-              (k_next_states_p<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
-              (N == 19 ? k_next_states_p<19, true><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)
-                       : k_next_states_p<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
+#define GG_K(R, F) k_next_states_p<R, F><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)
+  GG_DISPATCH_N(N);
+#undef GG_K
   return (int32_t)hipGetLastError();
 }
 
@@ -415,10 +420,9 @@ int32_t gg_batch_rollout_packed(uint32_t *packed, uint64_t *rng, int32_t *last_a
     return (int32_t)hipGetLastError();
   }
   const int grid = grid_for((B + 1) / 2);
-  GG_DISPATCH(N, (k_rollout2<9, false, true><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
-              (k_rollout2<13, false, true><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
-              (N == 19 ? k_rollout2<19, false, true, true><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
-                       : k_rollout2<19, false, true><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)));
+#define GG_K(R, F) k_rollout2<R, false, true, F><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
+  GG_DISPATCH_N(N);
+#undef GG_K
   return (int32_t)hipGetLastError();
 }
 
@@ -435,15 +439,13 @@ int32_t gg_batch_env_step_packed(uint32_t *packed, const int32_t *actions, uint6
   const int grid = grid_for((B + 1) / 2);
   uint8_t *st = reinterpret_cast<uint8_t *>(packed);
   if (reward_method == GG_REWARD_HEURISTIC) {
-    GG_DISPATCH(N, (k_env_step2<9, true, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
-                (k_env_step2<13, true, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
-                (N == 19 ? k_env_step2<19, true, true, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
-                         : k_env_step2<19, true, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)));
+#define GG_K(R, F) k_env_step2<R, true, true, F><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
+    GG_DISPATCH_N(N);
+#undef GG_K
   } else {
-    GG_DISPATCH(N, (k_env_step2<9, false, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
-                (k_env_step2<13, false, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)),
-                (N == 19 ? k_env_step2<19, false, true, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
-                         : k_env_step2<19, false, true><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)));
+#define GG_K(R, F) k_env_step2<R, false, true, F><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
+    GG_DISPATCH_N(N);
+#undef GG_K
   }
   return (int32_t)hipGetLastError();
 }
