@@ -220,12 +220,12 @@ def main():
         rcap = 9 if N <= 9 else 13 if N <= 13 else 19
         if os.environ.get('GG_KERNEL_VARIANT') == '1':
             kernel_name = 'k_rollout<%d>' % rcap
-        elif (F >= int(os.environ.get('GG_V3_MIN', '6')) and os.environ.get('GG_ROLLOUT_V2') != '1'
+        elif (F >= int(os.environ.get('GG_V3_MIN', '2')) and os.environ.get('GG_ROLLOUT_V2') != '1'
               and (count >= 32 * torch.cuda.get_device_properties(dev).multi_processor_count or os.environ.get('GG_V3_NB'))):
             # 12 boards per wave, liberty classes carried across plies; <row capacity, byte-plane I/O, drawn moves, N == capacity>
             kernel_name = 'k_rollout3<%d, 0, false, %s>' % (rcap, 'true' if N == rcap else 'false')
         else:
-            kernel_name = 'k_rollout2<%d, %s, false>' % (rcap, 'true' if F <= 2 else 'false')
+            kernel_name = 'k_rollout2<%d, %s, false, %s>' % (rcap, 'true' if F <= 2 else 'false', 'true' if N == rcap else 'false')
         line = {
             'metric': 'env steps/sec across batched games, 19x19 uniform-random rollouts',
             'value': round(value, 1), 'unit': 'env steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,

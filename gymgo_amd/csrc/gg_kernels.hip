@@ -85,12 +85,13 @@ int v3_boards_per_wave(int64_t B, int &grid) {
 }
 
 // v3 pays off once every SIMD can get a wave of >= 8 boards (9x9: 4 096 games 1.4e9 vs 2.0e9 on v2; 16 384 games on par;
-// 262 144 games 6.6e9 vs 2.9e9) and the launch is long enough to amortise the first (v2) analysis of every board
+// 262 144 games 9.7e9 vs 2.9e9); the first (v2) analysis of every board is amortised from two plies per launch on
+// (65 536 games, 2 / 3 / 5 plies per launch: 1.31 / 1.78 / 2.47e9 steps/s against 1.14 / 1.32 / 1.51e9 on v2)
 bool use_v3(int64_t B, int plies);
 
 int v3_min_plies() {
   static int v = -1;
-  if (v < 0) { const char *e = getenv("GG_V3_MIN"); v = e ? atoi(e) : 6; }
+  if (v < 0) { const char *e = getenv("GG_V3_MIN"); v = e ? atoi(e) : 2; }
   return v;
 }
 
