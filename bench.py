@@ -47,9 +47,23 @@ def cpu_baseline(size, cpu_seconds_total=20.0):
     with ctx.Pool(cores) as pool:
         steps = pool.map(_cpu_worker, [(size, seconds, 1000 + i) for i in range(cores)])
     wall = time.perf_counter() - t0
+    # the build's own C restatement (oracle/gg_oracle.c: bitboard-free flood fills, one thread) - reported, not the baseline
+    c_rate = None
+    try:
+        import numpy as np
+        from oracle import c_oracle
+        st = np.zeros((32, 6, size, size), np.uint8)
+        rg = c_oracle.rng_seed(7, 32)
+        st, rg, _ = c_oracle.batch_rollout(st, rg, 300, True)     # into the middle game
+        c0 = time.perf_counter()
+        st, rg, _ = c_oracle.batch_rollout(st, rg, 600, True)
+        c_rate = round(32 * 600 / (time.perf_counter() - c0), 1)
+    except Exception:
+        c_rate = None
     return {
         'value': round(sum(steps) / seconds, 1), 'unit': 'env steps/s', 'cores': cores, 'kind': 'port',
         'per_core': round(sum(steps) / seconds / cores, 1),
+        'c_restatement_steps_per_s_one_core': c_rate,
         'sample': '%d workers x %.1f s of %dx%d uniform-random self-play with auto-reset (oracle/np_oracle.py, '
                   'same scipy.ndimage calls per step as the reference); %d steps total, pool wall %.1f s'
                   % (cores, seconds, size, size, sum(steps), wall),
