@@ -28,6 +28,14 @@ def test_header_symbols_exported(built):
     assert built.lib().gg_version() == 1
 
 
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md is the binding contract a reference maintainer reads: it has to name every exported symbol."""
+    hdr = open(os.path.join(ROOT, 'include', 'gymgo_amd.h')).read()
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    declared = set(re.findall(r'^\s*(?:int32_t|int)\s+(gg_\w+)\s*\(', hdr, flags=re.M))
+    assert declared and not [n for n in sorted(declared) if n not in doc]
+
+
 def test_argument_validation_without_device(built):
     L = built.lib()
     # argument checks come before any device work
