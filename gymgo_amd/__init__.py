@@ -6,6 +6,23 @@ tensors).  There is no CPU fallback.
 """
 from gymgo_amd import govars  # noqa: F401
 
+
+def _register_if_gym_present():
+    # gym_go/__init__.py:3-10 registers 'go-v0' on import; do the same when gym / gymnasium exists (importing
+    # gymgo_amd.envs pulls in torch, so it only happens when there is something to register with)
+    import importlib.util
+    for name in ('gym', 'gymnasium'):
+        try:
+            if importlib.util.find_spec(name) is not None:
+                import gymgo_amd.envs  # noqa: F401  (registers on import)
+                return True
+        except (ImportError, ValueError):
+            continue
+    return False
+
+
+_register_if_gym_present()
+
 __all__ = ['govars', 'gogame', 'state_utils', 'envs', 'GoEnv', 'GoVecEnv', 'make', 'register_gym']
 
 

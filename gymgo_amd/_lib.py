@@ -10,7 +10,8 @@ import os
 import torch  # must be imported before the library so both share ONE HIP runtime (libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('GYMGO_AMD_LIB') or os.path.join(_HERE, 'libgymgo_amd.so')  # override: A/B experiments
+LIB_PATH = os.path.join(_HERE, 'libgymgo_amd.so')   # always the in-tree build: no override, no search path
+ABI_VERSION = 2                                      # GG_ABI_VERSION of include/gymgo_amd.h
 
 EXPORTS = (
     'gg_version', 'gg_device_cus', 'gg_batch_next_states', 'gg_batch_invalid_mask', 'gg_batch_areas',
@@ -31,7 +32,7 @@ _SIGNATURES = {
     'gg_batch_rollout': ([_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
     'gg_batch_env_step': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_float, _i32, _i32, _vp], _i32),
     'gg_batch_sample_actions': ([_vp, _vp, _vp, _i64, _i32, _vp], _i32),
-    'gg_batch_update_pieces': ([_vp, _vp, _vp, _vp, _i64, _i32, _vp], _i32),
+    'gg_batch_update_pieces': ([_vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp], _i32),
     'gg_batch_reset_finished': ([_vp, _i64, _i32, _vp], _i32),
     'gg_packed_words': ([_i32], _i32),
     'gg_batch_pack_states': ([_vp, _vp, _i64, _i32, _vp], _i32),
@@ -80,6 +81,9 @@ def lib():
         for name, (argtypes, restype) in _SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the .so does not export what the header declares
             fn.argtypes, fn.restype = argtypes, restype
+        if L.gg_version() != ABI_VERSION:
+            raise GymGoNativeError('%s has ABI version %d, this package binds version %d: rebuild it '
+                                   '(make -C gymgo_amd/csrc)' % (LIB_PATH, L.gg_version(), ABI_VERSION))
         _lib = L
     return _lib
 

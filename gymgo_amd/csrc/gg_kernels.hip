@@ -1,112 +1,84 @@
-// gg_kernels.hip - C-ABI (include/gymgo_amd.h) of the MI355X batched Go step path: argument checks, grid sizing,
-// dispatch on the board-size template and on the kernel family.  The kernels live in gg_common.h (shared building
-// blocks), gg_v1.h (one wavefront per board) and gg_v2.h (two boards per wavefront, default).
+// gg_kernels.hip - C-ABI (include/gymgo_amd.h) of the MI355X batched Go step path: argument checks, device selection,
+// grid sizing and dispatch on the board-size template.  The kernels live in gg_common.h (shared building blocks),
+// gg_v2.h (per-ply kernels: two boards per wavefront, every liberty class from scratch), gg_v3.h (multi-ply kernels:
+// twelve boards per wavefront, liberty classes carried from ply to ply) and gg_aux.h (stand-alone sampler and capture
+// resolution).  Which kernel serves an entry point depends on the arguments only (batch size, plies per launch): there
+// are no environment switches and no mutable global state besides the per-device CU-count cache below.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "gg_common.h"
-#include "gg_v1.h"
 #include "gg_v2.h"
 #include "gg_v3.h"
+#include "gg_aux.h"
 #include "gymgo_amd.h"
 
 namespace {
 
 using namespace gg;
 
+constexpr int kMaxDevices = 64;
+int g_cus[kMaxDevices];   // 0 = not queried yet; a benign race: every thread writes the same value
 
-int g_cus = -1;
-
-// kernel family: 2 = two boards per wavefront (default), 1 = one board per wavefront.  GG_KERNEL_VARIANT=1|2.
-int variant() {
-  static int v = 0;
-  if (v == 0) {
-    const char *e = getenv("GG_KERNEL_VARIANT");
-    v = (e && e[0] == '1') ? 1 : 2;
+int cus_of(int dev) {
+  if (dev < 0 || dev >= kMaxDevices) return 256;
+  int c = g_cus[dev];
+  if (c <= 0) {
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) return 256;
+    g_cus[dev] = c;
   }
-  return v;
+  return c;
 }
 
-int device_cus() {
-  if (g_cus < 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    g_cus = cus;
+// Kernels are launched on the device that OWNS the buffers (the stream handed over belongs to it too), whatever the
+// calling thread's current device is; the current device is restored on return.  One hipPointerGetAttributes per call.
+struct OnDeviceOf {
+  int prev = -1, dev = 0;
+  bool switched = false;
+  explicit OnDeviceOf(const void *p) {
+    (void)hipGetDevice(&prev);
+    dev = prev < 0 ? 0 : prev;
+    hipPointerAttribute_t at;
+    if (p && hipPointerGetAttributes(&at, p) == hipSuccess) dev = at.device;
+    else (void)hipGetLastError();   // a pointer HIP does not know: launch on the current device (and fail there)
+    if (dev != prev) switched = hipSetDevice(dev) == hipSuccess;
   }
-  return g_cus;
-}
+  ~OnDeviceOf() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  int cus() const { return cus_of(dev); }
+};
 
 // persistent grid: enough single-wave workgroups to fill every SIMD several times over
-int grid_for(int64_t work) {
-  int cus = device_cus();
-  if (cus <= 0) cus = 256;
+int grid_for(int cus, int64_t work) {
   int64_t cap = (int64_t)cus * 32;
   return (int)(work < cap ? (work > 0 ? work : 1) : cap);
 }
 
 // pipelined kernels: exactly the resident set (waves per SIMD x 4 SIMDs x CUs), so that each workgroup runs many
 // iterations and pays the un-overlapped first load / last store once
-int grid_resident(int64_t work, int waves_per_simd) {
-  int cus = device_cus();
-  if (cus <= 0) cus = 256;
+int grid_resident(int cus, int64_t work, int waves_per_simd) {
   int64_t cap = (int64_t)cus * 4 * waves_per_simd;
   return (int)(work < cap ? (work > 0 ? work : 1) : cap);
-}
-
-// GG_CHILDREN_FULL=1 selects the children kernel that re-analyses every child from scratch (k_children2) - A/B only
-bool children_full() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("GG_CHILDREN_FULL"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
-
-// GG_ROLLOUT_V2=1 keeps the fused rollout on the v2 kernel (full analysis per ply, 2 boards per wave) - A/B only
-bool rollout_v2() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("GG_ROLLOUT_V2"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
 }
 
 // v3 kernels: boards per wave (even, <= kNB3).  Twelve is the most efficient (the flood batch is shared by more boards:
 // 65 536 games run 3.4e9 steps/s with 12, 3.1e9 with 8, 1.9e9 with 4); small batches take fewer per wave so that
 // every SIMD still gets a wave.
-int v3_boards_per_wave(int64_t B, int &grid) {
-  int cus = device_cus();
-  if (cus <= 0) cus = 256;
+int v3_boards_per_wave(int cus, int64_t B, int &grid) {
   int64_t nb = B / ((int64_t)cus * 4);
-  if (const char *e = getenv("GG_V3_NB")) nb = atoi(e);
   if (nb > kNB3) nb = kNB3;
   nb &= ~(int64_t)1;
   if (nb < 2) nb = 2;
-  grid = grid_for((B + nb - 1) / nb);
+  grid = grid_for(cus, (B + nb - 1) / nb);
   return (int)nb;
 }
 
-// v3 pays off once every SIMD can get a wave of >= 8 boards (9x9: 4 096 games 1.4e9 vs 2.0e9 on v2; 16 384 games on par;
-// 262 144 games 9.7e9 vs 2.9e9); the first (v2) analysis of every board is amortised from two plies per launch on
-// (65 536 games, 2 / 3 / 5 plies per launch: 1.31 / 1.78 / 2.47e9 steps/s against 1.14 / 1.32 / 1.51e9 on v2)
-bool use_v3(int64_t B, int plies);
-
-int v3_min_plies() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("GG_V3_MIN"); v = e ? atoi(e) : 2; }
-  return v;
-}
-
-bool use_v3(int64_t B, int plies) {
-  int cus = device_cus();
-  if (cus <= 0) cus = 256;
-  return variant() == 2 && !rollout_v2() && plies >= v3_min_plies() && (B >= (int64_t)cus * 32 || getenv("GG_V3_NB"));
-}
-
-// GG_SYNC_IO=1 selects the non-pipelined (load, analyse, store) per-ply kernels - A/B measurements only
-bool sync_io() {
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("GG_SYNC_IO"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
+// Byte-plane / packed boards enter a multi-ply launch through one v2 analysis per board; v3 pays off once every SIMD
+// can get a wave of >= 8 boards (9x9: 4 096 games 1.4e9 vs 2.0e9 on v2; 16 384 games on par; 262 144 games 9.7e9 vs
+// 2.9e9) and from two plies per launch on (65 536 games, 2 / 3 / 5 plies per launch: 1.31 / 1.78 / 2.47e9 steps/s
+// against 1.14 / 1.32 / 1.51e9 on v2).  Tracked boards carry their classes and always run v3.
+bool use_v3(int cus, int64_t B, int plies) { return plies >= 2 && B >= (int64_t)cus * 32; }
 
 int32_t check(int64_t B, int32_t N) { return (N < 2 || N > GG_MAX_BOARD || B < 0) ? GG_E_BADSIZE : 0; }
 
@@ -154,147 +126,100 @@ extern "C" {
 
 int32_t gg_version(void) { return GG_ABI_VERSION; }
 
-int32_t gg_device_cus(void) { return device_cus(); }
+int32_t gg_device_cus(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  int c = 0;
+  if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  return c;
+}
+
+// common prologue: size checks, empty batch, the (exact) reciprocal of N, the owning device, the stream
+#define GG_ENTER(PTR)                                \
+  if (int32_t e_ = check(B, N)) return e_;           \
+  if (B == 0) return 0;                              \
+  const uint32_t inv = recip16(N);                   \
+  if (!inv) return GG_E_BADSIZE;                     \
+  if (!(PTR)) return GG_E_NULLPTR;                   \
+  OnDeviceOf on_dev(PTR);                            \
+  const int cus = on_dev.cus();                      \
+  hipStream_t s = (hipStream_t)hip_stream;           \
+  (void)cus; (void)inv
 
 int32_t gg_batch_next_states(const uint8_t *in, const int32_t *actions, uint8_t *out, int32_t *status, int64_t B,
                              int32_t N, int32_t canonical, void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
-  if (B == 0) return 0;
-  if (!in || !actions || !out) return GG_E_NULLPTR;
-  const uint32_t inv = recip16(N);
-  if (!inv) return GG_E_BADSIZE;
-  hipStream_t s = (hipStream_t)hip_stream;
-  int grid = grid_for(B);
-  if (variant() == 2) {
-    if (sync_io()) {
-      grid = grid_for((B + 1) / 2);
-      GG_DISPATCH(N, (k_next_states2s<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
-                  (k_next_states2s<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
-                  (k_next_states2s<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
-    } else {
-      grid = grid_resident((B + 1) / 2, GG_LB_PLY);
-      GG_DISPATCH(N, (k_next_states2<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
-                  (k_next_states2<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
-                  (k_next_states2<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
-    }
-  } else {
-    GG_DISPATCH(N, (k_next_states<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
-                (k_next_states<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
-                (k_next_states<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
-  }
+  GG_ENTER(in);
+  if (!actions || !out) return GG_E_NULLPTR;
+  const int grid = grid_resident(cus, (B + 1) / 2, GG_LB_PLY);
+  GG_DISPATCH(N, (k_next_states2<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+              (k_next_states2<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+              (k_next_states2<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
   return (int32_t)hipGetLastError();
 }
 
 int32_t gg_batch_invalid_mask(const uint8_t *states, const int32_t *ko, uint8_t *mask, int64_t B, int32_t N,
                               void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
-  if (B == 0) return 0;
-  if (!states || !mask) return GG_E_NULLPTR;
-  const uint32_t inv = recip16(N);
-  if (!inv) return GG_E_BADSIZE;
-  hipStream_t s = (hipStream_t)hip_stream;
-  int grid = grid_for(B);
-  if (variant() == 2) {
-    grid = grid_for((B + 1) / 2);
+  GG_ENTER(states);
+  if (!mask) return GG_E_NULLPTR;
+  const int grid = grid_for(cus, (B + 1) / 2);
 #define GG_K(R, F) k_invalid_mask2<R, F><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)
-    GG_DISPATCH_N(N);
+  GG_DISPATCH_N(N);
 #undef GG_K
-  } else {
-    GG_DISPATCH(N, (k_invalid_mask<9><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
-                (k_invalid_mask<13><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)),
-                (k_invalid_mask<19><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)));
-  }
   return (int32_t)hipGetLastError();
 }
 
 int32_t gg_batch_areas(const uint8_t *states, int32_t *black, int32_t *white, int64_t B, int32_t N, void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
-  if (B == 0) return 0;
-  if (!states || !black || !white) return GG_E_NULLPTR;
-  hipStream_t s = (hipStream_t)hip_stream;
-  int grid = grid_for(B);
-  if (variant() == 2) {
-    grid = grid_for((B + 1) / 2);
+  GG_ENTER(states);
+  if (!black || !white) return GG_E_NULLPTR;
+  const int grid = grid_for(cus, (B + 1) / 2);
 #define GG_K(R, F) k_areas2<R, F><<<grid, kWave, 0, s>>>(states, black, white, B, N)
-    GG_DISPATCH_N(N);
+  GG_DISPATCH_N(N);
 #undef GG_K
-  } else {
-    GG_DISPATCH(N, (k_areas<9><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
-                (k_areas<13><<<grid, kWave, 0, s>>>(states, black, white, B, N)),
-                (k_areas<19><<<grid, kWave, 0, s>>>(states, black, white, B, N)));
-  }
   return (int32_t)hipGetLastError();
+}
+
+// children: the per-parent analysis (4 flood batches at 19x19) is repeated by every chunk of a parent's slots, so
+// chunks only serve to fill the machine and to even out the tail (8 192 parents: 2 chunks each, measured best of 1..12)
+static int children_chunks(int cus, int64_t B, int A) {
+  int chunks = (int)(((int64_t)cus * 64 + B - 1) / B);
+  if (chunks < 1) chunks = 1;
+  if (chunks > A) chunks = A;
+  return chunks;
 }
 
 int32_t gg_batch_children(const uint8_t *states, uint8_t *children, int64_t B, int32_t N, int32_t canonical,
                           void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
-  if (B == 0) return 0;
-  if (!states || !children) return GG_E_NULLPTR;
-  const uint32_t inv = recip16(N);
-  if (!inv) return GG_E_BADSIZE;
-  hipStream_t s = (hipStream_t)hip_stream;
-  const int A = N * N + 1;
-  int cus = device_cus();
-  if (cus <= 0) cus = 256;
-  int64_t want = (int64_t)cus * 64;  // work items wanted to keep every SIMD busy
-  int chunks = (int)((want + B - 1) / B);
-  if (chunks < 1) chunks = 1;
-  if (chunks > A) chunks = A;
-  int grid = grid_for(B * chunks);
-  if (variant() == 2 && !children_full()) {
-    // incremental kernel: the per-parent analysis (4 flood batches at 19x19) is repeated by every chunk, so chunks only
-    // serve to fill the machine and to even out the tail (8 192 parents: 2 chunks each, measured best of 1..12)
-    want = (int64_t)cus * 64;
-    chunks = (int)((want + B - 1) / B);
-    if (chunks < 1) chunks = 1;
-    if (chunks > A) chunks = A;
-    grid = grid_for(B * chunks);
-    GG_DISPATCH(N, (k_children3<9><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
-                (k_children3<13><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
-                (k_children3<19><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)));
-  } else if (variant() == 2) {
-    GG_DISPATCH(N, (k_children2<9><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
-                (k_children2<13><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
-                (k_children2<19><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)));
-  } else {
-    GG_DISPATCH(N, (k_children<9><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
-                (k_children<13><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
-                (k_children<19><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)));
-  }
+  GG_ENTER(states);
+  if (!children) return GG_E_NULLPTR;
+  const int chunks = children_chunks(cus, B, N * N + 1);
+  const int grid = grid_for(cus, B * chunks);
+  GG_DISPATCH(N, (k_children3<9><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
+              (k_children3<13><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)),
+              (k_children3<19><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks)));
   return (int32_t)hipGetLastError();
 }
 
 int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B,
                          int32_t N, int32_t plies, int32_t auto_reset, void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
   if (plies < 0) return GG_E_BADARG;
-  if (B == 0 || plies == 0) return 0;
-  if (!states || !rng) return GG_E_NULLPTR;
-  const uint32_t inv = recip16(N);
-  if (!inv) return GG_E_BADSIZE;
-  hipStream_t s = (hipStream_t)hip_stream;
-  int grid = grid_for(B);
-  if (use_v3(B, plies)) {   // incremental classes, 12 boards per wave
-    const int nb = v3_boards_per_wave(B, grid);
+  GG_ENTER(states);
+  if (plies == 0) return 0;
+  if (!rng) return GG_E_NULLPTR;
+  if (use_v3(cus, B, plies)) {   // liberty classes carried across the plies, 12 boards per wave
+    int grid;
+    const int nb = v3_boards_per_wave(cus, B, grid);
     GG_DISPATCH3(N, 0, false, grid, states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
     return (int32_t)hipGetLastError();
   }
-  if (variant() == 2) {
-    grid = grid_for((B + 1) / 2);
-    if (plies <= 2) {
+  const int grid = grid_for(cus, (B + 1) / 2);
+  if (plies <= 2) {
 #define GG_K(R, F) k_rollout2<R, true, false, F><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
-      GG_DISPATCH_N(N);
+    GG_DISPATCH_N(N);
 #undef GG_K
-    } else {
-#define GG_K(R, F) k_rollout2<R, false, false, F><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
-      GG_DISPATCH_N(N);
-#undef GG_K
-    }
   } else {
-    GG_DISPATCH(N, (k_rollout<9><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
-                (k_rollout<13><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)),
-                (k_rollout<19><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)));
+#define GG_K(R, F) k_rollout2<R, false, false, F><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
+    GG_DISPATCH_N(N);
+#undef GG_K
   }
   return (int32_t)hipGetLastError();
 }
@@ -302,14 +227,10 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
 int32_t gg_batch_env_step(uint8_t *states, const int32_t *actions, uint64_t *rng, float *rewards, uint8_t *dones,
                           int32_t *status, int32_t *taken_actions, int64_t B, int32_t N, float komi,
                           int32_t reward_method, int32_t auto_reset, void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
   if (reward_method != GG_REWARD_REAL && reward_method != GG_REWARD_HEURISTIC) return GG_E_BADARG;
-  if (B == 0) return 0;
-  if (!states || (!actions && !rng)) return GG_E_NULLPTR;
-  const uint32_t inv = recip16(N);
-  if (!inv) return GG_E_BADSIZE;
-  hipStream_t s = (hipStream_t)hip_stream;
-  const int grid = grid_for((B + 1) / 2);
+  GG_ENTER(states);
+  if (!actions && !rng) return GG_E_NULLPTR;
+  const int grid = grid_for(cus, (B + 1) / 2);
   if (reward_method == GG_REWARD_HEURISTIC) {
 #define GG_K(R, F) k_env_step2<R, true, false, F><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
     GG_DISPATCH_N(N);
@@ -324,37 +245,29 @@ int32_t gg_batch_env_step(uint8_t *states, const int32_t *actions, uint64_t *rng
 
 int32_t gg_batch_sample_actions(const uint8_t *states, uint64_t *rng, int32_t *actions, int64_t B, int32_t N,
                                 void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
-  if (B == 0) return 0;
-  if (!states || !rng || !actions) return GG_E_NULLPTR;
-  hipStream_t s = (hipStream_t)hip_stream;
-  int grid = grid_for(B);
+  GG_ENTER(states);
+  if (!rng || !actions) return GG_E_NULLPTR;
+  const int grid = grid_for(cus, B);
   GG_DISPATCH(N, (k_sample<9><<<grid, kWave, 0, s>>>(states, rng, actions, B, N)),
               (k_sample<13><<<grid, kWave, 0, s>>>(states, rng, actions, B, N)),
               (k_sample<19><<<grid, kWave, 0, s>>>(states, rng, actions, B, N)));
   return (int32_t)hipGetLastError();
 }
 
-int32_t gg_batch_update_pieces(uint8_t *states, const int32_t *points, const int32_t *players, uint8_t *killed,
+int32_t gg_batch_update_pieces(uint8_t *states, const int32_t *adj, int32_t K, const int32_t *players, uint8_t *killed,
                                int64_t B, int32_t N, void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
-  if (B == 0) return 0;
-  if (!states || !points || !players) return GG_E_NULLPTR;
-  const uint32_t inv = recip16(N);
-  if (!inv) return GG_E_BADSIZE;
-  hipStream_t s = (hipStream_t)hip_stream;
-  int grid = grid_for(B);
-  GG_DISPATCH(N, (k_update_pieces<9><<<grid, kWave, 0, s>>>(states, points, players, killed, B, N, inv)),
-              (k_update_pieces<13><<<grid, kWave, 0, s>>>(states, points, players, killed, B, N, inv)),
-              (k_update_pieces<19><<<grid, kWave, 0, s>>>(states, points, players, killed, B, N, inv)));
+  if (K < 0) return GG_E_BADARG;
+  GG_ENTER(states);
+  if (!players || (K > 0 && !adj)) return GG_E_NULLPTR;
+  const int grid = grid_for(cus, B);
+  GG_DISPATCH(N, (k_update_pieces<9><<<grid, kWave, 0, s>>>(states, adj, K, players, killed, B, N, inv)),
+              (k_update_pieces<13><<<grid, kWave, 0, s>>>(states, adj, K, players, killed, B, N, inv)),
+              (k_update_pieces<19><<<grid, kWave, 0, s>>>(states, adj, K, players, killed, B, N, inv)));
   return (int32_t)hipGetLastError();
 }
 
 int32_t gg_batch_reset_finished(uint8_t *states, int64_t B, int32_t N, void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
-  if (B == 0) return 0;
-  if (!states) return GG_E_NULLPTR;
-  hipStream_t s = (hipStream_t)hip_stream;
+  GG_ENTER(states);
   int64_t waves = (B + kWave - 1) / kWave;
   int blocks = (int)((waves + 3) / 4);
   if (blocks > 4096) blocks = 4096;
@@ -365,11 +278,9 @@ int32_t gg_batch_reset_finished(uint8_t *states, int64_t B, int32_t N, void *hip
 int32_t gg_packed_words(int32_t N) { return (N < 2 || N > GG_MAX_BOARD) ? GG_E_BADSIZE : 3 * N + 1; }
 
 int32_t gg_batch_pack_states(const uint8_t *states, uint32_t *packed, int64_t B, int32_t N, void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
-  if (B == 0) return 0;
-  if (!states || !packed) return GG_E_NULLPTR;
-  hipStream_t s = (hipStream_t)hip_stream;
-  int grid = grid_for((B + 1) / 2);
+  GG_ENTER(states);
+  if (!packed) return GG_E_NULLPTR;
+  const int grid = grid_for(cus, (B + 1) / 2);
   GG_DISPATCH(N, (k_pack<9><<<grid, kWave, 0, s>>>(states, packed, B, N)),
               (k_pack<13><<<grid, kWave, 0, s>>>(states, packed, B, N)),
               (k_pack<19><<<grid, kWave, 0, s>>>(states, packed, B, N)));
@@ -377,11 +288,9 @@ int32_t gg_batch_pack_states(const uint8_t *states, uint32_t *packed, int64_t B,
 }
 
 int32_t gg_batch_unpack_states(const uint32_t *packed, uint8_t *states, int64_t B, int32_t N, void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
-  if (B == 0) return 0;
-  if (!states || !packed) return GG_E_NULLPTR;
-  hipStream_t s = (hipStream_t)hip_stream;
-  int grid = grid_for((B + 1) / 2);
+  GG_ENTER(packed);
+  if (!states) return GG_E_NULLPTR;
+  const int grid = grid_for(cus, (B + 1) / 2);
   GG_DISPATCH(N, (k_unpack<9><<<grid, kWave, 0, s>>>(packed, states, B, N, 3)),
               (k_unpack<13><<<grid, kWave, 0, s>>>(packed, states, B, N, 3)),
               (k_unpack<19><<<grid, kWave, 0, s>>>(packed, states, B, N, 3)));
@@ -391,13 +300,9 @@ int32_t gg_batch_unpack_states(const uint32_t *packed, uint8_t *states, int64_t 
 // ---- the same operations on packed boards (uint32 [B][3 N + 1], see gg_batch_pack_states): no byte-plane conversions
 int32_t gg_batch_next_states_packed(const uint32_t *in, const int32_t *actions, uint32_t *out, int32_t *status, int64_t B,
                                     int32_t N, int32_t canonical, void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
-  if (B == 0) return 0;
-  if (!in || !actions || !out) return GG_E_NULLPTR;
-  const uint32_t inv = recip16(N);
-  if (!inv) return GG_E_BADSIZE;
-  hipStream_t s = (hipStream_t)hip_stream;
-  const int grid = grid_for((B + 1) / 2);
+  GG_ENTER(in);
+  if (!actions || !out) return GG_E_NULLPTR;
+  const int grid = grid_for(cus, (B + 1) / 2);
 #define GG_K(R, F) k_next_states_p<R, F><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)
   GG_DISPATCH_N(N);
 #undef GG_K
@@ -406,21 +311,18 @@ int32_t gg_batch_next_states_packed(const uint32_t *in, const int32_t *actions, 
 
 int32_t gg_batch_rollout_packed(uint32_t *packed, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B,
                                 int32_t N, int32_t plies, int32_t auto_reset, void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
   if (plies < 0) return GG_E_BADARG;
-  if (B == 0 || plies == 0) return 0;
-  if (!packed || !rng) return GG_E_NULLPTR;
-  const uint32_t inv = recip16(N);
-  if (!inv) return GG_E_BADSIZE;
-  hipStream_t s = (hipStream_t)hip_stream;
+  GG_ENTER(packed);
+  if (plies == 0) return 0;
+  if (!rng) return GG_E_NULLPTR;
   uint8_t *st = reinterpret_cast<uint8_t *>(packed);
-  if (use_v3(B, plies)) {
+  if (use_v3(cus, B, plies)) {
     int grid3;
-    const int nb = v3_boards_per_wave(B, grid3);
+    const int nb = v3_boards_per_wave(cus, B, grid3);
     GG_DISPATCH3(N, 1, false, grid3, st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
     return (int32_t)hipGetLastError();
   }
-  const int grid = grid_for((B + 1) / 2);
+  const int grid = grid_for(cus, (B + 1) / 2);
 #define GG_K(R, F) k_rollout2<R, false, true, F><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
   GG_DISPATCH_N(N);
 #undef GG_K
@@ -430,14 +332,10 @@ int32_t gg_batch_rollout_packed(uint32_t *packed, uint64_t *rng, int32_t *last_a
 int32_t gg_batch_env_step_packed(uint32_t *packed, const int32_t *actions, uint64_t *rng, float *rewards, uint8_t *dones,
                                  int32_t *status, int32_t *taken_actions, int64_t B, int32_t N, float komi,
                                  int32_t reward_method, int32_t auto_reset, void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
   if (reward_method != GG_REWARD_REAL && reward_method != GG_REWARD_HEURISTIC) return GG_E_BADARG;
-  if (B == 0) return 0;
-  if (!packed || (!actions && !rng)) return GG_E_NULLPTR;
-  const uint32_t inv = recip16(N);
-  if (!inv) return GG_E_BADSIZE;
-  hipStream_t s = (hipStream_t)hip_stream;
-  const int grid = grid_for((B + 1) / 2);
+  GG_ENTER(packed);
+  if (!actions && !rng) return GG_E_NULLPTR;
+  const int grid = grid_for(cus, (B + 1) / 2);
   uint8_t *st = reinterpret_cast<uint8_t *>(packed);
   if (reward_method == GG_REWARD_HEURISTIC) {
 #define GG_K(R, F) k_env_step2<R, true, true, F><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
@@ -453,19 +351,10 @@ int32_t gg_batch_env_step_packed(uint32_t *packed, const int32_t *actions, uint6
 
 int32_t gg_batch_children_packed(const uint32_t *packed, uint32_t *children, int64_t B, int32_t N, int32_t canonical,
                                  void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
-  if (B == 0) return 0;
-  if (!packed || !children) return GG_E_NULLPTR;
-  const uint32_t inv = recip16(N);
-  if (!inv) return GG_E_BADSIZE;
-  hipStream_t s = (hipStream_t)hip_stream;
-  const int A = N * N + 1;
-  int cus = device_cus();
-  if (cus <= 0) cus = 256;
-  int chunks = (int)(((int64_t)cus * 64 + B - 1) / B);
-  if (chunks < 1) chunks = 1;
-  if (chunks > A) chunks = A;
-  const int grid = grid_for(B * chunks);
+  GG_ENTER(packed);
+  if (!children) return GG_E_NULLPTR;
+  const int chunks = children_chunks(cus, B, N * N + 1);
+  const int grid = grid_for(cus, B * chunks);
   const uint8_t *st = reinterpret_cast<const uint8_t *>(packed);
   uint8_t *ch = reinterpret_cast<uint8_t *>(children);
   GG_DISPATCH(N, (k_children3<9, true><<<grid, kWave, 0, s>>>(st, ch, B, N, inv, canonical, chunks)),
@@ -476,20 +365,16 @@ int32_t gg_batch_children_packed(const uint32_t *packed, uint32_t *children, int
 
 int32_t gg_batch_play_moves(uint8_t *states, const int32_t *moves, int32_t *played, int64_t B, int32_t N, int32_t T,
                             void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
   if (T < 0) return GG_E_BADARG;
-  if (B == 0) return 0;
-  if (!states || (T > 0 && !moves)) return GG_E_NULLPTR;
-  const uint32_t inv = recip16(N);
-  if (!inv) return GG_E_BADSIZE;
-  hipStream_t s = (hipStream_t)hip_stream;
-  if (use_v3(B, T)) {
+  GG_ENTER(states);
+  if (T > 0 && !moves) return GG_E_NULLPTR;
+  if (use_v3(cus, B, T)) {
     int grid3;
-    const int nb = v3_boards_per_wave(B, grid3);
+    const int nb = v3_boards_per_wave(cus, B, grid3);
     GG_DISPATCH3(N, 0, true, grid3, states, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played);
     return (int32_t)hipGetLastError();
   }
-  const int grid = grid_for((B + 1) / 2);
+  const int grid = grid_for(cus, (B + 1) / 2);
   GG_DISPATCH(N, (k_play_moves2<9, false><<<grid, kWave, 0, s>>>(states, moves, played, B, N, inv, T)),
               (k_play_moves2<13, false><<<grid, kWave, 0, s>>>(states, moves, played, B, N, inv, T)),
               (k_play_moves2<19, false><<<grid, kWave, 0, s>>>(states, moves, played, B, N, inv, T)));
@@ -498,21 +383,17 @@ int32_t gg_batch_play_moves(uint8_t *states, const int32_t *moves, int32_t *play
 
 int32_t gg_batch_play_moves_packed(uint32_t *packed, const int32_t *moves, int32_t *played, int64_t B, int32_t N, int32_t T,
                                    void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
   if (T < 0) return GG_E_BADARG;
-  if (B == 0) return 0;
-  if (!packed || (T > 0 && !moves)) return GG_E_NULLPTR;
-  const uint32_t inv = recip16(N);
-  if (!inv) return GG_E_BADSIZE;
-  hipStream_t s = (hipStream_t)hip_stream;
+  GG_ENTER(packed);
+  if (T > 0 && !moves) return GG_E_NULLPTR;
   uint8_t *st = reinterpret_cast<uint8_t *>(packed);
-  if (use_v3(B, T)) {
+  if (use_v3(cus, B, T)) {
     int grid3;
-    const int nb = v3_boards_per_wave(B, grid3);
+    const int nb = v3_boards_per_wave(cus, B, grid3);
     GG_DISPATCH3(N, 1, true, grid3, st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played);
     return (int32_t)hipGetLastError();
   }
-  const int grid = grid_for((B + 1) / 2);
+  const int grid = grid_for(cus, (B + 1) / 2);
   GG_DISPATCH(N, (k_play_moves2<9, true><<<grid, kWave, 0, s>>>(st, moves, played, B, N, inv, T)),
               (k_play_moves2<13, true><<<grid, kWave, 0, s>>>(st, moves, played, B, N, inv, T)),
               (k_play_moves2<19, true><<<grid, kWave, 0, s>>>(st, moves, played, B, N, inv, T)));
@@ -523,13 +404,9 @@ int32_t gg_batch_play_moves_packed(uint32_t *packed, const int32_t *moves, int32
 int32_t gg_tracked_words(int32_t N) { return (N < 2 || N > GG_MAX_BOARD) ? GG_E_BADSIZE : 5 * N + 1; }
 
 int32_t gg_batch_track_states(const uint8_t *states, uint32_t *tracked, int64_t B, int32_t N, void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
-  if (B == 0) return 0;
-  if (!states || !tracked) return GG_E_NULLPTR;
-  const uint32_t inv = recip16(N);
-  if (!inv) return GG_E_BADSIZE;
-  hipStream_t s = (hipStream_t)hip_stream;
-  const int grid = grid_for((B + 1) / 2);
+  GG_ENTER(states);
+  if (!tracked) return GG_E_NULLPTR;
+  const int grid = grid_for(cus, (B + 1) / 2);
   GG_DISPATCH(N, (k_track<9><<<grid, kWave, 0, s>>>(states, tracked, B, N, inv)),
               (k_track<13><<<grid, kWave, 0, s>>>(states, tracked, B, N, inv)),
               (k_track<19><<<grid, kWave, 0, s>>>(states, tracked, B, N, inv)));
@@ -537,11 +414,9 @@ int32_t gg_batch_track_states(const uint8_t *states, uint32_t *tracked, int64_t 
 }
 
 int32_t gg_batch_untrack_states(const uint32_t *tracked, uint8_t *states, int64_t B, int32_t N, void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
-  if (B == 0) return 0;
-  if (!states || !tracked) return GG_E_NULLPTR;
-  hipStream_t s = (hipStream_t)hip_stream;
-  const int grid = grid_for((B + 1) / 2);
+  GG_ENTER(tracked);
+  if (!states) return GG_E_NULLPTR;
+  const int grid = grid_for(cus, (B + 1) / 2);
   GG_DISPATCH(N, (k_unpack<9><<<grid, kWave, 0, s>>>(tracked, states, B, N, 5)),
               (k_unpack<13><<<grid, kWave, 0, s>>>(tracked, states, B, N, 5)),
               (k_unpack<19><<<grid, kWave, 0, s>>>(tracked, states, B, N, 5)));
@@ -550,32 +425,25 @@ int32_t gg_batch_untrack_states(const uint32_t *tracked, uint8_t *states, int64_
 
 int32_t gg_batch_rollout_tracked(uint32_t *tracked, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B,
                                  int32_t N, int32_t plies, int32_t auto_reset, void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
   if (plies < 0) return GG_E_BADARG;
-  if (B == 0 || plies == 0) return 0;
-  if (!tracked || !rng) return GG_E_NULLPTR;
-  const uint32_t inv = recip16(N);
-  if (!inv) return GG_E_BADSIZE;
-  hipStream_t s = (hipStream_t)hip_stream;
+  GG_ENTER(tracked);
+  if (plies == 0) return 0;
+  if (!rng) return GG_E_NULLPTR;
   uint8_t *st = reinterpret_cast<uint8_t *>(tracked);
   int grid3;
-  const int nb = v3_boards_per_wave(B, grid3);
+  const int nb = v3_boards_per_wave(cus, B, grid3);
   GG_DISPATCH3(N, 2, false, grid3, st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
   return (int32_t)hipGetLastError();
 }
 
 int32_t gg_batch_play_moves_tracked(uint32_t *tracked, const int32_t *moves, int32_t *played, int64_t B, int32_t N, int32_t T,
                                     void *hip_stream) {
-  if (int32_t e = check(B, N)) return e;
   if (T < 0) return GG_E_BADARG;
-  if (B == 0) return 0;
-  if (!tracked || (T > 0 && !moves)) return GG_E_NULLPTR;
-  const uint32_t inv = recip16(N);
-  if (!inv) return GG_E_BADSIZE;
-  hipStream_t s = (hipStream_t)hip_stream;
+  GG_ENTER(tracked);
+  if (T > 0 && !moves) return GG_E_NULLPTR;
   uint8_t *st = reinterpret_cast<uint8_t *>(tracked);
   int grid3;
-  const int nb = v3_boards_per_wave(B, grid3);
+  const int nb = v3_boards_per_wave(cus, B, grid3);
   GG_DISPATCH3(N, 2, true, grid3, st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played);
   return (int32_t)hipGetLastError();
 }
@@ -584,6 +452,7 @@ int32_t gg_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64
   if (B < 0) return GG_E_BADSIZE;
   if (B == 0) return 0;
   if (!rng) return GG_E_NULLPTR;
+  OnDeviceOf on_dev(rng);
   hipStream_t s = (hipStream_t)hip_stream;
   k_rng_seed<<<(unsigned)((B + 255) / 256), 256, 0, s>>>(rng, base_seed, first_game, B);
   return (int32_t)hipGetLastError();

@@ -1,15 +1,15 @@
-// gg_v2.h - kernel family v2 (default): TWO BOARDS PER WAVEFRONT, constant-weight liberty code.
+// gg_v2.h - the per-ply kernels: TWO BOARDS PER WAVEFRONT, every liberty class from scratch (constant-weight code).
 #pragma once
 #include "gg_common.h"
 
 namespace gg {
 
 // ===================================================================== v2: TWO BOARDS PER WAVEFRONT
-// Lanes 0-31 own board A, lanes 32-63 board B (h = lane >> 5, hl = lane & 31).  Everything that is
-// wave-uniform in v1 (action, turn, pass / done flags, ko point) is a per-lane value that is equal
-// inside a half; ballots are split into their 32-bit halves.
+// Lanes 0-31 own board A, lanes 32-63 board B (h = lane >> 5, hl = lane & 31).  Everything that would be
+// wave-uniform with one board per wave (action, turn, pass / done flags, ko point) is a per-lane value that is
+// equal inside a half; ballots are split into their 32-bit halves.
 //
-// Liberty classes: instead of 20 (bit, value) classes, a CONSTANT-WEIGHT CODE - point q = 19 r + c gets
+// Liberty classes: a CONSTANT-WEIGHT CODE - point q = 19 r + c gets
 // the q-th 11-bit word of weight 5 (C(11,5) = 462 >= 361); flood i (11 per colour, 22 lanes per board) is
 // seeded from the empty points whose word has bit i.  A group with one liberty is reached by exactly 5
 // floods, a group with two or more distinct liberties by >= 6 (two different weight-5 words), a group with
@@ -533,61 +533,6 @@ __global__ __launch_bounds__(kWave, 4) void k_next_states_p(const uint32_t *__re
   }
 }
 
-template <int R>
-__global__ __launch_bounds__(kWave, 3) void k_next_states2s(const uint8_t *__restrict__ in,
-                                                        const int32_t *__restrict__ actions,
-                                                        uint8_t *__restrict__ out, int32_t *__restrict__ status,
-                                                        int64_t B, int N, uint32_t inv, int canonical) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
-  const Half hf = make_half(threadIdx.x, N, inv);
-  __shared__ uint2 lut[256];
-  load_cw_table<R>(lds, hf.lane);
-  load_spread_lut(lut, hf.lane);
-  const int S = 6 * hf.P;
-  uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
-  const int64_t npairs = (B + 1) >> 1;
-  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
-    const int64_t b0 = 2 * p + hf.h;
-    const bool on = b0 < B;
-    const int64_t b = on ? b0 : B - 1;
-    const uint8_t *gi = in + b * (int64_t)S;
-    uint8_t *go = out + b * (int64_t)S;
-    int a = actions[b];
-    const bool in_range = a >= 0 && a <= hf.P;
-    const bool is_pass = a == hf.P;
-    uint32_t flags = load_flags_h(gi, hf.P, (in_range && !is_pass) ? a : 0, hf);
-    const bool illegal = !in_range || (!is_pass && (flags & 2u));
-    WAVE_SYNC();
-    const uint32_t mi = stage_in_h(gi, 2 * hf.P, io, hf.hl);
-    WAVE_SYNC();
-    if (__ballot(!illegal) == 0) {  // both rows pass through unchanged (gogame.py:59 / :117 would raise)
-      copy_row_h(gi, go, S, hf.hl, on);
-      if (status && on && hf.hl == 0) status[b] = GG_STATUS_ILLEGAL;
-      continue;
-    }
-    uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
-    uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
-    const int pl = flags & 1u;
-    uint32_t mine = pl ? white : black, opp = pl ? black : white;
-    // an illegal half still runs the (wave-wide) analysis on a harmless pass, its result is discarded
-    uint32_t atari_unused;
-    uint32_t invalid = step_core2<R, false>(mine, opp, illegal ? hf.P : a, hf, lds, 0u, false, atari_unused);
-    black = pl ? opp : mine;
-    white = pl ? mine : opp;
-    uint32_t passed = is_pass ? 1 : 0;
-    uint32_t done = ((flags & 8u) || (is_pass && (flags & 4u))) ? 1 : 0;
-    int nturn = 1 - pl;
-    if (canonical && nturn == 1) {
-      uint32_t t = black; black = white; white = t;
-      nturn = 0;
-    }
-    emit_store_h<R>(go, black, white, invalid, (uint32_t)nturn, passed, done, hf,
-                    reinterpret_cast<uint32_t *>(io), lut, on && !illegal);
-    if (illegal) copy_row_h(gi, go, S, hf.hl, on);  // rare: the row passes through unchanged
-    if (status && on && hf.hl == 0) status[b] = illegal ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
-  }
-}
-
 // ---------------------------------------------------------------- software-pipelined board I/O (LDS-DMA)
 // A per-ply kernel is a chain  load board -> analyse -> store board  per wave, and with 3-4 waves per SIMD the HBM
 // round trip of the load (and the acknowledgement of the store) is NOT hidden by the other waves: bytes in flight =
@@ -1033,109 +978,11 @@ __global__ __launch_bounds__(kWave, PACKED ? 4 : GG_LB_PLY) void k_env_step2(uin
   }
 }
 
-// all-zero child slot straight from registers (no LDS round trip), aligned vectors + one byte-store for the edges
-__device__ __forceinline__ void stage_zero_h(uint8_t *g, int nbytes, int hl, bool on) {
-  if (!on) return;
-  const uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
-  uint8_t *ga = g - mis;
-  const int end = (int)mis + nbytes;
-  const int v0 = mis ? 1 : 0, v1 = end >> 4;
-  const V16a z = {{0u, 0u, 0u, 0u}};
-  for (int v = v0 + hl; v < v1; v += 32) *reinterpret_cast<V16a *>(ga + 16 * v) = z;
-  if (v1 >= v0) {
-    const int head = mis ? 16 - (int)mis : 0, tail = end & 15;
-    int j = -1;
-    if (hl < 16) { if (hl < head) j = hl; }
-    else if (hl - 16 < tail) j = nbytes - tail + (hl - 16);
-    if (j >= 0) g[j] = 0;
-  } else {
-    for (int i = hl; i < nbytes; i += 32) g[i] = 0;
-  }
-}
-
-// gogame.children, two slots per wave pass.  The legal actions of the chunk are compacted first (k-th set bit of the
-// valid-point rows, as in the sampler) so that both halves always expand a legal action; the all-zero slots of
-// the illegal actions are written in a separate store-only loop.
-template <int R>
-__global__ __launch_bounds__(kWave, 4) void k_children2(const uint8_t *__restrict__ states,
-                                                        uint8_t *__restrict__ children, int64_t B, int N,
-                                                        uint32_t inv, int canonical, int chunks) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
-  const Half hf = make_half(threadIdx.x, N, inv);
-  __shared__ uint2 lut[256];
-  load_cw_table<R>(lds, hf.lane);
-  load_spread_lut(lut, hf.lane);
-  const int S = 6 * hf.P;
-  const int A = hf.P + 1;
-  uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
-  const int per = (A + chunks - 1) / chunks;
-  for (int64_t w = blockIdx.x; w < B * chunks; w += gridDim.x) {
-    const int64_t b = w / chunks;
-    const int ch = (int)(w - b * chunks);
-    const uint8_t *gi = states + b * (int64_t)S;
-    uint8_t *gc = children + b * A * (int64_t)S;
-    uint32_t flags = load_flags_h(gi, hf.P, 0, hf);
-    WAVE_SYNC();
-    const uint32_t mi = stage_in_h(gi, 4 * hf.P, io, hf.hl);  // both halves stage the same parent (second copy: L2)
-    WAVE_SYNC();
-    const uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
-    const uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
-    const uint32_t invd = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
-    const int pl = flags & 1u;
-    const int a0 = ch * per, a1 = min(A, a0 + per);
-    const int p1 = min(a1, hf.P);  // points of the chunk: [a0, p1); the pass slot is in the chunk iff a1 == A
-    // rows of this chunk's points
-    const int base = hf.hl * N;
-    const int lo = max(0, min(N, a0 - base)), hi = max(0, min(N, p1 - base));
-    const uint32_t inrange = (hi > lo) ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
-    const uint32_t vr = hf.full_l1 & ~invd & inrange;
-    const uint32_t incl = half_scan((uint32_t)__popc(vr));
-    const int npts = __builtin_amdgcn_readlane((int)incl, 31);
-    const int nv = npts + (a1 == A ? 1 : 0);
-    // The all-zero slots of the illegal points are store-only work; they are interleaved with the compute passes
-    // (q zero steps after every pass) so that the write stream is spread over the whole life of the wave.
-    int az = a0;
-    const int npass = (nv + 1) >> 1, nzero = (p1 - a0 + 1) >> 1;
-    const int q = npass > 0 ? (nzero + npass - 1) / npass : nzero;
-    auto zero_step = [&](int aj) {
-      const int a = aj + hf.h;
-      bool zero = false;
-      if (a < p1) {
-        const int ra = (int)(((uint32_t)a * inv) >> 16), ca = a - ra * N;
-        uint32_t row = __shfl(invd, (hf.lane & 32) + ra);
-        zero = ((row >> ca) & 1u) != 0;
-      }
-      stage_zero_h(gc + (int64_t)(a < p1 ? a : a0) * S, S, hf.hl, zero);
-    };
-#pragma unroll 1
-    for (int j = 0; j < nv; j += 2) {
-      const int k = j + hf.h;
-      const bool on = k < nv;
-      const int a = on ? pick_action2(vr, incl, (uint32_t)k, hf) : hf.P;  // k == npts -> pass
-      const bool is_pass = a == hf.P;
-      uint32_t mine = pl ? white : black, opp = pl ? black : white;
-      uint32_t atari_unused;
-      uint32_t invalid = step_core2<R, true>(mine, opp, a, hf, lds, 0u, false, atari_unused);
-      uint32_t nb = pl ? opp : mine, nw = pl ? mine : opp;
-      uint32_t passed = is_pass ? 1 : 0;
-      uint32_t done = ((flags & 8u) || (is_pass && (flags & 4u))) ? 1 : 0;
-      int nturn = 1 - pl;
-      if (canonical && nturn == 1) {
-        uint32_t t = nb; nb = nw; nw = t;
-        nturn = 0;
-      }
-      uint8_t *go = gc + (int64_t)a * S;
-      emit_store_h<R>(go, nb, nw, invalid, (uint32_t)nturn, passed, done, hf, reinterpret_cast<uint32_t *>(io), lut, on);
-      for (int t = 0; t < q && az < p1; ++t, az += 2) zero_step(az);
-    }
-    for (; az < p1; az += 2) zero_step(az);
-  }
-}
 
 // gogame.children (gym_go/gogame.py:175-186), INCREMENTAL: one parent per wave, analysed once, every child derived from it.
 //
-// k_children2 re-analyses every child from scratch (~950 VALU per pair of children, which makes the kernel VALU-bound
-// at half of the HBM-write roofline).  But a child differs from its parent by one stone plus its captures, and only
+// Re-analysing every child from scratch costs ~950 VALU per pair of children, which made the kernel VALU-bound at half
+// of the HBM-write roofline (round 1).  But a child differs from its parent by one stone plus its captures, and only
 // the groups adjacent to the new stone q (and, rarely, to a captured group) change their liberty count:
 //   * opponent groups adjacent to q lose exactly the liberty q: count 1 -> captured, 2 -> atari, >= 3 -> still >= 2;
 //   * the mover's groups adjacent to q merge with the new stone into G, whose liberties are dilate(G) & empty';

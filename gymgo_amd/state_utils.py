@@ -108,35 +108,36 @@ def _killed_groups(mask):
     return groups
 
 
-def _point_of(state_np, adj_locs, player):
-    """The just-placed stone is the one point of `player` adjacent to every location of adj_locs."""
-    n = state_np.shape[-1]
-    adj = np.asarray(adj_locs).reshape(-1, 2)
-    cand = None
-    for r, c in adj:
-        around = {(r + dr, c + dc) for dr, dc in neighbor_deltas if 0 <= r + dr < n and 0 <= c + dc < n}
-        cand = around if cand is None else cand & around
-    cand = [p for p in (cand or ()) if state_np[player, p[0], p[1]] == 1] or list(cand or ())
-    return cand[0][0] * n + cand[0][1] if cand else -1
+def _adj_table(batch_adj_locs, n):
+    """list of [k, 2] location arrays -> int32 [B, K] flat indices, padded with -1 (K = the longest list, >= 4)."""
+    rows = [np.asarray(a, dtype=np.int64).reshape(-1, 2) for a in batch_adj_locs]
+    K = max([4] + [len(r) for r in rows])
+    table = np.full((len(rows), K), -1, dtype=np.int32)
+    for i, r in enumerate(rows):
+        ok = ((r >= 0) & (r < n)).all(axis=1)
+        table[i, :len(r)] = np.where(ok, r[:, 0] * n + r[:, 1], -1)
+    return table
 
 
 def batch_update_pieces(batch_non_pass, batch_state, batch_adj_locs, batch_player):
     """gym_go/state_utils.py:183-211: removes captured opponent groups IN PLACE for the games listed in
     batch_non_pass and returns their killed groups (list per game of [k, 2] arrays).  Each game is treated
-    with update_pieces semantics (the reference's zip mis-alignment with passes, :187-193, is not reproduced)."""
+    with update_pieces semantics (the reference's zip mis-alignment with passes, :187-193, is not reproduced).
+    The adj_locs go to the kernel as they are (gg_batch_update_pieces): nothing is inferred about the position."""
     is_t = isinstance(batch_state, torch.Tensor)
-    host = batch_state.cpu().numpy() if is_t else np.asarray(batch_state)
+    host = batch_state if is_t else np.asarray(batch_state)
     idx = np.asarray(batch_non_pass, dtype=np.int64).reshape(-1)
     players = np.asarray(batch_player, dtype=np.int32).reshape(-1)
-    points = np.array([_point_of(host[i], adj, int(p)) for i, adj, p in zip(idx, batch_adj_locs, players)], np.int32)
+    n = host.shape[-1]
+    adj = _adj_table(batch_adj_locs, n)
     sub = _Box(host[idx] if not is_t else batch_state[torch.as_tensor(idx, device=batch_state.device)])
     t = sub.t.clone()
     B, _, N, _ = t.shape
     killed = torch.empty((B, N, N), dtype=torch.uint8, device=t.device)
-    pts = torch.from_numpy(points).to(t.device)
+    adj_t = torch.from_numpy(adj).to(t.device)
     pls = torch.from_numpy(players).to(t.device)
-    code = _lib.lib().gg_batch_update_pieces(_lib.dev_ptr(t, torch.uint8, 'states'), _lib.dev_ptr(pts, torch.int32, 'points'),
-                                             _lib.dev_ptr(pls, torch.int32, 'players'),
+    code = _lib.lib().gg_batch_update_pieces(_lib.dev_ptr(t, torch.uint8, 'states'), _lib.dev_ptr(adj_t, torch.int32, 'adj'),
+                                             adj.shape[1], _lib.dev_ptr(pls, torch.int32, 'players'),
                                              _lib.dev_ptr(killed, torch.uint8, 'killed'), B, N, _lib.stream_ptr(t.device))
     _lib.check(code, 'gg_batch_update_pieces')
     if is_t:

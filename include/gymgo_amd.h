@@ -11,9 +11,12 @@
  *     (0 black, 1 white, 2 turn, 3 invalid moves for the side to move, 4 previous move was a pass,
  *     5 game over).  Planes 2, 4 and 5 are uniform by construction (the reference only ever writes
  *     them whole: gym_go/gogame.py:49-56, gym_go/state_utils.py:241); the kernels read one byte of each.
- *   - Every pointer is a DEVICE pointer owned by the caller; the library allocates nothing, keeps no
- *     global state besides a cached device-property query, and never synchronises: work is enqueued
- *     on `hip_stream` (a hipStream_t, NULL = default stream) and the call returns immediately.
+ *   - Every pointer is a DEVICE pointer owned by the caller; the library allocates nothing, reads no environment
+ *     variable, keeps no mutable global state besides a per-device cache of the CU count, and never synchronises:
+ *     work is enqueued on `hip_stream` (a hipStream_t of the device that owns the buffers, NULL = its default
+ *     stream) and the call returns immediately.  The kernels run on the device that owns the first buffer argument,
+ *     whatever the calling thread's current device is (it is restored before the call returns).
+ *   - Which kernel serves a call depends on its arguments only (board size, batch size, plies per launch).
  *   - 2 <= N <= 19.  Actions are int32 in [0, N*N]; N*N = pass (gym_go/gogame.py:40-42).
  *   - Return value: 0 on success, a hipError_t (> 0) for launch/runtime errors, or a negative
  *     GG_E_* code for bad arguments.  Re-entrant; safe from several threads / one process per GPU.
@@ -27,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 1
+#define GG_ABI_VERSION 2
 #define GG_MAX_BOARD 19
 #define GG_NUM_CHNLS 6
 
@@ -42,7 +45,7 @@ extern "C" {
 
 int32_t gg_version(void);
 
-/* Number of compute units of the current device (0 if no device) - lets the host mirror size grids. */
+/* Number of compute units of the calling thread's current device (0 if no device) - lets the host mirror size grids. */
 int32_t gg_device_cus(void);
 
 /*
@@ -127,11 +130,15 @@ int32_t gg_batch_sample_actions(const uint8_t *states, uint64_t *rng, int32_t *a
 
 /*
  * state_utils.update_pieces / batch_update_pieces                       gym_go/state_utils.py:159-211
- * Stand-alone capture resolution (inside gg_batch_next_states it is fused): the stone of players[b] already
- * stands at points[b]; opponent groups touching it that have no liberty are removed IN PLACE (planes 0/1)
- * and marked in killed (uint8 [B][N][N], nullable).  points[b] outside [0, N*N): game b is left untouched.
+ * Stand-alone capture resolution (inside gg_batch_next_states it is fused), with the reference's own inputs:
+ * adj is int32 [B][K] - the locations whose opponent groups are examined, as flat indices r * N + c (the reference
+ * passes the on-board neighbours of the stone just placed: adj_locs of state_utils.adj_data, :214-223, so K = 4;
+ * entries outside [0, N*N) are unused) - and players[b] is the side that moved.  Every group of the OTHER colour that
+ * holds one of these locations and has no empty point next to it - liberties are taken on the position as given,
+ * before any removal, like `empties` at :164 - is removed IN PLACE (planes 0/1) and marked in killed
+ * (uint8 [B][N][N], nullable).  The position need not be reachable by legal play.
  */
-int32_t gg_batch_update_pieces(uint8_t *states, const int32_t *points, const int32_t *players, uint8_t *killed,
+int32_t gg_batch_update_pieces(uint8_t *states, const int32_t *adj, int32_t K, const int32_t *players, uint8_t *killed,
                                int64_t B, int32_t N, void *hip_stream);
 
 /*

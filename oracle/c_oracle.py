@@ -48,6 +48,8 @@ def lib():
         L.gg_oracle_batch_rollout.restype = None
         L.gg_oracle_batch_rollout.argtypes = [_u8p, _u64p, _i32p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                               ctypes.c_int32]
+        L.gg_oracle_update_pieces.restype = ctypes.c_int32
+        L.gg_oracle_update_pieces.argtypes = [_u8p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _u8p]
         _lib = L
     return _lib
 
@@ -121,3 +123,55 @@ def batch_rollout(states, rng, plies, auto_reset=True):
     lib().gg_oracle_batch_rollout(states.ctypes.data_as(_u8p), rng.ctypes.data_as(_u64p),
                                   last.ctypes.data_as(_i32p), B, N, int(plies), int(bool(auto_reset)))
     return states, rng, last
+
+
+def update_pieces(state, adj_flat, player):
+    """state_utils.update_pieces on a copy -> (state after, killed mask [N,N], number of killed groups)."""
+    state = np.array(state, dtype=np.uint8, copy=True, order='C')
+    N = state.shape[-1]
+    adj = np.ascontiguousarray(adj_flat, dtype=np.int32).reshape(-1)
+    killed = np.zeros((N, N), dtype=np.uint8)
+    n = lib().gg_oracle_update_pieces(state.ctypes.data_as(_u8p), N, adj.ctypes.data_as(_i32p), len(adj), int(player),
+                                      killed.ctypes.data_as(_u8p))
+    return state, killed, n
+
+
+def _chunks(B, workers):
+    step = max(1, (B + workers - 1) // workers)
+    return [(lo, min(B, lo + step)) for lo in range(0, B, step)]
+
+
+def parallel(fn, B, workers=None):
+    """Run fn(lo, hi) over slices of a batch on a thread pool (the C calls release the GIL): the oracle stays a
+    one-thread-per-board restatement, large parity batches just use every host core."""
+    import concurrent.futures as cf
+    workers = workers or min(32, os.cpu_count() or 1)
+    parts = _chunks(B, workers)
+    if len(parts) <= 1:
+        return [fn(0, B)]
+    with cf.ThreadPoolExecutor(len(parts)) as ex:
+        return list(ex.map(lambda p: fn(*p), parts))
+
+
+def batch_rollout_mt(states, rng, plies, auto_reset=True, workers=None):
+    """batch_rollout over host threads -> (states, rng, last_actions)."""
+    B = len(states)
+    out = parallel(lambda lo, hi: batch_rollout(states[lo:hi], rng[lo:hi], plies, auto_reset), B, workers)
+    return (np.concatenate([o[0] for o in out]), np.concatenate([o[1] for o in out]), np.concatenate([o[2] for o in out]))
+
+
+def batch_next_states_mt(states, actions, canonical=False, workers=None):
+    B = len(states)
+    out = parallel(lambda lo, hi: batch_next_states(states[lo:hi], actions[lo:hi], canonical), B, workers)
+    return np.concatenate([o[0] for o in out]), np.concatenate([o[1] for o in out])
+
+
+def batch_children_mt(states, canonical=False, workers=None):
+    B = len(states)
+    return np.concatenate(parallel(lambda lo, hi: batch_children(states[lo:hi], canonical), B, workers))
+
+
+def batch_areas_mt(states, workers=None):
+    B = len(states)
+    out = parallel(lambda lo, hi: batch_areas(states[lo:hi]), B, workers)
+    return np.concatenate([o[0] for o in out]), np.concatenate([o[1] for o in out])

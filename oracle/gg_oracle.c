@@ -149,13 +149,13 @@ static int adj_data(const uint8_t *state, int N, int a, int player, int *nbr, in
 /* gym_go/state_utils.py:159-180 update_pieces: remove the opponent groups adjacent to the move
  * that have no liberty.  Returns the number of killed groups; *single = flat index of the stone
  * when exactly one group of exactly one stone died, else -1. */
-static int update_pieces(uint8_t *state, int N, const int *nbr, int k, int player, int *single)
+static int update_pieces_n(uint8_t *state, int N, const int *nbr, int k, int player, int *single)
 {
     int P = N * N, killed = 0, killed_stones = 0, last = -1;
     uint8_t *oppp = state + (size_t)(1 - player) * P;
     uint8_t empties[GG_MAXP], libmap[GG_MAXP];
     int16_t lab[GG_MAXP];
-    int seen[4], ns = 0;
+    int seen[64], ns = 0;
     for (int p = 0; p < P; ++p) empties[p] = (uint8_t)(1 - (state[p] + state[P + p])); /* :163-164 */
     label4(oppp, N, lab);                                                              /* :166 */
     for (int i = 0; i < k; ++i) {                                                      /* :169-171 */
@@ -174,6 +174,28 @@ static int update_pieces(uint8_t *state, int N, const int *nbr, int k, int playe
     }
     *single = (killed == 1 && killed_stones == 1) ? last : -1;
     return killed;
+}
+
+/* The same as a stand-alone entry (state_utils.update_pieces as the reference exposes it: any state, any list of
+ * locations): planes 0/1 of `state` are edited in place, killed[p] = 1 for every removed stone (nullable).
+ * adj: k flat indices, entries outside [0, N*N) are skipped.  Returns the number of killed groups. */
+int32_t gg_oracle_update_pieces(uint8_t *state, int32_t N, const int32_t *adj, int32_t k, int32_t player, uint8_t *killed)
+{
+    int P = N * N, n = 0, single, nbr[64];
+    uint8_t before[GG_MAXP];
+    const uint8_t *oppp = state + (size_t)(1 - player) * P;
+    for (int i = 0; i < k && n < 64; ++i)
+        if (adj[i] >= 0 && adj[i] < P) nbr[n++] = adj[i];
+    memcpy(before, oppp, (size_t)P);
+    int groups = update_pieces_n(state, N, nbr, n, player, &single);
+    if (killed)
+        for (int p = 0; p < P; ++p) killed[p] = (uint8_t)(before[p] && !oppp[p]);
+    return groups;
+}
+
+static int update_pieces(uint8_t *state, int N, const int *nbr, int k, int player, int *single)
+{
+    return update_pieces_n(state, N, nbr, k, player, single);
 }
 
 static int plane_max(const uint8_t *pl, int P)

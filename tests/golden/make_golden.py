@@ -10,6 +10,11 @@ Outputs (committed; data only - inputs and expected outputs, no reference source
   batch_passes.npz   mixed pass / move batches answered by STACKED gogame.next_state.
   rollout.npz    actions drawn by the build's counter-based sampler (oracle/gg_oracle.c), replayed
                  through the reference's next_state: final states after K plies.
+  extras.npz     the helpers nothing else pins: gogame.str (text of several positions), gogame.all_symmetries (the 8
+                 views of a [C,N,N] image), state_utils.update_pieces on ARBITRARY (not legally reachable) positions
+                 incl. every corner / edge, with the location lists the reference's callers pass and longer ones.
+
+  python tests/golden/make_golden.py [name ...]     (no name = all of them)
 """
 import hashlib
 import json
@@ -225,13 +230,94 @@ def rollout(gogame, govars):
     np.savez_compressed(os.path.join(HERE, 'rollout.npz'), **out)
 
 
+def extras(gogame, govars, state_utils):
+    rng = np.random.default_rng(17)
+    out = {}
+    # --- gogame.str (gym_go/gogame.py:407-468): empty, mid-game, passed, ended; stones on every edge / corner
+    texts, tstates = [], []
+    for size in (2, 5, 9, 19):
+        s = gogame.init_state(size)
+        tstates.append(u8(s)); texts.append(gogame.str(s))
+        for ply in range(3 * size * size):
+            if gogame.game_ended(s):
+                break
+            valid = np.flatnonzero(np.append(s[govars.INVD_CHNL].ravel(), 0) == 0)
+            s = gogame.next_state(s, int(rng.choice(valid)))
+            if ply % max(1, size * size // 3) == 0 or gogame.prev_player_passed(s):
+                tstates.append(u8(s)); texts.append(gogame.str(s))
+        tstates.append(u8(s)); texts.append(gogame.str(s))
+    for i, (st, tx) in enumerate(zip(tstates, texts)):
+        out['str/%d/state' % i] = st
+        out['str/%d/text' % i] = np.array(tx)
+    out['str/count'] = np.array(len(texts), dtype=np.int32)
+    # --- gogame.all_symmetries (gym_go/gogame.py:362-382) on asymmetric images
+    for j, (c, n) in enumerate(((6, 5), (3, 9), (1, 19), (6, 2))):
+        img = rng.integers(0, 255, size=(c, n, n)).astype(np.uint8)
+        out['sym/%d/image' % j] = img
+        out['sym/%d/views' % j] = np.stack([np.ascontiguousarray(v) for v in gogame.all_symmetries(img)])
+    out['sym/count'] = np.array(4, dtype=np.int32)
+    # --- state_utils.update_pieces (gym_go/state_utils.py:159-180) on arbitrary positions
+    cases = []
+    for size in (2, 3, 5, 9, 19):
+        for trial in range(40 if size < 19 else 24):
+            dens = rng.uniform(0.3, 1.0)
+            cells = rng.random((size, size))
+            stone = cells < dens
+            colour = rng.random((size, size)) < rng.uniform(0.25, 0.75)
+            s = np.zeros((6, size, size))
+            s[0][stone & colour] = 1
+            s[1][stone & ~colour] = 1
+            player = int(rng.integers(0, 2))
+            mode = trial % 4
+            if mode == 0:      # the reference's own call shape: neighbours of a stone of `player`
+                own = np.argwhere(s[player] == 1)
+                if len(own) == 0:
+                    s[player, 0, 0] = 1; s[1 - player, 0, 0] = 0
+                    own = np.array([[0, 0]])
+                corner_bias = [p for p in own if (p[0] in (0, size - 1)) and (p[1] in (0, size - 1))]
+                pt = corner_bias[0] if corner_bias and trial % 8 == 0 else own[rng.integers(len(own))]
+                adj, _ = state_utils.adj_data(s, np.array(pt), player)
+            elif mode == 1:    # neighbours of each corner in turn (whatever stands on the corner)
+                cr = [(0, 0), (0, size - 1), (size - 1, 0), (size - 1, size - 1)][(trial // 4) % 4]
+                adj, _ = state_utils.adj_data(s, np.array(cr), player)
+            elif mode == 2:    # arbitrary locations, duplicates allowed, 1..4 of them
+                k = int(rng.integers(1, 5))
+                adj = rng.integers(0, size, size=(k, 2))
+            else:              # a long list (more than four locations)
+                k = int(rng.integers(5, 9))
+                adj = rng.integers(0, size, size=(k, 2))
+            before = u8(s)
+            groups = state_utils.update_pieces(s, np.asarray(adj), player)
+            killed = np.zeros((size, size), dtype=np.uint8)
+            for g in groups:
+                killed[g[:, 0], g[:, 1]] = 1
+            cases.append((before, np.asarray(adj, dtype=np.int32).reshape(-1, 2), player, u8(s), killed, len(groups)))
+    for i, (before, adj, player, after, killed, ng) in enumerate(cases):
+        k = 'up/%d/' % i
+        out[k + 'state'] = before
+        out[k + 'adj'] = adj
+        out[k + 'player'] = np.array(player, dtype=np.int32)
+        out[k + 'after'] = after
+        out[k + 'killed'] = killed
+        out[k + 'groups'] = np.array(ng, dtype=np.int32)
+    out['up/count'] = np.array(len(cases), dtype=np.int32)
+    n_kill = sum(int(c[5] > 0) for c in cases)
+    np.savez_compressed(os.path.join(HERE, 'extras.npz'), **out)
+    print('extras: %d texts, 4 symmetry images, %d update_pieces cases (%d with captures)' % (len(texts), len(cases), n_kill))
+
+
 def main():
-    gym, gogame, govars, _ = refimport.load()
-    scripted(gym, gogame)
-    random_games(gogame, govars)
-    children(gogame, govars)
-    batch_passes(gogame, govars)
-    rollout(gogame, govars)
+    gym, gogame, govars, state_utils = refimport.load()
+    jobs = {
+        'scripted': lambda: scripted(gym, gogame),
+        'random_games': lambda: random_games(gogame, govars),
+        'children': lambda: children(gogame, govars),
+        'batch_passes': lambda: batch_passes(gogame, govars),
+        'rollout': lambda: rollout(gogame, govars),
+        'extras': lambda: extras(gogame, govars, state_utils),
+    }
+    for name in (sys.argv[1:] or list(jobs)):
+        jobs[name]()
 
 
 if __name__ == '__main__':

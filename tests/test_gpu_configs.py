@@ -1,0 +1,172 @@
+"""-m gpu, run FIRST: one parity test per BASELINE.json config, at the config's own size, HIP (through the C-ABI)
+against the pinned C oracle.  Where the oracle cannot replay the whole batch in seconds it replays a strided
+sub-sample of the games (every game is independent and seeded by its global index, so a sub-sample is exact), and
+the rest of the batch is covered by a cross-check between two independent HIP kernels - named as such below."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+SEED = 20260927
+
+
+def _oracle_rng(c_oracle, idx):
+    return np.array([c_oracle.lib().gg_oracle_rng_seed(SEED, int(i)) for i in idx], dtype=np.uint64)
+
+
+def test_config3_19x19_65536_games_fused_rollout_vs_oracle():
+    """BASELINE config 3 (the headline): 19x19, 65 536 games, uniform-random rollouts with auto-reset, in launches of
+    2 / 30 / 64 / 104 plies (the multi-ply kernel).  ORACLE: 2 048 games (every 32nd) replayed from the empty board,
+    states + generator + last action compared after every launch (200 plies: opening to middle game, captures, kos).
+    HIP-vs-HIP cross-check for all 65 536 games: the same trajectory stepped one ply per launch by the per-ply kernel
+    (every liberty class from scratch each ply) must reach bit-identical states, generators and step counts."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    B, N = 65536, 19
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, SEED)
+    la = torch.empty(B, dtype=torch.int32, device='cuda')
+    sd = torch.zeros(B, dtype=torch.int64, device='cuda')
+    per_ply = st.clone()
+    per_ply_rng = rng.clone()
+    idx = np.arange(0, B, 32)
+    idx_t = torch.as_tensor(idx, device='cuda')
+    want = np.zeros((len(idx), 6, N, N), np.uint8)
+    want_rng = _oracle_rng(c_oracle, idx)
+    total = 0
+    for plies in (2, 30, 64, 104):
+        gogame.batch_rollout(st, rng, plies, True, la, sd)
+        total += plies
+        want, want_rng, want_last = c_oracle.batch_rollout_mt(want, want_rng, plies, True)
+        assert np.array_equal(st[idx_t].cpu().numpy(), want), ('states', total)
+        assert np.array_equal(rng[idx_t].cpu().numpy().view(np.uint64), want_rng), ('rng', total)
+        assert np.array_equal(la[idx_t].cpu().numpy(), want_last), ('last action', total)
+    assert int(sd.min()) == total and int(sd.max()) == total
+    assert int((st[:, 0] | st[:, 1]).sum()) > 100 * B          # the boards really are in the middle game
+    for _ in range(total):
+        gogame.batch_rollout(per_ply, per_ply_rng, 1, True)
+    assert torch.equal(per_ply, st) and torch.equal(per_ply_rng, rng)
+
+
+def test_config2_9x9_4096_games_rollout_vs_oracle():
+    """BASELINE config 2: 9x9, 4 096 games, 150 plies of uniform-random rollouts with auto-reset (whole games incl.
+    double passes and resets) in launches of 1 / 2 / 47 / 100 plies - EVERY game replayed by the oracle."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    B, N = 4096, 9
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, SEED)
+    la = torch.empty(B, dtype=torch.int32, device='cuda')
+    sd = torch.zeros(B, dtype=torch.int64, device='cuda')
+    want = np.zeros((B, 6, N, N), np.uint8)
+    want_rng = _oracle_rng(c_oracle, range(B))
+    for plies in (1, 2, 47, 100):
+        gogame.batch_rollout(st, rng, plies, True, la, sd)
+        want, want_rng, want_last = c_oracle.batch_rollout_mt(want, want_rng, plies, True)
+        assert np.array_equal(st.cpu().numpy(), want), plies
+        assert np.array_equal(rng.cpu().numpy().view(np.uint64), want_rng)
+        assert np.array_equal(la.cpu().numpy(), want_last)
+    assert int(sd.min()) == 150
+    b, w = gogame.batch_areas(st)
+    ob, ow = c_oracle.batch_areas_mt(want)
+    assert np.array_equal(b.cpu().numpy(), ob) and np.array_equal(w.cpu().numpy(), ow)
+
+
+def test_config5_children_of_8192_midgame_parents_vs_oracle():
+    """BASELINE config 5: 19x19, 8 192 mid-game parents (phases 60 ... 330 plies), the padded 362-slot expansion of each
+    (6.4 GB).  ORACLE: every 16th parent (512 parents x 362 slots, both canonical settings on half of them each).
+    HIP-vs-HIP cross-check for all parents: every legal slot equals gg_batch_next_states of the parent (an independent
+    kernel that analyses the child from scratch), every illegal slot is all zero."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    B, N = 8192, 19
+    A = N * N + 1
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, SEED)
+    for g in range(4):
+        gogame.batch_rollout(st[g * 2048:(g + 1) * 2048], rng[g * 2048:(g + 1) * 2048], 60 + 90 * g, auto_reset=False)
+    live = st[:, 5, 0, 0] == 0            # gogame.children of a finished game is undefined in the reference
+    assert int(live.sum()) > 8000
+    st[~live] = 0                          # keep the config's batch size: finished games become empty boards
+    kids = gogame.batch_children(st, canonical=False)
+    assert kids.shape == (B, A, 6, N, N)
+    sub = torch.arange(0, B, 16, device='cuda')
+    host = st[sub].cpu().numpy()
+    assert np.array_equal(kids[sub].cpu().numpy(), c_oracle.batch_children_mt(host, False))
+    half = sub[::2]
+    kids_c = gogame.batch_children(st[half].contiguous(), canonical=True)
+    assert np.array_equal(kids_c.cpu().numpy(), c_oracle.batch_children_mt(host[::2], True))
+    del kids_c
+    valid = torch.cat([st[:, 3].reshape(B, -1) == 0, torch.ones(B, 1, dtype=torch.bool, device='cuda')], 1)
+    assert not bool(kids[~valid].any())
+    acts = torch.arange(A, dtype=torch.int32, device='cuda')
+    for lo in range(0, B, 512):
+        v = valid[lo:lo + 512]
+        ix = v.nonzero()
+        out, status = gogame.batch_next_states(st[lo:lo + 512][ix[:, 0]].contiguous(), acts[ix[:, 1]].contiguous(), check=False)
+        assert int(status.sum()) == 0
+        assert torch.equal(kids[lo:lo + 512][v], out), lo
+
+
+def test_config4_one_rank_shard_of_1048576_games_vs_oracle():
+    """BASELINE config 4: 19x19, 1 048 576 games as 8 shards of 131 072 (one per GPU, no collective).  This is rank 5's
+    shard exactly as bench.py runs it (generator seeded by GLOBAL game index): 131 072 games, launches of 40 + 56 plies;
+    ORACLE: 1 024 games of the shard (every 128th) replayed by global index; and the shard equals the same index range
+    computed inside a larger single-rank batch (shard invariance, HIP-vs-HIP)."""
+    from gymgo_amd import gogame
+    from gymgo_amd.envs.vec_env import shard
+    from oracle import c_oracle
+    total, world, rank, N = 1048576, 8, 5, 19
+    first, count = shard(total, rank, world)
+    assert (first, count) == (5 * 131072, 131072)
+    st = gogame.batch_init_state(count, N, device='cuda')
+    rng = gogame.rng_seed(count, SEED, first)
+    sd = torch.zeros(count, dtype=torch.int64, device='cuda')
+    idx = np.arange(0, count, 128)
+    want = np.zeros((len(idx), 6, N, N), np.uint8)
+    want_rng = _oracle_rng(c_oracle, first + idx)
+    for plies in (40, 56):
+        gogame.batch_rollout(st, rng, plies, True, None, sd)
+        want, want_rng, _ = c_oracle.batch_rollout_mt(want, want_rng, plies, True)
+        assert np.array_equal(st[torch.as_tensor(idx, device='cuda')].cpu().numpy(), want), plies
+    assert int(sd.min()) == 96 and int(sd.max()) == 96
+    lo = first - 4096                      # the shard's first 20 480 games inside a batch that starts earlier
+    wide = gogame.batch_init_state(24576, N, device='cuda')
+    wide_rng = gogame.rng_seed(24576, SEED, lo)
+    gogame.batch_rollout(wide, wide_rng, 40, True)
+    gogame.batch_rollout(wide, wide_rng, 56, True)
+    assert torch.equal(wide[4096:], st[:20480])
+
+
+def test_config1_7x7_single_game_goenv_step_vs_oracle():
+    """BASELINE config 1 (plumbing): one 7x7 game through GoEnv.step - int, (r, c) and None actions - until it ends:
+    every returned state equals the oracle's next_state, info / done / reward agree with it, both reward methods."""
+    from gymgo_amd.envs import make
+    from oracle import c_oracle
+    rs = np.random.default_rng(7)
+    for method, komi in (('real', 0), ('heuristic', 2.5)):
+        env = make('gym_go:go-v0', size=7, komi=komi, reward_method=method)
+        s = env.reset()
+        want = np.zeros((6, 7, 7), np.uint8)
+        for ply in range(400):
+            valid = np.flatnonzero(env.valid_moves())
+            assert np.array_equal(valid, np.flatnonzero(np.append(want[3].ravel(), 0) == 0))
+            a = int(rs.choice(valid)) if ply < 60 or rs.random() < 0.7 else 49
+            arg = None if (a == 49 and ply % 2) else ((a // 7, a % 7) if (a < 49 and ply % 3 == 0) else a)
+            s, reward, done, info = env.step(arg)
+            want = c_oracle.next_state(want, a)
+            assert s.dtype == np.float64 and np.array_equal(s.astype(np.uint8), want), ply
+            assert info['turn'] == int(want[2, 0, 0]) and bool(info['prev_player_passed']) == bool(want[4, 0, 0])
+            assert int(done) == int(want[5, 0, 0])
+            ob, ow = c_oracle.batch_areas(want[None])
+            margin = float(ob[0]) - float(ow[0]) - komi
+            if method == 'real':
+                assert reward == (np.sign(margin) if done else 0)
+            else:
+                assert reward == ((49 if margin > 0 else -49) if done else margin)
+            if done:
+                break
+        assert done and env.game_ended()
+        with pytest.raises(AssertionError):
+            env.step(None)

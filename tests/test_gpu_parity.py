@@ -227,7 +227,7 @@ def test_unaligned_views(gg, oracle):
 def test_empty_batch_and_bad_args(gg):
     from gymgo_amd import _lib
     L = _lib.lib()
-    assert L.gg_version() == 1
+    assert L.gg_version() == _lib.ABI_VERSION == 2
     assert L.gg_batch_next_states(None, None, None, None, 0, 9, 0, None) == 0
     assert L.gg_batch_next_states(None, None, None, None, 4, 9, 0, None) == -2
     assert L.gg_batch_next_states(None, None, None, None, 4, 20, 0, None) == -1
@@ -235,122 +235,66 @@ def test_empty_batch_and_bad_args(gg):
     assert L.gg_device_cus() > 0
 
 
-def test_variant1_kernels_in_subprocess(oracle):
-    """The one-wavefront-per-board family (GG_KERNEL_VARIANT=1) stays bit-exact too (the default is variant 2)."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import numpy as np, torch
-from gymgo_amd import gogame
-from oracle import c_oracle
-for N, B, plies in ((19, 257, 130), (9, 130, 90), (5, 64, 60)):
-    rng = gogame.rng_seed(B, 41); rng_np = c_oracle.rng_seed(41, B)
-    st = torch.zeros((B, 6, N, N), dtype=torch.uint8, device="cuda"); want = np.zeros((B, 6, N, N), np.uint8)
-    gogame.batch_rollout(st, rng, plies, True); want, rng_np, _ = c_oracle.batch_rollout(want, rng_np, plies, True)
-    assert np.array_equal(st.cpu().numpy(), want), ("rollout", N)
-    acts = gogame.batch_sample_actions(st, rng)
-    nxt, status = gogame.batch_next_states(st, acts, canonical=True, check=False)
-    w2, ws = c_oracle.batch_next_states(want, acts.cpu().numpy(), True)
-    assert np.array_equal(nxt.cpu().numpy(), w2) and np.array_equal(status.cpu().numpy(), ws), ("next", N)
-    assert np.array_equal(gogame.batch_children(st[:5], False).cpu().numpy(), c_oracle.batch_children(want[:5], False)), ("children", N)
-print("variant1 ok")
-'''
-    env = dict(os.environ, GG_KERNEL_VARIANT='1')
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and 'variant1 ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-@pytest.mark.parametrize('nb', [12, 6, 2])
-def test_v3_rollout_kernel_forced_in_subprocess(oracle, nb):
-    """The incremental-class fused kernel (k_rollout3: liberty classes carried across plies, `nb` boards per wave) is
-    normally used from 8 192 games up; GG_V3_NB forces it for any batch so that the small oracle-checked batches run
-    through it: rollouts from the empty board and from mid-game, auto-reset on and off, every row capacity, odd batch
-    sizes, the packed form and the given-moves form."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import numpy as np, torch
-from gymgo_amd import gogame
-from oracle import c_oracle
-for N, B in ((19, 131), (13, 77), (9, 250), (6, 40), (2, 13)):
+@pytest.mark.parametrize('N,B', [(19, 12288), (19, 8201), (13, 10240), (11, 9000), (9, 12345), (6, 8192)])
+def test_multi_ply_kernel_at_its_dispatch_sizes(gg, oracle, N, B):
+    """The multi-ply kernel (liberty classes carried across the plies of a launch) serves gg_batch_rollout /
+    _packed / gg_batch_play_moves from 8 192 games and two plies per launch up, with 8, 10 or 12 boards per wave
+    depending on the batch.  Here at those sizes, every row capacity (N == capacity and N < capacity), odd batches:
+    rollouts from the empty board with and without auto-reset in launches of 8 / 9 / 33 / 64 plies, ORACLE replay of
+    every 32nd game (states, generator, last action); the packed form must equal the byte-plane form for every game;
+    then a recorded continuation, a third of the games corrupted, replayed in one launch (given moves) vs the oracle."""
+    idx = np.arange(0, B, 32)
+    idx_t = torch.as_tensor(idx, device='cuda')
     for auto in (True, False):
-        rng = gogame.rng_seed(B, 7 + N); rng_np = c_oracle.rng_seed(7 + N, B)
-        st = torch.zeros((B, 6, N, N), dtype=torch.uint8, device="cuda"); want = np.zeros((B, 6, N, N), np.uint8)
-        pk = gogame.batch_pack(st); prng = rng.clone()
-        la = torch.empty(B, dtype=torch.int32, device="cuda"); sd = torch.zeros(B, dtype=torch.int64, device="cuda")
+        rng = gg.rng_seed(B, 7 + N)
+        rng_np = np.array([oracle.lib().gg_oracle_rng_seed(7 + N, int(i)) for i in idx], dtype=np.uint64)
+        st = torch.zeros((B, 6, N, N), dtype=torch.uint8, device='cuda')
+        want = np.zeros((len(idx), 6, N, N), np.uint8)
+        pk = gg.batch_pack(st)
+        prng = rng.clone()
+        la = torch.empty(B, dtype=torch.int32, device='cuda')
+        sd = torch.zeros(B, dtype=torch.int64, device='cuda')
         total = 0
-        for plies in (8, 9, 33, 64, 150 if N > 6 else 40):
-            gogame.batch_rollout(st, rng, plies, auto, la, sd)
-            gogame.batch_rollout_packed(pk, prng, plies, auto)
-            want, rng_np, wl = c_oracle.batch_rollout(want, rng_np, plies, auto)
+        for plies in (8, 9, 33, 64 if N > 6 else 20):
+            gg.batch_rollout(st, rng, plies, auto, la, sd)
+            gg.batch_rollout_packed(pk, prng, plies, auto)
+            want, rng_np, wl = oracle.batch_rollout_mt(want, rng_np, plies, auto)
             total += plies
-            assert np.array_equal(st.cpu().numpy(), want), ("rollout", N, auto, total)
-            assert np.array_equal(rng.cpu().numpy().view(np.uint64), rng_np), ("rng", N, auto, total)
-            assert np.array_equal(la.cpu().numpy(), wl), ("last", N, auto, total)
-            assert torch.equal(gogame.batch_unpack(pk, N), st) and torch.equal(prng, rng), ("packed", N, auto, total)
+            assert np.array_equal(st[idx_t].cpu().numpy(), want), ('rollout', N, auto, total)
+            assert np.array_equal(rng[idx_t].cpu().numpy().view(np.uint64), rng_np), ('rng', N, auto, total)
+            assert np.array_equal(la[idx_t].cpu().numpy(), wl), ('last', N, auto, total)
+            assert torch.equal(gg.batch_unpack(pk, N), st) and torch.equal(prng, rng), ('packed', N, auto, total)
         if auto:
             assert int(sd.min()) == total
-    # given moves: record a continuation ply by ply, corrupt a third of the games, replay in one launch
-    T = 40
-    rec = torch.empty((B, T), dtype=torch.int32, device="cuda")
-    start = st.clone(); tmp = st.clone(); r2 = gogame.rng_seed(B, 99)
+    # given moves: record a continuation ply by ply (per-ply kernel), corrupt a third of the games, replay in one launch
+    T = 24
+    rec = torch.empty((B, T), dtype=torch.int32, device='cuda')
+    start, tmp, r2 = st.clone(), st.clone(), gg.rng_seed(B, 99)
     for t in range(T):
-        gogame.batch_rollout(tmp, r2, 1, False, la, None)
+        gg.batch_rollout(tmp, r2, 1, False, la, None)
         rec[:, t] = la
     moves = rec.cpu().numpy().copy()
     gen = np.random.default_rng(N)
     for i in gen.choice(B, max(1, B // 3), replace=False):
         moves[i, gen.integers(0, T)] = gen.integers(-2, N * N + 2)
-    host = start.cpu().numpy(); exp = host.copy(); played = np.zeros(B, np.int32)
-    for i in range(B):
-        s = host[i]
+    host = start[idx_t].cpu().numpy()
+    exp, played = host.copy(), np.zeros(len(idx), np.int32)
+    for j, i in enumerate(idx):
+        s = host[j]
         for t in range(T):
             a = int(moves[i, t])
             if s[5, 0, 0] or a < 0 or a > N * N or (a < N * N and s[3].reshape(-1)[a]):
                 break
-            s = c_oracle.next_state(s, a); played[i] += 1
-        exp[i] = s
-    got = gogame.batch_play_moves(start, torch.from_numpy(moves).cuda())
-    assert np.array_equal(got.cpu().numpy(), played) and np.array_equal(start.cpu().numpy(), exp), ("play_moves", N)
-print("v3 ok")
-'''
-    env = dict(os.environ, GG_V3_NB=str(nb))
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and 'v3 ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-def test_ab_kernels_in_subprocess(oracle):
-    """The A/B kernels kept behind switches - gg_batch_next_states without the LDS-DMA pipeline (GG_SYNC_IO=1) and
-    gg_batch_children re-analysing every child (GG_CHILDREN_FULL=1) - stay bit-exact with the oracle."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import numpy as np, torch
-from gymgo_amd import gogame
-from oracle import c_oracle
-for N, B, plies in ((19, 199, 150), (9, 130, 50), (4, 31, 9)):
-    rng = gogame.rng_seed(B, 3); st = torch.zeros((B, 6, N, N), dtype=torch.uint8, device="cuda")
-    gogame.batch_rollout(st, rng, plies, False)
-    host = st.cpu().numpy()
-    acts = gogame.batch_sample_actions(st, rng)
-    for canon in (False, True):
-        nxt, status = gogame.batch_next_states(st, acts, canonical=canon, check=False)
-        w, ws = c_oracle.batch_next_states(host, acts.cpu().numpy(), canon)
-        assert np.array_equal(nxt.cpu().numpy(), w) and np.array_equal(status.cpu().numpy(), ws), ("next", N, canon)
-    live = host[:, 5, 0, 0] == 0
-    kids = gogame.batch_children(st[torch.from_numpy(live).cuda()][:24].contiguous(), False).cpu().numpy()
-    assert np.array_equal(kids, c_oracle.batch_children(host[live][:24], False)), ("children", N)
-print("ab ok")
-'''
-    env = dict(os.environ, GG_SYNC_IO='1', GG_CHILDREN_FULL='1')
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and 'ab ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+            s = oracle.next_state(s, a)
+            played[j] += 1
+        exp[j] = s
+    pk = gg.batch_pack(start)
+    got = gg.batch_play_moves(start, torch.from_numpy(moves).cuda())
+    assert np.array_equal(got[idx_t].cpu().numpy(), played) and np.array_equal(start[idx_t].cpu().numpy(), exp), ('play_moves', N)
+    got2 = gg.batch_play_moves(pk, torch.from_numpy(moves).cuda())
+    assert torch.equal(got2, got) and torch.equal(gg.batch_unpack(pk, N), start)
+    untouched = torch.from_numpy((moves == rec.cpu().numpy()).all(axis=1)).cuda()
+    assert torch.equal(start[untouched], tmp[untouched])     # uncorrupted games: the replay equals the recording run
 
 
 def test_update_pieces_standalone(gg, oracle):

@@ -25,7 +25,7 @@ def test_header_symbols_exported(built):
     L = ctypes.CDLL(built.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert built.lib().gg_version() == 1
+    assert built.lib().gg_version() == built.ABI_VERSION == 2
 
 
 def test_integration_doc_names_every_entry_point():
@@ -133,9 +133,10 @@ def test_host_side_predicates_on_numpy():
     assert len(gogame.all_symmetries(s)) == 8
 
 
-def test_killed_group_listing_and_point_inference():
+def test_killed_group_listing_and_adj_table():
     """Host helpers of state_utils.update_pieces: killed mask -> per-group coordinate lists in raster order
-    (the order scipy.ndimage.label + np.argwhere give the reference), and the placed stone from adj_locs."""
+    (the order scipy.ndimage.label + np.argwhere give the reference); the adj_locs go to the kernel as a padded
+    table of flat indices - nothing is inferred about where a stone was placed."""
     from gymgo_amd import state_utils
     mask = np.zeros((5, 5), np.uint8)
     mask[0, 1] = mask[1, 0] = 1            # two single-stone groups
@@ -147,10 +148,14 @@ def test_killed_group_listing_and_point_inference():
     s[1, 2, 2] = 1
     adj, surrounded = state_utils.adj_data(s, (2, 2), 1)
     assert sorted(map(tuple, adj)) == [(1, 2), (2, 1), (2, 3), (3, 2)] and not surrounded
-    assert state_utils._point_of(s, adj, 1) == 12
     s[1, 0, 0] = 1
-    adj, _ = state_utils.adj_data(s, (0, 0), 1)
-    assert sorted(map(tuple, adj)) == [(0, 1), (1, 0)] and state_utils._point_of(s, adj, 1) == 0
+    adj2, _ = state_utils.adj_data(s, (0, 0), 1)
+    assert sorted(map(tuple, adj2)) == [(0, 1), (1, 0)]
+    table = state_utils._adj_table([adj, adj2, np.zeros((0, 2)), np.array([[4, 4], [9, 0], [0, -1], [1, 1], [2, 2], [3, 3]])], 5)
+    assert table.dtype == np.int32 and table.shape == (4, 6)
+    assert sorted(table[0][:4]) == [7, 11, 13, 17] and list(table[0][4:]) == [-1, -1]
+    assert sorted(table[1][:2]) == [1, 5] and (table[1][2:] == -1).all() and (table[2] == -1).all()
+    assert list(table[3]) == [24, -1, -1, 6, 12, 18]          # off-board locations are dropped, not wrapped
     s[0, 0, 1] = s[0, 1, 0] = 1
     assert state_utils.adj_data(s, (0, 0), 1)[1] is True
 

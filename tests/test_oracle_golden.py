@@ -131,3 +131,17 @@ def test_frozen_when_no_auto_reset():
     assert st[:, 5].all()      # both games ended and stayed ended
     st2, rng2, last = c_oracle.batch_rollout(st, rng, 5, False)
     assert np.array_equal(st2, st) and np.array_equal(rng2, rng) and (last == -1).all()
+
+
+def test_update_pieces_arbitrary_positions(golden):
+    """state_utils.update_pieces (gym_go/state_utils.py:159-180) as recorded from the reference on positions that are
+    not reachable by legal play (corners, duplicates, long location lists): the C restatement's stand-alone entry."""
+    z = golden('extras')
+    n = int(z['up/count'])
+    assert n >= 150
+    for i in range(n):
+        k = 'up/%d/' % i
+        state, adj, player = z[k + 'state'], z[k + 'adj'], int(z[k + 'player'])
+        after, killed, groups = c_oracle.update_pieces(state, adj[:, 0] * state.shape[-1] + adj[:, 1], player)
+        assert np.array_equal(after, z[k + 'after']) and np.array_equal(killed, z[k + 'killed']), i
+        assert groups == int(z[k + 'groups']), i
