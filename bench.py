@@ -1,19 +1,22 @@
 #!/usr/bin/env python
 """bench.py - env steps/sec across batched games, 19x19 uniform-random rollouts (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: the ranks are spawned here)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" = ONE PLY FOR EVERY GAME of the batch (B env transitions): sample a uniform valid action per
-game on the device, apply it (capture resolution, ko, new invalid-move mask, turn flip), auto-reset
-finished games.  Steps are issued as launches of gg_batch_rollout with `--fuse F` plies per launch
-(F = 1: the state makes a full HBM round trip every ply, the per-ply vector-env path; F > 1: the
-board stays on-chip for F plies).  K is rounded up to a multiple of F.  Inputs are resident in HBM
-before the timed region; nothing but the kernel launches sits inside it.
+A bench "step" = ONE LAUNCH of gg_batch_rollout over the whole resident batch: `--plies-per-step` (default 256)
+plies for every game - sample a uniform valid action per game on the device, apply it (capture resolution, ko, new
+invalid-move mask, turn flip), auto-reset finished games - with the boards resident on-chip between the plies of
+the launch.  K timed steps are exactly K launches (K x plies x games env steps); `value` = env steps per second.
+Inputs are resident in HBM before the timed region; nothing but the kernel launches sits inside it, and the
+number of env steps actually played is asserted from the kernel's own per-game counters.
 
-Multi-GPU: the game batch is sharded across ranks, no data-path collective (games never interact);
-only the barrier and the max-over-ranks timing use RCCL.  scaling = "weak" (fixed games per GPU).
-Rank 0 prints ONE JSON line.
+Multi-GPU: the game batch is sharded across ranks by global game index, no data-path collective (games never
+interact); only the barrier, the max-over-ranks time and the played-steps check use the process group (RCCL).
+scaling = "weak" (fixed games per GPU).  Rank 0 prints ONE JSON line.
+
+`run_rank()` is the per-rank driver; tests/test_multirank_gloo.py runs it at world_size 2 over gloo with the CPU
+oracle as the step backend, so the sharding / timing / reduction code tested there is the code that runs on 8 GPUs.
 """
 import argparse
 import json
@@ -22,12 +25,26 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_STEP = {19: 4336, 13: 2032, 9: 976, 7: 592}  # read 6N^2 + write 6N^2 + 4 B action
-HBM_PEAK_GBS = 8000.0                                        # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+METRIC = 'env steps/sec across batched games, 19x19 uniform-random rollouts'
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+SEED = 20260927
 
 
+def algo_bytes_per_step(n):
+    """one out-of-place transition reads 6 N^2 + writes 6 N^2 + a 4-byte action (4 336 B at 19x19)."""
+    return 12 * n * n + 4
+
+
+def fused_bytes_per_game(n):
+    """What a fused launch must move per game whatever its ply count: the board in, the board out, the generator state
+    in and out (6 N^2 + 6 N^2 + 16 B)."""
+    return 12 * n * n + 16
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def _cpu_worker(args):
     size, seconds, seed = args
     sys.path.insert(0, ROOT)
@@ -35,74 +52,375 @@ def _cpu_worker(args):
     return np_oracle.random_rollout_steps(size, seconds, seed)
 
 
-def cpu_baseline(size, cpu_seconds_total=20.0):
-    """The NumPy/SciPy port of the reference's next_state (oracle/np_oracle.py, same SciPy calls per step,
-    pinned bit-exact and speed-calibrated against the real reference) on this box's host cores:
-    one worker per core, each plays uniform-random games with auto-reset for a fixed wall time."""
+def cpu_baseline(size, seconds_per_worker=6.0, max_workers=64):
+    """The NumPy/SciPy port of the reference's next_state (oracle/np_oracle.py: the same scipy.ndimage calls per step,
+    pinned bit-exact and speed-calibrated against the real reference) on this box's host cores: one worker process per
+    core (capped at `max_workers`), each playing uniform-random games with auto-reset for a fixed wall time."""
     import multiprocessing as mp
-    cores = min(os.cpu_count() or 1, 16)
-    seconds = max(2.0, cpu_seconds_total / cores)
+    host = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = host
+    cores = max(1, min(usable, max_workers))
     ctx = mp.get_context('spawn')
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
-        steps = pool.map(_cpu_worker, [(size, seconds, 1000 + i) for i in range(cores)])
+        steps = pool.map(_cpu_worker, [(size, seconds_per_worker, 1000 + i) for i in range(cores)])
     wall = time.perf_counter() - t0
-    # the build's own C restatement (oracle/gg_oracle.c: bitboard-free flood fills, one thread) - reported, not the baseline
-    c_rate = None
+    c_rate = None   # the build's own C restatement, one thread: reported next to the baseline, it is not the baseline
     try:
         import numpy as np
         from oracle import c_oracle
         st = np.zeros((32, 6, size, size), np.uint8)
         rg = c_oracle.rng_seed(7, 32)
-        st, rg, _ = c_oracle.batch_rollout(st, rg, 300, True)     # into the middle game
+        st, rg, _ = c_oracle.batch_rollout(st, rg, 300, True)
         c0 = time.perf_counter()
         st, rg, _ = c_oracle.batch_rollout(st, rg, 600, True)
         c_rate = round(32 * 600 / (time.perf_counter() - c0), 1)
     except Exception:
         c_rate = None
+    total = float(sum(steps))
     return {
-        'value': round(sum(steps) / seconds, 1), 'unit': 'env steps/s', 'cores': cores, 'kind': 'port',
-        'per_core': round(sum(steps) / seconds / cores, 1),
+        'value': round(total / seconds_per_worker, 1), 'unit': 'env steps/s', 'cores': cores, 'kind': 'port',
+        'host_cpu_count': host, 'usable_cpus': usable, 'per_core': round(total / seconds_per_worker / cores, 1),
         'c_restatement_steps_per_s_one_core': c_rate,
-        'sample': '%d workers x %.1f s of %dx%d uniform-random self-play with auto-reset (oracle/np_oracle.py, '
-                  'same scipy.ndimage calls per step as the reference); %d steps total, pool wall %.1f s'
-                  % (cores, seconds, size, size, sum(steps), wall),
+        'sample': '%d worker processes (os.cpu_count() = %d, usable %d) x %.1f s of %dx%d uniform-random self-play with '
+                  'auto-reset (oracle/np_oracle.py, same scipy.ndimage calls per step as the reference); %d steps total, '
+                  'pool wall %.1f s' % (cores, host, usable, seconds_per_worker, size, size, int(total), wall),
     }
 
 
-def main():
+# ------------------------------------------------------------------------------------------------ step backends
+class HipBackend:
+    """The product path: uint8 [B,6,N,N] device tensor + gg_batch_rollout through the C-ABI on torch's current stream."""
+    name = 'hip'
+
+    def __init__(self, device):
+        import torch
+        from gymgo_amd import gogame
+        self.torch, self.gogame, self.device = torch, gogame, device
+
+    def setup(self, count, size, first_game):
+        t, g = self.torch, self.gogame
+        self.count, self.size = count, size
+        self.states = g.batch_init_state(count, size, device=self.device)
+        self.rng = g.rng_seed(count, SEED, first_game, self.device)
+        self.steps_done = t.zeros(count, dtype=t.int64, device=self.device)
+
+    def rollout(self, plies, lo=0, hi=None, count_steps=True):
+        hi = self.count if hi is None else hi
+        if lo == 0 and hi == self.count:
+            self.gogame.batch_rollout(self.states, self.rng, plies, True, None, self.steps_done if count_steps else None)
+        else:
+            self.gogame.batch_rollout(self.states[lo:hi], self.rng[lo:hi], plies, True)
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+    def played(self):
+        return int(self.steps_done.sum())
+
+    def timer(self):
+        t = self.torch
+        ev = (t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True))
+        return (lambda: ev[0].record()), (lambda: ev[1].record()), (lambda: ev[0].elapsed_time(ev[1]))
+
+    def comm_tensor(self, values):
+        return self.torch.tensor(values, dtype=self.torch.float64, device=self.device)
+
+    def state_digest(self):
+        import hashlib
+        return hashlib.sha256(self.states.cpu().numpy().tobytes()).hexdigest()
+
+
+def shard(total_games, rank, world_size):
+    """Contiguous equal split of the game index range [0, total_games) -> (first_game, count); the same function as
+    gymgo_amd.envs.vec_env.shard (kept importable without torch for the CPU tests)."""
+    base, rem = divmod(total_games, world_size)
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+def run_rank(rank, world, backend, opts, dist=None):
+    """The per-rank bench driver.  backend: a step backend (HipBackend on the GPU; the gloo test passes one built on the
+    CPU oracle).  dist: torch.distributed (already initialised) when world > 1.  Returns the result record on rank 0
+    (None elsewhere): value, wall time (max over ranks), kernel-event time of this rank, games and steps played."""
+    N, F, K, W = opts['size'], opts['plies_per_step'], opts['steps'], opts['warmup']
+    per_gpu = opts['games_per_gpu']
+    total_games = per_gpu * world
+    first, count = shard(total_games, rank, world)
+    backend.setup(count, N, first)
+    # De-synchronise the games first: slice g of 16 plays g * desync/16 extra plies, so that the batch holds every game
+    # phase at once (stationary mix: the mean game length of uniform-random 19x19 play is ~640 plies, SURVEY 6) and the
+    # timed window does not depend on where a lock-step batch happens to be.  Untimed, not counted.
+    if opts['desync']:
+        chunk = (count + 15) // 16
+        for g in range(1, 16):
+            lo, hi = g * chunk, min(count, (g + 1) * chunk)
+            if lo < hi:
+                backend.rollout(g * opts['desync'] // 16, lo, hi)
+    for _ in range(opts['burn_in_steps']):      # same launch shape as the timed ones (rocprof averages then agree)
+        backend.rollout(F, count_steps=False)
+    for _ in range(W):
+        backend.rollout(F, count_steps=False)
+
+    def fence():
+        backend.sync()
+        if world > 1:
+            dist.barrier()
+            backend.sync()
+
+    before = backend.played()
+    start, stop, elapsed_ms = backend.timer()
+    fence()
+    t0 = time.perf_counter()
+    start()
+    for _ in range(K):
+        backend.rollout(F)
+    stop()
+    fence()
+    wall = time.perf_counter() - t0
+    kernel_ms = elapsed_ms()
+    played = backend.played() - before
+    assert played == K * F * count, 'work was skipped inside the timed region (%d != %d)' % (played, K * F * count)
+    red = backend.comm_tensor([wall, float(played)])
+    if world > 1:
+        tmax = red[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = red[1:].clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        wall_max, played_all = float(tmax[0]), int(tsum[0])
+    else:
+        wall_max, played_all = wall, played
+    assert played_all == K * F * total_games
+    if rank != 0:
+        return None
+    return {'value': played_all / wall_max, 'wall_s': wall_max, 'kernel_ms': kernel_ms, 'total_games': total_games,
+            'games_per_gpu': per_gpu, 'count': count, 'first': first, 'steps_played': played_all}
+
+
+# ------------------------------------------------------------------------------------------------ roofline records
+def rollout_kernel_name(n, games, plies, cus):
+    """Mirror of gg_batch_rollout's dispatch (gymgo_amd/csrc/gg_kernels.hip): which kernel serves this launch."""
+    rcap = 9 if n <= 9 else 13 if n <= 13 else 19
+    full = 'true' if n == rcap else 'false'
+    if plies >= 2 and games >= 32 * cus:
+        return 'k_rollout3<%d, 0, false, %s>' % (rcap, full)
+    return 'k_rollout2<%d, %s, false, %s>' % (rcap, 'true' if plies <= 2 else 'false', full)
+
+
+def load_pmc(kernel, n, plies, games):
+    """Instruction mix and HBM traffic of this exact launch shape from the committed PMC passes
+    (profiles/pmc_rollout.json, written by tools/summarize_profiles.py from rocprofv3 --pmc runs of this command)."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_rollout.json')
+    try:
+        for rec in json.load(open(path)).get('records', []):
+            if (rec.get('kernel') == kernel and rec.get('size') == n and rec.get('plies_per_launch') == plies
+                    and rec.get('games') == games):
+                return rec
+    except Exception:
+        pass
+    return None
+
+
+def roofline_record(dev, n, games, plies, launch_ms, per_ply):
+    import torch
+    props = torch.cuda.get_device_properties(dev)
+    cus = props.multi_processor_count
+    clock_hz = float(getattr(props, 'clock_rate', 2400000)) * 1e3      # kHz -> Hz
+    kernel = rollout_kernel_name(n, games, plies, cus)
+    steps_per_launch = games * plies
+    steps_per_s = steps_per_launch / (launch_ms * 1e-3)
+    peak = cus * 4 * clock_hz / 2.0 / 1e9          # wave64 instructions per second, one per SIMD every 2 cycles
+    pmc = load_pmc(kernel, n, plies, games)
+    fused_bytes = fused_bytes_per_game(n) * games
+    rec = {
+        'bound': 'valu', 'kernel': kernel, 'unit': 'Gwave-instr/s', 'peak': round(peak, 2),
+        'peak_note': '%d CUs x 4 SIMDs x %.2f GHz / 2 cycles per wave64 VALU instruction (the fastest ops: '
+                     'profiles/r01_ubench_valu_rates.txt)' % (cus, clock_hz / 1e9),
+        'launch_ms': round(launch_ms, 5), 'steps_per_launch': steps_per_launch, 'env_steps_per_s': round(steps_per_s, 1),
+    }
+    if pmc:
+        ipe = pmc['instr_per_step']
+        issued = ipe['valu'] + ipe['salu'] + ipe['lds']
+        rec.update({
+            'achieved': round(issued * steps_per_s / 1e9, 2), 'frac': round(issued * steps_per_s / 1e9 / peak, 4),
+            'frac_valu_only': round(ipe['valu'] * steps_per_s / 1e9 / peak, 4),
+            'instr_per_step': ipe, 'traffic': pmc.get('hbm_bytes_per_launch'), 'pmc_source': pmc.get('source'),
+        })
+    else:
+        rec.update({'achieved': None, 'frac': None, 'traffic': None,
+                    'pmc_source': 'no PMC pass for this launch shape under profiles/ (tools/profile_round.sh collects one)'})
+    rec['hbm'] = {
+        'note': 'fused launch: board in + board out + generator per game per LAUNCH, whatever the ply count',
+        'algorithmic_bytes_per_launch': fused_bytes, 'achieved': round(fused_bytes / (launch_ms * 1e-3) / 1e9, 2),
+        'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(fused_bytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        'traffic': pmc.get('hbm_bytes_per_launch') if pmc else None,
+    }
+    if per_ply:
+        rec['per_ply'] = per_ply
+    return rec
+
+
+def event_rate(torch, dev, fn, units, reps):
+    """units/s by HIP events over `reps` back-to-back calls (after one untimed call)."""
+    fn()
+    torch.cuda.synchronize(dev)
+    a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a0.record()
+    for _ in range(reps):
+        fn()
+    a1.record()
+    torch.cuda.synchronize(dev)
+    ms = a0.elapsed_time(a1) / reps
+    return units / (ms * 1e-3), ms
+
+
+def extras(dev, back, opts):
+    """Untimed extras on rank 0 (outside the K timed steps): the per-ply paths on the same resident batch with their
+    SURVEY 8(d) roofline fractions, and one driver-timed number for every other BASELINE config."""
+    import torch
+    from gymgo_amd import _lib, gogame
+    from gymgo_amd.envs import make
+    N, count = opts['size'], back.count
+    states, rng = back.states, back.rng
+    algo = algo_bytes_per_step(N)
+    out, per_ply = {}, None
+    # --- per-ply kernels, config-3 batch: out-of-place step API with caller-owned outputs (no allocation per call)
+    acts = gogame.batch_sample_actions(states, rng)
+    nxt, status = torch.empty_like(states), torch.empty(count, dtype=torch.int32, device=dev)
+    r, ms = event_rate(torch, dev, lambda: gogame.batch_next_states(states, acts, check=False, out=nxt, status=status), count, 32)
+    per_ply = {'kernel': 'k_next_states2<%d>' % (9 if N <= 9 else 13 if N <= 13 else 19), 'entry': 'gg_batch_next_states',
+               'algorithmic_bytes_per_step': algo, 'launch_us': round(ms * 1e3, 2), 'env_steps_per_s': round(r, 1),
+               'achieved': round(algo * r / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+               'frac': round(algo * r / 1e9 / HBM_PEAK_GBS, 4), 'bound': 'hbm',
+               'note': 'through the Python API (ctypes call + launch), HIP events over 32 back-to-back calls'}
+    out['gg_batch_next_states_steps_per_s'] = round(r, 1)
+    del nxt
+    r, _ = event_rate(torch, dev, lambda: gogame.batch_rollout(states, rng, 1, True), count, 32)
+    out['rollout_1_ply_per_launch_steps_per_s'] = round(r, 1)
+    env_out = (torch.empty(count, dtype=torch.float32, device=dev), torch.empty(count, dtype=torch.uint8, device=dev),
+               torch.empty(count, dtype=torch.int32, device=dev), torch.empty(count, dtype=torch.int32, device=dev))
+    r, _ = event_rate(torch, dev, lambda: gogame.batch_env_step(states, None, rng, 7.5, 'real', True, out=env_out), count, 32)
+    out['gg_batch_env_step_steps_per_s'] = round(r, 1)
+    out['gg_batch_env_step_hbm_frac'] = round(algo * r / 1e9 / HBM_PEAK_GBS, 4)
+    configs = {}
+    F = opts['plies_per_step']
+    # --- config 2: 9x9, 4 096 games
+    b2 = HipBackend(dev)
+    b2.setup(4096, 9, 0)
+    for g in range(1, 16):
+        b2.rollout(g * 8, g * 256, (g + 1) * 256)
+    b2.rollout(F)
+    r, ms = event_rate(torch, dev, lambda: b2.rollout(F), 4096 * F, 8)
+    r1, ms1 = event_rate(torch, dev, lambda: b2.rollout(1), 4096, 64)
+    configs['config2_9x9_4096_games'] = {
+        'fused_rollout_steps_per_s': round(r, 1), 'plies_per_launch': F, 'launch_ms': round(ms, 4),
+        'kernel': rollout_kernel_name(9, 4096, F, torch.cuda.get_device_properties(dev).multi_processor_count),
+        'per_ply_rollout_steps_per_s': round(r1, 1), 'per_ply_launch_us': round(ms1 * 1e3, 2),
+        'per_ply_hbm_frac': round(algo_bytes_per_step(9) * r1 / 1e9 / HBM_PEAK_GBS, 4)}
+    del b2
+    # --- config 4's per-GPU batch (131 072 games) on this one GPU: the base for weak-scaling ratios
+    if opts['world'] == 1 and N == 19 and count != 131072:
+        b4 = HipBackend(dev)
+        b4.setup(131072, N, 0)
+        for g in range(1, 16):
+            b4.rollout(g * opts['desync'] // 16 if opts['desync'] else 0, g * 8192, (g + 1) * 8192)
+        b4.rollout(F)
+        r, ms = event_rate(torch, dev, lambda: b4.rollout(F), 131072 * F, 4)
+        configs['config4_per_gpu_batch_131072_games_on_one_gpu'] = {'fused_rollout_steps_per_s': round(r, 1),
+                                                                   'plies_per_launch': F, 'launch_ms': round(ms, 4)}
+        del b4
+    # --- config 5: 8 192 mid-game parents, padded 362-slot expansion
+    if N == 19 and count >= 8192:
+        parents = states[:8192]
+        kids = torch.empty((8192, N * N + 1, 6, N, N), dtype=torch.uint8, device=dev)
+        lib = _lib.lib()
+
+        def expand():
+            _lib.check(lib.gg_batch_children(_lib.dev_ptr(parents, torch.uint8, 'states'), _lib.dev_ptr(kids, torch.uint8, 'children'),
+                                             8192, N, 0, _lib.stream_ptr(dev)), 'gg_batch_children')
+        r, ms = event_rate(torch, dev, expand, 8192, 8)
+        bytes_per_parent = 6 * N * N + (N * N + 1) * 6 * N * N
+        configs['config5_children_8192_parents'] = {
+            'parents_per_s': round(r, 1), 'child_states_per_s': round(r * (N * N + 1), 1), 'launch_ms': round(ms, 4),
+            'roofline': {'bound': 'hbm', 'kernel': 'k_children3<19, false>', 'algorithmic_bytes_per_parent': bytes_per_parent,
+                         'achieved': round(bytes_per_parent * r / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(bytes_per_parent * r / 1e9 / HBM_PEAK_GBS, 4)}}
+        del kids
+    # --- config 1: one 7x7 game through GoEnv.step (device round trip per step: plumbing, not a throughput path)
+    import numpy as np
+    env = make('gym_go:go-v0', size=7)
+    env.reset()
+    rs = np.random.default_rng(1)
+    n_steps, t0 = 0, time.perf_counter()
+    while n_steps < 300:
+        if env.done:
+            env.reset()
+        env.step(int(rs.choice(np.flatnonzero(env.valid_moves()))))
+        n_steps += 1
+    configs['config1_7x7_single_game_GoEnv_step'] = {
+        'steps_per_s': round(n_steps / (time.perf_counter() - t0), 1),
+        'note': 'one H2D action + two launches + one D2H record per step; latency-bound plumbing by construction'}
+    out['configs'] = configs
+    out['note'] = ('per-ply rates: HIP events over back-to-back calls through the Python API on the resident config-3 batch; '
+                   'configs: one driver-timed number per BASELINE config that is not the headline')
+    return out, per_ply
+
+
+# ------------------------------------------------------------------------------------------------ entry
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=1024)
-    ap.add_argument('--warmup', type=int, default=128)
+    ap.add_argument('--steps', type=int, default=20, help='timed launches (each --plies-per-step plies for every game)')
+    ap.add_argument('--warmup', type=int, default=5, help='untimed launches before the timed ones')
     ap.add_argument('--size', type=int, default=19)
     ap.add_argument('--games-per-gpu', type=int, default=0, help='0 = 65536 at 1 GPU, 131072 per GPU otherwise')
-    ap.add_argument('--fuse', type=int, default=int(os.environ.get('GG_BENCH_FUSE', '256')),
-                    help='plies per kernel launch')
-    ap.add_argument('--burn-in', type=int, default=256, help='untimed plies before warmup (stationary board mix)')
+    ap.add_argument('--plies-per-step', '--fuse', dest='plies_per_step', type=int,
+                    default=int(os.environ.get('GG_BENCH_PLIES', '256')), help='plies per kernel launch (= per bench step)')
+    ap.add_argument('--burn-in', type=int, default=1, help='untimed launches before warm-up (same shape as the timed ones)')
     ap.add_argument('--desync', type=int, default=640, help='spread of extra burn-in plies across the batch (0 = lock-step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=32.0)
-    ap.add_argument('--no-also', action='store_true', help='skip the untimed per-ply extras (clean profiling passes)')
-    args = ap.parse_args()
+    ap.add_argument('--cpu-seconds', type=float, default=6.0, help='wall seconds per CPU-baseline worker')
+    ap.add_argument('--no-also', action='store_true', help='skip the untimed extras (clean profiling passes)')
+    return ap.parse_args(argv)
 
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _spawned(local_rank, world, port, argv):
+    os.environ.update({'RANK': str(local_rank), 'LOCAL_RANK': str(local_rank), 'WORLD_SIZE': str(world),
+                       'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+    main(argv)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher - one process per GPU, rendezvous on 127.0.0.1
+        import torch.multiprocessing as mp
+        mp.spawn(_spawned, args=(args.gpus, _free_port(), list(argv)), nprocs=args.gpus, join=True)
+        return
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
     cpu = None
-    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.size, args.cpu_seconds)   # before the GPU context exists (spawned workers)
 
     import torch
     import torch.distributed as dist
-    from gymgo_amd import _lib, gogame
-    from gymgo_amd.envs.vec_env import shard
-
     local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -110,164 +428,36 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
 
-    per_gpu = args.games_per_gpu or (65536 if world == 1 else 131072)
-    total_games = per_gpu * world
-    first, count = shard(total_games, rank, world)
-    N, F = args.size, max(1, args.fuse)
-    K, W = max(1, args.steps), max(0, args.warmup)    # EXACTLY K timed and W warm-up steps: full launches of F plies + a remainder
-    F = min(F, K)
+    opts = {'size': args.size, 'plies_per_step': max(1, args.plies_per_step), 'steps': max(1, args.steps),
+            'warmup': max(0, args.warmup), 'games_per_gpu': args.games_per_gpu or (65536 if world == 1 else 131072),
+            'desync': args.desync, 'burn_in_steps': max(0, args.burn_in), 'world': world}
+    back = HipBackend(dev)
+    res = run_rank(rank, world, back, opts, dist if world > 1 else None)
 
-    def run_plies(n):
-        for _ in range(n // F):
-            gogame.batch_rollout(states, rng, F, True, None, steps_done)
-        if n % F:
-            gogame.batch_rollout(states, rng, n % F, True, None, steps_done)
-
-    states = gogame.batch_init_state(count, N, device=dev)
-    rng = gogame.rng_seed(count, 20260927, first, dev)
-    steps_done = torch.zeros(count, dtype=torch.int64, device=dev)
-    # De-synchronise the games first: slice g of 16 plays g * desync/16 extra plies, so that the batch holds every
-    # game phase at once (stationary mix: mean game length of uniform-random 19x19 play is ~640 plies) and the
-    # timed window does not depend on where a lock-step batch happens to be.  Untimed, and not counted in steps_done.
-    if args.desync:
-        chunk = (count + 15) // 16
-        for gslice in range(1, 16):
-            lo, hi = gslice * chunk, min(count, (gslice + 1) * chunk)
-            if lo < hi:
-                gogame.batch_rollout(states[lo:hi], rng[lo:hi], gslice * args.desync // 16, True)
-    for _ in range((args.burn_in + F - 1) // F):   # same launch shape as the timed ones (rocprof averages then agree)
-        gogame.batch_rollout(states, rng, F, True, None, steps_done)
-    run_plies(W)
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    before = int(steps_done.sum())
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fence()
-    t0 = time.perf_counter()
-    ev0.record()            # launches go to torch's current stream (gymgo_amd/_lib.py: stream_ptr)
-    run_plies(K)
-    ev1.record()
-    fence()
-    wall = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1)
-    played = int(steps_done.sum()) - before
-    assert played == K * count, 'work was skipped inside the timed region (%d != %d)' % (played, K * count)
-
-    # Untimed extras (outside the K timed steps): the same games through the per-ply paths, rank 0 only.
-    also = {}
-    if rank == 0 and not args.no_also:
-        def rate(fn, reps):
-            fn()
-            torch.cuda.synchronize(dev)
-            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a0.record()
-            for _ in range(reps):
-                fn()
-            a1.record()
-            torch.cuda.synchronize(dev)
-            return count * reps / (a0.elapsed_time(a1) * 1e-3)
-        also['rollout_1_ply_per_launch_steps_per_s'] = round(rate(lambda: gogame.batch_rollout(states, rng, 1, True), 32), 1)
-        acts = gogame.batch_sample_actions(states, rng)
-        also['gg_batch_next_states_steps_per_s'] = round(
-            rate(lambda: gogame.batch_next_states(states, acts, check=False), 16), 1)
-        also['gg_batch_env_step_steps_per_s'] = round(
-            rate(lambda: gogame.batch_env_step(states, None, rng, 7.5, 'real', True), 16), 1)
-        if args.size == 19 and count >= 8192:   # BASELINE config 5: 8 192 mid-game parents, padded 362-slot expansion
-            parents = states[:8192]
-            kids = torch.empty((8192, args.size ** 2 + 1, 6, args.size, args.size), dtype=torch.uint8, device=dev)
-            lib, n = _lib.lib(), args.size
-
-            def expand():
-                _lib.check(lib.gg_batch_children(_lib.dev_ptr(parents, torch.uint8, 'states'), _lib.dev_ptr(kids, torch.uint8, 'children'),
-                                                 8192, n, 0, _lib.stream_ptr(dev)), 'gg_batch_children')
-            per_s = rate(expand, 8) * 8192 / count
-            also['gg_batch_children_parents_per_s'] = round(per_s, 1)
-            also['gg_batch_children_write_roofline_frac'] = round(per_s * 786258 / 8e12, 4)
-            del kids
-        also['note'] = ('same resident batch; kernel-event time of 1-ply launches / of the out-of-place step API / of the fused '
-                        'GoEnv.step (sample + step + areas + reward) / of the 362-slot children expansion of 8 192 parents')
-        if world == 1 and count == 65536 and not args.games_per_gpu:
-            # the per-GPU batch of the N > 1 lines (131 072 games, BASELINE config 4) on ONE GPU: the base for weak-scaling
-            # ratios - 65 536 games fill the resident waves 1.33 times, 131 072 games 2.67 times
-            big = 131072
-            st2 = gogame.batch_init_state(big, N, device=dev)
-            rg2 = gogame.rng_seed(big, 20260927, 0, dev)
-            if args.desync:
-                chunk2 = big // 16
-                for gslice in range(1, 16):
-                    gogame.batch_rollout(st2[gslice * chunk2:(gslice + 1) * chunk2], rg2[gslice * chunk2:(gslice + 1) * chunk2],
-                                         gslice * args.desync // 16, True)
-            gogame.batch_rollout(st2, rg2, F, True)
-            torch.cuda.synchronize(dev)
-            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            b0.record()
-            for _ in range(4):
-                gogame.batch_rollout(st2, rg2, F, True)
-            b1.record()
-            torch.cuda.synchronize(dev)
-            also['rollout_131072_games_steps_per_s'] = round(big * 4 * F / (b0.elapsed_time(b1) * 1e-3), 1)
-            del st2, rg2
-
-    t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max = float(t[0])
     if rank == 0:
-        value = K * total_games / wall_max
-        algo = ALGO_BYTES_PER_STEP.get(N, 12 * N * N + 4)
-        launch_ms = kernel_ms * F / K     # per F plies (K is a multiple of F by default: then the average launch time)
-        achieved = algo * count * F / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        tj = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-        if os.path.exists(tj):
-            try:
-                rec = json.load(open(tj))
-                if rec.get('size') == N and rec.get('fuse') == F and rec.get('games') == count:
-                    traffic = rec.get('bytes_per_launch')
-            except Exception:
-                traffic = None
-        rcap = 9 if N <= 9 else 13 if N <= 13 else 19
-        if os.environ.get('GG_KERNEL_VARIANT') == '1':
-            kernel_name = 'k_rollout<%d>' % rcap
-        elif (F >= int(os.environ.get('GG_V3_MIN', '2')) and os.environ.get('GG_ROLLOUT_V2') != '1'
-              and (count >= 32 * torch.cuda.get_device_properties(dev).multi_processor_count or os.environ.get('GG_V3_NB'))):
-            # 12 boards per wave, liberty classes carried across plies; <row capacity, byte-plane I/O, drawn moves, N == capacity>
-            kernel_name = 'k_rollout3<%d, 0, false, %s>' % (rcap, 'true' if N == rcap else 'false')
-        else:
-            kernel_name = 'k_rollout2<%d, %s, false, %s>' % (rcap, 'true' if F <= 2 else 'false', 'true' if N == rcap else 'false')
+        N, F, K, W = opts['size'], opts['plies_per_step'], opts['steps'], opts['warmup']
+        also, per_ply = ({}, None) if args.no_also else extras(dev, back, opts)
+        launch_ms = res['kernel_ms'] / K
         line = {
-            'metric': 'env steps/sec across batched games, 19x19 uniform-random rollouts',
-            'value': round(value, 1), 'unit': 'env steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
-            'ms_per_step': round(wall_max * 1e3 / K, 6), 'higher_is_better': True, 'scaling': 'weak',
+            'metric': METRIC, 'value': round(res['value'], 1), 'unit': 'env steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': round(res['wall_s'] * 1e3 / K, 6), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
             'config': {
-                'workload': '%dx%d, %d parallel games%s, uniform-random rollouts with auto-reset, %d plies per launch'
-                            % (N, N, total_games, '' if world == 1 else ' (%d per GPU)' % per_gpu, F),
-                'board': N, 'games': total_games, 'games_per_gpu': per_gpu, 'plies_per_launch': F,
-                'burn_in_plies': args.burn_in, 'desync_plies': args.desync, 'sharding': 'batch split across ranks, no collective',
+                'workload': '%dx%d, %d parallel games%s, uniform-random rollouts with auto-reset; one bench step = one '
+                            'launch of %d plies for every game' % (N, N, res['total_games'],
+                                                                   '' if world == 1 else ' (%d per GPU)' % res['games_per_gpu'], F),
+                'board': N, 'games': res['total_games'], 'games_per_gpu': res['games_per_gpu'], 'plies_per_step': F,
+                'env_steps_per_bench_step': F * res['total_games'], 'burn_in_steps': opts['burn_in_steps'],
+                'desync_plies': opts['desync'], 'sharding': 'batch split across ranks by global game index, no collective',
             },
-            'roofline': {
-                'bound': 'hbm', 'kernel': kernel_name,
-                'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
-                'algorithmic_bytes_per_step': algo, 'steps_per_launch': count * F,
-                'launch_ms': round(launch_ms, 5),
-                'note': ('achieved = algorithmic bytes of the per-ply path (read + write one board + action per step) / '
-                         'launch time; the fused kernel keeps the boards on-chip for all plies of a launch, so it can '
-                         'exceed what any per-ply streaming implementation could reach (frac > 1); `traffic` is the '
-                         'HBM traffic it really causes per launch'),
-            },
+            'roofline': roofline_record(dev, N, res['count'], F, launch_ms, per_ply),
         }
         if cpu is not None:
             line['cpu_baseline'] = cpu
         line['also'] = also
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -95,7 +95,8 @@ def check(code, what):
 
 
 def stream_ptr(device=None):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """torch's current stream on `device` as a hipStream_t: launches go where the caller's torch work goes."""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def dev_ptr(t, dtype, name):
@@ -108,4 +109,4 @@ def dev_ptr(t, dtype, name):
     if t.dtype != dtype or not t.is_contiguous():
         raise GymGoNativeError('%s must be contiguous %s (got %s, contiguous=%s)'
                                % (name, dtype, t.dtype, t.is_contiguous()))
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()

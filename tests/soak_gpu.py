@@ -16,7 +16,7 @@ def soak(N, B, plies, seed):
     while t < plies:
         k = int(np.random.default_rng(t).integers(1, 9))
         if k % 3 == 0:
-            k += 8    # long enough for the v3 kernel (used from 8 192 games up, or for any batch with GG_V3_NB set)
+            k += 8    # long enough for the v3 kernel (used from 8 192 games up)
             gogame.batch_rollout(st, rng, k, True, la, None)
             gogame.batch_rollout_packed(pk, prng, k, True)
         elif k % 3 == 1:

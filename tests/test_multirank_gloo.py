@@ -1,7 +1,10 @@
-"""CPU, world_size 2 over gloo: the sharded rollout driver (the N>1 path of bench.py) - each rank owns a
-contiguous slice of the game range, seeds it by GLOBAL game index, no data-path collective; the union of
-the shards equals the single-rank run.  The device kernels are replaced by the oracle here (this is a
-test of the sharding / seeding / reduction logic, which is all that differs between N=1 and N>1)."""
+"""CPU, world_size 2 over gloo: bench.py's OWN per-rank driver (bench.run_rank: sharding by global game index,
+de-synchronising burn-in, warm-up, barrier-fenced timed region, max-over-ranks time, played-steps reduction) with the
+CPU oracle as the step backend - the union of the two ranks' shards must equal the single-rank run of the whole batch,
+and the aggregate must count every step of every rank.  The N > 1 self-spawn path of `python bench.py --gpus N` is
+exercised too (argument plumbing only: it needs GPUs to go further)."""
+import hashlib
+import json
 import os
 import socket
 import sys
@@ -10,6 +13,8 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 
 def _free_port():
@@ -20,39 +25,111 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, total, size, plies, outdir):
+class OracleBackend:
+    """bench.py's backend interface on the C oracle (host arrays): what HipBackend does on the device."""
+    name = 'oracle'
+
+    def setup(self, count, size, first_game):
+        from oracle import c_oracle
+        import bench
+        self.c, self.count, self.size, self.first = c_oracle, count, size, first_game
+        self.states = np.zeros((count, 6, size, size), np.uint8)
+        self.rng = np.array([c_oracle.lib().gg_oracle_rng_seed(bench.SEED, first_game + b) for b in range(count)], np.uint64)
+        self.steps = 0
+
+    def rollout(self, plies, lo=0, hi=None, count_steps=True):
+        hi = self.count if hi is None else hi
+        st, rg, _ = self.c.batch_rollout(self.states[lo:hi], self.rng[lo:hi], plies, True)
+        self.states[lo:hi], self.rng[lo:hi] = st, rg
+        if count_steps and lo == 0 and hi == self.count:
+            self.steps += plies * self.count
+
+    def sync(self):
+        pass
+
+    def played(self):
+        return self.steps
+
+    def timer(self):
+        import time
+        t = [0.0, 0.0]
+        return (lambda: t.__setitem__(0, time.perf_counter())), (lambda: t.__setitem__(1, time.perf_counter())), \
+            (lambda: (t[1] - t[0]) * 1e3)
+
+    def comm_tensor(self, values):
+        import torch
+        return torch.tensor(values, dtype=torch.float64)
+
+
+OPTS = {'size': 9, 'plies_per_step': 5, 'steps': 3, 'warmup': 1, 'games_per_gpu': 24, 'desync': 32, 'burn_in_steps': 1}
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank), 'WORLD_SIZE': str(world)})
     sys.path.insert(0, ROOT)
-    import torch
     import torch.distributed as dist
-    from gymgo_amd.envs.vec_env import shard
-    from oracle import c_oracle
-    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
-    first, count = shard(total, rank, world)
-    rng = np.array([c_oracle.lib().gg_oracle_rng_seed(20260927, first + i) for i in range(count)], dtype=np.uint64)
-    states = np.zeros((count, 6, size, size), np.uint8)
+    import bench
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    back = OracleBackend()
+    res = bench.run_rank(rank, world, back, dict(OPTS, world=world), dist)
+    np.save(os.path.join(outdir, 'states_%d.npy' % rank), back.states)
+    np.save(os.path.join(outdir, 'rng_%d.npy' % rank), back.rng)
+    if rank == 0:
+        json.dump(res, open(os.path.join(outdir, 'res.json'), 'w'))
+    else:
+        assert res is None
     dist.barrier()
-    states, rng, _ = c_oracle.batch_rollout(states, rng, plies, True)
-    dist.barrier()
-    # the only cross-rank traffic of the N>1 path: scalar timing / step counters
-    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    steps = torch.tensor([count * plies], dtype=torch.int64)
-    dist.all_reduce(steps, op=dist.ReduceOp.SUM)
-    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), states=states, first=first, tmax=t.numpy(), steps=steps.numpy())
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_rollout(tmp_path):
+def test_bench_run_rank_two_ranks_over_gloo(tmp_path):
     import torch.multiprocessing as mp
-    from oracle import c_oracle
-    total, size, plies, world = 37, 7, 60, 2
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, total, size, plies, str(tmp_path)), nprocs=world, join=True)
-    parts = [np.load(tmp_path / ('rank%d.npz' % r)) for r in range(world)]
-    merged = np.concatenate([p['states'] for p in parts])
-    assert [int(p['first']) for p in parts] == [0, 19]
-    rng = c_oracle.rng_seed(20260927, total)
-    want, _, _ = c_oracle.batch_rollout(np.zeros((total, 6, size, size), np.uint8), rng, plies, True)
-    assert np.array_equal(merged, want)
-    assert all(float(p['tmax'][0]) == 2.0 for p in parts)          # MAX over ranks reached every rank
-    assert all(int(p['steps'][0]) == total * plies for p in parts)  # whole-job step count
+    import bench
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = json.load(open(tmp_path / 'res.json'))
+    total = OPTS['games_per_gpu'] * world
+    assert res['total_games'] == total and res['count'] == OPTS['games_per_gpu'] and res['first'] == 0
+    assert res['steps_played'] == OPTS['steps'] * OPTS['plies_per_step'] * total           # summed over BOTH ranks
+    assert res['value'] == pytest.approx(res['steps_played'] / res['wall_s']) and res['wall_s'] > 0
+    # the union of the shards == bench's own driver at world 1 over the whole batch with the same schedule per game:
+    # rank r's games get the schedule of a 24-game shard (de-sync slices are per shard), so rebuild it shard by shard
+    got = np.concatenate([np.load(tmp_path / ('states_%d.npy' % r)) for r in range(world)])
+    got_rng = np.concatenate([np.load(tmp_path / ('rng_%d.npy' % r)) for r in range(world)])
+    parts, parts_rng = [], []
+    for r in range(world):
+        first, count = bench.shard(total, r, world)
+        solo = OracleBackend()
+        solo.setup(count, OPTS['size'], first)           # the same global game indices, in one process
+        chunk = (count + 15) // 16
+        for g in range(1, 16):
+            lo, hi = g * chunk, min(count, (g + 1) * chunk)
+            if lo < hi:
+                solo.rollout(g * OPTS['desync'] // 16, lo, hi)
+        solo.rollout(OPTS['plies_per_step'] * (OPTS['burn_in_steps'] + OPTS['warmup'] + OPTS['steps']))
+        parts.append(solo.states)
+        parts_rng.append(solo.rng)
+    assert np.array_equal(got, np.concatenate(parts)) and np.array_equal(got_rng, np.concatenate(parts_rng))
+    assert hashlib.sha256(got.tobytes()).hexdigest() != hashlib.sha256(np.zeros_like(got).tobytes()).hexdigest()
+
+
+def test_bench_shard_is_the_package_shard():
+    import bench
+    from gymgo_amd.envs.vec_env import shard
+    for total, world in ((1048576, 8), (65536, 1), (100, 3), (7, 8)):
+        parts = [bench.shard(total, r, world) for r in range(world)]
+        assert parts == [shard(total, r, world) for r in range(world)]
+        assert parts[0][0] == 0 and sum(c for _, c in parts) == total
+        assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+
+
+def test_bench_argument_plumbing():
+    import bench
+    a = bench.parse_args(['--gpus', '8', '--steps', '20', '--warmup', '5'])
+    assert (a.gpus, a.steps, a.warmup, a.plies_per_step) == (8, 20, 5, 256)       # F is NOT tied to --steps
+    a = bench.parse_args(['--fuse', '64'])
+    assert a.plies_per_step == 64 and a.gpus == 1
+    assert bench.algo_bytes_per_step(19) == 4336 and bench.fused_bytes_per_game(19) == 4348
+    assert bench.rollout_kernel_name(19, 65536, 256, 256) == 'k_rollout3<19, 0, false, true>'
+    assert bench.rollout_kernel_name(9, 4096, 256, 256) == 'k_rollout2<9, false, false, true>'
+    assert bench.rollout_kernel_name(19, 65536, 1, 256) == 'k_rollout2<19, true, false, true>'

@@ -159,7 +159,6 @@ def main():
         gogame.batch_next_states(st[:1], torch.tensor([361], device='cuda', dtype=torch.int32), check=False)
     torch.cuda.synchronize()
     out['next_state_single_19x19_ms'] = (time.perf_counter() - t0) / 50 * 1e3
-    out['variant'] = os.environ.get('GG_KERNEL_VARIANT', '2')
     print(json.dumps(out, indent=1))
 
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Condense gpurun_out/<tag>/ (written by tools/profile_round.sh on the GPU box) into tracked files under
-profiles/: <tag>_bench.json, <tag>_kernel_stats.csv, <tag>_summary.md and hbm_traffic.json (read by bench.py)."""
+"""Condense gpurun_out/<tag>/ (written by tools/profile_round.sh on the GPU box) into tracked files under profiles/:
+<tag>_bench.json, <tag>_kernel_stats.csv, <tag>_summary.md, <tag>_ops*.{json,csv} and pmc_rollout.json - the
+instruction mix and HBM traffic per launch shape that bench.py's roofline record reads."""
 import collections
 import csv
 import json
@@ -9,87 +10,137 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 src = os.path.join(ROOT, 'gpurun_out', tag)
 dst = os.path.join(ROOT, 'profiles')
 os.makedirs(dst, exist_ok=True)
 
 bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(dst, tag + '_bench.json'), 'w'), indent=1)
-F = bench['config']['plies_per_launch']
+F = bench['config']['plies_per_step']
 games = bench['config']['games_per_gpu']
+N = bench['config']['board']
+kernel = bench['roofline']['kernel']
 shutil.copy(os.path.join(src, 'kt', 'kt_kernel_stats.csv'), os.path.join(dst, tag + '_kernel_stats.csv'))
 stats = list(csv.DictReader(open(os.path.join(src, 'kt', 'kt_kernel_stats.csv'))))
 
 
-def counters(sub, want='rollout'):
-    """Per-dispatch counters of the full-batch launches (the de-synchronising burn-in launches run on 1/16 slices)."""
-    rows = list(csv.DictReader(open(os.path.join(src, sub, 'p_counter_collection.csv'))))
-    full = max(int(r['Grid_Size']) for r in rows if want in r['Kernel_Name'])
+def counter_rows(sub):
+    return list(csv.DictReader(open(os.path.join(src, sub, 'p_counter_collection.csv'))))
+
+
+def counters(sub, want, skip=2):
+    """Per-dispatch counters of the full-batch launches of kernel `want` (the de-synchronising burn-in launches run on
+    1/16 slices: smaller grids), without the first `skip` (cold) ones."""
+    rows = [r for r in counter_rows(sub) if want in r['Kernel_Name']]
+    full = max(int(r['Grid_Size']) for r in rows)
     per = collections.defaultdict(dict)
     for r in rows:
-        if want in r['Kernel_Name'] and int(r['Grid_Size']) == full:
+        if int(r['Grid_Size']) == full:
             d = per[int(r['Dispatch_Id'])]
             d[r['Counter_Name']] = float(r['Counter_Value'])
             d['_vgpr'], d['_sgpr'], d['_lds'] = r.get('VGPR_Count'), r.get('SGPR_Count'), r.get('LDS_Block_Size')
     ids = sorted(per)
-    return [per[i] for i in ids[2:]]   # skip the first two (cold) launches; every launch is F plies
+    return [per[i] for i in ids[skip:]]
 
 
-md = ['# %s profile summary (MI355X, `bench.py --fuse %d`, %d games of %dx%d)\n' % (
-    tag, F, games, bench['config']['board'], bench['config']['board'])]
-md.append('bench line: value = %.4g %s, ms_per_step = %.5f, roofline.frac = %.4f (achieved %.1f GB/s algorithmic)\n'
-          % (bench['value'], bench['unit'], bench['ms_per_step'], bench['roofline']['frac'], bench['roofline']['achieved']))
-md.append('## rocprofv3 --kernel-trace --stats (same command)\n')
+def mean(xs):
+    xs = list(xs)
+    return sum(xs) / len(xs)
+
+
+kshort = kernel.split('<')[0]
+md = ['# %s profile summary (MI355X, `bench.py --steps 20 --warmup 5 --plies-per-step %d`, %d games of %dx%d)\n' % (tag, F, games, N, N)]
+rf = bench['roofline']
+md.append('bench line: value = %.4g %s, ms_per_step = %.5f (one step = one launch of %d plies); roofline: bound %s, '
+          'achieved %s %s of peak %s -> frac %s; fused HBM frac %s; per-ply `%s` HBM frac %s\n'
+          % (bench['value'], bench['unit'], bench['ms_per_step'], F, rf['bound'], rf.get('achieved'), rf['unit'], rf['peak'],
+             rf.get('frac'), rf['hbm']['frac'], rf.get('per_ply', {}).get('kernel'), rf.get('per_ply', {}).get('frac')))
+md.append('## rocprofv3 --kernel-trace --stats (same command, extras and CPU baseline off)\n')
 md.append('| kernel | calls | avg ns | total % |\n|---|---|---|---|')
-for r in stats[:4]:
-    md.append('| `%s` | %s | %.0f | %s |' % (r['Name'][:70], r['Calls'], float(r['AverageNs']), r['Percentage']))
-trace = [r for r in csv.DictReader(open(os.path.join(src, 'kt', 'kt_kernel_trace.csv'))) if 'k_rollout' in r['Kernel_Name']]
+for r in stats[:5]:
+    md.append('| `%s` | %s | %.0f | %s |' % (r['Name'][:80], r['Calls'], float(r['AverageNs']), r['Percentage']))
+trace = [r for r in csv.DictReader(open(os.path.join(src, 'kt', 'kt_kernel_trace.csv'))) if kshort in r['Kernel_Name']]
 full = max(int(r['Grid_Size_X']) for r in trace)
 fullrows = [r for r in trace if int(r['Grid_Size_X']) == full]
-kname = fullrows[0]['Kernel_Name']
 durs = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in fullrows]
-other = [r for r in trace if int(r['Grid_Size_X']) != full]
-md.append('\nbench.py live launch_ms = %.4f; rocprofv3 average of the %d full-batch launches of `%s` (burn-in, warm-up, '
-          'timed: %d plies each) = %.4f ms.  The other %d rollout launches of the trace are the de-synchronising burn-in '
-          'launches on 1/16 slices of the batch (4 096 games each: below 8 192 games `gg_batch_rollout` uses the v2 kernel).'
-          % (bench['roofline']['launch_ms'], len(durs), kname.split('(')[0].replace('void gg::', ''), F,
-             sum(durs) / len(durs) / 1e6, len(other)))
+md.append('\nbench.py live launch_ms (HIP events over the 20 timed launches) = %.4f; rocprofv3 average of the %d full-batch '
+          'launches of `%s` (burn-in, warm-up, timed: %d plies each) = %.4f ms (min %.4f, max %.4f).'
+          % (rf['launch_ms'], len(durs), kernel, F, mean(durs) / 1e6, min(durs) / 1e6, max(durs) / 1e6))
+
+# ---- calibration of the traffic counters on launches with known byte counts (tools/calib_traffic.py)
+cal = {}
+calB = 65536
+known = {'k_unpack': {'read': 232 * calB, 'write': 2166 * calB}, 'k_pack': {'read': (3 * 361 + 3) * calB, 'write': 232 * calB}}
+try:
+    for cname, sub in (('FETCH_SIZE', 'cal_fetch'), ('WRITE_SIZE', 'cal_write')):
+        for k in known:
+            vals = [d[cname] for d in counters(sub, k, skip=1)]
+            cal.setdefault(k, {})[cname] = mean(vals) * 1024
+    md.append('\n## counter calibration (tools/calib_traffic.py: 65 536 boards, known bytes per launch)\n')
+    md.append('| kernel | known read | FETCH_SIZE x 1 KiB | ratio | known write | WRITE_SIZE x 1 KiB | ratio |\n|---|---|---|---|---|---|---|')
+    for k in known:
+        md.append('| `%s` | %.1f MB | %.1f MB | %.3f | %.1f MB | %.1f MB | %.3f |' % (
+            k, known[k]['read'] / 1e6, cal[k]['FETCH_SIZE'] / 1e6, cal[k]['FETCH_SIZE'] / known[k]['read'],
+            known[k]['write'] / 1e6, cal[k]['WRITE_SIZE'] / 1e6, cal[k]['WRITE_SIZE'] / known[k]['write']))
+    fetch_scale = known['k_pack']['read'] / cal['k_pack']['FETCH_SIZE']      # wide coalesced reads of byte planes
+    write_scale = known['k_unpack']['write'] / cal['k_unpack']['WRITE_SIZE']  # the rollout kernel's own store pattern
+    md.append('\ncorrection factors used below: FETCH_SIZE x %.3f (the guide prescribes x2 for wide coalesced reads on gfx950), '
+              'WRITE_SIZE x %.3f (calibrated on `k_unpack`, the same emitter as the write-back of `%s`)' % (fetch_scale, write_scale, kshort))
+except Exception as e:   # calibration pass missing: fall back to the guide's prescription
+    fetch_scale, write_scale = 2.0, 1.0
+    md.append('\n(calibration pass not available: %s; using FETCH_SIZE x2, WRITE_SIZE x1)' % e)
 
 steps = games * F
 traffic = {}
 for name, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
-    vals = [d[name] for d in counters(sub)]
-    traffic[name] = sum(vals) / len(vals)
-fetch_b = traffic['FETCH_SIZE'] * 1024 * 2   # gfx950: FETCH_SIZE reports 1/2 of a wide coalesced stream (MI355X_MICROARCH.md, HBM)
-write_b = traffic['WRITE_SIZE'] * 1024
-md.append('\n## HBM traffic per launch (PMC, separate passes; FETCH_SIZE x2 gfx950 correction, KiB units)\n')
-md.append('FETCH_SIZE = %.0f KiB -> %.1f MB read; WRITE_SIZE = %.0f KiB -> %.1f MB written; total %.1f MB per launch '
-          '= %.0f B per game per launch (algorithmic: %d B x %d steps = %.1f MB)'
+    traffic[name] = mean(d[name] for d in counters(sub, kshort))
+fetch_b = traffic['FETCH_SIZE'] * 1024 * fetch_scale
+write_b = traffic['WRITE_SIZE'] * 1024 * write_scale
+fused = rf['hbm']['algorithmic_bytes_per_launch']
+md.append('\n## HBM traffic per launch (PMC, separate passes)\n')
+md.append('FETCH_SIZE = %.0f KiB -> %.1f MB read; WRITE_SIZE = %.0f KiB -> %.1f MB written; total %.1f MB per launch = %.0f B '
+          'per game per launch.  A fused launch must move %.1f MB (board in + board out + generator per game): traffic / '
+          'algorithmic = %.2f.  At %.3f ms per launch that is %.0f GB/s = %.4f of the 8 TB/s peak - the kernel is not HBM-bound.'
           % (traffic['FETCH_SIZE'], fetch_b / 1e6, traffic['WRITE_SIZE'], write_b / 1e6, (fetch_b + write_b) / 1e6,
-             (fetch_b + write_b) / games, bench['roofline']['algorithmic_bytes_per_step'], steps,
-             bench['roofline']['algorithmic_bytes_per_step'] * steps / 1e6))
-json.dump({'size': bench['config']['board'], 'fuse': F, 'games': games,
-           'bytes_per_launch': round(fetch_b + write_b), 'fetch_bytes': round(fetch_b), 'write_bytes': round(write_b),
-           'source': 'profiles/%s_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)' % tag},
-          open(os.path.join(dst, 'hbm_traffic.json'), 'w'), indent=1)
+             (fetch_b + write_b) / games, fused / 1e6, (fetch_b + write_b) / fused, rf['launch_ms'],
+             (fetch_b + write_b) / (rf['launch_ms'] * 1e-3) / 1e9, (fetch_b + write_b) / (rf['launch_ms'] * 1e-3) / 8e12))
 
 md.append('\n## instruction mix per env step (PMC / (games x plies))\n')
+mix = {}
 for sub in ('pmc_inst', 'pmc_act'):
-    c = counters(sub)
+    c = counters(sub, kshort)
     keys = [k for k in c[0] if not k.startswith('_')]
-    avg = {k: sum(d[k] for d in c) / len(c) / steps for k in keys}
-    md.append('- ' + ', '.join('%s %.1f' % (k, v) for k, v in sorted(avg.items())))
-    md.append('  (LDS %s B per 64-thread workgroup)' % c[0]['_lds'])
-md.append('\nSQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles. The kernel is VALU-issue / dependency-latency bound, '
-          'not HBM-bound: per-op issue costs (2 or 4 cycles per wave64) are in profiles/r01_ubench_valu_rates.txt.')
+    avg = {k: mean(d[k] for d in c) / steps for k in keys}
+    mix.update(avg)
+    md.append('- ' + ', '.join('%s %.2f' % (k, v) for k, v in sorted(avg.items())))
+    md.append('  (VGPRs %s, LDS %s B per 64-thread workgroup)' % (c[0]['_vgpr'], c[0]['_lds']))
+md.append('\nSQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles.  bench.py prints achieved = (VALU + SALU + LDS instructions '
+          'per step) x env steps/s against a peak of one wave64 instruction per SIMD every 2 cycles.')
+
+# ---- the record bench.py reads
+pmc_path = os.path.join(dst, 'pmc_rollout.json')
+try:
+    allrec = json.load(open(pmc_path)).get('records', [])
+except Exception:
+    allrec = []
+rec = {'kernel': kernel, 'size': N, 'plies_per_launch': F, 'games': games,
+       'instr_per_step': {'valu': round(mix['SQ_INSTS_VALU'], 3), 'salu': round(mix['SQ_INSTS_SALU'], 3),
+                          'lds': round(mix['SQ_INSTS_LDS'], 3)},
+       'hbm_bytes_per_launch': round(fetch_b + write_b), 'fetch_bytes': round(fetch_b), 'write_bytes': round(write_b),
+       'fetch_scale': round(fetch_scale, 4), 'write_scale': round(write_scale, 4),
+       'source': 'profiles/%s_summary.md (rocprofv3 --pmc passes of `bench.py --plies-per-step %d`, tools/profile_round.sh)' % (tag, F)}
+allrec = [r for r in allrec if not (r['kernel'] == kernel and r['size'] == N and r['plies_per_launch'] == F and r['games'] == games)]
+allrec.append(rec)
+json.dump({'records': allrec}, open(pmc_path, 'w'), indent=1)
+
 ops_stats = os.path.join(src, 'kt_ops', 'kt_kernel_stats.csv')
 if os.path.exists(ops_stats):
     shutil.copy(ops_stats, os.path.join(dst, tag + '_ops_kernel_stats.csv'))
     shutil.copy(os.path.join(src, 'ops.json'), os.path.join(dst, tag + '_ops.json'))
     md.append('\n## the other entry points (`tools/bench_ops.py`, rocprofv3 --kernel-trace --stats; %s_ops.json has the rates)\n' % tag)
     md.append('| kernel | calls | avg ns |\n|---|---|---|')
-    for r in list(csv.DictReader(open(ops_stats)))[:14]:
+    for r in list(csv.DictReader(open(ops_stats)))[:16]:
         md.append('| `%s` | %s | %.0f |' % (r['Name'][:80], r['Calls'], float(r['AverageNs'])))
 open(os.path.join(dst, tag + '_summary.md'), 'w').write('\n'.join(md) + '\n')
 print('\n'.join(md))
