@@ -206,7 +206,7 @@ def rollout_kernel_name(n, games, plies, cus):
     rcap = 9 if n <= 9 else 13 if n <= 13 else 19
     full = 'true' if n == rcap else 'false'
     if plies >= 2 and games >= 32 * cus:
-        return 'k_rollout3<%d, 0, false, %s>' % (rcap, full)
+        return 'k_rollout4<%d, 0, false, %s>' % (rcap, full)
     return 'k_rollout2<%d, %s, false, %s>' % (rcap, 'true' if plies <= 2 else 'false', full)
 
 

@@ -1,7 +1,7 @@
 // gg_kernels.hip - C-ABI (include/gymgo_amd.h) of the MI355X batched Go step path: argument checks, device selection,
 // grid sizing and dispatch on the board-size template.  The kernels live in gg_common.h (shared building blocks),
-// gg_v2.h (per-ply kernels: two boards per wavefront, every liberty class from scratch), gg_v3.h (multi-ply kernels:
-// twelve boards per wavefront, liberty classes carried from ply to ply) and gg_aux.h (stand-alone sampler and capture
+// gg_v2.h (per-ply kernels: two boards per wavefront, every liberty class from scratch), gg_v4.h (multi-ply kernels:
+// sixteen boards per wavefront, liberty classes carried from ply to ply) and gg_aux.h (stand-alone sampler and capture
 // resolution).  Which kernel serves an entry point depends on the arguments only (batch size, plies per launch): there
 // are no environment switches and no mutable global state besides the per-device CU-count cache below.
 #include <hip/hip_runtime.h>
@@ -9,7 +9,7 @@
 
 #include "gg_common.h"
 #include "gg_v2.h"
-#include "gg_v3.h"
+#include "gg_v4.h"
 #include "gg_aux.h"
 #include "gymgo_amd.h"
 
@@ -62,23 +62,24 @@ int grid_resident(int cus, int64_t work, int waves_per_simd) {
   return (int)(work < cap ? (work > 0 ? work : 1) : cap);
 }
 
-// v3 kernels: boards per wave (even, <= kNB3).  Twelve is the most efficient (the flood batch is shared by more boards:
-// 65 536 games run 3.4e9 steps/s with 12, 3.1e9 with 8, 1.9e9 with 4); small batches take fewer per wave so that
-// every SIMD still gets a wave.
-int v3_boards_per_wave(int cus, int64_t B, int &grid) {
+// multi-ply kernel: boards per wave (even, <= kNB4 = 16).  The flood batch of a ply costs the same for 2 or 16 boards, so
+// the more the better; small batches take fewer per wave so that every SIMD still gets a wave.  65 536 games on 256 CUs:
+// 16 boards x 4 096 waves = exactly the resident set (4 waves per SIMD).
+int boards_per_wave(int cus, int64_t B, int &grid) {
   int64_t nb = B / ((int64_t)cus * 4);
-  if (nb > kNB3) nb = kNB3;
+  if (nb > kNB4) nb = kNB4;
   nb &= ~(int64_t)1;
   if (nb < 2) nb = 2;
   grid = grid_for(cus, (B + nb - 1) / nb);
   return (int)nb;
 }
 
-// Byte-plane / packed boards enter a multi-ply launch through one v2 analysis per board; v3 pays off once every SIMD
-// can get a wave of >= 8 boards (9x9: 4 096 games 1.4e9 vs 2.0e9 on v2; 16 384 games on par; 262 144 games 9.7e9 vs
-// 2.9e9) and from two plies per launch on (65 536 games, 2 / 3 / 5 plies per launch: 1.31 / 1.78 / 2.47e9 steps/s
-// against 1.14 / 1.32 / 1.51e9 on v2).  Tracked boards carry their classes and always run v3.
-bool use_v3(int cus, int64_t B, int plies) { return plies >= 2 && B >= (int64_t)cus * 32; }
+// Byte-plane / packed boards enter a multi-ply launch through one full analysis per board; the multi-ply kernel pays
+// off once every SIMD can get a wave of >= 8 boards and from two plies per launch on (round-1 measurements: 9x9 x 4 096
+// games 1.4e9 vs 2.0e9 steps/s on the per-ply kernel, 16 384 games on par, 262 144 games 9.7e9 vs 2.9e9; 65 536 games at
+// 2 / 3 / 5 plies per launch 1.31 / 1.78 / 2.47e9 against 1.14 / 1.32 / 1.51e9).  Tracked boards carry their classes
+// and always run it.
+bool use_multi_ply(int cus, int64_t B, int plies) { return plies >= 2 && B >= (int64_t)cus * 32; }
 
 int32_t check(int64_t B, int32_t N) { return (N < 2 || N > GG_MAX_BOARD || B < 0) ? GG_E_BADSIZE : 0; }
 
@@ -90,15 +91,15 @@ uint32_t recip16(int32_t N) {
   return inv;
 }
 
-// v3 kernels: the instantiation with compile-time N when the board fills its row capacity (9, 13, 19)
-#define GG_DISPATCH3(N, IO, MOVES, GRID, ...)                                                          \
+// multi-ply kernel: the instantiation with compile-time N when the board fills its row capacity (9, 13, 19)
+#define GG_DISPATCH4(N, IO, MOVES, GRID, ...)                                                          \
   do {                                                                                                  \
-    if ((N) == 9) { k_rollout3<9, IO, MOVES, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }        \
-    else if ((N) < 9) { k_rollout3<9, IO, MOVES, false><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }   \
-    else if ((N) == 13) { k_rollout3<13, IO, MOVES, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
-    else if ((N) < 13) { k_rollout3<13, IO, MOVES, false><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
-    else if ((N) == 19) { k_rollout3<19, IO, MOVES, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
-    else { k_rollout3<19, IO, MOVES, false><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }               \
+    if ((N) == 9) { k_rollout4<9, IO, MOVES, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }        \
+    else if ((N) < 9) { k_rollout4<9, IO, MOVES, false><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }   \
+    else if ((N) == 13) { k_rollout4<13, IO, MOVES, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
+    else if ((N) < 13) { k_rollout4<13, IO, MOVES, false><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
+    else if ((N) == 19) { k_rollout4<19, IO, MOVES, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
+    else { k_rollout4<19, IO, MOVES, false><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }               \
   } while (0)
 
 #define GG_DISPATCH(N, CALL9, CALL13, CALL19) \
@@ -205,10 +206,10 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
   GG_ENTER(states);
   if (plies == 0) return 0;
   if (!rng) return GG_E_NULLPTR;
-  if (use_v3(cus, B, plies)) {   // liberty classes carried across the plies, 12 boards per wave
+  if (use_multi_ply(cus, B, plies)) {   // liberty classes carried across the plies, 16 boards per wave
     int grid;
-    const int nb = v3_boards_per_wave(cus, B, grid);
-    GG_DISPATCH3(N, 0, false, grid, states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
+    const int nb = boards_per_wave(cus, B, grid);
+    GG_DISPATCH4(N, 0, false, grid, states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
     return (int32_t)hipGetLastError();
   }
   const int grid = grid_for(cus, (B + 1) / 2);
@@ -316,10 +317,10 @@ int32_t gg_batch_rollout_packed(uint32_t *packed, uint64_t *rng, int32_t *last_a
   if (plies == 0) return 0;
   if (!rng) return GG_E_NULLPTR;
   uint8_t *st = reinterpret_cast<uint8_t *>(packed);
-  if (use_v3(cus, B, plies)) {
+  if (use_multi_ply(cus, B, plies)) {
     int grid3;
-    const int nb = v3_boards_per_wave(cus, B, grid3);
-    GG_DISPATCH3(N, 1, false, grid3, st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
+    const int nb = boards_per_wave(cus, B, grid3);
+    GG_DISPATCH4(N, 1, false, grid3, st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
     return (int32_t)hipGetLastError();
   }
   const int grid = grid_for(cus, (B + 1) / 2);
@@ -368,10 +369,10 @@ int32_t gg_batch_play_moves(uint8_t *states, const int32_t *moves, int32_t *play
   if (T < 0) return GG_E_BADARG;
   GG_ENTER(states);
   if (T > 0 && !moves) return GG_E_NULLPTR;
-  if (use_v3(cus, B, T)) {
+  if (use_multi_ply(cus, B, T)) {
     int grid3;
-    const int nb = v3_boards_per_wave(cus, B, grid3);
-    GG_DISPATCH3(N, 0, true, grid3, states, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played);
+    const int nb = boards_per_wave(cus, B, grid3);
+    GG_DISPATCH4(N, 0, true, grid3, states, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played);
     return (int32_t)hipGetLastError();
   }
   const int grid = grid_for(cus, (B + 1) / 2);
@@ -387,10 +388,10 @@ int32_t gg_batch_play_moves_packed(uint32_t *packed, const int32_t *moves, int32
   GG_ENTER(packed);
   if (T > 0 && !moves) return GG_E_NULLPTR;
   uint8_t *st = reinterpret_cast<uint8_t *>(packed);
-  if (use_v3(cus, B, T)) {
+  if (use_multi_ply(cus, B, T)) {
     int grid3;
-    const int nb = v3_boards_per_wave(cus, B, grid3);
-    GG_DISPATCH3(N, 1, true, grid3, st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played);
+    const int nb = boards_per_wave(cus, B, grid3);
+    GG_DISPATCH4(N, 1, true, grid3, st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played);
     return (int32_t)hipGetLastError();
   }
   const int grid = grid_for(cus, (B + 1) / 2);
@@ -400,7 +401,7 @@ int32_t gg_batch_play_moves_packed(uint32_t *packed, const int32_t *moves, int32
   return (int32_t)hipGetLastError();
 }
 
-// ---- tracked boards (uint32 [B][5 N + 1]): packed boards that carry their liberty classes (see gg_v3.h)
+// ---- tracked boards (uint32 [B][5 N + 1]): packed boards that carry their liberty classes (see gg_v4.h)
 int32_t gg_tracked_words(int32_t N) { return (N < 2 || N > GG_MAX_BOARD) ? GG_E_BADSIZE : 5 * N + 1; }
 
 int32_t gg_batch_track_states(const uint8_t *states, uint32_t *tracked, int64_t B, int32_t N, void *hip_stream) {
@@ -431,8 +432,8 @@ int32_t gg_batch_rollout_tracked(uint32_t *tracked, uint64_t *rng, int32_t *last
   if (!rng) return GG_E_NULLPTR;
   uint8_t *st = reinterpret_cast<uint8_t *>(tracked);
   int grid3;
-  const int nb = v3_boards_per_wave(cus, B, grid3);
-  GG_DISPATCH3(N, 2, false, grid3, st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
+  const int nb = boards_per_wave(cus, B, grid3);
+  GG_DISPATCH4(N, 2, false, grid3, st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
   return (int32_t)hipGetLastError();
 }
 
@@ -443,8 +444,8 @@ int32_t gg_batch_play_moves_tracked(uint32_t *tracked, const int32_t *moves, int
   if (T > 0 && !moves) return GG_E_NULLPTR;
   uint8_t *st = reinterpret_cast<uint8_t *>(tracked);
   int grid3;
-  const int nb = v3_boards_per_wave(cus, B, grid3);
-  GG_DISPATCH3(N, 2, true, grid3, st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played);
+  const int nb = boards_per_wave(cus, B, grid3);
+  GG_DISPATCH4(N, 2, true, grid3, st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played);
   return (int32_t)hipGetLastError();
 }
 

@@ -1,0 +1,681 @@
+// gg_v4.h - the multi-ply kernel: SIXTEEN BOARDS PER WAVEFRONT (one DPP quad of lanes per board), liberty classes
+// carried from ply to ply in registers.
+#pragma once
+#include "gg_v2.h"
+
+namespace gg {
+
+// ===================================================================== v4: incremental analysis, 16 boards per wave
+// A per-ply kernel (gg_v2.h) re-derives every group's liberty class each ply with 22 floods per board.  The cost of a
+// flood batch does not depend on how many of the wave's 64 lanes carry a flood, so the lever is floods per board: a
+// move at q only changes the groups ADJACENT to q (and, rarely, to a captured group).  The kernel keeps, per board,
+// the stones whose group has >= 2 liberties (`M`; every other stone is in atari: a legal position has no
+// liberty-less group) and the next mover's invalid-move mask, and updates them per ply from at most FOUR floods:
+//   * the mover's group G that the new stone joins - only when q has a friendly neighbour (otherwise G = {q}, whose
+//     liberties are q's empty neighbours: no flood);
+//   * the opponent's group at each neighbour of q that holds an opponent stone.
+// A friendly neighbour leaves at most three opponent neighbours, so four lanes always suffice: the roles are
+// assigned per ply (opponent neighbours in direction order on lanes 0.., G on lane 3).  Round 1's kernel gave every
+// board five fixed roles (12 boards x 5 lanes); with four lanes a board is exactly one DPP QUAD - every
+// board-level reduction is two quad_perm moves - 16 boards share a flood batch instead of 12, and 65 536 games are
+// exactly 4 096 waves = ONE resident set of an MI355X (256 CUs x 4 SIMDs x 4 waves): no second, part-filled round.
+// A ply is three phases on ONE lane assignment (board = lane / 4, t = lane % 4; in phases 1 and 3 lane t owns the
+// RPL = ceil(R / 4) adjacent rows RPL t .. RPL t + RPL - 1):
+//   1. sampling: liveness, the generator (drawn redundantly by the four lanes), the k-th valid point of the mask (a
+//      lane counts its own rows, the board's prefix / total come from a two-step quad scan, the lane that holds the
+//      point selects row and bit), the stone ORed into the mover's plane; auto-reset on a rare path;
+//   2. one lane per (board, role): role assignment from the six rows around q, the flood, then the liberties (dilate
+//      & empty, saturated at 2) and the size of the lane's own group, all rows in registers; an opponent group that
+//      keeps >= 2 liberties zeroes its result, so phase 3 never sees it;
+//   3. class patch, all sixteen boards in one pass: an opponent group next to q with no liberty left is captured, with
+//      one left it leaves M; G takes the class of its own count (+ the captured points next to it); a mover's group in
+//      atari next to a captured stone gains a liberty (rare; a flood through the atari set in this layout); every
+//      other group keeps its class.  The invalid-move mask follows from the classes exactly as in the per-ply kernels.
+// M and the mask are produced and consumed by the same lanes (phases 3 -> 1 -> 3), so they live in REGISTERS for the
+// whole launch (2 x RPL VGPRs); LDS holds the two stone planes (which the flood lanes read in the other layout), the
+// flood results and a few words per board: 8 704 B per wave at 19x19.
+constexpr int kNB4 = 16;
+
+template <int R>
+struct Lds4 {
+  static constexpr int RS = Cfg<R>::kRowStride;
+  static constexpr int RPL = (R + 3) / 4;                        // rows per lane in phases 1 and 3
+  static_assert(4 * RPL <= RS, "a quad's rows must fit the row stride");
+  static constexpr int kState = 0;                               // [2][kNB4][RS]: black, white
+  static constexpr int kMeta = kState + 2 * kNB4 * RS;           // flags[16], act[16], last[16], played[16], rng[32]
+  static constexpr int kInfo = kMeta + 6 * kNB4;                 // per board: what phase 2 learnt about q's neighbours
+  static constexpr int kTmp = kInfo + kNB4;                      // [2][2][RS]: layout change of one pair at load / store
+  static constexpr int kUnion = kTmp + 4 * RS;
+  // ply loop: per flood lane its result word (liberty class, size, role, seed) + the transpose buffer of the group masks
+  static constexpr int kCls = kUnion;
+  static constexpr int kSc = kCls + kWave;
+  static constexpr int kLoopEnd = kSc + kWave * RS;
+  // load / store: the v2 analysis in its compact form (region 0 only: staging / transpose buffer); at store time the
+  // emitter's scratch (2 x 128 words) and the spread table (uint2[256]); tracked boards: the parked mask / class rows
+  static constexpr int kV2 = kUnion;
+  static constexpr int kLut = kV2 + 256;
+  static constexpr int kIoEnd = kV2 + (Lds2<R>::kRegion0 > 768 ? Lds2<R>::kRegion0 : 768);
+  static constexpr int kTotal = kLoopEnd > kIoEnd ? kLoopEnd : kIoEnd;
+  static_assert(kUnion % 4 == 0, "16-byte alignment of the flood blocks");
+  static_assert(3 * kNB4 * RS <= kWave * RS + kWave, "parked tracked rows fit the flood blocks");
+};
+
+// DPP inside a quad (quad_perm: lane i of each quad reads lane perm[i]); bound_ctrl off: every source lane exists
+constexpr int QP_SHR1 = 0x90;   // [0,0,1,2]: lane i reads lane i-1 (lane 0 reads itself: mask it)
+constexpr int QP_SHR2 = 0x40;   // [0,0,0,1]: lanes 2, 3 read lanes 0, 1
+constexpr int QP_B0 = 0x00, QP_B3 = 0xFF;   // broadcast of lane 0 / lane 3
+constexpr int QP_X1 = 0xB1, QP_X2 = 0x4E;   // [1,0,3,2] / [2,3,0,1]: butterfly
+__device__ __forceinline__ uint32_t quad_or(uint32_t x) { x |= dpp0<QP_X1>(x); return x | dpp0<QP_X2>(x); }
+__device__ __forceinline__ uint32_t quad_sum(uint32_t x) { x += dpp0<QP_X1>(x); return x + dpp0<QP_X2>(x); }
+
+// 4-neighbourhood dilation of the RPL adjacent rows of a lane: the row above x[0] / below x[RPL-1] sits in the
+// neighbouring lane (a non-existent row of a quad's last lane is zero in every set that is dilated, so nothing leaks
+// from the previous board; what leaks into such a row from the next board is masked by the caller).  The centre point
+// is not part of the result.
+template <int RPL>
+__device__ __forceinline__ void dilate_rows(const uint32_t (&x)[RPL], uint32_t (&d)[RPL]) {
+  const uint32_t up = dpp0<0x138>(x[RPL - 1]), dn = dpp0<0x130>(x[0]);
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    const uint32_t above = r == 0 ? up : x[r - 1], below = r == RPL - 1 ? dn : x[r + 1];
+    d[r] = B3(shl1(x[r]), x[r] >> 1, above, T_OR3) | below;
+  }
+}
+
+// cls word of a flood lane: bits 0-1 liberties of the group (saturated at 2), 2 the group is one stone, 3 the group
+// exists (the seed was a stone), 4 the lane flooded G (the mover's group), 8-15 / 16-23 row / column of the seed
+constexpr uint32_t CL_LIBS = 3u, CL_ONE = 4u, CL_ANY = 8u, CL_G = 16u;
+// per-board word of phase 2: bits 0-1 empty neighbours of q (saturated at 2), 2 q has a friendly neighbour, 3 every
+// on-board neighbour of q holds an opponent stone (state_utils.adj_data's `surrounded`, gym_go/state_utils.py:214-223)
+constexpr uint32_t BI_EMPTY = 3u, BI_FRIEND = 4u, BI_BOXED = 8u;
+
+// MOVES: the moves are given (moves: int32 [B][plies], gg_batch_play_moves) instead of drawn: a game stops at its first
+// move that is out of range, on an invalid point or made after the game has ended; played_out[b] = moves applied.
+// IO: 0 = byte planes (uint8 [B][6][N][N]), 1 = packed boards (uint32 [B][3N+1]), 2 = TRACKED boards (uint32 [B][5N+1]:
+// the rows of black, white, invalid, multi_black, multi_white + the flag word - a packed board that carries its
+// liberty classes, so that a launch needs no first analysis: per-ply stepping at the fused kernel's rate).
+// FULLN: the board fills the row capacity (N == R: 9, 13, 19) - the per-row "r < N" guards fold away at compile time.
+template <int R, int IO, bool MOVES = false, bool FULLN = false>
+__global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+                                                       int32_t *__restrict__ last_actions, int64_t *__restrict__ steps_done,
+                                                       int64_t B, int N, uint32_t inv, int plies, int auto_reset,
+                                                       int nb, const int32_t *__restrict__ moves = nullptr,
+                                                       int32_t *__restrict__ played_out = nullptr) {
+  constexpr int RS = Lds4<R>::RS;
+  constexpr int RV = (R + 3) / 4;
+  constexpr int RPL = Lds4<R>::RPL;
+  constexpr int PL = kNB4 * RS;   // words per plane of all boards
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds4<R>::kTotal];
+  if (FULLN) N = R;   // a compile-time constant from here on: row masks, r * N + c and the "row exists" tests fold
+  const Half hf = make_half(threadIdx.x, N, inv);
+  uint32_t *st = lds + Lds4<R>::kState;     // st[colour * PL + board * RS + row]
+  uint32_t *flagsv = lds + Lds4<R>::kMeta;  // bit 0 turn, 1 passed, 2 done, 3 on, 4 stopped (given moves)
+  int *actv = reinterpret_cast<int *>(lds + Lds4<R>::kMeta + kNB4);
+  int *lastv = reinterpret_cast<int *>(lds + Lds4<R>::kMeta + 2 * kNB4);
+  int *playedv = reinterpret_cast<int *>(lds + Lds4<R>::kMeta + 3 * kNB4);
+  uint32_t *rngv = lds + Lds4<R>::kMeta + 4 * kNB4;   // [2 * s], [2 * s + 1]
+  uint32_t *binfo = lds + Lds4<R>::kInfo;
+  uint32_t *tmp = lds + Lds4<R>::kTmp;      // tmp[(half * 2 + set) * RS + row], set 0 = invalid, 1 = M
+  uint32_t *clsv = lds + Lds4<R>::kCls;
+  uint32_t *sc = lds + Lds4<R>::kSc;
+  uint32_t *v2 = lds + Lds4<R>::kV2;
+  uint32_t *park = lds + Lds4<R>::kV2;      // tracked I/O: park[set * PL + board * RS + row], set 0 invalid, 1 mb, 2 mw
+  uint2 *lut = reinterpret_cast<uint2 *>(lds + Lds4<R>::kLut);
+  constexpr bool PACKED = IO == 1, TRACKED = IO == 2;
+  const int S = 6 * hf.P, W = (TRACKED ? 5 : 3) * N + 1;
+  const bool row = hf.hl < RS;
+  // nb (even, <= kNB4) boards per wave: the host picks it so that the groups fill the resident waves evenly
+  const int64_t ngroups = (B + nb - 1) / nb;
+  const int q4 = hf.lane >> 2, t4 = hf.lane & 3, r04 = RPL * t4;   // outside the ply loop: board / first row of this lane
+
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t b_first = g * nb;
+    // the next mover's invalid-move mask and the stones of groups with >= 2 liberties, rows r04 .. r04 + RPL - 1 of
+    // board q4: in registers from here to the write-back
+    uint32_t inv_r[RPL], M[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) inv_r[r] = M[r] = 0u;
+    // ---------------------------------------------------------------- load
+    WAVE_SYNC();
+    if (TRACKED) {
+      // the group's boards are ONE contiguous block of nb x (5 N + 1) words: a flat, fully coalesced copy (all loads in
+      // flight at once); the stone planes go to their place, the mask / class rows are parked in the flood blocks and
+      // picked up by their owner lanes
+      const int64_t nbrd = (B - b_first) < nb ? (B - b_first) : nb;
+      const int nw = (int)nbrd * W;
+      const uint32_t *gp = reinterpret_cast<const uint32_t *>(states) + b_first * (int64_t)W;
+      for (int i = hf.lane; i < 2 * PL; i += kWave) st[i] = 0;      // rows N .. RS-1 and absent boards read as zero
+      for (int i = hf.lane; i < 3 * PL; i += kWave) park[i] = 0;
+      const uint32_t invW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;   // i / W exactly for i < 16 * 96
+      WAVE_SYNC();
+      for (int i = hf.lane; i < nw; i += kWave) {
+        const uint32_t v = gp[i];
+        const int sb = (int)(((uint32_t)i * invW) >> 20), w = i - sb * W;
+        if (w == 5 * N) {
+          flagsv[sb] = (v & 7u) | 8u;
+        } else {
+          const int pl = (int)(((uint32_t)w * hf.inv) >> 16), rw = w - pl * N;
+          if (pl < 2) st[pl * PL + sb * RS + rw] = v;
+          else park[(pl - 2) * PL + sb * RS + rw] = v;
+        }
+      }
+      if (hf.lane < kNB4) {
+        const int sb = hf.lane;
+        const bool on = sb < nb && b_first + sb < B;
+        if (!on) flagsv[sb] = 0;
+        lastv[sb] = -1;
+        playedv[sb] = 0;
+        if (!MOVES) {
+          const uint64_t x = rng[on ? b_first + sb : B - 1];
+          rngv[2 * sb] = (uint32_t)x;
+          rngv[2 * sb + 1] = (uint32_t)(x >> 32);
+        }
+      }
+      WAVE_SYNC();
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        inv_r[r] = park[0 * PL + q4 * RS + r04 + r];
+        M[r] = park[1 * PL + q4 * RS + r04 + r] | park[2 * PL + q4 * RS + r04 + r];
+      }
+      WAVE_SYNC();
+    } else {
+      if (hf.lane < kNB4) flagsv[hf.lane] = 0;                       // boards beyond nb: off
+      for (int i = hf.lane; i < 2 * PL; i += kWave) st[i] = 0;
+      WAVE_SYNC();
+    }
+#pragma unroll 1
+    for (int i = 0; i < (TRACKED ? 0 : nb / 2); ++i) {   // byte planes / packed boards: pairs, first classes by the v2 analysis
+      const int s = 2 * i + hf.h;
+      const bool on = b_first + s < B;
+      const int64_t b = on ? b_first + s : B - 1;
+      uint32_t black, white, invalid, mb = 0, mw = 0;
+      int turn, passed, done;
+      if (PACKED) {
+        uint32_t fw;
+        load_packed_h(reinterpret_cast<const uint32_t *>(states) + b * (int64_t)W, N, hf, black, white, invalid, fw);
+        turn = fw & 1u; passed = (fw >> 1) & 1u; done = (fw >> 2) & 1u;
+      } else {
+        const uint8_t *gs = states + b * (int64_t)S;
+        uint8_t *io = reinterpret_cast<uint8_t *>(v2) + hf.h * Cfg<R>::kIoBytes;
+        const uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
+        WAVE_SYNC();
+        const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
+        WAVE_SYNC();
+        black = plane_to_row<R>(io + mi, N, hf.hl);
+        white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+        invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
+        turn = flags & 1u; passed = (flags >> 2) & 1u; done = (flags >> 3) & 1u;
+      }
+      {
+        uint32_t ab;
+        analyze2<R, false>(black, white, hf.full_l1 & ~(black | white), hf, v2, mb, ab, mw, nullptr, nullptr, true);
+      }
+      if (row) {
+        st[0 * PL + s * RS + hf.hl] = black;
+        st[1 * PL + s * RS + hf.hl] = white;
+        tmp[(hf.h * 2 + 0) * RS + hf.hl] = invalid;
+        tmp[(hf.h * 2 + 1) * RS + hf.hl] = mb | mw;
+      }
+      if (hf.hl == 0) {
+        flagsv[s] = (uint32_t)turn | ((uint32_t)passed << 1) | ((uint32_t)done << 2) | (on ? 8u : 0u);
+        lastv[s] = -1;
+        playedv[s] = 0;
+        if (!MOVES) {
+          const uint64_t x = rng[b];
+          rngv[2 * s] = (uint32_t)x;
+          rngv[2 * s + 1] = (uint32_t)(x >> 32);
+        }
+      }
+      WAVE_SYNC();
+      if ((hf.lane >> 3) == i) {   // the two quads that own this pair pick their rows up
+        const uint32_t *tp = tmp + ((q4 & 1) * 2) * RS + r04;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          inv_r[r] = tp[r];
+          M[r] = tp[RS + r];
+        }
+      }
+      WAVE_SYNC();
+    }
+
+    // ---------------------------------------------------------------- the plies
+    int mv_next = 0;
+#pragma unroll 1
+    for (int t = 0; t < plies; ++t) {
+      // the lane-derived indices of the three phases are recomputed every ply (a few VALU ops) instead of being hoisted
+      // out of the loop, where they end up in scratch: a reload is a vector-memory round trip at the top of each phase
+      // (volatile asm: neither hoisted nor merged)
+      int ln;   // = hf.lane (one wave per workgroup), straight from the hardware
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      const int s4 = ln >> 2, t5 = ln & 3, r0 = RPL * t5;   // board, lane of the quad, first row of this lane
+      const bool bl = s4 < nb;
+      uint32_t full[RPL];   // the N-bit row mask of the lane's rows that exist
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) full[r] = (r0 + r < N) ? (1u << N) - 1u : 0u;
+
+      // phase 1 - four lanes per board, RPL rows each: liveness, the generator (drawn redundantly by the four lanes),
+      // the k-th valid point of the mask (or the given move)
+      {
+        const uint32_t fl = flagsv[s4];
+        const bool on = bl && ((fl >> 3) & 1u);
+        const bool done = (fl >> 2) & 1u;
+        bool live, reset, place = false, wr_act;
+        int rabs = 0, a;
+        uint32_t pos = 0;
+        uint64_t x = 0;
+        if (MOVES) {
+          // the move of this ply was fetched during the previous one (mv_next), the next one is requested now
+          const int64_t bm = (b_first + s4 < B) ? b_first + s4 : B - 1;
+          const int mv = t == 0 ? moves[bm * (int64_t)plies] : mv_next;
+          if (t + 1 < plies) mv_next = moves[bm * (int64_t)plies + t + 1];
+          reset = false;
+          live = on && !done && !((fl >> 4) & 1u) && mv >= 0 && mv <= hf.P;
+          a = hf.P;
+          const bool pt = live && mv < hf.P;
+          int ar = 0, ac = 0;
+          if (pt) split_action(mv, N, hf.inv, ar, ac);
+          // the lane that owns row ar tests the mask bit, the quad shares the verdict
+          uint32_t bad = 0;
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) bad |= (pt && r0 + r == ar) ? ((inv_r[r] >> ac) & 1u) : 0u;
+          const bool illegal = quad_or(bad) != 0u;
+          if (pt) {
+            live = !illegal;
+            rabs = ar; pos = (uint32_t)ac;
+            a = mv;
+          }
+          wr_act = bl && t5 == 0;
+          if (on && !live && wr_act) flagsv[s4] = fl | 16u;   // stopped for good
+          if (!live) a = -1;
+          place = wr_act && a >= 0 && a < hf.P;
+        } else {
+          live = on && !(done && !auto_reset);
+          reset = live && done;           // auto-reset: the board is init_state from now on
+          uint32_t v[RPL], p[RPL];
+          const uint32_t rm = reset ? ~0u : 0u;   // a board being reset plays on the empty board
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) {
+            v[r] = B3(full[r], rm, inv_r[r], TA & (TB | (~TC & 0xFF)));   // full: 0 for rows >= N
+            p[r] = (uint32_t)__popc(v[r]) + (r ? p[r - 1] : 0u);
+          }
+          const uint32_t T = p[RPL - 1];
+          // valid points of the board up to and including this lane (Sx) and on the whole board (n): quad scan
+          // (the DPP moves are evaluated by every lane, THEN masked: inside a conditional the source lanes would be off)
+          const uint32_t sh1 = dpp0<QP_SHR1>(T);
+          const uint32_t x1 = T + (t5 >= 1 ? sh1 : 0u);
+          const uint32_t sh2 = dpp0<QP_SHR2>(x1);
+          const uint32_t Sx = x1 + (t5 >= 2 ? sh2 : 0u);
+          const uint32_t n = dpp0<QP_B3>(Sx), P = Sx - T;
+          x = ((uint64_t)rngv[2 * s4 + 1] << 32) | rngv[2 * s4];
+          const uint64_t u = splitmix_next(x);
+          const uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(n + 1)) >> 32);   // k == n: the pass
+          const bool hit = k >= P && k < P + T;        // this lane holds the k-th valid point
+          uint32_t tt = k - P, vr = v[0], base = 0;
+          int rr = 0;
+#pragma unroll
+          for (int r = 1; r < RPL; ++r)
+            if (tt >= p[r - 1]) { rr = r; vr = v[r]; base = p[r - 1]; }
+          tt -= base;
+#pragma unroll
+          for (int sh = 16; sh >= 1; sh >>= 1) {   // the tt-th set bit of vr
+            const uint32_t c = (uint32_t)__popc((vr >> pos) & ((1u << sh) - 1u));
+            if (tt >= c) { tt -= c; pos += sh; }
+          }
+          rabs = r0 + rr;
+          // -1: the board does not move this ply.  The lane with the point announces it; a pass / an idle board is
+          // announced by the board's first lane
+          a = !live ? -1 : (k < n ? rabs * N + (int)pos : hf.P);
+          wr_act = bl && (live && k < n ? hit : t5 == 0);
+          place = bl && live && hit;
+        }
+        if (wr_act) actv[s4] = a;
+        if (!MOVES && bl && t5 == 0 && live) { rngv[2 * s4] = (uint32_t)x; rngv[2 * s4 + 1] = (uint32_t)(x >> 32); }
+        if (__ballot(live) == 0) break;
+        uint64_t resetm = __ballot(reset && t5 == 0);
+        if (resetm) {   // rare
+          if (reset) {
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) inv_r[r] = M[r] = 0u;
+          }
+          while (resetm) {
+            const int s = (__ffsll((unsigned long long)resetm) - 1) >> 2;   // lane 4 s -> board s
+            resetm &= resetm - 1;
+            for (int i = hf.lane; i < 2 * RS; i += kWave) st[(i / RS) * PL + s * RS + (i % RS)] = 0;
+            if (hf.lane == 0) flagsv[s] = 8u;
+          }
+        }
+        WAVE_SYNC();
+        // the new stone goes into the mover's plane right away: every later phase sees the position with it
+        if (place) {
+          const int turn = reset ? 0 : (int)(fl & 1u);
+          st[turn * PL + s4 * RS + rabs] |= 1u << pos;
+        }
+      }
+      WAVE_SYNC();
+
+      // phase 2 - one lane per (board, role).  The six rows around q say which neighbours hold a friendly / an
+      // opponent stone; the opponent neighbours take lanes 0.. in the order up, down, left, right, G takes lane 3 when
+      // q has a friendly neighbour (then at most three neighbours are the opponent's).
+      {
+        const int a = bl ? actv[s4] : -1;
+        const int turn = flagsv[s4] & 1u;
+        const bool moving = a >= 0 && a < hf.P;
+        int ar = 0, ac = 0;
+        if (moving) split_action(a, N, hf.inv, ar, ac);
+        const uint32_t bit = moving ? (1u << ac) : 0u;
+        const uint32_t *pm = st + turn * PL + s4 * RS, *po = st + (1 - turn) * PL + s4 * RS;
+        const int aru = ar > 0 ? ar - 1 : 0;
+        const uint32_t upok = ar > 0 ? bit : 0u;
+        const uint32_t mU = pm[aru], mC = pm[ar], mD = pm[ar + 1], oU = po[aru], oC = po[ar], oD = po[ar + 1];
+        // direction bits: 1 up, 2 down, 4 left, 8 right (rows / columns off the board read as empty: no stone there)
+        const uint32_t fm = ((mU & upok) ? 1u : 0u) | ((mD & bit) ? 2u : 0u) | ((mC & (bit >> 1)) ? 4u : 0u) | ((mC & shl1(bit)) ? 8u : 0u);
+        const uint32_t om = ((oU & upok) ? 1u : 0u) | ((oD & bit) ? 2u : 0u) | ((oC & (bit >> 1)) ? 4u : 0u) | ((oC & shl1(bit)) ? 8u : 0u);
+        const bool friendly = fm != 0u;
+        uint32_t mk = om;                      // the t5-th opponent direction
+        if (t5 >= 1) mk &= mk - 1u;
+        if (t5 >= 2) mk &= mk - 1u;
+        if (t5 >= 3) mk &= mk - 1u;
+        const uint32_t d = mk & (0u - mk);
+        const bool isG = friendly && t5 == 3;  // (then om has at most three bits: d == 0 on lane 3)
+        const int sr = ar + (isG ? 0 : ((d & 1u) ? -1 : ((d & 2u) ? 1 : 0)));
+        const int scol = ac + (isG ? 0 : ((d & 4u) ? -1 : ((d & 8u) ? 1 : 0)));
+        const uint32_t sbit = isG ? bit : (d ? (1u << scol) : 0u);
+        const uint32_t *own = isG ? pm : po;   // the colour this lane floods
+        const uint32_t *oth = isG ? po : pm;
+        if (t5 == 0 && bl) {
+          const uint32_t onb = (ar > 0 ? 1u : 0u) | (ar < N - 1 ? 2u : 0u) | (ac > 0 ? 4u : 0u) | (ac < N - 1 ? 8u : 0u);
+          const uint32_t ne = (uint32_t)__popc(onb & ~(om | fm));
+          binfo[s4] = (ne < 2u ? ne : 2u) | (friendly ? BI_FRIEND : 0u) | ((onb & ~om) == 0u ? BI_BOXED : 0u);
+        }
+        uint32_t cnt = 0, sz = 0;
+        {
+          uint32_t m[R];
+          {
+            uint32_t mrev[R], f[R];
+            uint32_t mt[RV * 4];
+            const uint4 *pmv = reinterpret_cast<const uint4 *>(own);
+#pragma unroll
+            for (int i = 0; i < RV; ++i) {
+              const uint4 x = pmv[i];
+              mt[4 * i] = x.x; mt[4 * i + 1] = x.y; mt[4 * i + 2] = x.z; mt[4 * i + 3] = x.w;
+            }
+            // the seed is one bit of row sr: a one-hot row selector turns "r == sr" into a sign-extending bit extract
+            // (the flood keeps its odd rows bit-reversed: their seeds are cut out of mrev with the reversed seed bit)
+            const uint32_t onehot = (sbit != 0u) ? (1u << sr) : 0u;
+            const uint32_t sbit_rev = __brev(sbit);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              m[r] = mt[r];
+              mrev[r] = __brev(m[r]);
+              const uint32_t sel = (uint32_t)__builtin_amdgcn_sbfe((int)onehot, r, 1);   // 0 or ~0
+              f[r] = (r & 1) ? B3(mrev[r], sbit_rev, sel, TA & TB & TC) : B3(m[r], sbit, sel, TA & TB & TC);
+            }
+            flood2_serial<R, true>(m, mrev, f, sc + ln * RS);
+          }
+          // liberties of this lane's group on the position with the new stone (captures not yet removed); m[] still
+          // holds the flooded colour's rows
+          uint32_t gt[RV * 4], ot[RV * 4];
+          const uint4 *pg = reinterpret_cast<const uint4 *>(sc + ln * RS);
+          const uint4 *pov = reinterpret_cast<const uint4 *>(oth);
+#pragma unroll
+          for (int i = 0; i < RV; ++i) {
+            const uint4 x = pg[i], y = pov[i];
+            gt[4 * i] = x.x; gt[4 * i + 1] = x.y; gt[4 * i + 2] = x.z; gt[4 * i + 3] = x.w;
+            ot[4 * i] = y.x; ot[4 * i + 1] = y.y; ot[4 * i + 2] = y.z; ot[4 * i + 3] = y.w;
+          }
+          const uint32_t fullrow = (1u << N) - 1u;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const uint32_t e = (FULLN || r < N) ? B3(ot[r], m[r], fullrow, ~(TA | TB) & TC & 0xFF) : 0u;   // empty points
+            const uint32_t up = r > 0 ? gt[r - 1] : 0u, dn = r + 1 < R ? gt[r + 1] : 0u;   // rows >= R are not written
+            const uint32_t dd = B3(shl1(gt[r]), gt[r] >> 1, up, T_OR3);
+            const uint32_t l = B3(dd, dn, e, (TA | TB) & TC);
+            cnt += (uint32_t)__popc(l);   // only min(cnt, 2) is used: one accumulating v_bcnt per row
+            sz += gt[r];   // sum of the row words: equals the seed bit iff the group is the seed stone alone
+          }
+        }
+        clsv[ln] = (cnt < 2u ? cnt : 2u) | ((sz != 0u && sz == sbit) ? CL_ONE : 0u) | (sz != 0u ? CL_ANY : 0u) |
+                   (isG ? CL_G : 0u) | ((uint32_t)(sr & 0xFF) << 8) | ((uint32_t)(scol & 0xFF) << 16);
+        // an opponent group that keeps >= 2 liberties keeps its class: phase 3 must not see it
+        if (!isG && cnt >= 2u) {
+          uint4 *pz = reinterpret_cast<uint4 *>(sc + ln * RS);
+#pragma unroll
+          for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
+      WAVE_SYNC();
+
+      // phase 3 - all sixteen boards in ONE pass, RPL adjacent rows per lane: patch the classes, resolve captures and
+      // ko, the next mover's mask
+      {
+        const int av = actv[s4];
+        const int a = bl ? av : -1;
+        const bool moves_now = a >= 0;
+        const uint32_t fl = flagsv[s4];
+        int turn = fl & 1u, passed = (fl >> 1) & 1u, done = (fl >> 2) & 1u;
+        const uint4 cq = *reinterpret_cast<const uint4 *>(clsv + 4 * s4);
+        const uint32_t c0 = cq.x, c1 = cq.y, c2 = cq.z, c3 = cq.w;
+        const uint32_t bi = binfo[s4];
+        const bool is_pass = a == hf.P;
+        const bool stone = moves_now && !is_pass;
+        int ar = 0, ac = 0;
+        if (stone) split_action(a, N, hf.inv, ar, ac);
+        uint32_t *pmine = st + turn * PL + s4 * RS + r0;
+        uint32_t *popp = st + (1 - turn) * PL + s4 * RS + r0;
+        const uint32_t *gr = sc + (4 * s4) * RS + r0;   // block j: gr[j * RS + r]
+        const uint32_t gmask = (c3 & CL_G) ? ~0u : 0u;   // lane 3 flooded G (else: an opponent group or nothing)
+        const bool loneG = stone && !(bi & BI_FRIEND);  // G is the new stone alone
+        uint32_t mine1[RPL], opp0[RPL], g0[RPL], gch[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          mine1[r] = pmine[r];   // (rows >= N are zero)
+          opp0[r] = popp[r];
+          const uint32_t b0 = gr[r], b1 = gr[RS + r], b2 = gr[2 * RS + r], b3 = gr[3 * RS + r];
+          const uint32_t one = (loneG && r0 + r == ar) ? (1u << ac) : 0u;
+          g0[r] = B3(b3, gmask, one, T_ANDOR) & full[r];
+          gch[r] = B3(B3(b0, b1, b2, T_OR3), b3, gmask, TA | (TB & ~TC & 0xFF)) & full[r];   // the opponent groups whose class changes
+        }
+        const bool k0 = (c0 & (CL_LIBS | CL_ANY | CL_G)) == CL_ANY, k1 = (c1 & (CL_LIBS | CL_ANY | CL_G)) == CL_ANY,
+                   k2 = (c2 & (CL_LIBS | CL_ANY | CL_G)) == CL_ANY, k3 = (c3 & (CL_LIBS | CL_ANY | CL_G)) == CL_ANY;
+        uint32_t cap[RPL], Mm_fix[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) cap[r] = Mm_fix[r] = 0u;
+        uint32_t libsG = (c3 & CL_G) ? (c3 & CL_LIBS) : (bi & BI_EMPTY);   // liberties of G among the empty points (saturated at 2)
+        int ko_r = -1, ko_c = 0;
+        const bool capt = stone && (k0 || k1 || k2 || k3);
+        if (__ballot(capt)) {   // a capture on some board
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) {
+            const uint32_t b0 = k0 ? gr[r] : 0u, b1 = k1 ? gr[RS + r] : 0u, b2 = k2 ? gr[2 * RS + r] : 0u,
+                           b3 = k3 ? gr[3 * RS + r] : 0u;
+            cap[r] = capt ? ((b0 | b1 | b2 | b3) & full[r]) : 0u;
+          }
+          // captured stones next to G are liberties of G too
+          {
+            uint32_t dg[RPL];
+            dilate_rows<RPL>(g0, dg);
+            uint32_t cntc = 0;
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) cntc += (uint32_t)__popc(dg[r] & cap[r]);
+            const uint32_t tot = quad_sum(cntc < 2u ? cntc : 2u);
+            libsG += tot < 2u ? tot : 2u;
+          }
+          // gogame.py:72-75: ko iff exactly one stone died and the new stone is boxed in
+          const uint32_t ncap1 = (k0 && (c0 & CL_ONE) ? 1u : 0u) + (k1 && (c1 & CL_ONE) ? 1u : 0u) +
+                                 (k2 && (c2 & CL_ONE) ? 1u : 0u) + (k3 && (c3 & CL_ONE) ? 1u : 0u);
+          const uint32_t ncapn = (k0 ? 1u : 0u) + (k1 ? 1u : 0u) + (k2 ? 1u : 0u) + (k3 ? 1u : 0u);
+          if (capt && (bi & BI_BOXED) && ncapn == 1u && ncap1 == 1u) {
+            const uint32_t ck = k0 ? c0 : (k1 ? c1 : (k2 ? c2 : c3));
+            ko_r = (int)((ck >> 8) & 0xFFu);
+            ko_c = (int)((ck >> 16) & 0xFFu);
+          }
+          // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties
+          uint32_t atari[RPL], f[RPL];
+          dilate_rows<RPL>(cap, f);
+          uint32_t anyf = 0;
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) { atari[r] = mine1[r] & ~M[r] & ~g0[r]; f[r] &= atari[r]; anyf |= f[r]; }
+          if (__ballot(anyf != 0)) {
+#pragma unroll 1
+            for (int it = 0; it < R * R; ++it) {
+              uint32_t dd[RPL], chg = 0;
+              dilate_rows<RPL>(f, dd);
+#pragma unroll
+              for (int r = 0; r < RPL; ++r) {
+                const uint32_t nw = B3(dd[r], atari[r], f[r], T_ANDOR);
+                chg |= nw ^ f[r];
+                f[r] = nw;
+              }
+              if (__ballot(chg != 0) == 0) break;
+            }
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) Mm_fix[r] = f[r];
+          }
+        }
+        const uint32_t gsel = libsG >= 2u ? ~0u : 0u;
+        uint32_t Mo2[RPL], opp1[RPL], Mm2[RPL], e[RPL], x[RPL], nbr[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          const uint32_t Mm = M[r] & mine1[r], Mo = M[r] & opp0[r];
+          Mo2[r] = Mo & ~gch[r];
+          opp1[r] = opp0[r] & ~cap[r];
+          Mm2[r] = B3(Mm, gsel, g0[r], (TA & ~TC & 0xFF) | (TB & TC)) | Mm_fix[r];   // (Mm & ~g0) | (gsel & g0)
+          // state_utils.compute_invalid_moves on the lane's rows (invalid_from2, RPL rows per lane)
+          e[r] = full[r] & ~(opp1[r] | mine1[r]);
+          x[r] = B3(e[r], opp1[r] & Mo2[r], mine1[r] & ~Mm2[r], T_OR3);
+        }
+        dilate_rows<RPL>(x, nbr);
+        if (moves_now) {
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) {
+            uint32_t invalid = full[r] & ~(e[r] & nbr[r]);
+            if (r0 + r == ko_r) invalid |= 1u << ko_c;
+            inv_r[r] = invalid;
+            M[r] = Mm2[r] | Mo2[r];
+            if (capt) popp[r] = opp1[r];
+          }
+          if (is_pass) { if (passed) done = 1; passed = 1; } else passed = 0;
+          turn ^= 1;
+          if (t5 == 0) {
+            flagsv[s4] = (uint32_t)turn | ((uint32_t)passed << 1) | ((uint32_t)done << 2) | 8u;
+            lastv[s4] = a;
+            playedv[s4] += 1;
+          }
+        }
+      }
+      WAVE_SYNC();
+    }
+
+    // ---------------------------------------------------------------- store
+    WAVE_SYNC();
+    if (TRACKED) {
+      // park the register rows, then one flat coalesced copy of the group's contiguous block
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        if (r04 + r < RS) {
+          const uint32_t bk = st[0 * PL + q4 * RS + r04 + r], wh = st[1 * PL + q4 * RS + r04 + r];
+          park[0 * PL + q4 * RS + r04 + r] = inv_r[r];
+          park[1 * PL + q4 * RS + r04 + r] = M[r] & bk;
+          park[2 * PL + q4 * RS + r04 + r] = M[r] & wh;
+        }
+      }
+      WAVE_SYNC();
+      const int64_t nbrd = (B - b_first) < nb ? (B - b_first) : nb;
+      const int nw = (int)nbrd * W;
+      uint32_t *gp = reinterpret_cast<uint32_t *>(states) + b_first * (int64_t)W;
+      const uint32_t invW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;
+      for (int i = hf.lane; i < nw; i += kWave) {
+        const int sb = (int)(((uint32_t)i * invW) >> 20), w = i - sb * W;
+        if (playedv[sb] == 0) continue;                 // untouched boards are not rewritten
+        uint32_t v;
+        if (w == 5 * N) {
+          v = flagsv[sb] & 7u;
+        } else {
+          const int pl = (int)(((uint32_t)w * hf.inv) >> 16), rw = w - pl * N;
+          v = pl < 2 ? st[pl * PL + sb * RS + rw] : park[(pl - 2) * PL + sb * RS + rw];
+        }
+        gp[i] = v;
+      }
+      if (hf.lane < nb && b_first + hf.lane < B) {
+        const int sb = hf.lane;
+        const int64_t b = b_first + sb;
+        const int played = playedv[sb];
+        if (!MOVES) rng[b] = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
+        if (last_actions) last_actions[b] = lastv[sb];
+        if (steps_done) steps_done[b] += played;
+        if (MOVES && played_out) played_out[b] = played;
+      }
+      WAVE_SYNC();
+    }
+    if (IO == 0) load_spread_lut(lut, hf.lane);
+#pragma unroll 1
+    for (int i = 0; i < (TRACKED ? 0 : nb / 2); ++i) {
+      if ((hf.lane >> 3) == i) {   // the pair's owner quads hand their mask rows over
+        uint32_t *tp = tmp + ((q4 & 1) * 2) * RS + r04;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) tp[r] = inv_r[r];
+      }
+      WAVE_SYNC();
+      const int s = 2 * i + hf.h;
+      const uint32_t fl = flagsv[s];
+      const bool on = (fl >> 3) & 1u;
+      const int64_t b = on ? b_first + s : B - 1;
+      const int played = playedv[s];
+      uint32_t black = 0, white = 0, invalid = 0;
+      if (row) {
+        black = st[0 * PL + s * RS + hf.hl];
+        white = st[1 * PL + s * RS + hf.hl];
+        invalid = tmp[(hf.h * 2) * RS + hf.hl];
+      }
+      const bool wr = on && played != 0;
+      if (PACKED) {
+        store_packed_h(reinterpret_cast<uint32_t *>(states) + b * (int64_t)W, N, hf, black, white, invalid, fl & 1u,
+                       (fl >> 1) & 1u, (fl >> 2) & 1u, wr);
+      } else if (__ballot(wr)) {
+        emit_store_h<R>(states + b * (int64_t)S, black, white, invalid, fl & 1u, (fl >> 1) & 1u, (fl >> 2) & 1u, hf,
+                        v2 + hf.h * 128, lut, wr);
+      }
+      if (on && hf.hl == 0) {
+        if (!MOVES) rng[b] = ((uint64_t)rngv[2 * s + 1] << 32) | rngv[2 * s];
+        if (last_actions) last_actions[b] = lastv[s];
+        if (steps_done) steps_done[b] += played;
+        if (MOVES && played_out) played_out[b] = played;
+      }
+      WAVE_SYNC();
+    }
+  }
+}
+
+// byte planes -> tracked boards: the rows of planes 0 / 1 / 3 and the liberty classes of one v2 analysis
+template <int R>
+__global__ __launch_bounds__(kWave, 4) void k_track(const uint8_t *__restrict__ states, uint32_t *__restrict__ tracked,
+                                                     int64_t B, int N, uint32_t inv) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
+  const Half hf = make_half(threadIdx.x, N, inv);
+  load_cw_table<R>(lds, hf.lane);
+  const int S = 6 * hf.P, W = 5 * N + 1;
+  uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
+  const int64_t npairs = (B + 1) >> 1;
+  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+    const bool on = 2 * p + hf.h < B;
+    const int64_t b = on ? 2 * p + hf.h : B - 1;
+    const uint8_t *gs = states + b * (int64_t)S;
+    const uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
+    WAVE_SYNC();
+    const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
+    WAVE_SYNC();
+    const uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
+    const uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+    const uint32_t invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
+    uint32_t mb, ab, mw;
+    analyze2<R, false>(black, white, hf.full_l1 & ~(black | white), hf, lds, mb, ab, mw);
+    uint32_t *gp = tracked + b * (int64_t)W;
+    if (on && hf.hl < N) {
+      gp[hf.hl] = black; gp[N + hf.hl] = white; gp[2 * N + hf.hl] = invalid;
+      gp[3 * N + hf.hl] = mb; gp[4 * N + hf.hl] = mw;
+    }
+    if (on && hf.hl == 31) gp[5 * N] = (flags & 1u) | ((flags >> 1) & 6u);
+  }
+}
+
+}  // namespace gg
