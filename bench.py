@@ -303,8 +303,20 @@ def extras(dev, back, opts):
     env_out = (torch.empty(count, dtype=torch.float32, device=dev), torch.empty(count, dtype=torch.uint8, device=dev),
                torch.empty(count, dtype=torch.int32, device=dev), torch.empty(count, dtype=torch.int32, device=dev))
     r, _ = event_rate(torch, dev, lambda: gogame.batch_env_step(states, None, rng, 7.5, 'real', True, out=env_out), count, 32)
+    out['gg_batch_env_step_byte_planes_steps_per_s'] = round(r, 1)
+    # the batched env as GoVecEnv runs it: boards resident in the tracked format, one launch per step that also writes the
+    # uint8 [B,6,N,N] observation (reads 384 B + 12 B, writes 384 B + 2 166 B + 13 B per game and step)
+    tracked = gogame.batch_track(states)
+    obs = torch.empty_like(states)
+    r, ms = event_rate(torch, dev, lambda: gogame.batch_env_step_tracked(tracked, None, rng, 7.5, 'real', True, out=env_out,
+                                                                         states_out=obs), count, 32)
     out['gg_batch_env_step_steps_per_s'] = round(r, 1)
     out['gg_batch_env_step_hbm_frac'] = round(algo * r / 1e9 / HBM_PEAK_GBS, 4)
+    out['gg_batch_env_step_note'] = ('GoVecEnv.step (layout tracked): gg_batch_env_step_tracked incl. the byte-plane observation; '
+                                     'the fraction prices the SURVEY 8(d) per-step bytes (4 336 B) against 8 TB/s')
+    r, _ = event_rate(torch, dev, lambda: gogame.batch_env_step_tracked(tracked, None, rng, 7.5, 'real', True, out=env_out), count, 32)
+    out['gg_batch_env_step_no_observation_steps_per_s'] = round(r, 1)
+    del tracked, obs
     configs = {}
     F = opts['plies_per_step']
     # --- config 2: 9x9, 4 096 games

@@ -18,7 +18,8 @@ EXPORTS = (
     'gg_batch_children', 'gg_batch_rollout', 'gg_batch_env_step', 'gg_batch_sample_actions', 'gg_batch_update_pieces', 'gg_batch_reset_finished', 'gg_packed_words', 'gg_batch_pack_states',
     'gg_batch_unpack_states', 'gg_batch_next_states_packed', 'gg_batch_rollout_packed', 'gg_batch_env_step_packed',
     'gg_batch_children_packed', 'gg_batch_play_moves', 'gg_batch_play_moves_packed', 'gg_tracked_words', 'gg_batch_track_states',
-    'gg_batch_untrack_states', 'gg_batch_rollout_tracked', 'gg_batch_play_moves_tracked', 'gg_rng_seed',
+    'gg_batch_untrack_states', 'gg_batch_rollout_tracked', 'gg_batch_play_moves_tracked', 'gg_batch_env_step_tracked',
+    'gg_rng_seed',
 )
 
 _vp, _i64, _i32, _u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64
@@ -48,6 +49,7 @@ _SIGNATURES = {
     'gg_batch_untrack_states': ([_vp, _vp, _i64, _i32, _vp], _i32),
     'gg_batch_rollout_tracked': ([_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
     'gg_batch_play_moves_tracked': ([_vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
+    'gg_batch_env_step_tracked': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_float, _i32, _i32, _vp], _i32),
     'gg_rng_seed': ([_vp, _u64, _i64, _i64, _vp], _i32),
 }
 

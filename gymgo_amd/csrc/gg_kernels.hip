@@ -6,6 +6,9 @@
 // are no environment switches and no mutable global state besides the per-device CU-count cache below.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifdef GG_AB
+#include <stdlib.h>   // A/B builds only (make ab): tuning overrides read from the environment; never in the shipped library
+#endif
 
 #include "gg_common.h"
 #include "gg_v2.h"
@@ -67,6 +70,9 @@ int grid_resident(int cus, int64_t work, int waves_per_simd) {
 // 16 boards x 4 096 waves = exactly the resident set (4 waves per SIMD).
 int boards_per_wave(int cus, int64_t B, int &grid) {
   int64_t nb = B / ((int64_t)cus * 4);
+#ifdef GG_AB
+  if (const char *e = getenv("GG_AB_NB")) nb = atoi(e);
+#endif
   if (nb > kNB4) nb = kNB4;
   nb &= ~(int64_t)1;
   if (nb < 2) nb = 2;
@@ -100,6 +106,17 @@ uint32_t recip16(int32_t N) {
     else if ((N) < 13) { k_rollout4<13, IO, MOVES, false><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
     else if ((N) == 19) { k_rollout4<19, IO, MOVES, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
     else { k_rollout4<19, IO, MOVES, false><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }               \
+  } while (0)
+
+// the env-step instantiation (tracked boards, one ply, GoEnv.step outputs)
+#define GG_DISPATCH4E(N, MOVES, GRID, ...)                                                                \
+  do {                                                                                                     \
+    if ((N) == 9) { k_rollout4<9, 2, MOVES, true, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }        \
+    else if ((N) < 9) { k_rollout4<9, 2, MOVES, false, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }   \
+    else if ((N) == 13) { k_rollout4<13, 2, MOVES, true, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
+    else if ((N) < 13) { k_rollout4<13, 2, MOVES, false, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
+    else if ((N) == 19) { k_rollout4<19, 2, MOVES, true, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
+    else { k_rollout4<19, 2, MOVES, false, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }               \
   } while (0)
 
 #define GG_DISPATCH(N, CALL9, CALL13, CALL19) \
@@ -446,6 +463,26 @@ int32_t gg_batch_play_moves_tracked(uint32_t *tracked, const int32_t *moves, int
   int grid3;
   const int nb = boards_per_wave(cus, B, grid3);
   GG_DISPATCH4(N, 2, true, grid3, st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played);
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_env_step_tracked(uint32_t *tracked, const int32_t *actions, uint64_t *rng, float *rewards, uint8_t *dones,
+                                  int32_t *status, int32_t *taken_actions, uint8_t *states_out, int64_t B, int32_t N,
+                                  float komi, int32_t reward_method, int32_t auto_reset, void *hip_stream) {
+  if (reward_method != GG_REWARD_REAL && reward_method != GG_REWARD_HEURISTIC) return GG_E_BADARG;
+  GG_ENTER(tracked);
+  if (!actions && !rng) return GG_E_NULLPTR;
+  uint8_t *st = reinterpret_cast<uint8_t *>(tracked);
+  int grid;
+  const int nb = boards_per_wave(cus, B, grid);
+  EnvArgs env;
+  env.actions = actions; env.rewards = rewards; env.dones = dones; env.status = status; env.taken = taken_actions;
+  env.states_out = states_out; env.komi = komi; env.heuristic = reward_method == GG_REWARD_HEURISTIC;
+  if (actions) {
+    GG_DISPATCH4E(N, true, grid, st, nullptr, nullptr, nullptr, B, N, inv, 1, auto_reset, nb, actions, nullptr, env);
+  } else {
+    GG_DISPATCH4E(N, false, grid, st, rng, nullptr, nullptr, B, N, inv, 1, auto_reset, nb, nullptr, nullptr, env);
+  }
   return (int32_t)hipGetLastError();
 }
 

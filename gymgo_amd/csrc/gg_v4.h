@@ -55,7 +55,10 @@ struct Lds4 {
   static constexpr int kV2 = kUnion;
   static constexpr int kLut = kV2 + 256;
   static constexpr int kIoEnd = kV2 + (Lds2<R>::kRegion0 > 768 ? Lds2<R>::kRegion0 : 768);
-  static constexpr int kTotal = kLoopEnd > kIoEnd ? kLoopEnd : kIoEnd;
+  // env step: the mask rows of all boards parked behind the emitter's scratch + table while the observation is emitted
+  static constexpr int kEnvInv = kV2 + 768;                      // [kNB4][RS]
+  static constexpr int kEnvEnd = kEnvInv + kNB4 * RS;
+  static constexpr int kTotal = (kLoopEnd > kIoEnd ? kLoopEnd : kIoEnd) > kEnvEnd ? (kLoopEnd > kIoEnd ? kLoopEnd : kIoEnd) : kEnvEnd;
   static_assert(kUnion % 4 == 0, "16-byte alignment of the flood blocks");
   static_assert(3 * kNB4 * RS <= kWave * RS + kWave, "parked tracked rows fit the flood blocks");
 };
@@ -95,12 +98,28 @@ constexpr uint32_t BI_EMPTY = 3u, BI_FRIEND = 4u, BI_BOXED = 8u;
 // the rows of black, white, invalid, multi_black, multi_white + the flag word - a packed board that carries its
 // liberty classes, so that a launch needs no first analysis: per-ply stepping at the fused kernel's rate).
 // FULLN: the board fills the row capacity (N == R: 9, 13, 19) - the per-row "r < N" guards fold away at compile time.
-template <int R, int IO, bool MOVES = false, bool FULLN = false>
+// ENV (tracked boards, one ply): GoEnv.step for every game (gym_go/envs/go_env.py:49-76) - the action is given
+// (MOVES, env.actions) or drawn; a finished game is reset first when auto_reset, refused otherwise; after the ply the
+// kernel also writes status / dones / the action used / GoEnv.reward (:128-149, Tromp-Taylor areas on a rare path for
+// the `real` method, every ply for `heuristic`) and, when asked, the byte-plane observation of every board.
+struct EnvArgs {
+  const int32_t *actions;   // int32 [B] or nullptr (MOVES instantiation only)
+  float *rewards;           // each nullable
+  uint8_t *dones;
+  int32_t *status;
+  int32_t *taken;
+  uint8_t *states_out;      // uint8 [B][6][N][N]: the resulting position of EVERY game, or nullptr
+  float komi;
+  int heuristic;
+};
+
+template <int R, int IO, bool MOVES = false, bool FULLN = false, bool ENV = false>
 __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                        int32_t *__restrict__ last_actions, int64_t *__restrict__ steps_done,
                                                        int64_t B, int N, uint32_t inv, int plies, int auto_reset,
                                                        int nb, const int32_t *__restrict__ moves = nullptr,
-                                                       int32_t *__restrict__ played_out = nullptr) {
+                                                       int32_t *__restrict__ played_out = nullptr, EnvArgs env = EnvArgs()) {
+  static_assert(!ENV || IO == 2, "the env step runs on tracked boards");
   constexpr int RS = Lds4<R>::RS;
   constexpr int RV = (R + 3) / 4;
   constexpr int RPL = Lds4<R>::RPL;
@@ -109,7 +128,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
   if (FULLN) N = R;   // a compile-time constant from here on: row masks, r * N + c and the "row exists" tests fold
   const Half hf = make_half(threadIdx.x, N, inv);
   uint32_t *st = lds + Lds4<R>::kState;     // st[colour * PL + board * RS + row]
-  uint32_t *flagsv = lds + Lds4<R>::kMeta;  // bit 0 turn, 1 passed, 2 done, 3 on, 4 stopped (given moves)
+  uint32_t *flagsv = lds + Lds4<R>::kMeta;  // bit 0 turn, 1 passed, 2 done, 3 on, 4 stopped / refused, 5 reset (dirty)
   int *actv = reinterpret_cast<int *>(lds + Lds4<R>::kMeta + kNB4);
   int *lastv = reinterpret_cast<int *>(lds + Lds4<R>::kMeta + 2 * kNB4);
   int *playedv = reinterpret_cast<int *>(lds + Lds4<R>::kMeta + 3 * kNB4);
@@ -268,16 +287,18 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
           const int64_t bm = (b_first + s4 < B) ? b_first + s4 : B - 1;
           const int mv = t == 0 ? moves[bm * (int64_t)plies] : mv_next;
           if (t + 1 < plies) mv_next = moves[bm * (int64_t)plies + t + 1];
-          reset = false;
-          live = on && !done && !((fl >> 4) & 1u) && mv >= 0 && mv <= hf.P;
+          // (gg_batch_play_moves passes auto_reset = 0: a finished game stops; the env step may reset it first, and the
+          // reset stands even when the move is then refused - GoEnv.reset comes before the action check)
+          reset = on && done && auto_reset != 0 && !((fl >> 4) & 1u);
+          live = on && (!done || reset) && !((fl >> 4) & 1u) && mv >= 0 && mv <= hf.P;
           a = hf.P;
           const bool pt = live && mv < hf.P;
           int ar = 0, ac = 0;
           if (pt) split_action(mv, N, hf.inv, ar, ac);
-          // the lane that owns row ar tests the mask bit, the quad shares the verdict
+          // the lane that owns row ar tests the mask bit, the quad shares the verdict (a board being reset is empty)
           uint32_t bad = 0;
 #pragma unroll
-          for (int r = 0; r < RPL; ++r) bad |= (pt && r0 + r == ar) ? ((inv_r[r] >> ac) & 1u) : 0u;
+          for (int r = 0; r < RPL; ++r) bad |= (pt && !reset && r0 + r == ar) ? ((inv_r[r] >> ac) & 1u) : 0u;
           const bool illegal = quad_or(bad) != 0u;
           if (pt) {
             live = !illegal;
@@ -327,6 +348,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
           a = !live ? -1 : (k < n ? rabs * N + (int)pos : hf.P);
           wr_act = bl && (live && k < n ? hit : t5 == 0);
           place = bl && live && hit;
+          if (ENV && on && !live && t5 == 0) flagsv[s4] = fl | 16u;   // a frozen game refuses the step
         }
         if (wr_act) actv[s4] = a;
         if (!MOVES && bl && t5 == 0 && live) { rngv[2 * s4] = (uint32_t)x; rngv[2 * s4 + 1] = (uint32_t)(x >> 32); }
@@ -341,7 +363,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
             const int s = (__ffsll((unsigned long long)resetm) - 1) >> 2;   // lane 4 s -> board s
             resetm &= resetm - 1;
             for (int i = hf.lane; i < 2 * RS; i += kWave) st[(i / RS) * PL + s * RS + (i % RS)] = 0;
-            if (hf.lane == 0) flagsv[s] = 8u;
+            if (hf.lane == 0) flagsv[s] = (flagsv[s] & 16u) | 8u | 32u;   // on, reset (written back even if nothing is played)
           }
         }
         WAVE_SYNC();
@@ -586,7 +608,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       const uint32_t invW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;
       for (int i = hf.lane; i < nw; i += kWave) {
         const int sb = (int)(((uint32_t)i * invW) >> 20), w = i - sb * W;
-        if (playedv[sb] == 0) continue;                 // untouched boards are not rewritten
+        if (playedv[sb] == 0 && !(flagsv[sb] & 32u)) continue;   // untouched boards are not rewritten
         uint32_t v;
         if (w == 5 * N) {
           v = flagsv[sb] & 7u;
@@ -606,6 +628,89 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         if (MOVES && played_out) played_out[b] = played;
       }
       WAVE_SYNC();
+    }
+    if (ENV) {
+      // ---- GoEnv.step outputs.  Tromp-Taylor areas (gym_go/gogame.py:275-300) in the quad layout: the empty points
+      // reachable from a neighbour of a black / a white stone (an empty region borders a colour iff that colour's
+      // flood covers it); needed for a finished game (reward `real`) or for every game (`heuristic`).
+      const uint32_t fl = flagsv[q4];
+      const bool onb = (fl >> 3) & 1u;
+      const bool doneb = (fl >> 2) & 1u;
+      int area_b = 0, area_w = 0;
+      if (__ballot(onb && (env.heuristic != 0 || doneb))) {
+        uint32_t bk[RPL], wh[RPL], e[RPL], fb[RPL], fw[RPL], d[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          const uint32_t fullr = (r04 + r < N) ? (1u << N) - 1u : 0u;
+          bk[r] = st[0 * PL + q4 * RS + r04 + r];
+          wh[r] = st[1 * PL + q4 * RS + r04 + r];
+          e[r] = fullr & ~(bk[r] | wh[r]);
+        }
+        dilate_rows<RPL>(bk, d);
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) fb[r] = d[r] & e[r];
+        dilate_rows<RPL>(wh, d);
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) fw[r] = d[r] & e[r];
+#pragma unroll 1
+        for (int it = 0; it < R * R; ++it) {
+          uint32_t chg = 0;
+          dilate_rows<RPL>(fb, d);
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) { const uint32_t nw = B3(d[r], e[r], fb[r], T_ANDOR); chg |= nw ^ fb[r]; fb[r] = nw; }
+          dilate_rows<RPL>(fw, d);
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) { const uint32_t nw = B3(d[r], e[r], fw[r], T_ANDOR); chg |= nw ^ fw[r]; fw[r] = nw; }
+          if (__ballot(chg != 0) == 0) break;
+        }
+        uint32_t cb = 0, cw = 0;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          cb += (uint32_t)__popc(bk[r]) + (uint32_t)__popc(fb[r] & ~fw[r]);
+          cw += (uint32_t)__popc(wh[r]) + (uint32_t)__popc(fw[r] & ~fb[r]);
+        }
+        area_b = (int)quad_sum(cb);
+        area_w = (int)quad_sum(cw);
+      }
+      if (t4 == 0 && onb) {
+        const int64_t b = b_first + q4;
+        const float margin = (float)(area_b - area_w) - env.komi;
+        float rwd;   // GoEnv.reward (gym_go/envs/go_env.py:128-149), black's perspective
+        if (env.heuristic) rwd = doneb ? (margin > 0.f ? 1.f : -1.f) * (float)hf.P : margin;
+        else rwd = doneb ? (margin > 0.f ? 1.f : (margin < 0.f ? -1.f : 0.f)) : 0.f;
+        if (env.rewards) env.rewards[b] = rwd;
+        if (env.dones) env.dones[b] = (uint8_t)doneb;
+        if (env.status) env.status[b] = ((fl >> 4) & 1u) ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
+        if (env.taken) env.taken[b] = MOVES ? env.actions[b] : lastv[q4];
+      }
+      if (env.states_out) {
+        // the observation: every board of the group as byte planes (the emitter of the byte-plane write-back).  The mask
+        // rows of all sixteen boards are parked once behind the emitter's scratch and table (the registers are free from
+        // here on), then the pairs are emitted back to back.
+        uint32_t *invp = lds + Lds4<R>::kEnvInv;   // [kNB4][RS]
+        WAVE_SYNC();
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) invp[q4 * RS + r04 + r] = inv_r[r];
+        load_spread_lut(lut, hf.lane);
+#pragma unroll 1
+        for (int i = 0; i < nb / 2; ++i) {
+          const int s = 2 * i + hf.h;
+          const uint32_t fs = flagsv[s];
+          const bool on = (fs >> 3) & 1u;
+          const int64_t b = on ? b_first + s : B - 1;
+          uint32_t black = 0, white = 0, invalid = 0;
+          if (row) {
+            black = st[0 * PL + s * RS + hf.hl];
+            white = st[1 * PL + s * RS + hf.hl];
+            invalid = invp[s * RS + hf.hl];
+          }
+          if (__ballot(on)) {
+            emit_store_h<R>(env.states_out + b * (int64_t)S, black, white, invalid, fs & 1u, (fs >> 1) & 1u, (fs >> 2) & 1u, hf,
+                            v2 + hf.h * 128, lut, on);
+          }
+          WAVE_SYNC();
+        }
+      }
     }
     if (IO == 0) load_spread_lut(lut, hf.lane);
 #pragma unroll 1
@@ -627,7 +732,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         white = st[1 * PL + s * RS + hf.hl];
         invalid = tmp[(hf.h * 2) * RS + hf.hl];
       }
-      const bool wr = on && played != 0;
+      const bool wr = on && (played != 0 || (fl & 32u));
       if (PACKED) {
         store_packed_h(reinterpret_cast<uint32_t *>(states) + b * (int64_t)W, N, hf, black, white, invalid, fl & 1u,
                        (fl >> 1) & 1u, (fl >> 2) & 1u, wr);

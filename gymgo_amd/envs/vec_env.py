@@ -1,8 +1,16 @@
-"""GoVecEnv - B independent games as ONE uint8 [B, 6, N, N] device tensor (no reference counterpart:
-the reference has one game per GoEnv; this is the batched form its gogame.batch_* functions imply).
+"""GoVecEnv - B independent games on ONE device (no reference counterpart: the reference has one game per GoEnv; this
+is the batched form its gogame.batch_* functions imply).
 
-One process drives one GPU; to use several GPUs run one process per GPU with `shard(rank, world)`
-slices of the game range - games never interact, so there is no collective on the data path.
+One process drives one GPU; to use several GPUs run one process per GPU with `shard(rank, world)` slices of the game
+range - games never interact, so there is no collective on the data path.
+
+Three resident layouts (`layout=`):
+  'tracked' (default)  int32 [B, 5N+1]: bit-packed boards that carry their liberty classes.  A step needs no per-ply
+             liberty analysis (gg_batch_env_step_tracked, the multi-ply kernel run for one ply) and writes the uint8
+             [B,6,N,N] observation in the same launch; `states` is that observation buffer (refreshed lazily after
+             rollouts) - treat it as read-only, assign `env.states = x` to load positions.
+  'bytes'    uint8 [B,6,N,N] is the resident state itself (every step re-analyses every board: gg_batch_env_step).
+  'packed'   int32 [B, 3N+1] bit-packed boards without classes (gg_batch_*_packed); `states` unpacks on demand.
 """
 import torch
 
@@ -17,19 +25,22 @@ def shard(total_games, rank, world_size):
 
 
 class GoVecEnv:
-    """packed=True keeps the boards bit-packed on the device ([B, 3N+1] int32, 232 B per 19x19 board) and steps them
-    with the gg_batch_*_packed kernels (1.7x the per-ply rate); `states` then unpacks a fresh uint8 [B,6,N,N] view
-    on demand (e.g. as network input), `packed_states` is the resident tensor."""
-
     def __init__(self, batch_size, size, komi=0, reward_method='real', device=None, seed=20260927, first_game=0,
-                 auto_reset=True, packed=False):
+                 auto_reset=True, packed=False, layout=None):
         self.batch_size, self.size, self.komi = batch_size, size, komi
         self.reward_method = reward_method
         self.device = torch.device(device) if device is not None else gogame._device()
         self.auto_reset = auto_reset
-        self.packed = bool(packed)
-        if self.packed:
+        self.layout = layout or ('packed' if packed else 'tracked')
+        if self.layout not in ('tracked', 'bytes', 'packed'):
+            raise ValueError("layout must be 'tracked', 'bytes' or 'packed'")
+        self.packed = self.layout == 'packed'
+        if self.layout == 'packed':
             self.packed_states = torch.zeros((batch_size, gogame.packed_words(size)), dtype=torch.int32, device=self.device)
+        elif self.layout == 'tracked':
+            self.tracked = torch.zeros((batch_size, gogame.tracked_words(size)), dtype=torch.int32, device=self.device)
+            self._obs = gogame.batch_init_state(batch_size, size, device=self.device)
+            self._obs_fresh = True          # the observation buffer shows the tracked boards
         else:
             self._states = gogame.batch_init_state(batch_size, size, device=self.device)
         self.rng = gogame.rng_seed(batch_size, seed, first_game, self.device)
@@ -43,21 +54,38 @@ class GoVecEnv:
 
     @property
     def states(self):
-        return gogame.batch_unpack(self.packed_states, self.size) if self.packed else self._states
+        """uint8 [B,6,N,N] view of the games (the resident tensor itself only with layout='bytes')."""
+        if self.layout == 'packed':
+            return gogame.batch_unpack(self.packed_states, self.size)
+        if self.layout == 'tracked':
+            if not self._obs_fresh:
+                gogame.batch_untrack(self.tracked, out=self._obs)
+                self._obs_fresh = True
+            return self._obs
+        return self._states
 
     @states.setter
     def states(self, value):
-        if self.packed:
+        if self.layout == 'packed':
             self.packed_states = gogame.batch_pack(value)
+        elif self.layout == 'tracked':
+            self.tracked.copy_(gogame.batch_track(value.contiguous()))
+            self._obs.copy_(value)
+            self._obs_fresh = True
         else:
             self._states = value
 
+    def _store(self):
+        return {'packed': lambda: self.packed_states, 'tracked': lambda: self.tracked, 'bytes': lambda: self._states}[self.layout]()
+
     def reset(self, mask=None):
-        store = self.packed_states if self.packed else self._states
+        store = self._store()
         if mask is None:
             store.zero_()
         else:
-            store[mask] = 0
+            store[mask] = 0                  # an all-zero packed / tracked board is the empty board
+        if self.layout == 'tracked':
+            self._obs_fresh = False
         return self.states
 
     def valid_moves(self):
@@ -68,26 +96,34 @@ class GoVecEnv:
         return gogame.batch_sample_actions(self.states, self.rng)
 
     def step(self, actions=None, check=False):
-        """One GoEnv.step per game in ONE launch -> (states, rewards, dones, status); `states` is the resident tensor
-        (the packed one when packed=True).  actions=None draws a
-        uniform-random valid action per game on the device (it is left in self.last_actions).  Finished games are
-        reset first when auto_reset; rewards are float32, black's perspective (gym_go/envs/go_env.py:128-149).
-        The returned rewards / dones / status are views of fixed buffers, overwritten by the next step()."""
+        """One GoEnv.step per game in ONE launch -> (states, rewards, dones, status); `states` is the uint8 observation
+        (layout 'tracked': written by the step itself; 'bytes': the resident tensor; 'packed': the packed tensor).
+        actions=None draws a uniform-random valid action per game on the device (it is left in self.last_actions).
+        Finished games are reset first when auto_reset; rewards are float32, black's perspective
+        (gym_go/envs/go_env.py:128-149).  The returned tensors are fixed buffers, overwritten by the next step()."""
         if actions is not None:
             actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
-        fn, store = ((gogame.batch_env_step_packed, self.packed_states) if self.packed
-                     else (gogame.batch_env_step, self._states))
-        rewards, dones, status, taken = fn(store, actions, self.rng, self.komi, self.reward_method, self.auto_reset,
-                                           out=self._step_out)
+        if self.layout == 'tracked':
+            rewards, dones, status, taken = gogame.batch_env_step_tracked(
+                self.tracked, actions, self.rng, self.komi, self.reward_method, self.auto_reset, out=self._step_out,
+                states_out=self._obs)
+            self._obs_fresh = True
+            obs = self._obs
+        else:
+            fn, store = ((gogame.batch_env_step_packed, self.packed_states) if self.packed
+                         else (gogame.batch_env_step, self._states))
+            rewards, dones, status, taken = fn(store, actions, self.rng, self.komi, self.reward_method, self.auto_reset,
+                                               out=self._step_out)
+            obs = store
         if check and bool((status != 0).any()):
             raise AssertionError('illegal move in batch')
         self.steps_done += (status == 0)
-        return (self.packed_states if self.packed else self._states), rewards, dones, status
+        return obs, rewards, dones, status
 
     def step_unfused(self, actions, check=False):
         """The same step as separate launches (reset, next_states, areas + torch reward arithmetic); float64 rewards."""
-        if self.packed:
-            raise NotImplementedError('step_unfused works on byte-plane states (packed=False)')
+        if self.layout != 'bytes':
+            raise NotImplementedError("step_unfused works on byte-plane states (layout='bytes')")
         if self.auto_reset:
             gogame.batch_reset_finished(self.states)
         actions = actions.to(device=self.device, dtype=torch.int32)
@@ -100,10 +136,14 @@ class GoVecEnv:
         return self.states, self.rewards(dones), dones, status
 
     def rollout(self, plies):
-        """`plies` uniform-random steps per game, fused on the device (board stays on-chip)."""
-        if self.packed:
+        """`plies` uniform-random steps per game, fused on the device (boards stay on-chip)."""
+        if self.layout == 'packed':
             gogame.batch_rollout_packed(self.packed_states, self.rng, plies, self.auto_reset, self.last_actions, self.steps_done)
             return self.packed_states
+        if self.layout == 'tracked':
+            gogame.batch_rollout_tracked(self.tracked, self.rng, plies, self.auto_reset, self.last_actions, self.steps_done)
+            self._obs_fresh = False
+            return self.tracked
         gogame.batch_rollout(self._states, self.rng, plies, self.auto_reset, self.last_actions, self.steps_done)
         return self._states
 

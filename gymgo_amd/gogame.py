@@ -628,11 +628,13 @@ def batch_track(batch_states):
     return tracked
 
 
-def batch_untrack(tracked):
-    """tracked int32 [B, 5N+1] -> uint8 [B,6,N,N] (gg_batch_untrack_states)."""
+def batch_untrack(tracked, out=None):
+    """tracked int32 [B, 5N+1] -> uint8 [B,6,N,N] (gg_batch_untrack_states); out: the tensor to write into (optional)."""
     N = _tracked_size(tracked)
     B = tracked.shape[0]
-    states = torch.empty((B, govars.NUM_CHNLS, N, N), dtype=_U8, device=tracked.device)
+    states = out if out is not None else torch.empty((B, govars.NUM_CHNLS, N, N), dtype=_U8, device=tracked.device)
+    if tuple(states.shape) != (B, govars.NUM_CHNLS, N, N):
+        raise ValueError('out must be uint8 [B, 6, N, N]')
     code = _lib.lib().gg_batch_untrack_states(_lib.dev_ptr(tracked, _I32, 'tracked'), _lib.dev_ptr(states, _U8, 'states'),
                                               B, N, _lib.stream_ptr(tracked.device))
     _lib.check(code, 'gg_batch_untrack_states')
@@ -662,3 +664,28 @@ def batch_play_moves_tracked(tracked, moves, played=None):
                                                   _lib.stream_ptr(tracked.device))
     _lib.check(code, 'gg_batch_play_moves_tracked')
     return played
+
+
+def batch_env_step_tracked(tracked, actions=None, rng=None, komi=0.0, reward_method='real', auto_reset=True, out=None,
+                           states_out=None):
+    """IN PLACE GoEnv.step (gym_go/envs/go_env.py:49-76) of every game on TRACKED boards in ONE launch
+    (gg_batch_env_step_tracked): no per-ply analysis.  -> (rewards, dones, status, taken) like batch_env_step;
+    states_out: a uint8 [B,6,N,N] device tensor that receives the byte-plane observation of every game (optional)."""
+    N = _tracked_size(tracked)
+    B = tracked.shape[0]
+    dev = tracked.device
+    if actions is None and rng is None:
+        raise ValueError('batch_env_step_tracked needs actions or an rng state to draw them with')
+    if out is None:
+        out = (torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=_U8, device=dev),
+               torch.empty(B, dtype=_I32, device=dev), torch.empty(B, dtype=_I32, device=dev))
+    if states_out is not None and tuple(states_out.shape) != (B, govars.NUM_CHNLS, N, N):
+        raise ValueError('states_out must be uint8 [B, 6, N, N]')
+    rewards, dones, status, taken = out
+    code = _lib.lib().gg_batch_env_step_tracked(
+        _lib.dev_ptr(tracked, _I32, 'tracked'), _lib.dev_ptr(actions, _I32, 'actions'), _lib.dev_ptr(rng, _I64, 'rng'),
+        _lib.dev_ptr(rewards, torch.float32, 'rewards'), _lib.dev_ptr(dones, _U8, 'dones'), _lib.dev_ptr(status, _I32, 'status'),
+        _lib.dev_ptr(taken, _I32, 'taken'), _lib.dev_ptr(states_out, _U8, 'states_out'), B, N, float(komi),
+        REWARD_METHODS[reward_method], int(bool(auto_reset)), _lib.stream_ptr(dev))
+    _lib.check(code, 'gg_batch_env_step_tracked')
+    return out

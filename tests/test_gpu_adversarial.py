@@ -209,13 +209,14 @@ def test_children_single_chunk_path():
     assert np.array_equal(kids, c_oracle.batch_children(host[live], False))
 
 
-def test_env_step_config3_size_matches_fused_rollout():
+@pytest.mark.parametrize('layout', ['tracked', 'bytes'])
+def test_env_step_config3_size_matches_fused_rollout(layout):
     """65 536 x 19x19 (BASELINE config 3): K fused GoEnv.step launches with on-device sampling walk exactly the
     trajectory of one K-ply gg_batch_rollout launch (same generator), rewards/dones consistent with the states."""
     from gymgo_amd import gogame
     from gymgo_amd.envs import GoVecEnv
     B, N, K = 65536, 19, 24
-    env = GoVecEnv(B, N, komi=7.5, reward_method='heuristic', seed=11)
+    env = GoVecEnv(B, N, komi=7.5, reward_method='heuristic', seed=11, layout=layout)
     env.rollout(200)
     ref = env.states.clone()
     ref_rng = env.rng.clone()

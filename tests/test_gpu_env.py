@@ -73,11 +73,15 @@ def test_goenv_misc_api():
     assert len(gogame.children(env.state(), padded=False)) == int(env.valid_moves().sum())
 
 
-def test_vecenv_step_and_rollout_agree_with_oracle():
+LAYOUTS = ['tracked', 'bytes']
+
+
+@pytest.mark.parametrize('layout', LAYOUTS)
+def test_vecenv_step_and_rollout_agree_with_oracle(layout):
     from gymgo_amd.envs import GoVecEnv
     from oracle import c_oracle
     B, N = 300, 9
-    env = GoVecEnv(B, N, komi=5.5, reward_method='real', seed=77)
+    env = GoVecEnv(B, N, komi=5.5, reward_method='real', seed=77, layout=layout)
     want = np.zeros((B, 6, N, N), np.uint8)
     rng = c_oracle.rng_seed(77, B)
     for t in range(120):
@@ -109,14 +113,16 @@ def _ref_reward(states, komi, method, N):
     return np.where(over, np.where(margin > 0, 1.0, -1.0) * N * N, margin)
 
 
+@pytest.mark.parametrize('layout', LAYOUTS)
 @pytest.mark.parametrize('N,B,method,komi', [(19, 257, 'heuristic', 7.5), (9, 300, 'real', 0.0), (5, 64, 'real', 2.0),
-                                             (13, 33, 'heuristic', 0.0), (2, 17, 'real', 0.0)])
-def test_fused_env_step_sampled_matches_oracle(N, B, method, komi):
-    """gg_batch_env_step with on-device sampling: states, drawn actions, dones and GoEnv.reward vs the oracle
-    (gym_go/envs/go_env.py:49-76, :128-149) over many plies incl. game ends and auto-resets."""
+                                             (13, 33, 'heuristic', 0.0), (2, 17, 'real', 0.0), (9, 5000, 'real', 6.5)])
+def test_fused_env_step_sampled_matches_oracle(N, B, method, komi, layout):
+    """gg_batch_env_step / gg_batch_env_step_tracked with on-device sampling: states (the observation the step
+    returns), drawn actions, dones and GoEnv.reward vs the oracle (gym_go/envs/go_env.py:49-76, :128-149) over many
+    plies incl. game ends and auto-resets."""
     from gymgo_amd.envs import GoVecEnv
     from oracle import c_oracle
-    env = GoVecEnv(B, N, komi=komi, reward_method=method, seed=4242)
+    env = GoVecEnv(B, N, komi=komi, reward_method=method, seed=4242, layout=layout)
     want = np.zeros((B, 6, N, N), np.uint8)
     rng = c_oracle.rng_seed(4242, B)
     seen_done = 0
@@ -134,12 +140,13 @@ def test_fused_env_step_sampled_matches_oracle(N, B, method, komi):
         assert seen_done > 0   # the reset + terminal-reward branches were exercised
 
 
-def test_fused_env_step_refuses_illegal_and_frozen():
+@pytest.mark.parametrize('layout', LAYOUTS)
+def test_fused_env_step_refuses_illegal_and_frozen(layout):
     from gymgo_amd import gogame
     from gymgo_amd.envs import GoVecEnv
     from oracle import c_oracle
     B, N = 203, 9
-    env = GoVecEnv(B, N, komi=0.5, reward_method='heuristic', seed=5, auto_reset=False)
+    env = GoVecEnv(B, N, komi=0.5, reward_method='heuristic', seed=5, auto_reset=False, layout=layout)
     env.rollout(40)
     before = env.states.clone()
     host = before.cpu().numpy()
@@ -162,12 +169,12 @@ def test_fused_env_step_refuses_illegal_and_frozen():
     assert np.array_equal(dones.cpu().numpy(), want[:, 5, 0, 0])
     assert np.array_equal(rewards.cpu().numpy().astype(np.float64), _ref_reward(want, 0.5, 'heuristic', N))
     # the separate-launch form of the same step agrees
-    env2 = GoVecEnv(B, N, komi=0.5, reward_method='heuristic', seed=5, auto_reset=False)
+    env2 = GoVecEnv(B, N, komi=0.5, reward_method='heuristic', seed=5, auto_reset=False, layout='bytes')
     env2.states = before.clone()
     legal = torch.from_numpy(np.where(bad, N * N, acts).astype(np.int32)).cuda()
     s2, r2, d2, st2 = env2.step_unfused(legal)
     live = torch.from_numpy(~over).cuda()
-    env3 = GoVecEnv(B, N, komi=0.5, reward_method='heuristic', seed=5, auto_reset=False)
+    env3 = GoVecEnv(B, N, komi=0.5, reward_method='heuristic', seed=5, auto_reset=False, layout=layout)
     env3.states = before.clone()
     s3, r3, d3, st3 = env3.step(legal)
     assert torch.equal(s2[live], s3[live]) and torch.equal(r2[live].float(), r3[live])
@@ -176,15 +183,39 @@ def test_fused_env_step_refuses_illegal_and_frozen():
         gogame.batch_env_step(env.states)
     with pytest.raises(KeyError):
         gogame.batch_env_step(env.states, legal, reward_method='nope')
+    with pytest.raises(ValueError):
+        gogame.batch_env_step_tracked(gogame.batch_track(env.states))
+    # an auto-resetting env resets a finished game even when the move given for it is then refused (GoEnv.reset comes
+    # before the action check), and a reset game accepts any in-range move
+    env4 = GoVecEnv(B, N, komi=0.5, reward_method='real', seed=5, auto_reset=True, layout=layout)
+    env4.states = before.clone()
+    acts4 = acts.copy()
+    acts4[np.flatnonzero(over)[::2]] = -1               # half of the finished games get an out-of-range move
+    s4, r4, d4, st4 = env4.step(torch.from_numpy(acts4).cuda())
+    start = host.copy()
+    start[over] = 0
+    inval4 = start[:, 3].reshape(B, -1)
+    in_range = (acts4 >= 0) & (acts4 <= N * N)
+    bad4 = ~in_range
+    for i in range(B):
+        if in_range[i] and acts4[i] < N * N and inval4[i, acts4[i]]:
+            bad4[i] = True
+    want4 = start.copy()
+    ok4 = np.flatnonzero(~bad4)
+    want4[ok4] = c_oracle.batch_next_states(start[ok4], acts4[ok4])[0]
+    assert np.array_equal(st4.cpu().numpy(), bad4.astype(np.int32))
+    assert np.array_equal(s4.cpu().numpy(), want4)
+    assert over.any() and (bad4 & over).any()
 
 
-def test_vecenv_step_captured_in_hipgraph():
+@pytest.mark.parametrize('layout', LAYOUTS)
+def test_vecenv_step_captured_in_hipgraph(layout):
     """GoVecEnv.step() allocates nothing (fixed output buffers), so K steps with on-device sampling can be captured
     in a hipGraph; a replay walks the same trajectory as the fused rollout and leaves the last step's rewards."""
     from gymgo_amd import gogame
     from gymgo_amd.envs import GoVecEnv
     B, N, K = 2048, 9, 10
-    env = GoVecEnv(B, N, komi=0.5, reward_method='heuristic', seed=3)
+    env = GoVecEnv(B, N, komi=0.5, reward_method='heuristic', seed=3, layout=layout)
     env.rollout(25)
     s0, r0, n0 = env.states.clone(), env.rng.clone(), env.steps_done.clone()
     side = torch.cuda.Stream()
@@ -192,12 +223,17 @@ def test_vecenv_step_captured_in_hipgraph():
     with torch.cuda.stream(side):
         env.step()
     torch.cuda.current_stream().wait_stream(side)
-    env.states.copy_(s0); env.rng.copy_(r0); env.steps_done.copy_(n0)
+    env.states = s0.clone(); env.rng.copy_(r0); env.steps_done.copy_(n0)
+    states_buf = env.states
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         for _ in range(K):
             states, rewards, dones, status = env.step()
-    env.states.copy_(s0); env.rng.copy_(r0); env.steps_done.copy_(n0)
+    if layout == 'bytes':
+        states_buf.copy_(s0)
+    else:
+        env.states = s0.clone()
+    env.rng.copy_(r0); env.steps_done.copy_(n0)
     graph.replay()
     torch.cuda.synchronize()
     want, wr = s0.clone(), r0.clone()

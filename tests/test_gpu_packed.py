@@ -111,7 +111,7 @@ def test_packed_children_single_chunk_and_bad_arguments():
 def test_packed_vecenv_walks_the_same_games():
     from gymgo_amd.envs import GoVecEnv
     B, N = 777, 9
-    a = GoVecEnv(B, N, komi=1.5, reward_method='real', seed=8)
+    a = GoVecEnv(B, N, komi=1.5, reward_method='real', seed=8, layout='bytes')
     b = GoVecEnv(B, N, komi=1.5, reward_method='real', seed=8, packed=True)
     a.rollout(21); b.rollout(21)
     for t in range(90):

@@ -52,12 +52,16 @@ def main():
         out['vecenv_step_api_%dx%d_B%d' % (N, N, B)] = {'steps_per_s': B / t, 'note': 'reset_finished + sample_actions + next_states per ply'}
         from gymgo_amd.envs import GoVecEnv
         for method in ('real', 'heuristic'):
-            env = GoVecEnv(B, N, komi=7.5, reward_method=method)
+            for layout in ('tracked', 'bytes'):
+                env = GoVecEnv(B, N, komi=7.5, reward_method=method, layout=layout)
+                env.rollout(plies)
+                t = timed(lambda: env.step(), 50)
+                out['GoVecEnv_step_%s_reward_%s_%dx%d_B%d' % (method, layout, N, N, B)] = {
+                    'steps_per_s': B / t, 'algorithmic_GBps': B * (2 * S + 29) / t / 1e9, 'roofline_frac': B * (2 * S + 29) / t / PEAK,
+                    'note': 'one launch: sample + auto-reset + step + areas + rewards + dones + the uint8 observation (tracked: '
+                            'gg_batch_env_step_tracked on resident tracked boards; bytes: gg_batch_env_step in place)'}
+            env = GoVecEnv(B, N, komi=7.5, reward_method=method, layout='bytes')
             env.rollout(plies)
-            t = timed(lambda: env.step(), 50)
-            out['GoVecEnv_step_%s_reward_%dx%d_B%d' % (method, N, N, B)] = {
-                'steps_per_s': B / t, 'algorithmic_GBps': B * (2 * S + 29) / t / 1e9, 'roofline_frac': B * (2 * S + 29) / t / PEAK,
-                'note': 'gg_batch_env_step: sample + auto-reset + step + areas + rewards + dones, ONE launch, in place'}
             t = timed(lambda: env.step_unfused(env.sample_actions()), 30)
             out['GoVecEnv_step_unfused_%s_reward_%dx%d_B%d' % (method, N, N, B)] = {'steps_per_s': B / t, 'note': 'same step as separate launches'}
         st2, _ = midgame(B, N, plies, 5)
