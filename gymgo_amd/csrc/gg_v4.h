@@ -589,16 +589,23 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
     }
 
     // ---------------------------------------------------------------- store
+    // The lane-derived values of the write-back are recomputed from a fresh (volatile) lane id: hoisted above the ply
+    // loop they are spilled there and every reload is a scratch round trip on the tail of a short launch.
+    int lnS;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lnS));
+    const Half hs = make_half(lnS, N, inv);
+    const int q4s = lnS >> 2, t4s = lnS & 3, r04s = RPL * t4s;
+    const bool rowS = hs.hl < RS;
     WAVE_SYNC();
     if (TRACKED) {
       // park the register rows, then one flat coalesced copy of the group's contiguous block
 #pragma unroll
       for (int r = 0; r < RPL; ++r) {
-        if (r04 + r < RS) {
-          const uint32_t bk = st[0 * PL + q4 * RS + r04 + r], wh = st[1 * PL + q4 * RS + r04 + r];
-          park[0 * PL + q4 * RS + r04 + r] = inv_r[r];
-          park[1 * PL + q4 * RS + r04 + r] = M[r] & bk;
-          park[2 * PL + q4 * RS + r04 + r] = M[r] & wh;
+        if (r04s + r < RS) {
+          const uint32_t bk = st[0 * PL + q4s * RS + r04s + r], wh = st[1 * PL + q4s * RS + r04s + r];
+          park[0 * PL + q4s * RS + r04s + r] = inv_r[r];
+          park[1 * PL + q4s * RS + r04s + r] = M[r] & bk;
+          park[2 * PL + q4s * RS + r04s + r] = M[r] & wh;
         }
       }
       WAVE_SYNC();
@@ -606,20 +613,20 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       const int nw = (int)nbrd * W;
       uint32_t *gp = reinterpret_cast<uint32_t *>(states) + b_first * (int64_t)W;
       const uint32_t invW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;
-      for (int i = hf.lane; i < nw; i += kWave) {
+      for (int i = hs.lane; i < nw; i += kWave) {
         const int sb = (int)(((uint32_t)i * invW) >> 20), w = i - sb * W;
         if (playedv[sb] == 0 && !(flagsv[sb] & 32u)) continue;   // untouched boards are not rewritten
         uint32_t v;
         if (w == 5 * N) {
           v = flagsv[sb] & 7u;
         } else {
-          const int pl = (int)(((uint32_t)w * hf.inv) >> 16), rw = w - pl * N;
+          const int pl = (int)(((uint32_t)w * hs.inv) >> 16), rw = w - pl * N;
           v = pl < 2 ? st[pl * PL + sb * RS + rw] : park[(pl - 2) * PL + sb * RS + rw];
         }
         gp[i] = v;
       }
-      if (hf.lane < nb && b_first + hf.lane < B) {
-        const int sb = hf.lane;
+      if (hs.lane < nb && b_first + hs.lane < B) {
+        const int sb = hs.lane;
         const int64_t b = b_first + sb;
         const int played = playedv[sb];
         if (!MOVES) rng[b] = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
@@ -633,7 +640,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       // ---- GoEnv.step outputs.  Tromp-Taylor areas (gym_go/gogame.py:275-300) in the quad layout: the empty points
       // reachable from a neighbour of a black / a white stone (an empty region borders a colour iff that colour's
       // flood covers it); needed for a finished game (reward `real`) or for every game (`heuristic`).
-      const uint32_t fl = flagsv[q4];
+      const uint32_t fl = flagsv[q4s];
       const bool onb = (fl >> 3) & 1u;
       const bool doneb = (fl >> 2) & 1u;
       int area_b = 0, area_w = 0;
@@ -641,9 +648,9 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         uint32_t bk[RPL], wh[RPL], e[RPL], fb[RPL], fw[RPL], d[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-          const uint32_t fullr = (r04 + r < N) ? (1u << N) - 1u : 0u;
-          bk[r] = st[0 * PL + q4 * RS + r04 + r];
-          wh[r] = st[1 * PL + q4 * RS + r04 + r];
+          const uint32_t fullr = (r04s + r < N) ? (1u << N) - 1u : 0u;
+          bk[r] = st[0 * PL + q4s * RS + r04s + r];
+          wh[r] = st[1 * PL + q4s * RS + r04s + r];
           e[r] = fullr & ~(bk[r] | wh[r]);
         }
         dilate_rows<RPL>(bk, d);
@@ -672,16 +679,16 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         area_b = (int)quad_sum(cb);
         area_w = (int)quad_sum(cw);
       }
-      if (t4 == 0 && onb) {
-        const int64_t b = b_first + q4;
+      if (t4s == 0 && onb) {
+        const int64_t b = b_first + q4s;
         const float margin = (float)(area_b - area_w) - env.komi;
         float rwd;   // GoEnv.reward (gym_go/envs/go_env.py:128-149), black's perspective
-        if (env.heuristic) rwd = doneb ? (margin > 0.f ? 1.f : -1.f) * (float)hf.P : margin;
+        if (env.heuristic) rwd = doneb ? (margin > 0.f ? 1.f : -1.f) * (float)hs.P : margin;
         else rwd = doneb ? (margin > 0.f ? 1.f : (margin < 0.f ? -1.f : 0.f)) : 0.f;
         if (env.rewards) env.rewards[b] = rwd;
         if (env.dones) env.dones[b] = (uint8_t)doneb;
         if (env.status) env.status[b] = ((fl >> 4) & 1u) ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
-        if (env.taken) env.taken[b] = MOVES ? env.actions[b] : lastv[q4];
+        if (env.taken) env.taken[b] = MOVES ? env.actions[b] : lastv[q4s];
       }
       if (env.states_out) {
         // the observation: every board of the group as byte planes (the emitter of the byte-plane write-back).  The mask
@@ -690,57 +697,57 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         uint32_t *invp = lds + Lds4<R>::kEnvInv;   // [kNB4][RS]
         WAVE_SYNC();
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) invp[q4 * RS + r04 + r] = inv_r[r];
-        load_spread_lut(lut, hf.lane);
+        for (int r = 0; r < RPL; ++r) invp[q4s * RS + r04s + r] = inv_r[r];
+        load_spread_lut(lut, hs.lane);
 #pragma unroll 1
         for (int i = 0; i < nb / 2; ++i) {
-          const int s = 2 * i + hf.h;
+          const int s = 2 * i + hs.h;
           const uint32_t fs = flagsv[s];
           const bool on = (fs >> 3) & 1u;
           const int64_t b = on ? b_first + s : B - 1;
           uint32_t black = 0, white = 0, invalid = 0;
-          if (row) {
-            black = st[0 * PL + s * RS + hf.hl];
-            white = st[1 * PL + s * RS + hf.hl];
-            invalid = invp[s * RS + hf.hl];
+          if (rowS) {
+            black = st[0 * PL + s * RS + hs.hl];
+            white = st[1 * PL + s * RS + hs.hl];
+            invalid = invp[s * RS + hs.hl];
           }
           if (__ballot(on)) {
-            emit_store_h<R>(env.states_out + b * (int64_t)S, black, white, invalid, fs & 1u, (fs >> 1) & 1u, (fs >> 2) & 1u, hf,
-                            v2 + hf.h * 128, lut, on);
+            emit_store_h<R>(env.states_out + b * (int64_t)S, black, white, invalid, fs & 1u, (fs >> 1) & 1u, (fs >> 2) & 1u, hs,
+                            v2 + hs.h * 128, lut, on);
           }
           WAVE_SYNC();
         }
       }
     }
-    if (IO == 0) load_spread_lut(lut, hf.lane);
+    if (IO == 0) load_spread_lut(lut, hs.lane);
 #pragma unroll 1
     for (int i = 0; i < (TRACKED ? 0 : nb / 2); ++i) {
-      if ((hf.lane >> 3) == i) {   // the pair's owner quads hand their mask rows over
-        uint32_t *tp = tmp + ((q4 & 1) * 2) * RS + r04;
+      if ((hs.lane >> 3) == i) {   // the pair's owner quads hand their mask rows over
+        uint32_t *tp = tmp + ((q4s & 1) * 2) * RS + r04s;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) tp[r] = inv_r[r];
       }
       WAVE_SYNC();
-      const int s = 2 * i + hf.h;
+      const int s = 2 * i + hs.h;
       const uint32_t fl = flagsv[s];
       const bool on = (fl >> 3) & 1u;
       const int64_t b = on ? b_first + s : B - 1;
       const int played = playedv[s];
       uint32_t black = 0, white = 0, invalid = 0;
-      if (row) {
-        black = st[0 * PL + s * RS + hf.hl];
-        white = st[1 * PL + s * RS + hf.hl];
-        invalid = tmp[(hf.h * 2) * RS + hf.hl];
+      if (rowS) {
+        black = st[0 * PL + s * RS + hs.hl];
+        white = st[1 * PL + s * RS + hs.hl];
+        invalid = tmp[(hs.h * 2) * RS + hs.hl];
       }
       const bool wr = on && (played != 0 || (fl & 32u));
       if (PACKED) {
-        store_packed_h(reinterpret_cast<uint32_t *>(states) + b * (int64_t)W, N, hf, black, white, invalid, fl & 1u,
+        store_packed_h(reinterpret_cast<uint32_t *>(states) + b * (int64_t)W, N, hs, black, white, invalid, fl & 1u,
                        (fl >> 1) & 1u, (fl >> 2) & 1u, wr);
       } else if (__ballot(wr)) {
-        emit_store_h<R>(states + b * (int64_t)S, black, white, invalid, fl & 1u, (fl >> 1) & 1u, (fl >> 2) & 1u, hf,
-                        v2 + hf.h * 128, lut, wr);
+        emit_store_h<R>(states + b * (int64_t)S, black, white, invalid, fl & 1u, (fl >> 1) & 1u, (fl >> 2) & 1u, hs,
+                        v2 + hs.h * 128, lut, wr);
       }
-      if (on && hf.hl == 0) {
+      if (on && hs.hl == 0) {
         if (!MOVES) rng[b] = ((uint64_t)rngv[2 * s + 1] << 32) | rngv[2 * s];
         if (last_actions) last_actions[b] = lastv[s];
         if (steps_done) steps_done[b] += played;

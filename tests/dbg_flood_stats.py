@@ -11,7 +11,7 @@ import numpy as np
 from oracle import c_oracle
 
 N = 19
-NB = 12
+NB = int(os.environ.get("NB", "16"))
 
 
 def rows_of(plane):

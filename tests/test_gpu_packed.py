@@ -206,3 +206,46 @@ def test_tracked_boards_step_like_the_oracle(N, B):
         assert np.array_equal(played.cpu().numpy(), ok.astype(np.int32)), (N, t)
         assert np.array_equal(gogame.batch_untrack(tr).cpu().numpy(), exp), (N, t)
     assert torch.equal(tr, gogame.batch_track(gogame.batch_untrack(tr)))
+
+
+@pytest.mark.parametrize('N,B,plies', [(19, 16384, 420), (13, 8200, 200), (9, 12300, 260)])
+def test_multi_ply_kernel_soak_all_layouts(N, B, plies):
+    """The multi-ply kernel at its own dispatch sizes over whole games: byte-plane, packed and tracked boards walk the same
+    trajectory through launches of random length, with the tracked env step (observation checked) and one-ply tracked
+    launches in between; every 16th game is replayed by the oracle after every round; the class rows stay exactly what
+    a fresh analysis gives."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    seed = 100 + N
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, seed)
+    pk, prng = gogame.batch_pack(st), rng.clone()
+    tr, trng = gogame.batch_track(st), rng.clone()
+    idx = np.arange(0, B, 16)
+    idx_t = torch.as_tensor(idx, device='cuda')
+    want = np.zeros((len(idx), 6, N, N), np.uint8)
+    orng = np.array([c_oracle.lib().gg_oracle_rng_seed(seed, int(i)) for i in idx], dtype=np.uint64)
+    obs = torch.empty_like(st)
+    gen = np.random.default_rng(seed)
+    t = 0
+    while t < plies:
+        k = int(gen.integers(2, 70))
+        gogame.batch_rollout(st, rng, k, True)
+        gogame.batch_rollout_packed(pk, prng, k, True)
+        mode = int(gen.integers(0, 3))
+        if mode == 0:
+            gogame.batch_rollout_tracked(tr, trng, k, True)
+        elif mode == 1:
+            for _ in range(k):
+                gogame.batch_env_step_tracked(tr, None, trng, 6.5, 'real', True, states_out=obs)
+        else:
+            for _ in range(k):
+                gogame.batch_rollout_tracked(tr, trng, 1, True)
+        want, orng, _ = c_oracle.batch_rollout_mt(want, orng, k, True)
+        t += k
+        assert np.array_equal(st[idx_t].cpu().numpy(), want), (N, B, t)
+        assert torch.equal(gogame.batch_unpack(pk, N), st) and torch.equal(prng, rng), (N, B, t, 'packed')
+        assert torch.equal(gogame.batch_untrack(tr), st) and torch.equal(trng, rng), (N, B, t, 'tracked', mode)
+        if mode == 1:
+            assert torch.equal(obs, st), (N, B, t, 'observation')
+        assert torch.equal(tr, gogame.batch_track(st)), (N, B, t, 'classes')
