@@ -144,7 +144,7 @@ def shard(total_games, rank, world_size):
 
 def run_rank(rank, world, backend, opts, dist=None):
     """The per-rank bench driver.  backend: a step backend (HipBackend on the GPU; the gloo test passes one built on the
-    CPU oracle).  dist: torch.distributed (already initialised) when world > 1.  Returns the result record on rank 0
+    CPU oracle).  dist: torch.distributed (already initialised) when launched as ranks, else None.  Returns the result record on rank 0
     (None elsewhere): value, wall time (max over ranks), kernel-event time of this rank, games and steps played."""
     N, F, K, W = opts['size'], opts['plies_per_step'], opts['steps'], opts['warmup']
     per_gpu = opts['games_per_gpu']
@@ -167,7 +167,7 @@ def run_rank(rank, world, backend, opts, dist=None):
 
     def fence():
         backend.sync()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             backend.sync()
 
@@ -185,7 +185,7 @@ def run_rank(rank, world, backend, opts, dist=None):
     played = backend.played() - before
     assert played == K * F * count, 'work was skipped inside the timed region (%d != %d)' % (played, K * F * count)
     red = backend.comm_tensor([wall, float(played)])
-    if world > 1:
+    if dist is not None:
         tmax = red[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = red[1:].clone()
@@ -399,6 +399,17 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def _flush_c_stdio():
+    """RCCL prints a version banner through C stdio (buffered when stdout is a pipe): push it out now, so that the JSON
+    line printed at the very end is the LAST line of stdout."""
+    try:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -436,15 +447,22 @@ def main(argv=None):
     local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # under a launcher (WORLD_SIZE set, also with one rank) the process group is real: barrier and reductions run over RCCL
+    use_dist = 'WORLD_SIZE' in os.environ
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('NCCL_DEBUG', 'WARN')       # no version banner on stdout unless asked for
         dist.init_process_group('nccl', device_id=dev)
+        dist.barrier()                                    # the communicator exists from here on (banner printed, if any)
+        _flush_c_stdio()
 
     opts = {'size': args.size, 'plies_per_step': max(1, args.plies_per_step), 'steps': max(1, args.steps),
             'warmup': max(0, args.warmup), 'games_per_gpu': args.games_per_gpu or (65536 if world == 1 else 131072),
             'desync': args.desync, 'burn_in_steps': max(0, args.burn_in), 'world': world}
     back = HipBackend(dev)
-    res = run_rank(rank, world, back, opts, dist if world > 1 else None)
+    res = run_rank(rank, world, back, opts, dist if use_dist else None)
 
     if rank == 0:
         N, F, K, W = opts['size'], opts['plies_per_step'], opts['steps'], opts['warmup']
@@ -467,10 +485,12 @@ def main(argv=None):
         if cpu is not None:
             line['cpu_baseline'] = cpu
         line['also'] = also
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(line), flush=True)   # the last line of stdout
 
 
 if __name__ == '__main__':

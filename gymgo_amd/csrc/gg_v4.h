@@ -432,6 +432,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
               const uint32_t sel = (uint32_t)__builtin_amdgcn_sbfe((int)onehot, r, 1);   // 0 or ~0
               f[r] = (r & 1) ? B3(mrev[r], sbit_rev, sel, TA & TB & TC) : B3(m[r], sbit, sel, TA & TB & TC);
             }
+            // (measured on this kernel, 65 536 games x 256 plies: the two-chain flood2_dual 2.78 ms against 2.33 ms, a first
+            // closure test already after the second sweep 2.43 ms)
             flood2_serial<R, true>(m, mrev, f, sc + ln * RS);
           }
           // liberties of this lane's group on the position with the new stone (captures not yet removed); m[] still
