@@ -142,6 +142,16 @@ uint32_t recip16(int32_t N) {
 
 extern "C" {
 
+#ifdef GG_AB_PROF
+// A/B builds only: read and clear the phase clocks of k_rollout4
+int32_t gg_ab_prof_read(unsigned long long *out8) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gg::gg_prof), sizeof(z)) != hipSuccess) return 2;
+  return hipMemcpyToSymbol(HIP_SYMBOL(gg::gg_prof), z, sizeof(z)) == hipSuccess ? 0 : 3;
+}
+#endif
+
 int32_t gg_version(void) { return GG_ABI_VERSION; }
 
 int32_t gg_device_cus(void) {

@@ -36,6 +36,18 @@ namespace gg {
 // flood results and a few words per board: 8 704 B per wave at 19x19.
 constexpr int kNB4 = 16;
 
+#ifdef GG_AB_PROF
+// A/B builds only: shader-clock time of the phases of a ply as one wave experiences them (incl. waiting for the SIMD)
+__device__ unsigned long long gg_prof[8];
+#define GG_PROF_DECL unsigned long long tph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc_ = clock64()
+#define GG_PROF(k) do { const unsigned long long n_ = clock64(); tph_[k] += n_ - tc_; tc_ = n_; } while (0)
+#define GG_PROF_FLUSH do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&gg_prof[k_], tph_[k_]); } while (0)
+#else
+#define GG_PROF_DECL do {} while (0)
+#define GG_PROF(k) do {} while (0)
+#define GG_PROF_FLUSH do {} while (0)
+#endif
+
 template <int R>
 struct Lds4 {
   static constexpr int RS = Cfg<R>::kRowStride;
@@ -258,6 +270,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
     }
 
     // ---------------------------------------------------------------- the plies
+    GG_PROF_DECL;
+    GG_PROF(6);   // load
     int mv_next = 0;
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
@@ -374,6 +388,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         }
       }
       WAVE_SYNC();
+      GG_PROF(0);
 
       // phase 2 - one lane per (board, role).  The six rows around q say which neighbours hold a friendly / an
       // opponent stone; the opponent neighbours take lanes 0.. in the order up, down, left, right, G takes lane 3 when
@@ -434,7 +449,9 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
             }
             // (measured on this kernel, 65 536 games x 256 plies: the two-chain flood2_dual 2.78 ms against 2.33 ms, a first
             // closure test already after the second sweep 2.43 ms)
+            GG_PROF(1);
             flood2_serial<R, true>(m, mrev, f, sc + ln * RS);
+            GG_PROF(2);
           }
           // liberties of this lane's group on the position with the new stone (captures not yet removed); m[] still
           // holds the flooded colour's rows
@@ -468,52 +485,59 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         }
       }
       WAVE_SYNC();
+      GG_PROF(3);
 
       // phase 3 - all sixteen boards in ONE pass, RPL adjacent rows per lane: patch the classes, resolve captures and
-      // ko, the next mover's mask
+      // ko, the next mover's mask.  Conditions are kept as 0 / ~0 words in VGPRs and applied with bit operations: a
+      // boolean that goes through v_cmp -> s_and_b64 -> v_cndmask (or through an EXEC branch around three instructions)
+      // is a VALU -> SALU -> VALU round trip on this wave's critical path, and with 16 boards per wave the "rare"
+      // capture path runs on 85 % of the plies (some board of the wave captures), so it is straight-line code too.
       {
         const int av = actv[s4];
         const int a = bl ? av : -1;
-        const bool moves_now = a >= 0;
         const uint32_t fl = flagsv[s4];
-        int turn = fl & 1u, passed = (fl >> 1) & 1u, done = (fl >> 2) & 1u;
         const uint4 cq = *reinterpret_cast<const uint4 *>(clsv + 4 * s4);
         const uint32_t c0 = cq.x, c1 = cq.y, c2 = cq.z, c3 = cq.w;
         const uint32_t bi = binfo[s4];
-        const bool is_pass = a == hf.P;
-        const bool stone = moves_now && !is_pass;
-        int ar = 0, ac = 0;
-        if (stone) split_action(a, N, hf.inv, ar, ac);
-        uint32_t *pmine = st + turn * PL + s4 * RS + r0;
-        uint32_t *popp = st + (1 - turn) * PL + s4 * RS + r0;
+        const int turn0 = fl & 1u;
+        uint32_t *pmine = st + turn0 * PL + s4 * RS + r0;
+        uint32_t *popp = st + (1 - turn0) * PL + s4 * RS + r0;
         const uint32_t *gr = sc + (4 * s4) * RS + r0;   // block j: gr[j * RS + r]
-        const uint32_t gmask = (c3 & CL_G) ? ~0u : 0u;   // lane 3 flooded G (else: an opponent group or nothing)
-        const bool loneG = stone && !(bi & BI_FRIEND);  // G is the new stone alone
-        uint32_t mine1[RPL], opp0[RPL], g0[RPL], gch[RPL];
+        uint32_t mine1[RPL], opp0[RPL], b0[RPL], b1[RPL], b2[RPL], b3[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
           mine1[r] = pmine[r];   // (rows >= N are zero)
           opp0[r] = popp[r];
-          const uint32_t b0 = gr[r], b1 = gr[RS + r], b2 = gr[2 * RS + r], b3 = gr[3 * RS + r];
-          const uint32_t one = (loneG && r0 + r == ar) ? (1u << ac) : 0u;
-          g0[r] = B3(b3, gmask, one, T_ANDOR) & full[r];
-          gch[r] = B3(B3(b0, b1, b2, T_OR3), b3, gmask, TA | (TB & ~TC & 0xFF)) & full[r];   // the opponent groups whose class changes
+          b0[r] = gr[r]; b1[r] = gr[RS + r]; b2[r] = gr[2 * RS + r]; b3[r] = gr[3 * RS + r];
         }
-        const bool k0 = (c0 & (CL_LIBS | CL_ANY | CL_G)) == CL_ANY, k1 = (c1 & (CL_LIBS | CL_ANY | CL_G)) == CL_ANY,
-                   k2 = (c2 & (CL_LIBS | CL_ANY | CL_G)) == CL_ANY, k3 = (c3 & (CL_LIBS | CL_ANY | CL_G)) == CL_ANY;
-        uint32_t cap[RPL], Mm_fix[RPL];
+        const bool moves_now = a >= 0;
+        const bool is_pass = a == hf.P;
+        const uint32_t stone_m = (moves_now && !is_pass) ? ~0u : 0u;
+        int ar, ac;
+        split_action(a, N, hf.inv, ar, ac);                       // (garbage for a pass / an idle board: masked below)
+        const uint32_t bitc = stone_m & (1u << (ac & 31));
+        const uint32_t gmask = (uint32_t)__builtin_amdgcn_sbfe((int)c3, 4, 1);   // CL_G: lane 3 flooded G
+        // G is the new stone alone (no friendly neighbour): its row as a one-hot selector of this lane's rows
+        const uint32_t dr = (uint32_t)(ar - r0);
+        const uint32_t lone_m = stone_m & ~(uint32_t)__builtin_amdgcn_sbfe((int)bi, 2, 1);   // !BI_FRIEND
+        const uint32_t oh = (dr < (uint32_t)RPL) ? (lone_m & (1u << (dr & 31))) : 0u;
+        // captured = an opponent group (not G) that exists and has no liberty left
+        const uint32_t kmask = CL_LIBS | CL_ANY | CL_G;
+        const uint32_t km0 = stone_m & (((c0 & kmask) == CL_ANY) ? ~0u : 0u), km1 = stone_m & (((c1 & kmask) == CL_ANY) ? ~0u : 0u),
+                       km2 = stone_m & (((c2 & kmask) == CL_ANY) ? ~0u : 0u), km3 = stone_m & (((c3 & kmask) == CL_ANY) ? ~0u : 0u);
+        const uint32_t capt_m = km0 | km1 | km2 | km3;
+        uint32_t g0[RPL], gch[RPL], cap[RPL], Mm_fix[RPL];
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) cap[r] = Mm_fix[r] = 0u;
-        uint32_t libsG = (c3 & CL_G) ? (c3 & CL_LIBS) : (bi & BI_EMPTY);   // liberties of G among the empty points (saturated at 2)
-        int ko_r = -1, ko_c = 0;
-        const bool capt = stone && (k0 || k1 || k2 || k3);
-        if (__ballot(capt)) {   // a capture on some board
-#pragma unroll
-          for (int r = 0; r < RPL; ++r) {
-            const uint32_t b0 = k0 ? gr[r] : 0u, b1 = k1 ? gr[RS + r] : 0u, b2 = k2 ? gr[2 * RS + r] : 0u,
-                           b3 = k3 ? gr[3 * RS + r] : 0u;
-            cap[r] = capt ? ((b0 | b1 | b2 | b3) & full[r]) : 0u;
-          }
+        for (int r = 0; r < RPL; ++r) {
+          const uint32_t one = (uint32_t)__builtin_amdgcn_sbfe((int)oh, r, 1) & bitc;
+          g0[r] = B3(b3[r], gmask, one, T_ANDOR) & full[r];
+          gch[r] = B3(B3(b0[r], b1[r], b2[r], T_OR3), b3[r], gmask, TA | (TB & ~TC & 0xFF)) & full[r];   // the opponent groups whose class changes
+          cap[r] = B3(b3[r], km3, B3(b2[r], km2, B3(b1[r], km1, b0[r] & km0, T_ANDOR), T_ANDOR), T_ANDOR) & full[r];
+          Mm_fix[r] = 0u;
+        }
+        uint32_t libsG = gmask ? (c3 & CL_LIBS) : (bi & BI_EMPTY);   // liberties of G among the empty points (saturated at 2)
+        uint32_t ko_oh = 0u, ko_bit = 0u;
+        if (__ballot(capt_m != 0u)) {   // a capture on some board of the wave (85 % of the plies at 16 boards per wave)
           // captured stones next to G are liberties of G too
           {
             uint32_t dg[RPL];
@@ -525,14 +549,13 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
             libsG += tot < 2u ? tot : 2u;
           }
           // gogame.py:72-75: ko iff exactly one stone died and the new stone is boxed in
-          const uint32_t ncap1 = (k0 && (c0 & CL_ONE) ? 1u : 0u) + (k1 && (c1 & CL_ONE) ? 1u : 0u) +
-                                 (k2 && (c2 & CL_ONE) ? 1u : 0u) + (k3 && (c3 & CL_ONE) ? 1u : 0u);
-          const uint32_t ncapn = (k0 ? 1u : 0u) + (k1 ? 1u : 0u) + (k2 ? 1u : 0u) + (k3 ? 1u : 0u);
-          if (capt && (bi & BI_BOXED) && ncapn == 1u && ncap1 == 1u) {
-            const uint32_t ck = k0 ? c0 : (k1 ? c1 : (k2 ? c2 : c3));
-            ko_r = (int)((ck >> 8) & 0xFFu);
-            ko_c = (int)((ck >> 16) & 0xFFu);
-          }
+          const uint32_t ncapn = 0u - (km0 + km1 + km2 + km3);    // masks are 0 / -1
+          const uint32_t ncap1 = ((c0 >> 2) & km0 & 1u) + ((c1 >> 2) & km1 & 1u) + ((c2 >> 2) & km2 & 1u) + ((c3 >> 2) & km3 & 1u);
+          const uint32_t ck = B3(c3, km3, B3(c2, km2, B3(c1, km1, c0 & km0, T_ANDOR), T_ANDOR), T_ANDOR);   // the one captured group's word
+          const bool ko = (bi & BI_BOXED) && ncapn == 1u && ncap1 == 1u;
+          const uint32_t kr = ((ck >> 8) & 0xFFu) - (uint32_t)r0;
+          ko_oh = (ko && kr < (uint32_t)RPL) ? (1u << (kr & 31)) : 0u;
+          ko_bit = 1u << ((ck >> 16) & 31u);
           // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties
           uint32_t atari[RPL], f[RPL];
           dilate_rows<RPL>(cap, f);
@@ -569,26 +592,30 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
           x[r] = B3(e[r], opp1[r] & Mo2[r], mine1[r] & ~Mm2[r], T_OR3);
         }
         dilate_rows<RPL>(x, nbr);
-        if (moves_now) {
+        const uint32_t mv_m = moves_now ? ~0u : 0u;
 #pragma unroll
-          for (int r = 0; r < RPL; ++r) {
-            uint32_t invalid = full[r] & ~(e[r] & nbr[r]);
-            if (r0 + r == ko_r) invalid |= 1u << ko_c;
-            inv_r[r] = invalid;
-            M[r] = Mm2[r] | Mo2[r];
-            if (capt) popp[r] = opp1[r];
-          }
-          if (is_pass) { if (passed) done = 1; passed = 1; } else passed = 0;
-          turn ^= 1;
-          if (t5 == 0) {
-            flagsv[s4] = (uint32_t)turn | ((uint32_t)passed << 1) | ((uint32_t)done << 2) | 8u;
-            lastv[s4] = a;
-            playedv[s4] += 1;
-          }
+        for (int r = 0; r < RPL; ++r) {
+          const uint32_t invalid = (full[r] & ~(e[r] & nbr[r])) | ((uint32_t)__builtin_amdgcn_sbfe((int)ko_oh, r, 1) & ko_bit);
+          inv_r[r] = B3(mv_m, invalid, inv_r[r], T_SEL);
+          M[r] = B3(mv_m, Mm2[r] | Mo2[r], M[r], T_SEL);
+        }
+        if (capt_m) {
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) popp[r] = opp1[r];
+        }
+        if (moves_now && t5 == 0) {
+          const uint32_t passed0 = (fl >> 1) & 1u, done0 = (fl >> 2) & 1u;
+          const uint32_t passed = is_pass ? 1u : 0u, done = done0 | (passed & passed0);
+          flagsv[s4] = (uint32_t)(turn0 ^ 1) | (passed << 1) | (done << 2) | 8u;
+          lastv[s4] = a;
+          playedv[s4] += 1;
         }
       }
       WAVE_SYNC();
+      GG_PROF(4);
     }
+    GG_PROF(5);
+    GG_PROF_FLUSH;
 
     // ---------------------------------------------------------------- store
     // The lane-derived values of the write-back are recomputed from a fresh (volatile) lane id: hoisted above the ply
