@@ -206,7 +206,7 @@ def rollout_kernel_name(n, games, plies, cus):
     rcap = 9 if n <= 9 else 13 if n <= 13 else 19
     full = 'true' if n == rcap else 'false'
     if plies >= 2 and games >= 32 * cus:
-        return 'k_rollout4<%d, 0, false, %s>' % (rcap, full)
+        return 'k_rollout4<%d, 0, false, %s, false>' % (rcap, full)
     return 'k_rollout2<%d, %s, false, %s>' % (rcap, 'true' if plies <= 2 else 'false', full)
 
 
@@ -215,10 +215,22 @@ def load_pmc(kernel, n, plies, games):
     (profiles/pmc_rollout.json, written by tools/summarize_profiles.py from rocprofv3 --pmc runs of this command)."""
     path = os.path.join(ROOT, 'profiles', 'pmc_rollout.json')
     try:
+        same_shape = None
         for rec in json.load(open(path)).get('records', []):
-            if (rec.get('kernel') == kernel and rec.get('size') == n and rec.get('plies_per_launch') == plies
-                    and rec.get('games') == games):
-                return rec
+            if rec.get('kernel') == kernel and rec.get('size') == n and rec.get('plies_per_launch') == plies:
+                if rec.get('games') == games:
+                    return rec
+                same_shape = rec
+        if same_shape is not None:
+            # another batch size of the same kernel and launch length (the multi-GPU lines run 131 072 games per GPU):
+            # the instruction mix per env step does not depend on the batch, the traffic scales with the games
+            rec = dict(same_shape)
+            scale = games / float(same_shape['games'])
+            for k in ('hbm_bytes_per_launch', 'fetch_bytes', 'write_bytes'):
+                if rec.get(k) is not None:
+                    rec[k] = int(round(rec[k] * scale))
+            rec['source'] = '%s; measured at %d games, traffic scaled to %d' % (same_shape.get('source'), same_shape['games'], games)
+            return rec
     except Exception:
         pass
     return None

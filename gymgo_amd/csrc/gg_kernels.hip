@@ -206,10 +206,15 @@ int32_t gg_batch_areas(const uint8_t *states, int32_t *black, int32_t *white, in
   return (int32_t)hipGetLastError();
 }
 
-// children: the per-parent analysis (4 flood batches at 19x19) is repeated by every chunk of a parent's slots, so
-// chunks only serve to fill the machine and to even out the tail (8 192 parents: 2 chunks each, measured best of 1..12)
+// children: the per-parent analysis (4 flood batches at 19x19) is repeated by every chunk of a parent's slots, so chunks
+// only serve to fill the machine: enough work items for two rounds of the resident waves (4 per SIMD), one chunk per
+// parent from 8 192 parents up (round 2, on a box whose stores are not the limit: 1 / 2 / 4 / 8 chunks per parent
+// 6.64 / 6.31 / 6.19 / 6.02e6 parents/s)
 static int children_chunks(int cus, int64_t B, int A) {
-  int chunks = (int)(((int64_t)cus * 64 + B - 1) / B);
+  int chunks = (int)(((int64_t)cus * 32 + B - 1) / B);
+#ifdef GG_AB
+  if (const char *e = getenv("GG_AB_CHUNKS")) chunks = atoi(e);
+#endif
   if (chunks < 1) chunks = 1;
   if (chunks > A) chunks = A;
   return chunks;

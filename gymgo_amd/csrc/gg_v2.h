@@ -38,7 +38,7 @@ constexpr CwTable make_cw_table() {
 __constant__ CwTable kCw = make_cw_table();
 
 #ifndef GG_LB_CH3
-#define GG_LB_CH3 3   // waves per SIMD k_children3 is compiled for
+#define GG_LB_CH3 4   // waves per SIMD k_children3 is compiled for (128 VGPRs, no spills; 3 waves / 140 VGPRs measures the same +-3 %)
 #endif
 #ifndef GG_LB_PLY
 #define GG_LB_PLY 3   // waves per SIMD the per-ply kernels are compiled for

@@ -109,6 +109,32 @@ __global__ void kJ(uint8_t *p, int64_t nregions, int misalign) {   // B with the
     for (int64_t o = 0; o < per - 1024; o += 1024) *reinterpret_cast<V16 *>(q + o + threadIdx.x * 16) = z;
   }
 }
+// K: NON-persistent: one workgroup of T threads per tile of T x 16 x U bytes, tiles in address order (what a fill kernel
+// does: the dispatcher keeps a sliding window of tiles in flight); L: the same with single-wave workgroups
+template <int U>
+__global__ void kK(uint8_t *p, int64_t total) {
+  const V16 z = {{0, 0, 0, 0}};
+  const int64_t base = (int64_t)blockIdx.x * blockDim.x * 16 * U;
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    const int64_t o = base + ((int64_t)k * blockDim.x + threadIdx.x) * 16;
+    if (o + 16 <= total) *reinterpret_cast<V16 *>(p + o) = z;
+  }
+}
+// M: persistent waves, but each wave takes the NEXT tile of 16 KB from a global atomic counter (dynamic sliding window)
+__global__ void kM(uint8_t *p, int64_t total, unsigned long long *ctr) {
+  const V16 z = {{0, 0, 0, 0}};
+  const int64_t ntiles = total / 16384;
+  for (;;) {
+    unsigned long long t = 0;
+    if (threadIdx.x == 0) t = atomicAdd(ctr, 1ull);
+    t = __shfl(t, 0);
+    if ((int64_t)t >= ntiles) break;
+    uint8_t *q = p + t * 16384;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) *reinterpret_cast<V16 *>(q + k * 1024 + threadIdx.x * 16) = z;
+  }
+}
 template <class F> float timeit(F f) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   f(); hipDeviceSynchronize();
@@ -118,7 +144,20 @@ template <class F> float timeit(F f) {
 int main() {
   const int64_t P = 8192, total = P * REGION;
   uint8_t *p; hipMalloc(&p, total + 4096);
-  for (int G : {3072, 8192}) {
+  {
+    float t;
+    unsigned long long *ctr; hipMalloc(&ctr, 8);
+    t = timeit([&] { kK<1><<<(unsigned)((total + 4095) / 4096), 256>>>(p, total); }); printf("K tiles 4 KB, 256 thr      %6.3f ms %6.2f TB/s\n", t, total / t / 1e9);
+    t = timeit([&] { kK<4><<<(unsigned)((total + 16383) / 16384), 256>>>(p, total); }); printf("K tiles 16 KB, 256 thr     %6.3f ms %6.2f TB/s\n", t, total / t / 1e9);
+    t = timeit([&] { kK<16><<<(unsigned)((total + 65535) / 65536), 256>>>(p, total); }); printf("K tiles 64 KB, 256 thr     %6.3f ms %6.2f TB/s\n", t, total / t / 1e9);
+    t = timeit([&] { kK<4><<<(unsigned)((total + 4095) / 4096), 64>>>(p, total); }); printf("L tiles 4 KB, 64 thr       %6.3f ms %6.2f TB/s\n", t, total / t / 1e9);
+    t = timeit([&] { kK<16><<<(unsigned)((total + 16383) / 16384), 64>>>(p, total); }); printf("L tiles 16 KB, 64 thr      %6.3f ms %6.2f TB/s\n", t, total / t / 1e9);
+    t = timeit([&] { kK<64><<<(unsigned)((total + 65535) / 65536), 64>>>(p, total); }); printf("L tiles 64 KB, 64 thr      %6.3f ms %6.2f TB/s\n", t, total / t / 1e9);
+    for (int G : {3072, 8192, 16384}) {
+      t = timeit([&] { hipMemsetAsync(ctr, 0, 8, 0); kM<<<G, 64>>>(p, total, ctr); }); printf("M atomic 16 KB tiles G=%5d %6.3f ms %6.2f TB/s\n", G, t, total / t / 1e9);
+    }
+  }
+  for (int G : {3072}) {
     float t;
     t = timeit([&] { hipMemsetAsync(p, 0, total, 0); }); printf("memset            %6.3f ms %6.2f TB/s\n", t, total / t / 1e9);
     t = timeit([&] { kA<<<G, 64>>>(p, total); }); printf("A grid-stride  G=%5d %6.3f ms %6.2f TB/s\n", G, t, total / t / 1e9);
