@@ -309,7 +309,20 @@ def extras(dev, back, opts):
                'frac': round(algo * r / 1e9 / HBM_PEAK_GBS, 4), 'bound': 'hbm',
                'note': 'through the Python API (ctypes call + launch), HIP events over 32 back-to-back calls'}
     out['gg_batch_next_states_steps_per_s'] = round(r, 1)
-    del nxt
+    # the same API as a rollout loop (every output is the next input, passes keep the loop stationary) with the
+    # caller-owned workspace that carries the liberty classes from call to call (gg_batch_next_states_ws)
+    wsp = gogame.next_states_workspace(count, N, dev)
+    passes = torch.full((count,), N * N, dtype=torch.int32, device=dev)
+    pp = [states.clone(), nxt]
+
+    def loop_step():
+        gogame.batch_next_states(pp[0], passes, check=False, out=pp[1], status=status, workspace=wsp)
+        pp[0], pp[1] = pp[1], pp[0]
+    loop_step()
+    r, ms = event_rate(torch, dev, loop_step, count, 32)
+    out['gg_batch_next_states_workspace_loop_steps_per_s'] = round(r, 1)
+    out['gg_batch_next_states_workspace_loop_hbm_frac'] = round(algo * r / 1e9 / HBM_PEAK_GBS, 4)
+    del nxt, wsp, pp
     r, _ = event_rate(torch, dev, lambda: gogame.batch_rollout(states, rng, 1, True), count, 32)
     out['rollout_1_ply_per_launch_steps_per_s'] = round(r, 1)
     env_out = (torch.empty(count, dtype=torch.float32, device=dev), torch.empty(count, dtype=torch.uint8, device=dev),

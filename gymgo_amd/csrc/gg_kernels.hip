@@ -185,6 +185,18 @@ int32_t gg_batch_next_states(const uint8_t *in, const int32_t *actions, uint8_t 
   return (int32_t)hipGetLastError();
 }
 
+int32_t gg_batch_next_states_ws(const uint8_t *in, const int32_t *actions, uint8_t *out, int32_t *status, uint32_t *workspace,
+                                int64_t B, int32_t N, int32_t canonical, void *hip_stream) {
+  GG_ENTER(in);
+  if (!actions || !out || !workspace) return GG_E_NULLPTR;
+  int grid;
+  const int nb = boards_per_wave(cus, B, grid);
+  EnvArgs env = EnvArgs();
+  env.status = status; env.states_out = out; env.ws = workspace; env.canonical = canonical;
+  GG_DISPATCH4(N, 3, true, grid, const_cast<uint8_t *>(in), nullptr, nullptr, nullptr, B, N, inv, 1, 0, nb, actions, nullptr, env);
+  return (int32_t)hipGetLastError();
+}
+
 int32_t gg_batch_invalid_mask(const uint8_t *states, const int32_t *ko, uint8_t *mask, int64_t B, int32_t N,
                               void *hip_stream) {
   GG_ENTER(states);

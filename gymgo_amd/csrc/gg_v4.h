@@ -40,7 +40,8 @@ constexpr int kNB4 = 16;
 // A/B builds only: shader-clock time of the phases of a ply as one wave experiences them (incl. waiting for the SIMD)
 __device__ unsigned long long gg_prof[8];
 #define GG_PROF_DECL unsigned long long tph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc_ = clock64()
-#define GG_PROF(k) do { const unsigned long long n_ = clock64(); tph_[k] += n_ - tc_; tc_ = n_; } while (0)
+#define GG_PROF(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    const unsigned long long n_ = clock64(); __builtin_amdgcn_sched_barrier(0); tph_[k] += n_ - tc_; tc_ = n_; } while (0)
 #define GG_PROF_FLUSH do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&gg_prof[k_], tph_[k_]); } while (0)
 #else
 #define GG_PROF_DECL do {} while (0)
@@ -109,6 +110,12 @@ constexpr uint32_t BI_EMPTY = 3u, BI_FRIEND = 4u, BI_BOXED = 8u;
 // IO: 0 = byte planes (uint8 [B][6][N][N]), 1 = packed boards (uint32 [B][3N+1]), 2 = TRACKED boards (uint32 [B][5N+1]:
 // the rows of black, white, invalid, multi_black, multi_white + the flag word - a packed board that carries its
 // liberty classes, so that a launch needs no first analysis: per-ply stepping at the fused kernel's rate).
+// IO == 3 (with MOVES, one ply): gogame.batch_next_states OUT OF PLACE on byte planes with a caller-owned WORKSPACE of
+// tracked boards: `states` is the input batch (planes 0 / 1 and four flag bytes are read), env.states_out the output,
+// env.ws holds the tracked form of whatever the previous call wrote for this game slot.  A board whose stones equal
+// its workspace rows EXACTLY takes its liberty classes from there (a rollout that feeds every output back as the
+// next input: every board, every call); any other board is analysed from scratch, so the result never depends on what
+// the workspace holds as long as it was produced by this kernel or zero-filled.
 // FULLN: the board fills the row capacity (N == R: 9, 13, 19) - the per-row "r < N" guards fold away at compile time.
 // ENV (tracked boards, one ply): GoEnv.step for every game (gym_go/envs/go_env.py:49-76) - the action is given
 // (MOVES, env.actions) or drawn; a finished game is reset first when auto_reset, refused otherwise; after the ply the
@@ -123,6 +130,8 @@ struct EnvArgs {
   uint8_t *states_out;      // uint8 [B][6][N][N]: the resulting position of EVERY game, or nullptr
   float komi;
   int heuristic;
+  uint32_t *ws;             // IO == 3 only: the caller's workspace, uint32 [B][5N+1] (tracked boards of the last outputs)
+  int canonical;            // IO == 3 only
 };
 
 template <int R, int IO, bool MOVES = false, bool FULLN = false, bool ENV = false>
@@ -132,6 +141,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
                                                        int nb, const int32_t *__restrict__ moves = nullptr,
                                                        int32_t *__restrict__ played_out = nullptr, EnvArgs env = EnvArgs()) {
   static_assert(!ENV || IO == 2, "the env step runs on tracked boards");
+  static_assert(IO != 3 || (MOVES && !ENV), "the workspace step replays one given move per game");
   constexpr int RS = Lds4<R>::RS;
   constexpr int RV = (R + 3) / 4;
   constexpr int RPL = Lds4<R>::RPL;
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
   if (FULLN) N = R;   // a compile-time constant from here on: row masks, r * N + c and the "row exists" tests fold
   const Half hf = make_half(threadIdx.x, N, inv);
   uint32_t *st = lds + Lds4<R>::kState;     // st[colour * PL + board * RS + row]
-  uint32_t *flagsv = lds + Lds4<R>::kMeta;  // bit 0 turn, 1 passed, 2 done, 3 on, 4 stopped / refused, 5 reset (dirty)
+  uint32_t *flagsv = lds + Lds4<R>::kMeta;  // bit 0 turn, 1 passed, 2 done, 3 on, 4 stopped / refused, 5 reset (dirty), 6 illegal move (IO 3)
   int *actv = reinterpret_cast<int *>(lds + Lds4<R>::kMeta + kNB4);
   int *lastv = reinterpret_cast<int *>(lds + Lds4<R>::kMeta + 2 * kNB4);
   int *playedv = reinterpret_cast<int *>(lds + Lds4<R>::kMeta + 3 * kNB4);
@@ -152,8 +162,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
   uint32_t *v2 = lds + Lds4<R>::kV2;
   uint32_t *park = lds + Lds4<R>::kV2;      // tracked I/O: park[set * PL + board * RS + row], set 0 invalid, 1 mb, 2 mw
   uint2 *lut = reinterpret_cast<uint2 *>(lds + Lds4<R>::kLut);
-  constexpr bool PACKED = IO == 1, TRACKED = IO == 2;
-  const int S = 6 * hf.P, W = (TRACKED ? 5 : 3) * N + 1;
+  constexpr bool PACKED = IO == 1, TRACKED = IO == 2, CACHED = IO == 3;
+  const int S = 6 * hf.P, W = ((TRACKED || CACHED) ? 5 : 3) * N + 1;
   const bool row = hf.hl < RS;
   // nb (even, <= kNB4) boards per wave: the host picks it so that the groups fill the resident waves evenly
   const int64_t ngroups = (B + nb - 1) / nb;
@@ -166,6 +176,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
     uint32_t inv_r[RPL], M[RPL];
 #pragma unroll
     for (int r = 0; r < RPL; ++r) inv_r[r] = M[r] = 0u;
+    GG_PROF_DECL;
     // ---------------------------------------------------------------- load
     WAVE_SYNC();
     if (TRACKED) {
@@ -214,13 +225,60 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       for (int i = hf.lane; i < 2 * PL; i += kWave) st[i] = 0;
       WAVE_SYNC();
     }
+    // Byte planes / packed boards: pairs, first classes by the per-ply-style analysis.  The global loads of pair i + 1 are
+    // issued (into registers) before pair i is converted: a launch of few plies is a latency chain, and eight
+    // dependent load -> LDS -> convert rounds in a row were a third of a one-ply launch.
+    constexpr int NVL = CACHED ? (2 * R * R + 15 + 15) / 512 + 1 : (4 * R * R + 15 + 15) / 512 + 1;   // 16-byte vectors per lane
+    static_assert(NVL <= 3, "vectors per lane of a staged board");
+    if (CACHED) {   // the actions of the whole group first: the address of a board's INVD[action] byte depends on them
+      if (hf.lane < kNB4) actv[hf.lane] = (b_first + hf.lane < B) ? moves[b_first + hf.lane] : 0;
+      WAVE_SYNC();
+    }
+    if (!MOVES && !TRACKED && hf.lane < kNB4) {   // the generator states of the whole group: one coalesced load, not one per pair
+      const uint64_t x = rng[(b_first + hf.lane < B) ? b_first + hf.lane : B - 1];
+      rngv[2 * hf.lane] = (uint32_t)x;
+      rngv[2 * hf.lane + 1] = (uint32_t)(x >> 32);
+    }
+    // (plain scalars, not a struct: the prefetched values must stay in registers)
+    uint4 cv0 = make_uint4(0, 0, 0, 0), cv1 = cv0, cv2 = cv0, nv0 = cv0, nv1 = cv0, nv2 = cv0;
+    uint32_t cfb = 0, cwb = 0, cww = 0, cwm = 0, nfb = 0, nwb = 0, nww = 0, nwm = 0;
+    int ca = 0, na = 0;
+#define GG_ISSUE_PAIR(I, V0, V1, V2, FB, WB, WW, WM, A)                                                               \
+    do {                                                                                                               \
+      const int s_ = 2 * (I) + hf.h;                                                                                   \
+      const int64_t b_ = (b_first + s_ < B) ? b_first + s_ : B - 1;                                                    \
+      if (!PACKED) {                                                                                                   \
+        const uint8_t *gs_ = states + b_ * (int64_t)S;                                                                 \
+        int pt_ = 0;                                                                                                   \
+        if (CACHED) {                                                                                                  \
+          A = actv[s_];                                                                                                \
+          pt_ = (A >= 0 && A < hf.P) ? A : 0;                                                                          \
+          const uint32_t *wsb_ = env.ws + b_ * (int64_t)W;                                                             \
+          if (hf.hl < N) { WB = wsb_[hf.hl]; WW = wsb_[N + hf.hl]; WM = wsb_[3 * N + hf.hl] | wsb_[4 * N + hf.hl]; }   \
+        }                                                                                                              \
+        FB = 0;                                                                                                        \
+        if (hf.hl < 4) {                                                                                               \
+          const int off_ = hf.hl == 0 ? 2 * hf.P : hf.hl == 1 ? 3 * hf.P + pt_ : hf.hl == 2 ? 4 * hf.P : 5 * hf.P;     \
+          FB = gs_[off_];                                                                                              \
+        }                                                                                                              \
+        const uint32_t mis_ = (uint32_t)((uintptr_t)gs_ & 15u);                                                        \
+        const uint4 *ga_ = reinterpret_cast<const uint4 *>(gs_ - mis_);                                                \
+        const int nv_ = (int)(mis_ + (CACHED ? 2 : 4) * hf.P + 15) >> 4;                                               \
+        if (hf.hl < nv_) V0 = ga_[hf.hl];                                                                              \
+        if (NVL > 1 && hf.hl + 32 < nv_) V1 = ga_[hf.hl + 32];                                                         \
+        if (NVL > 2 && hf.hl + 64 < nv_) V2 = ga_[hf.hl + 64];                                                         \
+      }                                                                                                                \
+    } while (0)
+    if (!TRACKED && nb >= 2) GG_ISSUE_PAIR(0, cv0, cv1, cv2, cfb, cwb, cww, cwm, ca);
 #pragma unroll 1
-    for (int i = 0; i < (TRACKED ? 0 : nb / 2); ++i) {   // byte planes / packed boards: pairs, first classes by the v2 analysis
+    for (int i = 0; i < (TRACKED ? 0 : nb / 2); ++i) {
+      if (i + 1 < nb / 2) GG_ISSUE_PAIR(i + 1, nv0, nv1, nv2, nfb, nwb, nww, nwm, na);
       const int s = 2 * i + hf.h;
       const bool on = b_first + s < B;
       const int64_t b = on ? b_first + s : B - 1;
       uint32_t black, white, invalid, mb = 0, mw = 0;
       int turn, passed, done;
+      bool illegal = false;   // IO == 3: the given move is out of range or on a set point of plane 3
       if (PACKED) {
         uint32_t fw;
         load_packed_h(reinterpret_cast<const uint32_t *>(states) + b * (int64_t)W, N, hf, black, white, invalid, fw);
@@ -228,16 +286,34 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       } else {
         const uint8_t *gs = states + b * (int64_t)S;
         uint8_t *io = reinterpret_cast<uint8_t *>(v2) + hf.h * Cfg<R>::kIoBytes;
-        const uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
+        const uint32_t mi = (uint32_t)((uintptr_t)gs & 15u);
+        const int nv = (int)(mi + (CACHED ? 2 : 4) * hf.P + 15) >> 4;
+        const uint32_t flags = half_of(__ballot(cfb != 0), hf.h) & 0xFu;   // bit 0 turn, 1 INVD[pt], 2 passed, 3 done
         WAVE_SYNC();
-        const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
+        uint4 *iov = reinterpret_cast<uint4 *>(io);
+        if (hf.hl < nv) iov[hf.hl] = cv0;
+        if (NVL > 1 && hf.hl + 32 < nv) iov[hf.hl + 32] = cv1;
+        if (NVL > 2 && hf.hl + 64 < nv) iov[hf.hl + 64] = cv2;
         WAVE_SYNC();
         black = plane_to_row<R>(io + mi, N, hf.hl);
         white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
-        invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
         turn = flags & 1u; passed = (flags >> 2) & 1u; done = (flags >> 3) & 1u;
+        if (CACHED) {
+          // the classes come from the workspace when its stones are this board's stones (planes 0 / 1, exactly)
+          invalid = 0;
+          const bool in_range = ca >= 0 && ca <= hf.P;
+          illegal = !in_range || (ca < hf.P && (flags & 2u));   // gogame.py:59
+          const bool miss = half_of(__ballot(black != cwb || white != cww), hf.h) != 0u;
+          if (__ballot(on && miss)) {   // some board of the pair is new to the workspace: analyse (both halves run)
+            uint32_t ab;
+            analyze2<R, false>(black, white, hf.full_l1 & ~(black | white), hf, v2, mb, ab, mw, nullptr, nullptr, true);
+          }
+          if (!miss) { mb = cwm; mw = 0; }
+        } else {
+          invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
+        }
       }
-      {
+      if (!CACHED) {
         uint32_t ab;
         analyze2<R, false>(black, white, hf.full_l1 & ~(black | white), hf, v2, mb, ab, mw, nullptr, nullptr, true);
       }
@@ -248,14 +324,9 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         tmp[(hf.h * 2 + 1) * RS + hf.hl] = mb | mw;
       }
       if (hf.hl == 0) {
-        flagsv[s] = (uint32_t)turn | ((uint32_t)passed << 1) | ((uint32_t)done << 2) | (on ? 8u : 0u);
+        flagsv[s] = (uint32_t)turn | ((uint32_t)passed << 1) | ((uint32_t)done << 2) | (on ? 8u : 0u) | (illegal ? 64u : 0u);
         lastv[s] = -1;
         playedv[s] = 0;
-        if (!MOVES) {
-          const uint64_t x = rng[b];
-          rngv[2 * s] = (uint32_t)x;
-          rngv[2 * s + 1] = (uint32_t)(x >> 32);
-        }
       }
       WAVE_SYNC();
       if ((hf.lane >> 3) == i) {   // the two quads that own this pair pick their rows up
@@ -267,10 +338,11 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         }
       }
       WAVE_SYNC();
+      cv0 = nv0; cv1 = nv1; cv2 = nv2; cfb = nfb; cwb = nwb; cww = nww; cwm = nwm; ca = na;
     }
+#undef GG_ISSUE_PAIR
 
     // ---------------------------------------------------------------- the plies
-    GG_PROF_DECL;
     GG_PROF(6);   // load
     int mv_next = 0;
 #pragma unroll 1
@@ -303,8 +375,9 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
           if (t + 1 < plies) mv_next = moves[bm * (int64_t)plies + t + 1];
           // (gg_batch_play_moves passes auto_reset = 0: a finished game stops; the env step may reset it first, and the
           // reset stands even when the move is then refused - GoEnv.reset comes before the action check)
-          reset = on && done && auto_reset != 0 && !((fl >> 4) & 1u);
-          live = on && (!done || reset) && !((fl >> 4) & 1u) && mv >= 0 && mv <= hf.P;
+          reset = !CACHED && on && done && auto_reset != 0 && !((fl >> 4) & 1u);
+          // (gogame.next_state itself does not look at the game-over plane: the workspace step plays on, like the reference)
+          live = on && (CACHED || !done || reset) && !((fl >> 4) & 1u) && mv >= 0 && mv <= hf.P && !(CACHED && ((fl >> 6) & 1u));
           a = hf.P;
           const bool pt = live && mv < hf.P;
           int ar = 0, ac = 0;
@@ -312,7 +385,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
           // the lane that owns row ar tests the mask bit, the quad shares the verdict (a board being reset is empty)
           uint32_t bad = 0;
 #pragma unroll
-          for (int r = 0; r < RPL; ++r) bad |= (pt && !reset && r0 + r == ar) ? ((inv_r[r] >> ac) & 1u) : 0u;
+          for (int r = 0; r < RPL; ++r) bad |= (!CACHED && pt && !reset && r0 + r == ar) ? ((inv_r[r] >> ac) & 1u) : 0u;
           const bool illegal = quad_or(bad) != 0u;
           if (pt) {
             live = !illegal;
@@ -614,8 +687,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       WAVE_SYNC();
       GG_PROF(4);
     }
-    GG_PROF(5);
-    GG_PROF_FLUSH;
+    GG_PROF(5);   // (nothing between the last ply and the write-back)
 
     // ---------------------------------------------------------------- store
     // The lane-derived values of the write-back are recomputed from a fresh (volatile) lane id: hoisted above the ply
@@ -626,7 +698,23 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
     const int q4s = lnS >> 2, t4s = lnS & 3, r04s = RPL * t4s;
     const bool rowS = hs.hl < RS;
     WAVE_SYNC();
-    if (TRACKED) {
+    if (CACHED && env.canonical) {
+      // canonical_form (gogame.py:313-321) of a board whose next mover is white: colours swapped, turn plane cleared -
+      // done on the LDS planes, so that the byte planes and the workspace rows written below agree
+      const uint32_t fc = flagsv[q4s];
+      if ((fc & 1u) && playedv[q4s] != 0) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          const uint32_t bk = st[0 * PL + q4s * RS + r04s + r], wh = st[1 * PL + q4s * RS + r04s + r];
+          st[0 * PL + q4s * RS + r04s + r] = wh;
+          st[1 * PL + q4s * RS + r04s + r] = bk;
+        }
+      }
+      WAVE_SYNC();
+      if (hs.lane < kNB4 && (flagsv[hs.lane] & 1u) && playedv[hs.lane] != 0) flagsv[hs.lane] &= ~1u;
+      WAVE_SYNC();
+    }
+    if (TRACKED || CACHED) {
       // park the register rows, then one flat coalesced copy of the group's contiguous block
 #pragma unroll
       for (int r = 0; r < RPL; ++r) {
@@ -640,7 +728,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       WAVE_SYNC();
       const int64_t nbrd = (B - b_first) < nb ? (B - b_first) : nb;
       const int nw = (int)nbrd * W;
-      uint32_t *gp = reinterpret_cast<uint32_t *>(states) + b_first * (int64_t)W;
+      uint32_t *gp = (CACHED ? env.ws : reinterpret_cast<uint32_t *>(states)) + b_first * (int64_t)W;
       const uint32_t invW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;
       for (int i = hs.lane; i < nw; i += kWave) {
         const int sb = (int)(((uint32_t)i * invW) >> 20), w = i - sb * W;
@@ -658,12 +746,43 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         const int sb = hs.lane;
         const int64_t b = b_first + sb;
         const int played = playedv[sb];
-        if (!MOVES) rng[b] = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
-        if (last_actions) last_actions[b] = lastv[sb];
-        if (steps_done) steps_done[b] += played;
-        if (MOVES && played_out) played_out[b] = played;
+        if (CACHED) {
+          if (env.status) env.status[b] = played ? GG_STATUS_OK : GG_STATUS_ILLEGAL;
+        } else {
+          if (!MOVES) rng[b] = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
+          if (last_actions) last_actions[b] = lastv[sb];
+          if (steps_done) steps_done[b] += played;
+          if (MOVES && played_out) played_out[b] = played;
+        }
       }
       WAVE_SYNC();
+    }
+    if (CACHED) {
+      // the output batch: the new position of every game that moved, the input row unchanged for a refused move
+      uint32_t *invp = lds + Lds4<R>::kEnvInv;   // [kNB4][RS]
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) invp[q4s * RS + r04s + r] = inv_r[r];
+      load_spread_lut(lut, hs.lane);
+#pragma unroll 1
+      for (int i = 0; i < nb / 2; ++i) {
+        const int s = 2 * i + hs.h;
+        const uint32_t fs = flagsv[s];
+        const bool on = (fs >> 3) & 1u;
+        const int64_t b = on ? b_first + s : B - 1;
+        const bool wr = on && playedv[s] != 0;
+        uint32_t black = 0, white = 0, invalid = 0;
+        if (rowS) {
+          black = st[0 * PL + s * RS + hs.hl];
+          white = st[1 * PL + s * RS + hs.hl];
+          invalid = invp[s * RS + hs.hl];
+        }
+        if (__ballot(wr)) {
+          emit_store_h<R>(env.states_out + b * (int64_t)S, black, white, invalid, fs & 1u, (fs >> 1) & 1u, (fs >> 2) & 1u, hs,
+                          v2 + hs.h * 128, lut, wr);
+        }
+        if (on && !wr) copy_row_h(states + b * (int64_t)S, env.states_out + b * (int64_t)S, S, hs.hl, true);   // rare
+        WAVE_SYNC();
+      }
     }
     if (ENV) {
       // ---- GoEnv.step outputs.  Tromp-Taylor areas (gym_go/gogame.py:275-300) in the quad layout: the empty points
@@ -750,7 +869,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
     }
     if (IO == 0) load_spread_lut(lut, hs.lane);
 #pragma unroll 1
-    for (int i = 0; i < (TRACKED ? 0 : nb / 2); ++i) {
+    for (int i = 0; i < ((TRACKED || CACHED) ? 0 : nb / 2); ++i) {
       if ((hs.lane >> 3) == i) {   // the pair's owner quads hand their mask rows over
         uint32_t *tp = tmp + ((q4s & 1) * 2) * RS + r04s;
 #pragma unroll
@@ -784,6 +903,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       }
       WAVE_SYNC();
     }
+    GG_PROF(7);   // write-back
+    GG_PROF_FLUSH;
   }
 }
 

@@ -61,6 +61,18 @@ int32_t gg_batch_next_states(const uint8_t *in, const int32_t *actions, uint8_t 
                              int64_t B, int32_t N, int32_t canonical, void *hip_stream);
 
 /*
+ * gogame.batch_next_states with a caller-owned WORKSPACE                gym_go/gogame.py:90-150
+ * Same arguments, results and status as gg_batch_next_states, plus `workspace`: uint32 [B][gg_tracked_words(N)], zero-filled
+ * before its first use and otherwise opaque.  The call leaves in it the tracked form (stones + liberty classes) of every
+ * position it wrote to `out`; the next call takes the liberty classes of game b from there when planes 0 / 1 of in[b]
+ * equal the workspace's stones EXACTLY (checked per board, every call) and analyses the board from scratch otherwise.
+ * A loop that feeds each output batch back as the next input - a rollout through the step API - therefore pays the
+ * full liberty analysis once; results never depend on the workspace content.
+ */
+int32_t gg_batch_next_states_ws(const uint8_t *in, const int32_t *actions, uint8_t *out, int32_t *status, uint32_t *workspace,
+                                int64_t B, int32_t N, int32_t canonical, void *hip_stream);
+
+/*
  * state_utils.batch_compute_invalid_moves                              gym_go/state_utils.py:86-156
  * Recomputes plane 3 (invalid moves for the side to move, plane 2) from planes 0-2:
  * mask[b] = compute_invalid_moves(states[b], player = 1 - turn(states[b]), ko[b]).

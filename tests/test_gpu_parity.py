@@ -179,6 +179,51 @@ def test_step_api_vs_oracle_large(gg, oracle, size, B, plies):
     assert np.array_equal(kids, oracle.batch_children(want[8:12], False))
 
 
+@pytest.mark.parametrize('N,B,plies', [(19, 64, 90), (19, 8200, 100), (13, 4097, 80), (9, 300, 120), (5, 33, 50), (2, 17, 16)])
+@pytest.mark.parametrize('canonical', [False, True])
+def test_next_states_with_workspace_matches_oracle(gg, oracle, N, B, plies, canonical):
+    """gg_batch_next_states_ws: a rollout through the out-of-place step API that feeds every output back as the next
+    input, with the caller-owned workspace (liberty classes of the last outputs, reused when a board's stones match
+    exactly).  Every call against the oracle - states and status - while the test also corrupts moves (refused rows
+    pass through), swaps boards behind the workspace's back (those must be analysed afresh) and restarts finished
+    games; both canonical settings; then the workspace really is the tracked form of the last output."""
+    gen = np.random.default_rng(5 + N)
+    st = torch.zeros((B, 6, N, N), dtype=torch.uint8, device='cuda')
+    rng = gg.rng_seed(B, 5 + N)
+    ws = gg.next_states_workspace(B, N)
+    out = torch.empty_like(st)
+    status = torch.empty(B, dtype=torch.int32, device='cuda')
+    want = np.zeros((B, 6, N, N), np.uint8)
+    hits = 0
+    for t in range(plies):
+        a = gg.batch_sample_actions(st, rng).cpu().numpy().copy()
+        if t % 7 == 3:
+            idx = gen.choice(B, max(1, B // 10), replace=False)
+            a[idx] = gen.integers(-2, N * N + 3, size=len(idx))
+        if t % 11 == 5:
+            idx = gen.choice(B, max(1, B // 8), replace=False)
+            src = gen.choice(B, len(idx))
+            st[torch.as_tensor(idx, device='cuda')] = st[torch.as_tensor(src, device='cuda')]
+            want[idx] = want[src]
+        if t % 9 == 8:   # how many boards will take their classes from the workspace in this call
+            hits += int((gg.batch_pack(st)[:, :2 * N] == ws[:, :2 * N]).all(dim=1).sum())
+        gg.batch_next_states(st, torch.from_numpy(a).cuda(), canonical=canonical, check=False, out=out, status=status, workspace=ws)
+        want, wst = oracle.batch_next_states_mt(want, a, canonical)
+        assert np.array_equal(status.cpu().numpy(), wst), (N, t)
+        assert np.array_equal(out.cpu().numpy(), want), (N, t, canonical)
+        st, out = out, st
+        if t == plies - 1:   # the workspace is the tracked form of what the call just wrote (refused rows: untouched)
+            moved = (status == 0)
+            assert torch.equal(ws[moved], gg.batch_track(st)[moved])
+        over = want[:, 5, 0, 0] == 1
+        if over.any() and t % 5 == 0:
+            want[over] = 0
+            st[torch.from_numpy(over).cuda()] = 0
+    assert hits > B * (plies // 9) // 2                     # the workspace was used, not just carried along
+    with pytest.raises(ValueError):
+        gg.batch_next_states(st, torch.zeros(B, dtype=torch.int32, device='cuda'), check=False, out=out, workspace=ws[:, :-1])
+
+
 def test_illegal_moves_status_and_passthrough(gg, oracle):
     size, B = 9, 256
     rng = gg.rng_seed(B, 5)

@@ -44,6 +44,8 @@ def test_argument_validation_without_device(built):
     assert L.gg_batch_next_states(None, None, None, None, -1, 9, 0, None) == -1
     assert L.gg_batch_next_states(None, None, None, None, 0, 9, 0, None) == 0
     assert L.gg_batch_next_states(None, None, None, None, 2, 9, 0, None) == -2
+    assert L.gg_batch_next_states_ws(None, None, None, None, None, 2, 9, 0, None) == -2
+    assert L.gg_batch_next_states_ws(None, None, None, None, None, 2, 20, 0, None) == -1
     assert L.gg_batch_rollout(None, None, None, None, 2, 9, -1, 1, None) == -3
     assert L.gg_batch_children(None, None, 0, 19, 0, None) == 0
     assert L.gg_batch_env_step(None, None, None, None, None, None, None, 2, 9, 0.0, 0, 1, None) == -2
