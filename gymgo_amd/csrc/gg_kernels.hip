@@ -505,6 +505,7 @@ int32_t gg_batch_env_step_tracked(uint32_t *tracked, const int32_t *actions, uin
   EnvArgs env;
   env.actions = actions; env.rewards = rewards; env.dones = dones; env.status = status; env.taken = taken_actions;
   env.states_out = states_out; env.komi = komi; env.heuristic = reward_method == GG_REWARD_HEURISTIC;
+  env.ws = nullptr; env.canonical = 0;
   if (actions) {
     GG_DISPATCH4E(N, true, grid, st, nullptr, nullptr, nullptr, B, N, inv, 1, auto_reset, nb, actions, nullptr, env);
   } else {
