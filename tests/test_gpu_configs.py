@@ -17,8 +17,8 @@ def _oracle_rng(c_oracle, idx):
 
 def test_config3_19x19_65536_games_fused_rollout_vs_oracle():
     """BASELINE config 3 (the headline): 19x19, 65 536 games, uniform-random rollouts with auto-reset, in launches of
-    2 / 30 / 64 / 104 plies (the multi-ply kernel).  ORACLE: 2 048 games (every 32nd) replayed from the empty board,
-    states + generator + last action compared after every launch (200 plies: opening to middle game, captures, kos).
+    2 / 30 / 64 / 104 / 160 plies (the multi-ply kernel).  ORACLE: 8 192 games (every 8th) replayed from the empty board,
+    states + generator + last action compared after every launch (360 plies: opening to late middle game, captures, kos).
     HIP-vs-HIP cross-check for all 65 536 games: the same trajectory stepped one ply per launch by the per-ply kernel
     (every liberty class from scratch each ply) must reach bit-identical states, generators and step counts."""
     from gymgo_amd import gogame
@@ -30,12 +30,12 @@ def test_config3_19x19_65536_games_fused_rollout_vs_oracle():
     sd = torch.zeros(B, dtype=torch.int64, device='cuda')
     per_ply = st.clone()
     per_ply_rng = rng.clone()
-    idx = np.arange(0, B, 32)
+    idx = np.arange(0, B, 8)
     idx_t = torch.as_tensor(idx, device='cuda')
     want = np.zeros((len(idx), 6, N, N), np.uint8)
     want_rng = _oracle_rng(c_oracle, idx)
     total = 0
-    for plies in (2, 30, 64, 104):
+    for plies in (2, 30, 64, 104, 160):
         gogame.batch_rollout(st, rng, plies, True, la, sd)
         total += plies
         want, want_rng, want_last = c_oracle.batch_rollout_mt(want, want_rng, plies, True)
@@ -43,7 +43,7 @@ def test_config3_19x19_65536_games_fused_rollout_vs_oracle():
         assert np.array_equal(rng[idx_t].cpu().numpy().view(np.uint64), want_rng), ('rng', total)
         assert np.array_equal(la[idx_t].cpu().numpy(), want_last), ('last action', total)
     assert int(sd.min()) == total and int(sd.max()) == total
-    assert int((st[:, 0] | st[:, 1]).sum()) > 100 * B          # the boards really are in the middle game
+    assert int((st[:, 0] | st[:, 1]).sum()) > 150 * B          # the boards really are in the middle game
     for _ in range(total):
         gogame.batch_rollout(per_ply, per_ply_rng, 1, True)
     assert torch.equal(per_ply, st) and torch.equal(per_ply_rng, rng)
@@ -75,7 +75,7 @@ def test_config2_9x9_4096_games_rollout_vs_oracle():
 
 def test_config5_children_of_8192_midgame_parents_vs_oracle():
     """BASELINE config 5: 19x19, 8 192 mid-game parents (phases 60 ... 330 plies), the padded 362-slot expansion of each
-    (6.4 GB).  ORACLE: every 16th parent (512 parents x 362 slots, both canonical settings on half of them each).
+    (6.4 GB).  ORACLE: every 8th parent (1 024 parents x 362 slots; canonical = True on half of them too).
     HIP-vs-HIP cross-check for all parents: every legal slot equals gg_batch_next_states of the parent (an independent
     kernel that analyses the child from scratch), every illegal slot is all zero."""
     from gymgo_amd import gogame
@@ -91,7 +91,7 @@ def test_config5_children_of_8192_midgame_parents_vs_oracle():
     st[~live] = 0                          # keep the config's batch size: finished games become empty boards
     kids = gogame.batch_children(st, canonical=False)
     assert kids.shape == (B, A, 6, N, N)
-    sub = torch.arange(0, B, 16, device='cuda')
+    sub = torch.arange(0, B, 8, device='cuda')
     host = st[sub].cpu().numpy()
     assert np.array_equal(kids[sub].cpu().numpy(), c_oracle.batch_children_mt(host, False))
     half = sub[::2]
@@ -112,7 +112,7 @@ def test_config5_children_of_8192_midgame_parents_vs_oracle():
 def test_config4_one_rank_shard_of_1048576_games_vs_oracle():
     """BASELINE config 4: 19x19, 1 048 576 games as 8 shards of 131 072 (one per GPU, no collective).  This is rank 5's
     shard exactly as bench.py runs it (generator seeded by GLOBAL game index): 131 072 games, launches of 40 + 56 plies;
-    ORACLE: 1 024 games of the shard (every 128th) replayed by global index; and the shard equals the same index range
+    ORACLE: 2 048 games of the shard (every 64th) replayed by global index; and the shard equals the same index range
     computed inside a larger single-rank batch (shard invariance, HIP-vs-HIP)."""
     from gymgo_amd import gogame
     from gymgo_amd.envs.vec_env import shard
@@ -123,7 +123,7 @@ def test_config4_one_rank_shard_of_1048576_games_vs_oracle():
     st = gogame.batch_init_state(count, N, device='cuda')
     rng = gogame.rng_seed(count, SEED, first)
     sd = torch.zeros(count, dtype=torch.int64, device='cuda')
-    idx = np.arange(0, count, 128)
+    idx = np.arange(0, count, 64)
     want = np.zeros((len(idx), 6, N, N), np.uint8)
     want_rng = _oracle_rng(c_oracle, first + idx)
     for plies in (40, 56):
