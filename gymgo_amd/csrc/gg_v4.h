@@ -68,10 +68,14 @@ struct Lds4 {
   static constexpr int kV2 = kUnion;
   static constexpr int kLut = kV2 + 256;
   static constexpr int kIoEnd = kV2 + (Lds2<R>::kRegion0 > 768 ? Lds2<R>::kRegion0 : 768);
-  // env step: the mask rows of all boards parked behind the emitter's scratch + table while the observation is emitted
-  static constexpr int kEnvInv = kV2 + 768;                      // [kNB4][RS]
-  static constexpr int kEnvEnd = kEnvInv + kNB4 * RS;
-  static constexpr int kTotal = (kLoopEnd > kIoEnd ? kLoopEnd : kIoEnd) > kEnvEnd ? (kLoopEnd > kIoEnd ? kLoopEnd : kIoEnd) : kEnvEnd;
+  // byte-plane write-back of a whole group (emit_group): the group's 16 boards are ONE contiguous byte range, built as a
+  // bit-string (bit i = byte i of the range) + the 8 bits -> 8 bytes table
+  static constexpr int kGrpBits = kV2;
+  static constexpr int kGrpWords = ((15 + kNB4 * 6 * R * R + 31) / 32 + 4) & ~3;
+  static constexpr int kGrpLut = kGrpBits + kGrpWords;           // uint2[256]
+  static constexpr int kGrpEnd = kGrpLut + 512;
+  static constexpr int kTotal = (kLoopEnd > kIoEnd ? kLoopEnd : kIoEnd) > kGrpEnd ? (kLoopEnd > kIoEnd ? kLoopEnd : kIoEnd) : kGrpEnd;
+  static_assert(kTotal * 4 <= 10240, "four waves per SIMD: 10 KB of LDS per wave");
   static_assert(kUnion % 4 == 0, "16-byte alignment of the flood blocks");
   static_assert(3 * kNB4 * RS <= kWave * RS + kWave, "parked tracked rows fit the flood blocks");
 };
@@ -96,6 +100,70 @@ __device__ __forceinline__ void dilate_rows(const uint32_t (&x)[RPL], uint32_t (
     const uint32_t above = r == 0 ? up : x[r - 1], below = r == RPL - 1 ? dn : x[r + 1];
     d[r] = B3(shl1(x[r]), x[r] >> 1, above, T_OR3) | below;
   }
+}
+
+// Byte-plane write-back of a whole group of the multi-ply kernel.  The boards of a group are one contiguous byte range
+// [g, g + nbrd * 6 N^2): it is built as a bit-string in LDS - every quad ORs the rows of its board (stones from the LDS
+// planes, the mask from its registers, the three uniform planes from the flag word) - and leaves as aligned 1 KB blocks,
+// 64 lanes x 16 B through the 8 bits -> 8 bytes table: one hand-off instead of one per pair of boards, two ragged edges
+// per group instead of two per board, and the store pattern that streams best (tools/ubench/write_patterns.hip).
+template <int R, int RPL>
+__device__ __forceinline__ void emit_group(uint8_t *g, int nbrd, int N, const uint32_t *st, int PL, int RS,
+                                           const uint32_t (&inv_r)[RPL], const uint32_t *flagsv, uint32_t *bs, uint2 *lut,
+                                           int lane) {
+  const int P = N * N, S = 6 * P;
+  const uint32_t mo = (uint32_t)((uintptr_t)g & 15u);
+  const int nbits = (int)mo + nbrd * S;
+  const int q4 = lane >> 2, r04 = RPL * (lane & 3);
+  WAVE_SYNC();
+  for (int i = lane; i < (nbits + 31) / 32 + 1; i += kWave) bs[i] = 0;
+  for (int e = lane; e < 256; e += kWave)
+    lut[e] = make_uint2(__umul24((uint32_t)e & 15u, 0x204081u) & 0x01010101u, __umul24((uint32_t)e >> 4, 0x204081u) & 0x01010101u);
+  WAVE_SYNC();
+  if (q4 < nbrd) {
+    const uint32_t fl = flagsv[q4];
+    const uint32_t fullrow = (1u << N) - 1u;
+    const uint32_t tp = (fl & 1u) ? fullrow : 0u, pp = (fl & 2u) ? fullrow : 0u, dp = (fl & 4u) ? fullrow : 0u;
+    const uint32_t base = mo + (uint32_t)(q4 * S);
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      const int rr = r04 + r;
+      if (rr < N) {
+        const uint32_t rows[6] = {st[0 * PL + q4 * RS + rr], st[1 * PL + q4 * RS + rr], tp, inv_r[r], pp, dp};
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+          if (rows[p]) {
+            const uint32_t q = base + (uint32_t)(p * P + rr * N);
+            const uint64_t x = (uint64_t)rows[p] << (q & 31u);
+            atomicOr(bs + (q >> 5), (uint32_t)x);
+            if ((uint32_t)(x >> 32)) atomicOr(bs + (q >> 5) + 1, (uint32_t)(x >> 32));
+          }
+        }
+      }
+    }
+  }
+  WAVE_SYNC();
+  uint8_t *ga = g - mo;
+  const int v0 = mo ? 1 : 0, v1 = nbits >> 4;
+  const uint8_t *bb = reinterpret_cast<const uint8_t *>(bs);
+  typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+  u4v *gv = reinterpret_cast<u4v *>(__builtin_assume_aligned(ga, 16));   // one global_store_dwordx4 per lane and round
+  for (int v = v0 + lane; v < v1; v += kWave) {
+    const uint2 lo = lut[bb[2 * v]], hi = lut[bb[2 * v + 1]];
+    u4v o;
+    o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
+    gv[v] = o;
+  }
+  // the ragged vectors at either end of the group (shared with the neighbouring groups): single bytes
+  const int head = mo ? 16 - (int)mo : 0, tail = nbits & 15;
+  int j = -1;   // byte index inside the group
+  if (lane < 16) { if (lane < head) j = lane; }
+  else if (lane < 32 && lane - 16 < tail) j = nbrd * S - tail + (lane - 16);
+  if (j >= 0 && j < nbrd * S) {
+    const uint32_t q = mo + (uint32_t)j;
+    g[j] = (uint8_t)((bs[q >> 5] >> (q & 31u)) & 1u);
+  }
+  WAVE_SYNC();
 }
 
 // cls word of a flood lane: bits 0-1 liberties of the group (saturated at 2), 2 the group is one stone, 3 the group
@@ -189,16 +257,31 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       for (int i = hf.lane; i < 2 * PL; i += kWave) st[i] = 0;      // rows N .. RS-1 and absent boards read as zero
       for (int i = hf.lane; i < 3 * PL; i += kWave) park[i] = 0;
       const uint32_t invW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;   // i / W exactly for i < 16 * 96
+      // eight loads of the block are in flight at a time (a plain copy loop waits for each load in turn: 24 dependent
+      // round trips on the head of a launch; all 24 at once cost 47 spilled registers)
       WAVE_SYNC();
-      for (int i = hf.lane; i < nw; i += kWave) {
-        const uint32_t v = gp[i];
-        const int sb = (int)(((uint32_t)i * invW) >> 20), w = i - sb * W;
-        if (w == 5 * N) {
-          flagsv[sb] = (v & 7u) | 8u;
-        } else {
-          const int pl = (int)(((uint32_t)w * hf.inv) >> 16), rw = w - pl * N;
-          if (pl < 2) st[pl * PL + sb * RS + rw] = v;
-          else park[(pl - 2) * PL + sb * RS + rw] = v;
+#pragma unroll 1
+      for (int i0 = 0; i0 < nw; i0 += 8 * kWave) {
+        uint32_t buf[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = i0 + hf.lane + kWave * k;
+          buf[k] = gp[i < nw ? i : nw - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = i0 + hf.lane + kWave * k;
+          if (i < nw) {
+            const uint32_t v = buf[k];
+            const int sb = (int)(((uint32_t)i * invW) >> 20), w = i - sb * W;
+            if (w == 5 * N) {
+              flagsv[sb] = (v & 7u) | 8u;
+            } else {
+              const int pl = (int)(((uint32_t)w * hf.inv) >> 16), rw = w - pl * N;
+              if (pl < 2) st[pl * PL + sb * RS + rw] = v;
+              else park[(pl - 2) * PL + sb * RS + rw] = v;
+            }
+          }
         }
       }
       if (hf.lane < kNB4) {
@@ -758,30 +841,22 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       WAVE_SYNC();
     }
     if (CACHED) {
-      // the output batch: the new position of every game that moved, the input row unchanged for a refused move
-      uint32_t *invp = lds + Lds4<R>::kEnvInv;   // [kNB4][RS]
-#pragma unroll
-      for (int r = 0; r < RPL; ++r) invp[q4s * RS + r04s + r] = inv_r[r];
-      load_spread_lut(lut, hs.lane);
+      // the output batch: the new position of every game of the group in one contiguous write; a refused move (rare)
+      // gets the input row instead, copied afterwards (stores of one wave to one address land in program order)
+      const int nbrd = (int)((B - b_first) < nb ? (B - b_first) : nb);
+      emit_group<R, RPL>(env.states_out + b_first * (int64_t)S, nbrd, N, st, PL, RS, inv_r, flagsv,
+                         lds + Lds4<R>::kGrpBits, reinterpret_cast<uint2 *>(lds + Lds4<R>::kGrpLut), hs.lane);
+      bool refused_any = false;
+      if (hs.lane < nbrd) refused_any = playedv[hs.lane] == 0;
+      if (__ballot(refused_any)) {
 #pragma unroll 1
-      for (int i = 0; i < nb / 2; ++i) {
-        const int s = 2 * i + hs.h;
-        const uint32_t fs = flagsv[s];
-        const bool on = (fs >> 3) & 1u;
-        const int64_t b = on ? b_first + s : B - 1;
-        const bool wr = on && playedv[s] != 0;
-        uint32_t black = 0, white = 0, invalid = 0;
-        if (rowS) {
-          black = st[0 * PL + s * RS + hs.hl];
-          white = st[1 * PL + s * RS + hs.hl];
-          invalid = invp[s * RS + hs.hl];
+        for (int i = 0; i < nb / 2; ++i) {
+          const int s = 2 * i + hs.h;
+          if (s < nbrd && playedv[s] == 0) {
+            const int64_t b = b_first + s;
+            copy_row_h(states + b * (int64_t)S, env.states_out + b * (int64_t)S, S, hs.hl, true);
+          }
         }
-        if (__ballot(wr)) {
-          emit_store_h<R>(env.states_out + b * (int64_t)S, black, white, invalid, fs & 1u, (fs >> 1) & 1u, (fs >> 2) & 1u, hs,
-                          v2 + hs.h * 128, lut, wr);
-        }
-        if (on && !wr) copy_row_h(states + b * (int64_t)S, env.states_out + b * (int64_t)S, S, hs.hl, true);   // rare
-        WAVE_SYNC();
       }
     }
     if (ENV) {
@@ -839,37 +914,34 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         if (env.taken) env.taken[b] = MOVES ? env.actions[b] : lastv[q4s];
       }
       if (env.states_out) {
-        // the observation: every board of the group as byte planes (the emitter of the byte-plane write-back).  The mask
-        // rows of all sixteen boards are parked once behind the emitter's scratch and table (the registers are free from
-        // here on), then the pairs are emitted back to back.
-        uint32_t *invp = lds + Lds4<R>::kEnvInv;   // [kNB4][RS]
-        WAVE_SYNC();
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) invp[q4s * RS + r04s + r] = inv_r[r];
-        load_spread_lut(lut, hs.lane);
-#pragma unroll 1
-        for (int i = 0; i < nb / 2; ++i) {
-          const int s = 2 * i + hs.h;
-          const uint32_t fs = flagsv[s];
-          const bool on = (fs >> 3) & 1u;
-          const int64_t b = on ? b_first + s : B - 1;
-          uint32_t black = 0, white = 0, invalid = 0;
-          if (rowS) {
-            black = st[0 * PL + s * RS + hs.hl];
-            white = st[1 * PL + s * RS + hs.hl];
-            invalid = invp[s * RS + hs.hl];
-          }
-          if (__ballot(on)) {
-            emit_store_h<R>(env.states_out + b * (int64_t)S, black, white, invalid, fs & 1u, (fs >> 1) & 1u, (fs >> 2) & 1u, hs,
-                            v2 + hs.h * 128, lut, on);
-          }
-          WAVE_SYNC();
-        }
+        // the observation: every board of the group as byte planes, one contiguous write
+        const int nbrd = (int)((B - b_first) < nb ? (B - b_first) : nb);
+        emit_group<R, RPL>(env.states_out + b_first * (int64_t)S, nbrd, N, st, PL, RS, inv_r, flagsv,
+                           lds + Lds4<R>::kGrpBits, reinterpret_cast<uint2 *>(lds + Lds4<R>::kGrpLut), hs.lane);
       }
     }
-    if (IO == 0) load_spread_lut(lut, hs.lane);
+    if (IO == 0) {
+      // byte planes in place: the whole group in one contiguous write (a board that did not move is rewritten with what
+      // was loaded from it), then the per-game outputs
+      const int nbrd = (int)((B - b_first) < nb ? (B - b_first) : nb);
+      bool any_wr = false;
+      if (hs.lane < nbrd) any_wr = playedv[hs.lane] != 0 || (flagsv[hs.lane] & 32u);
+      if (__ballot(any_wr))
+        emit_group<R, RPL>(states + b_first * (int64_t)S, nbrd, N, st, PL, RS, inv_r, flagsv, lds + Lds4<R>::kGrpBits,
+                           reinterpret_cast<uint2 *>(lds + Lds4<R>::kGrpLut), hs.lane);
+      if (hs.lane < nbrd) {
+        const int sb = hs.lane;
+        const int64_t b = b_first + sb;
+        const int played = playedv[sb];
+        if (!MOVES) rng[b] = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
+        if (last_actions) last_actions[b] = lastv[sb];
+        if (steps_done) steps_done[b] += played;
+        if (MOVES && played_out) played_out[b] = played;
+      }
+      WAVE_SYNC();
+    }
 #pragma unroll 1
-    for (int i = 0; i < ((TRACKED || CACHED) ? 0 : nb / 2); ++i) {
+    for (int i = 0; i < (PACKED ? nb / 2 : 0); ++i) {
       if ((hs.lane >> 3) == i) {   // the pair's owner quads hand their mask rows over
         uint32_t *tp = tmp + ((q4s & 1) * 2) * RS + r04s;
 #pragma unroll
