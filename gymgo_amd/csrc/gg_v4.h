@@ -33,7 +33,8 @@ namespace gg {
 //      other group keeps its class.  The invalid-move mask follows from the classes exactly as in the per-ply kernels.
 // M and the mask are produced and consumed by the same lanes (phases 3 -> 1 -> 3), so they live in REGISTERS for the
 // whole launch (2 x RPL VGPRs); LDS holds the two stone planes (which the flood lanes read in the other layout), the
-// flood results and a few words per board: 8 704 B per wave at 19x19.
+// flood results and a few words per board: 8 704 B per wave at 19x19 in the ply loop, 9 728 B with the write-back's group
+// bit-string and table (the limit for four waves per SIMD is 10 240 B).
 constexpr int kNB4 = 16;
 
 #ifdef GG_AB_PROF
