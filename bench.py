@@ -421,6 +421,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=6.0, help='wall seconds per CPU-baseline worker')
     ap.add_argument('--no-also', action='store_true', help='skip the untimed extras (clean profiling passes)')
+    ap.add_argument('--comm', choices=('nccl', 'gloo'), default='nccl',
+                    help='process-group backend for barrier + reductions (gloo: rehearse the N > 1 path on a box with fewer '
+                         'GPUs than ranks - ranks then share devices round-robin)')
     return ap.parse_args(argv)
 
 
@@ -479,7 +482,10 @@ def main(argv=None):
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('NCCL_DEBUG', 'WARN')       # no version banner on stdout unless asked for
-        dist.init_process_group('nccl', device_id=dev)
+        if args.comm == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group('gloo')
         dist.barrier()                                    # the communicator exists from here on (banner printed, if any)
         _flush_c_stdio()
 
