@@ -249,3 +249,55 @@ def test_multi_ply_kernel_soak_all_layouts(N, B, plies):
         if mode == 1:
             assert torch.equal(obs, st), (N, B, t, 'observation')
         assert torch.equal(tr, gogame.batch_track(st)), (N, B, t, 'classes')
+
+
+@pytest.mark.parametrize('nb', [2, 4, 6, 8, 10, 12, 14, 16])
+def test_every_boards_per_wave_value_of_the_multi_ply_kernel(nb):
+    """The library picks the boards per wave of the multi-ply kernel from the batch size (B / (4 CUs), even, 2 ... 16):
+    one ragged batch per value (last wave partly filled), 9x9 so that whole games incl. resets fit into 150 plies.
+    Tracked launches of 1 / 7 / 40 plies, the tracked env step with its observation, and the workspace loop of
+    gg_batch_next_states walk the same trajectory; ORACLE replay of every 64th game, the per-ply byte-plane kernel
+    (HIP vs HIP) for all of them."""
+    from gymgo_amd import _lib, gogame
+    from oracle import c_oracle
+    N = 9
+    cus = _lib.lib().gg_device_cus()
+    B = cus * 4 * nb + 7 if nb < 16 else cus * 4 * 16 + 23
+    seed = 500 + nb
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, seed)
+    tr, trng = gogame.batch_track(st), rng.clone()
+    ws = gogame.next_states_workspace(B, N, 'cuda')
+    pp, prng = [st.clone(), torch.empty_like(st)], rng.clone()
+    status = torch.empty(B, dtype=torch.int32, device='cuda')
+    idx = np.arange(0, B, 64)
+    idx_t = torch.as_tensor(idx, device='cuda')
+    want = np.zeros((len(idx), 6, N, N), np.uint8)
+    orng = np.array([c_oracle.lib().gg_oracle_rng_seed(seed, int(i)) for i in idx], dtype=np.uint64)
+    obs = torch.empty_like(st)
+    t = 0
+    for k, mode in ((1, 0), (7, 0), (40, 0), (12, 1), (40, 0), (10, 2), (40, 0)):
+        for _ in range(k):
+            gogame.batch_rollout(st, rng, 1, True)                     # per-ply kernel, classes from scratch
+        if mode == 0:
+            gogame.batch_rollout_tracked(tr, trng, k, True)
+        elif mode == 1:
+            for _ in range(k):
+                gogame.batch_env_step_tracked(tr, None, trng, 0.5, 'heuristic', True, states_out=obs)
+            assert torch.equal(obs, st), (nb, t, 'observation')
+        else:
+            gogame.batch_rollout_tracked(tr, trng, k, True)
+        # the workspace loop plays the same moves through the out-of-place step API
+        for _ in range(k):
+            gogame.batch_reset_finished(pp[0])
+            a = gogame.batch_sample_actions(pp[0], prng)
+            gogame.batch_next_states(pp[0], a, check=False, out=pp[1], status=status, workspace=ws)
+            pp[0], pp[1] = pp[1], pp[0]
+        assert int(status.sum()) == 0
+        want, orng, _ = c_oracle.batch_rollout_mt(want, orng, k, True)
+        t += k
+        assert np.array_equal(st[idx_t].cpu().numpy(), want), (nb, t)
+        assert torch.equal(gogame.batch_untrack(tr), st) and torch.equal(trng, rng), (nb, t, 'tracked')
+        assert torch.equal(pp[0], st) and torch.equal(prng, rng), (nb, t, 'workspace loop')
+        assert torch.equal(tr, gogame.batch_track(st)), (nb, t, 'classes')
+    assert int(st[:, 5, 0, 0].sum()) + int((st[:, :2].sum(dim=(1, 2, 3)) < 20).sum()) > 0   # games ended / were reset on the way
