@@ -261,6 +261,13 @@ def roofline_record(dev, n, games, plies, launch_ms, per_ply):
             'frac_valu_only': round(ipe['valu'] * steps_per_s / 1e9 / peak, 4),
             'instr_per_step': ipe, 'traffic': pmc.get('hbm_bytes_per_launch'), 'pmc_source': pmc.get('source'),
         })
+        cpi = pmc.get('valu_issue_cycles_per_instr')
+        if cpi:
+            # `frac` prices every instruction at the 2-cycle peak; about a third of this kernel's VALU instructions are
+            # 4-cycle ops (v_bfrev, v_bcnt, v_cndmask, v_cmp ...): the share of cycles the VALU pipe is actually busy
+            rec['valu_pipe_busy_estimate'] = round(ipe['valu'] * steps_per_s / 1e9 / peak * cpi / 2.0, 4)
+            rec['valu_pipe_busy_note'] = ('frac_valu_only x %.2f / 2 issue cycles per VALU instruction: %s'
+                                          % (cpi, pmc.get('valu_issue_cycles_source')))
     else:
         rec.update({'achieved': None, 'frac': None, 'traffic': None,
                     'pmc_source': 'no PMC pass for this launch shape under profiles/ (tools/profile_round.sh collects one)'})

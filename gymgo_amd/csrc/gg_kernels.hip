@@ -85,7 +85,13 @@ int boards_per_wave(int cus, int64_t B, int &grid) {
 // games 1.4e9 vs 2.0e9 steps/s on the per-ply kernel, 16 384 games on par, 262 144 games 9.7e9 vs 2.9e9; 65 536 games at
 // 2 / 3 / 5 plies per launch 1.31 / 1.78 / 2.47e9 against 1.14 / 1.32 / 1.51e9).  Tracked boards carry their classes
 // and always run it.
-bool use_multi_ply(int cus, int64_t B, int plies) { return plies >= 2 && B >= (int64_t)cus * 32; }
+bool use_multi_ply(int cus, int64_t B, int plies) {
+  int64_t min_games = (int64_t)cus * 32;
+#ifdef GG_AB
+  if (const char *e = getenv("GG_AB_MULTI_MIN")) min_games = atoll(e);
+#endif
+  return plies >= 2 && B >= min_games;
+}
 
 int32_t check(int64_t B, int32_t N) { return (N < 2 || N > GG_MAX_BOARD || B < 0) ? GG_E_BADSIZE : 0; }
 

@@ -1,0 +1,84 @@
+"""Static instruction mix of the multi-ply kernel's ply loop, priced with the measured issue rates of
+profiles/r01_ubench_valu_rates*.txt (2 cycles per wave64 instruction for v_and/or/xor/add/sub/lshrrev/bitop3/mov, 4 for the
+rest: v_bfrev, v_bcnt, v_cndmask, v_cmp, v_lshlrev, three-operand ops, DPP moves ...).
+
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -S --cuda-device-only -o /tmp/gg.s gymgo_amd/csrc/gg_kernels.hip
+    python tools/isa_mix.py /tmp/gg.s > profiles/rNN_isa_mix.txt
+
+The ply loop is the code between the two `v_mbcnt_lo` markers of k_rollout4<19, 0, false, true, false> (the kernel reads
+its lane id afresh at the top of every ply and once more before the write-back).  Inner loops are weighted by the trip
+counts measured on mid-game boards (tests/dbg_flood_stats.py: 3.07 flood sweeps per wave-ply on average; a capture on
+some board of the wave on 85 % of the plies; the auto-reset block is rare)."""
+import collections
+import re
+import sys
+
+FAST = {'v_xor_b32', 'v_and_b32', 'v_or_b32', 'v_add_u32', 'v_sub_u32', 'v_subrev_u32', 'v_lshrrev_b32', 'v_bitop3_b32',
+        'v_mov_b32', 'v_not_b32', 'v_add_co_u32'}
+KERNEL = '_ZN2gg10k_rollout4ILi19ELi0ELb0ELb1ELb0E'
+
+
+def main(path):
+    text = open(path).read().split('\n')
+    start = next(i for i, l in enumerate(text) if l.startswith(KERNEL))
+    end = next(i for i in range(start, len(text)) if 's_endpgm' in text[i])
+    body = text[start:end]
+    marks = [i for i, l in enumerate(body) if 'v_mbcnt_lo_u32_b32' in l]
+    assert len(marks) == 2, marks
+    loop = body[marks[0]:marks[1]]
+    # blocks of the loop in program order: (first line, label, depth)
+    depth, blocks = 2, []
+    for i, l in enumerate(loop):
+        if re.match(r'^\.LBB\d+_\d+:', l):
+            # "in Loop: Header=BBx_y Depth=d", or for a loop header several comment lines ending in "This ... Header: Depth=d"
+            found, j = re.findall(r'Depth=(\d+)', l), i + 1
+            while j < len(loop) and loop[j].strip().startswith(';'):
+                found += re.findall(r'Depth=(\d+)', loop[j])
+                j += 1
+            depth = int(found[-1]) if found else 2
+        blocks.append(depth)
+    # depth-3 runs in program order: [0] auto-reset clear loop, [1] the flood, [2] the atari re-flood after a capture
+    runs, prev = [], 2
+    for i, d in enumerate(blocks):
+        if d >= 3 and prev < 3:
+            runs.append([i, i])
+        if d >= 3:
+            runs[-1][1] = i
+        prev = d
+    weights = [1.0] * len(loop)
+    names = ['auto-reset clear (rare)', 'flood', 'atari re-flood after a capture']
+    trip = [0.02, None, 0.3]
+    for k, (a, b) in enumerate(runs[:3]):
+        for i in range(a, b + 1):
+            weights[i] = trip[k] if trip[k] is not None else 3.07 / 2.0   # the flood loop body holds two sweeps (down, up)
+    tot, cyc = collections.Counter(), 0.0
+    slow = collections.Counter()
+    for l, w in zip(loop, weights):
+        l = l.strip()
+        if not l or l[0] in '.;' or l.endswith(':'):
+            continue
+        op = l.split()[0]
+        base = re.sub(r'_e(32|64)$', '', op)
+        if op.startswith('v_'):
+            fast = base in FAST and 'dpp' not in l
+            tot['valu fast (2 cycles)' if fast else 'valu slow (4 cycles)'] += w
+            cyc += w * (2 if fast else 4)
+            if not fast:
+                slow[base] += w
+        elif op.startswith('s_'):
+            tot['salu'] += w
+        elif op.startswith('ds_'):
+            tot['lds'] += w
+        else:
+            tot['other'] += w
+    print('ply loop of %s...: %d static lines; depth-3 runs: %s' % (KERNEL, len(loop), [(names[k], b - a + 1) for k, (a, b) in enumerate(runs[:3])]))
+    for k in sorted(tot):
+        print('  %-22s %8.1f per wave-ply  (%.1f per env step at 16 boards per wave)' % (k, tot[k], tot[k] / 16))
+    valu = tot['valu fast (2 cycles)'] + tot['valu slow (4 cycles)']
+    print('  VALU issue cycles per wave-ply: %.0f  (%.2f cycles per VALU instruction on average)' % (cyc, cyc / valu))
+    print('  slow ops: ' + ', '.join('%s %.0f' % (k, v) for k, v in slow.most_common(12)))
+    print('  => VALU pipe busy = frac_valu_only x %.2f / 2 (bench.py prices every VALU instruction at the 2-cycle peak)' % (cyc / valu))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])

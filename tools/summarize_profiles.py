@@ -130,6 +130,14 @@ rec = {'kernel': kernel, 'size': N, 'plies_per_launch': F, 'games': games,
        'hbm_bytes_per_launch': round(fetch_b + write_b), 'fetch_bytes': round(fetch_b), 'write_bytes': round(write_b),
        'fetch_scale': round(fetch_scale, 4), 'write_scale': round(write_scale, 4),
        'source': 'profiles/%s_summary.md (rocprofv3 --pmc passes of `bench.py --plies-per-step %d`, tools/profile_round.sh)' % (tag, F)}
+# static issue-cycle estimate of the ply loop (tools/isa_mix.py), when this round recorded one
+try:
+    mixtxt = open(os.path.join(dst, '%s_isa_mix.txt' % tag)).read()
+    import re
+    rec['valu_issue_cycles_per_instr'] = float(re.search(r'\(([0-9.]+) cycles per VALU instruction', mixtxt).group(1))
+    rec['valu_issue_cycles_source'] = 'profiles/%s_isa_mix.txt (tools/isa_mix.py: static mix of the ply loop x measured issue rates)' % tag
+except Exception:
+    pass
 allrec = [r for r in allrec if not (r['kernel'] == kernel and r['size'] == N and r['plies_per_launch'] == F and r['games'] == games)]
 allrec.append(rec)
 json.dump({'records': allrec}, open(pmc_path, 'w'), indent=1)
