@@ -1,0 +1,69 @@
+"""-m gpu: bench.py's driver-facing contract, run the way the driver runs it (a subprocess; plain for one GPU, under
+torch.distributed.run and self-spawned for two ranks - rehearsed over gloo with both ranks on this box's GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+            'vs_baseline', 'dtype', 'data', 'config', 'roofline')
+
+
+def _run(cmd, timeout=420):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    return json.loads(lines[-1])          # the JSON line is the LAST line of stdout
+
+
+def _check(line, n_gpus, steps, warmup):
+    for k in REQUIRED:
+        assert k in line, k
+    assert line['n_gpus'] == n_gpus and line['steps'] == steps and line['warmup'] == warmup
+    assert line['metric'].startswith('env steps/sec')
+    assert line['higher_is_better'] is True and line['scaling'] == 'weak' and line['vs_baseline'] is None
+    assert line['dtype'] == 'u8' and line['data'] == 'synthetic' and 'workload' in line['config']
+    assert line['value'] > 1e8 and line['ms_per_step'] > 0
+    # value is the whole job: every rank's games x plies per step / the step time
+    per_step = line['config']['env_steps_per_bench_step']
+    assert per_step == line['config']['games'] * line['config']['plies_per_step']
+    assert line['value'] == pytest.approx(per_step / (line['ms_per_step'] * 1e-3), rel=1e-3)
+    roof = line['roofline']
+    assert roof['bound'] == 'valu' and roof['peak'] > 0
+    if roof['frac'] is not None:
+        assert 0 < roof['frac'] <= 1 and 0 < roof['hbm']['frac'] <= 1
+        assert roof['traffic'] is not None and roof['traffic'] > 0
+
+
+def test_bench_one_gpu_plain_invocation():
+    line = _run([sys.executable, 'bench.py', '--gpus', '1', '--steps', '3', '--warmup', '1', '--cpu-seconds', '0.5'])
+    _check(line, 1, 3, 1)
+    assert line['config']['games'] == 65536 and line['config']['board'] == 19 and line['config']['plies_per_step'] == 256
+    assert line['roofline']['frac'] is not None                       # the committed PMC record matches the default shape
+    assert 0 < line['roofline']['per_ply']['frac'] <= 1
+    cpu = line['cpu_baseline']
+    assert cpu['kind'] == 'port' and cpu['cores'] >= 1 and cpu['value'] > 0 and cpu['unit'] == line['unit']
+    also = line['also']
+    assert also['gg_batch_env_step_steps_per_s'] > 0 and set(also['configs']) >= {
+        'config2_9x9_4096_games', 'config5_children_8192_parents', 'config1_7x7_single_game_GoEnv_step'}
+
+
+@pytest.mark.parametrize('launcher', ['torch.distributed.run', 'self-spawn'])
+def test_bench_two_ranks(launcher):
+    tail = ['bench.py', '--gpus', '2', '--comm', 'gloo', '--games-per-gpu', '16384', '--steps', '2', '--warmup', '1', '--no-also']
+    if launcher == 'self-spawn':
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', '29541'] + tail
+    line = _run(cmd)
+    _check(line, 2, 2, 1)
+    assert line['config']['games'] == 32768 and line['config']['games_per_gpu'] == 16384
+    assert 'cpu_baseline' not in line                                   # rank 0 at N = 1 only
