@@ -1,6 +1,7 @@
-// gg_aux.h - the two stand-alone single-board kernels (one wavefront per board, L1 "row per lane" only): the sampler
-// of gg_batch_sample_actions and the capture resolution of gg_batch_update_pieces.  Neither is on the bench path; both
-// exist because the reference exposes the operation on its own (gym_go/envs/go_env.py:78-81, gym_go/state_utils.py:159-211).
+// gg_aux.h - stand-alone kernels off the bench path, which exist because the reference exposes the operation on its own:
+// the sampler of gg_batch_sample_actions and the capture resolution of gg_batch_update_pieces (one wavefront per board, L1
+// "row per lane" only; gym_go/envs/go_env.py:78-81, gym_go/state_utils.py:159-211) and the area scoring of gg_batch_areas
+// (sixteen boards per wavefront; gym_go/gogame.py:275-300).
 #pragma once
 #include "gg_common.h"
 
@@ -139,5 +140,129 @@ __global__ __launch_bounds__(kWave) void k_update_pieces(uint8_t *__restrict__ s
     }
   }
 }
+
+// ---------------------------------------------------------------- gogame.areas for a batch, sixteen boards per wavefront
+// gym_go/gogame.py:275-300 (Tromp-Taylor: a colour owns its stones plus the empty regions that touch only that colour).
+// An empty region touches a colour iff the flood of the EMPTY points seeded next to that colour's stones covers it, so
+// a board needs two floods and a wave of 64 lanes serves sixteen boards with its lower half (lane 2 s + c: board s,
+// colour c) - the round-1 kernel flooded 4 lanes per wave (two boards).  Only planes 0 and 1 are read (2 N^2 bytes of
+// the 6 N^2): all loads of the group are issued up front (aligned 16-byte vectors, 12 per lane at 19x19), then staged
+// through LDS eight boards at a time and packed into row masks by all 64 lanes (one row of one plane each).
+template <int R>
+struct LdsAreas {
+  static constexpr int kRS = Cfg<R>::kRowStride;
+  static constexpr int kBoards = 16, kHalf = 8;
+  static constexpr int kVec = (2 * R * R + 15 + 15) / 16 + 1;                     // 16-byte vectors covering planes 0 / 1 at any alignment
+  static constexpr int kStageBoard = kVec * 16;
+  static constexpr int kPerLane = (kHalf * kVec + kWave - 1) / kWave;             // vectors per lane and half
+  static constexpr int kStage = 0;                                                // bytes: kHalf * kStageBoard
+  static constexpr int kSt = (kHalf * kStageBoard + 3) / 4;                       // words: [2][kBoards][kRS] stone rows
+  static constexpr int kSc = kSt + 2 * kBoards * kRS;                             // words: [32][kRS] converged floods
+  static constexpr int kTotal = kSc + 2 * kBoards * kRS;
+  static_assert(kHalf * kStageBoard >= 4 * 2 * kBoards * kRS, "the staging area doubles as the idle lanes' flood output");
+};
+
+template <int R, bool FULLN>
+__global__ __launch_bounds__(kWave) void k_areas4(const uint8_t *__restrict__ states, int32_t *__restrict__ black_area,
+                                                  int32_t *__restrict__ white_area, int64_t B, int N) {
+  using L = LdsAreas<R>;
+  if (FULLN) N = R;
+  constexpr int RS = L::kRS, RV = (R + 3) / 4, PL = L::kBoards * RS;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[L::kTotal];
+  uint8_t *stage = reinterpret_cast<uint8_t *>(lds);
+  uint32_t *st = lds + L::kSt, *sc = lds + L::kSc;
+  const int lane = threadIdx.x;
+  const int P = N * N, S = 6 * P;
+  const int64_t b_first = (int64_t)blockIdx.x * L::kBoards;
+  const int nv = (15 + 2 * P + 15) / 16 + 1;        // vectors fetched per board (an upper bound of the covering set)
+  // ---- every load of the group, before anything waits for one
+  uint4 v[2][L::kPerLane];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int k = 0; k < L::kPerLane; ++k) {
+      const int j = lane + kWave * k, i = j / L::kVec, w = j - i * L::kVec;
+      int64_t b = b_first + L::kHalf * h + i;
+      if (b >= B) b = B - 1;
+      const uint8_t *g = states + b * (int64_t)S;
+      const uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
+      // (the covering vectors of a board: mis + 2 P bytes; a vector past them would lie past the board's planes 2..5 never)
+      const bool need = i < L::kHalf && w < nv && 16 * w < (int)mis + 2 * P;
+      v[h][k] = need ? reinterpret_cast<const uint4 *>(g - mis)[w] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < L::kPerLane; ++k) {
+      const int j = lane + kWave * k, i = j / L::kVec, w = j - i * L::kVec;
+      if (i < L::kHalf) *reinterpret_cast<uint4 *>(stage + i * L::kStageBoard + 16 * w) = v[h][k];
+    }
+    WAVE_SYNC();
+    // one row of one plane per lane and round: unit u = (board i, plane p, row r)
+    for (int u = lane; u < L::kHalf * 2 * N; u += kWave) {
+      const int i = u / (2 * N), rem = u - i * 2 * N, p = rem >= N ? 1 : 0, r = rem - p * N;
+      int64_t b = b_first + L::kHalf * h + i;
+      if (b >= B) b = B - 1;
+      const uint32_t mis = (uint32_t)((uintptr_t)(states + b * (int64_t)S) & 15u);
+      st[p * PL + (L::kHalf * h + i) * RS + r] = plane_to_row<R>(stage + i * L::kStageBoard + mis + p * P, N, r);
+    }
+  }
+  if (N < RS) {   // rows N .. RS-1 of every board: no stones
+    for (int u = lane; u < 2 * L::kBoards * (RS - N); u += kWave) {
+      const int q = u / (RS - N), r = N + (u - q * (RS - N));
+      st[q * RS + r] = 0;
+    }
+  }
+  WAVE_SYNC();
+  // ---- lane 2 s + c floods the empty points of board s from the neighbours of colour c
+  const int s = (lane >> 1) & (L::kBoards - 1), c = lane & 1;
+  uint32_t cnt = 0;
+  {
+    uint32_t m[R], mrev[R], f[R];
+    {
+      uint32_t own[RV * 4 + 1], oth[RV * 4];
+      const uint4 *po = reinterpret_cast<const uint4 *>(st + c * PL + s * RS);
+      const uint4 *pt = reinterpret_cast<const uint4 *>(st + (1 - c) * PL + s * RS);
+#pragma unroll
+      for (int i = 0; i < RV; ++i) {
+        const uint4 a = po[i], d = pt[i];
+        own[4 * i] = a.x; own[4 * i + 1] = a.y; own[4 * i + 2] = a.z; own[4 * i + 3] = a.w;
+        oth[4 * i] = d.x; oth[4 * i + 1] = d.y; oth[4 * i + 2] = d.z; oth[4 * i + 3] = d.w;
+      }
+      own[RV * 4] = 0;
+      const uint32_t use = lane < 2 * L::kBoards ? (1u << N) - 1u : 0u;   // the upper half of the wave carries no flood
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t e = (FULLN || r < N) ? B3(own[r], oth[r], use, ~(TA | TB) & TC & 0xFF) : 0u;   // empty points
+        const uint32_t x = r > 0 ? B3(shl1(own[r]), own[r] >> 1, own[r - 1], T_OR3) : (shl1(own[r]) | (own[r] >> 1));
+        m[r] = e;
+        mrev[r] = __brev(e);
+        f[r] = B3(e, x, r < R - 1 ? own[r + 1] : 0u, T_AND_OR2);
+        cnt += (uint32_t)__popc(own[r]);
+      }
+    }
+    WAVE_SYNC();
+    // (the idle upper half converges at once; its rows go to the staging area, which is free by now)
+    flood2_serial<R>(m, mrev, f, lane < 2 * L::kBoards ? sc + lane * RS : lds + (lane - 2 * L::kBoards) * RS);
+  }
+  WAVE_SYNC();
+  if (lane < 2 * L::kBoards) {
+    uint32_t fo[RV * 4], fp[RV * 4];
+    const uint4 *pf = reinterpret_cast<const uint4 *>(sc + lane * RS);
+    const uint4 *pp = reinterpret_cast<const uint4 *>(sc + (lane ^ 1) * RS);
+#pragma unroll
+    for (int i = 0; i < RV; ++i) {
+      const uint4 a = pf[i], d = pp[i];
+      fo[4 * i] = a.x; fo[4 * i + 1] = a.y; fo[4 * i + 2] = a.z; fo[4 * i + 3] = a.w;
+      fp[4 * i] = d.x; fp[4 * i + 1] = d.y; fp[4 * i + 2] = d.z; fp[4 * i + 3] = d.w;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) cnt += (uint32_t)__popc(fo[r] & ~fp[r]);   // (word R of a block is never written)
+    if (b_first + s < B) (c ? white_area : black_area)[b_first + s] = (int32_t)cnt;
+  }
+}
+
 
 }  // namespace gg

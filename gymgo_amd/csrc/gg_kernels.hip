@@ -217,8 +217,10 @@ int32_t gg_batch_invalid_mask(const uint8_t *states, const int32_t *ko, uint8_t 
 int32_t gg_batch_areas(const uint8_t *states, int32_t *black, int32_t *white, int64_t B, int32_t N, void *hip_stream) {
   GG_ENTER(states);
   if (!black || !white) return GG_E_NULLPTR;
-  const int grid = grid_for(cus, (B + 1) / 2);
-#define GG_K(R, F) k_areas2<R, F><<<grid, kWave, 0, s>>>(states, black, white, B, N)
+  const int64_t groups = (B + LdsAreas<19>::kBoards - 1) / LdsAreas<19>::kBoards;   // one wave per sixteen boards
+  if (groups > 0x7FFFFFFF) return GG_E_BADSIZE;
+  const int grid = (int)groups;
+#define GG_K(R, F) k_areas4<R, F><<<grid, kWave, 0, s>>>(states, black, white, B, N)
   GG_DISPATCH_N(N);
 #undef GG_K
   return (int32_t)hipGetLastError();

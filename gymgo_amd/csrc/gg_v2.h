@@ -1355,77 +1355,6 @@ __global__ __launch_bounds__(kWave, 4) void k_invalid_mask2(const uint8_t *__res
   }
 }
 
-// gogame.areas (gym_go/gogame.py:275-300), two boards per wave: in each half lane 0 floods the empty points from
-// those touching black, lane 1 from those touching white; a region reached by exactly one colour belongs to it.
-template <int R, bool FULLN = false>
-__global__ __launch_bounds__(kWave) void k_areas2(const uint8_t *__restrict__ states, int32_t *__restrict__ black_area,
-                                                  int32_t *__restrict__ white_area, int64_t B, int N) {
-  if (FULLN) N = R;   // N == R: a compile-time constant (see k_env_step2)
-  constexpr int RS = Cfg<R>::kRowStride;
-  constexpr int RV = (R + 3) / 4;
-  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
-  const Half hf = make_half(threadIdx.x, N, 0);
-  const int S = 6 * hf.P;
-  uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
-  uint32_t *sc = lds;
-  uint32_t *my5 = lds + Lds2<R>::kRows5 + hf.h * kRowBuf;
-  const int64_t npairs = (B + 1) >> 1;
-  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
-    const bool on = 2 * p + hf.h < B;
-    const int64_t b = on ? 2 * p + hf.h : B - 1;
-    WAVE_SYNC();
-    const uint32_t mi = stage_in_h(states + b * (int64_t)S, 2 * hf.P, io, hf.hl);
-    WAVE_SYNC();
-    const uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
-    const uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
-    const uint32_t e = hf.full_l1 & ~(black | white);
-    WAVE_SYNC();
-    my5[hf.hl] = e;
-    my5[32 + hf.hl] = __brev(e);
-    my5[64 + hf.hl] = black;
-    my5[96 + hf.hl] = white;
-    WAVE_SYNC();
-    uint32_t m[R], mrev[R], f[R];
-    {
-      uint32_t mt[RV * 4], mr[RV * 4], src[RV * 4 + 1];
-      const uint4 *pm = reinterpret_cast<const uint4 *>(my5);
-      const uint4 *pr = reinterpret_cast<const uint4 *>(my5 + 32);
-      const uint4 *ps = reinterpret_cast<const uint4 *>(my5 + (hf.hl == 1 ? 96 : 64));
-#pragma unroll
-      for (int i = 0; i < RV; ++i) {
-        uint4 a = pm[i], c = pr[i], d = ps[i];
-        mt[4 * i] = a.x; mt[4 * i + 1] = a.y; mt[4 * i + 2] = a.z; mt[4 * i + 3] = a.w;
-        mr[4 * i] = c.x; mr[4 * i + 1] = c.y; mr[4 * i + 2] = c.z; mr[4 * i + 3] = c.w;
-        src[4 * i] = d.x; src[4 * i + 1] = d.y; src[4 * i + 2] = d.z; src[4 * i + 3] = d.w;
-      }
-      src[RV * 4] = 0;
-      const uint32_t use = hf.hl < 2 ? 0xFFFFFFFFu : 0u;  // only lanes 0 / 1 of a half carry a flood
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        m[r] = mt[r];
-        mrev[r] = mr[r];
-        uint32_t x = r > 0 ? B3(shl1(src[r]), src[r] >> 1, src[r - 1], T_OR3) : (shl1(src[r]) | (src[r] >> 1));
-        f[r] = B3(m[r], x, r < R - 1 ? src[r + 1] : 0u, T_AND_OR2) & use;
-      }
-    }
-    WAVE_SYNC();
-    flood2_dual<R>(m, mrev, f, sc + hf.lane * RS);
-    WAVE_SYNC();
-    uint32_t cb = 0, cw = 0;
-    if (hf.hl < R) {
-      const uint32_t fb = sc[(hf.h * 32) * RS + hf.hl], fw = sc[(hf.h * 32 + 1) * RS + hf.hl];
-      cb = (uint32_t)__popc(black) + (uint32_t)__popc(fb & ~fw);
-      cw = (uint32_t)__popc(white) + (uint32_t)__popc(fw & ~fb);
-    }
-    cb = half_scan(cb);
-    cw = half_scan(cw);
-    if (on && hf.hl == 31) {
-      black_area[b] = (int32_t)cb;
-      white_area[b] = (int32_t)cw;
-    }
-  }
-}
-
 // ---------------------------------------------------------------- bit-packed state format
 // One board = 3 N + 1 uint32: N row masks (bit c = column c) of plane 0 (black), plane 1 (white), plane 3 (invalid
 // moves), then one flag word (bit 0 turn, bit 1 previous move was a pass, bit 2 game over).  19x19: 232 B instead of

@@ -342,6 +342,26 @@ def test_multi_ply_kernel_at_its_dispatch_sizes(gg, oracle, N, B):
     assert torch.equal(start[untouched], tmp[untouched])     # uncorrupted games: the replay equals the recording run
 
 
+@pytest.mark.parametrize('size', list(range(2, 20)))
+def test_areas_vs_oracle_all_sizes(gg, oracle, size):
+    """gg_batch_areas (sixteen boards per wave, planes 0 / 1 staged eight boards at a time): boards from every game
+    phase incl. finished games and empty boards, a batch that is no multiple of 16, read through an UNALIGNED view
+    (board stride 6 N^2 bytes, first board 3 boards in) - every game vs the oracle's areas (gym_go/gogame.py:275-310)."""
+    N, B = size, 1000 + size
+    st = gg.batch_init_state(B, N, device='cuda')
+    rng = gg.rng_seed(B, 40 + N)
+    for g in range(4):
+        hi = (g + 1) * 250 + (N if g == 3 else 0)
+        gg.batch_rollout(st[g * 250:hi], rng[g * 250:hi], (g * N * N) // 3, False)
+    view = st[3:]
+    black, white = gg.batch_areas(view)
+    ob, ow = oracle.batch_areas_mt(view.cpu().numpy())
+    assert np.array_equal(black.cpu().numpy(), ob) and np.array_equal(white.cpu().numpy(), ow)
+    assert int(black[:200].sum()) == 0 and int(white[:200].sum()) == 0            # empty boards: nobody's area
+    one = gg.batch_areas(view[5:6])                                               # a single board: a wave of one
+    assert int(one[0][0]) == int(ob[5]) and int(one[1][0]) == int(ow[5])
+
+
 def test_update_pieces_standalone(gg, oracle):
     """state_utils.update_pieces / batch_update_pieces (gg_batch_update_pieces): stones after capture resolution equal
     planes 0/1 of the oracle's next_state; killed groups are reported per group in raster order."""
