@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kWave) void k_areas4(const uint8_t *__restrict__ st
                                                   int32_t *__restrict__ white_area, int64_t B, int N) {
   using L = LdsAreas<R>;
   if (FULLN) N = R;
-  constexpr int RS = L::kRS, RV = (R + 3) / 4, PL = L::kBoards * RS;
+  constexpr int RS = L::kRS, PL = L::kBoards * RS;
   __shared__ __attribute__((aligned(16))) uint32_t lds[L::kTotal];
   uint8_t *stage = reinterpret_cast<uint8_t *>(lds);
   uint32_t *st = lds + L::kSt, *sc = lds + L::kSc;
@@ -216,52 +216,11 @@ __global__ __launch_bounds__(kWave) void k_areas4(const uint8_t *__restrict__ st
     }
   }
   WAVE_SYNC();
-  // ---- lane 2 s + c floods the empty points of board s from the neighbours of colour c
-  const int s = (lane >> 1) & (L::kBoards - 1), c = lane & 1;
-  uint32_t cnt = 0;
-  {
-    uint32_t m[R], mrev[R], f[R];
-    {
-      uint32_t own[RV * 4 + 1], oth[RV * 4];
-      const uint4 *po = reinterpret_cast<const uint4 *>(st + c * PL + s * RS);
-      const uint4 *pt = reinterpret_cast<const uint4 *>(st + (1 - c) * PL + s * RS);
-#pragma unroll
-      for (int i = 0; i < RV; ++i) {
-        const uint4 a = po[i], d = pt[i];
-        own[4 * i] = a.x; own[4 * i + 1] = a.y; own[4 * i + 2] = a.z; own[4 * i + 3] = a.w;
-        oth[4 * i] = d.x; oth[4 * i + 1] = d.y; oth[4 * i + 2] = d.z; oth[4 * i + 3] = d.w;
-      }
-      own[RV * 4] = 0;
-      const uint32_t use = lane < 2 * L::kBoards ? (1u << N) - 1u : 0u;   // the upper half of the wave carries no flood
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const uint32_t e = (FULLN || r < N) ? B3(own[r], oth[r], use, ~(TA | TB) & TC & 0xFF) : 0u;   // empty points
-        const uint32_t x = r > 0 ? B3(shl1(own[r]), own[r] >> 1, own[r - 1], T_OR3) : (shl1(own[r]) | (own[r] >> 1));
-        m[r] = e;
-        mrev[r] = __brev(e);
-        f[r] = B3(e, x, r < R - 1 ? own[r + 1] : 0u, T_AND_OR2);
-        cnt += (uint32_t)__popc(own[r]);
-      }
-    }
-    WAVE_SYNC();
-    // (the idle upper half converges at once; its rows go to the staging area, which is free by now)
-    flood2_serial<R>(m, mrev, f, lane < 2 * L::kBoards ? sc + lane * RS : lds + (lane - 2 * L::kBoards) * RS);
-  }
-  WAVE_SYNC();
-  if (lane < 2 * L::kBoards) {
-    uint32_t fo[RV * 4], fp[RV * 4];
-    const uint4 *pf = reinterpret_cast<const uint4 *>(sc + lane * RS);
-    const uint4 *pp = reinterpret_cast<const uint4 *>(sc + (lane ^ 1) * RS);
-#pragma unroll
-    for (int i = 0; i < RV; ++i) {
-      const uint4 a = pf[i], d = pp[i];
-      fo[4 * i] = a.x; fo[4 * i + 1] = a.y; fo[4 * i + 2] = a.z; fo[4 * i + 3] = a.w;
-      fp[4 * i] = d.x; fp[4 * i + 1] = d.y; fp[4 * i + 2] = d.z; fp[4 * i + 3] = d.w;
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) cnt += (uint32_t)__popc(fo[r] & ~fp[r]);   // (word R of a block is never written)
-    if (b_first + s < B) (c ? white_area : black_area)[b_first + s] = (int32_t)cnt;
-  }
+  // ---- lane 2 s + c floods the empty points of board s from the neighbours of colour c (the idle upper half's rows go
+  // to the staging area, which is free by now)
+  const uint32_t cnt = areas16<R, FULLN>(st, sc, lds, N, lane);
+  const int s = lane >> 1, c = lane & 1;
+  if (lane < 2 * L::kBoards && b_first + s < B) (c ? white_area : black_area)[b_first + s] = (int32_t)cnt;
 }
 
 

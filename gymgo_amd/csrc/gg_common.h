@@ -183,6 +183,59 @@ __device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint
 }
 
 
+// Tromp-Taylor areas (gym_go/gogame.py:275-300) of sixteen boards whose stone rows sit in LDS as
+// st[colour * 16 RS + board * RS + row] (rows >= N zero): a colour owns its stones plus the empty regions that touch only
+// that colour, and an empty region touches a colour iff the flood of the EMPTY points seeded next to that colour's stones
+// covers it.  Lane 2 s + c (the lower half of the wave) floods board s for colour c and returns that colour's area;
+// `blocks` (32 RS words) receives the floods, `idle_out` (32 RS words) the rows of the idle upper half.
+template <int R, bool FULLN>
+__device__ __forceinline__ uint32_t areas16(const uint32_t *st, uint32_t *blocks, uint32_t *idle_out, int N, int lane) {
+  constexpr int RS = Cfg<R>::kRowStride, RV = (R + 3) / 4, PL = 16 * RS;
+  const int s = (lane >> 1) & 15, c = lane & 1;
+  uint32_t cnt = 0;
+  {
+    uint32_t m[R], mrev[R], f[R];
+    {
+      uint32_t own[RV * 4 + 1], oth[RV * 4];
+      const uint4 *po = reinterpret_cast<const uint4 *>(st + c * PL + s * RS);
+      const uint4 *pt = reinterpret_cast<const uint4 *>(st + (1 - c) * PL + s * RS);
+#pragma unroll
+      for (int i = 0; i < RV; ++i) {
+        const uint4 a = po[i], d = pt[i];
+        own[4 * i] = a.x; own[4 * i + 1] = a.y; own[4 * i + 2] = a.z; own[4 * i + 3] = a.w;
+        oth[4 * i] = d.x; oth[4 * i + 1] = d.y; oth[4 * i + 2] = d.z; oth[4 * i + 3] = d.w;
+      }
+      own[RV * 4] = 0;
+      const uint32_t use = lane < 32 ? (1u << N) - 1u : 0u;   // the upper half of the wave carries no flood
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t e = (FULLN || r < N) ? B3(own[r], oth[r], use, ~(TA | TB) & TC & 0xFF) : 0u;   // empty points
+        const uint32_t x = r > 0 ? B3(shl1(own[r]), own[r] >> 1, own[r - 1], T_OR3) : (shl1(own[r]) | (own[r] >> 1));
+        m[r] = e;
+        mrev[r] = __brev(e);
+        f[r] = B3(e, x, r < R - 1 ? own[r + 1] : 0u, T_AND_OR2);
+        cnt += (uint32_t)__popc(own[r]);
+      }
+    }
+    WAVE_SYNC();
+    flood2_serial<R>(m, mrev, f, lane < 32 ? blocks + lane * RS : idle_out + (lane - 32) * RS);
+  }
+  WAVE_SYNC();
+  uint32_t fo[RV * 4], fp[RV * 4];
+  const uint4 *pf = reinterpret_cast<const uint4 *>(blocks + (lane & 31) * RS);
+  const uint4 *pp = reinterpret_cast<const uint4 *>(blocks + ((lane & 31) ^ 1) * RS);
+#pragma unroll
+  for (int i = 0; i < RV; ++i) {
+    const uint4 a = pf[i], d = pp[i];
+    fo[4 * i] = a.x; fo[4 * i + 1] = a.y; fo[4 * i + 2] = a.z; fo[4 * i + 3] = a.w;
+    fp[4 * i] = d.x; fp[4 * i + 1] = d.y; fp[4 * i + 2] = d.z; fp[4 * i + 3] = d.w;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) cnt += (uint32_t)__popc(fo[r] & ~fp[r]);   // (word R of a block is never written)
+  return cnt;
+}
+
+
 // ---------------------------------------------------------------- staging: HBM <-> LDS <-> bitboards
 // Boards start at arbitrary byte offsets (6 N^2 is only a multiple of 2) and rows are N bytes long, but on gfx950
 // unaligned 4/8/16-byte LDS accesses are ~22x slower than aligned ones and unaligned 16-byte global accesses run

@@ -861,47 +861,21 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       }
     }
     if (ENV) {
-      // ---- GoEnv.step outputs.  Tromp-Taylor areas (gym_go/gogame.py:275-300) in the quad layout: the empty points
-      // reachable from a neighbour of a black / a white stone (an empty region borders a colour iff that colour's
-      // flood covers it); needed for a finished game (reward `real`) or for every game (`heuristic`).
+      // ---- GoEnv.step outputs.  Tromp-Taylor areas (gym_go/gogame.py:275-300, areas16): needed for a finished game
+      // (reward `real`) or for every game (`heuristic`).
       const uint32_t fl = flagsv[q4s];
       const bool onb = (fl >> 3) & 1u;
       const bool doneb = (fl >> 2) & 1u;
       int area_b = 0, area_w = 0;
       if (__ballot(onb && (env.heuristic != 0 || doneb))) {
-        uint32_t bk[RPL], wh[RPL], e[RPL], fb[RPL], fw[RPL], d[RPL];
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) {
-          const uint32_t fullr = (r04s + r < N) ? (1u << N) - 1u : 0u;
-          bk[r] = st[0 * PL + q4s * RS + r04s + r];
-          wh[r] = st[1 * PL + q4s * RS + r04s + r];
-          e[r] = fullr & ~(bk[r] | wh[r]);
-        }
-        dilate_rows<RPL>(bk, d);
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) fb[r] = d[r] & e[r];
-        dilate_rows<RPL>(wh, d);
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) fw[r] = d[r] & e[r];
-#pragma unroll 1
-        for (int it = 0; it < R * R; ++it) {
-          uint32_t chg = 0;
-          dilate_rows<RPL>(fb, d);
-#pragma unroll
-          for (int r = 0; r < RPL; ++r) { const uint32_t nw = B3(d[r], e[r], fb[r], T_ANDOR); chg |= nw ^ fb[r]; fb[r] = nw; }
-          dilate_rows<RPL>(fw, d);
-#pragma unroll
-          for (int r = 0; r < RPL; ++r) { const uint32_t nw = B3(d[r], e[r], fw[r], T_ANDOR); chg |= nw ^ fw[r]; fw[r] = nw; }
-          if (__ballot(chg != 0) == 0) break;
-        }
-        uint32_t cb = 0, cw = 0;
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) {
-          cb += (uint32_t)__popc(bk[r]) + (uint32_t)__popc(fb[r] & ~fw[r]);
-          cw += (uint32_t)__popc(wh[r]) + (uint32_t)__popc(fw[r] & ~fb[r]);
-        }
-        area_b = (int)quad_sum(cb);
-        area_w = (int)quad_sum(cw);
+        // two floods of the empty points per board, in lanes 2 s + c of the lower half (the flood blocks of the plies are
+        // free by now); the counts reach the boards' quads through the class words
+        const uint32_t cnt = areas16<R, FULLN>(st, sc, sc + 32 * RS, N, lnS);
+        WAVE_SYNC();
+        if (lnS < 32) clsv[lnS] = cnt;
+        WAVE_SYNC();
+        area_b = (int)clsv[2 * q4s];
+        area_w = (int)clsv[2 * q4s + 1];
       }
       if (t4s == 0 && onb) {
         const int64_t b = b_first + q4s;
