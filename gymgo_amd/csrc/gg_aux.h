@@ -1,71 +1,114 @@
 // gg_aux.h - stand-alone kernels off the bench path, which exist because the reference exposes the operation on its own:
-// the sampler of gg_batch_sample_actions and the capture resolution of gg_batch_update_pieces (one wavefront per board, L1
-// "row per lane" only; gym_go/envs/go_env.py:78-81, gym_go/state_utils.py:159-211) and the area scoring of gg_batch_areas
-// (sixteen boards per wavefront; gym_go/gogame.py:275-300).
+// the sampler of gg_batch_sample_actions (gym_go/envs/go_env.py:78-81) and the area scoring of gg_batch_areas
+// (gym_go/gogame.py:275-300) - sixteen boards per wavefront, every load of the group issued up front - and the capture
+// resolution of gg_batch_update_pieces (gym_go/state_utils.py:159-211; one wavefront per board, L1 "row per lane").
 #pragma once
 #include "gg_common.h"
+#include "gg_v4.h"   // the quad DPP helpers
 
 namespace gg {
 
-// Read the uniform-plane flags + the INVD byte of point `pt` of a board in HBM:
-// bit0 turn, bit1 INVD[pt], bit2 previous move was a pass, bit3 game over.
-__device__ __forceinline__ uint32_t load_flags(const uint8_t *g, int P, int pt, int lane) {
-  uint8_t fb = 0;
-  if (lane < 4) {
-    int off = lane == 0 ? 2 * P : lane == 1 ? 3 * P + pt : lane == 2 ? 4 * P : 5 * P;
-    fb = g[off];
-  }
-  return (uint32_t)__ballot(fb != 0) & 0xFu;
-}
-
-// k-th (0-based) valid action in ascending index order; valid = L1 rows of playable points; k >= count -> pass (P)
-__device__ __forceinline__ int pick_action(uint32_t valid, uint32_t k, int N, int P, int lane) {
-  int incl = __popc(valid);  // inclusive prefix over lanes 0..31 (rows live in lanes < 32)
-#pragma unroll
-  for (int off = 1; off < 32; off <<= 1) {
-    int t = __shfl_up(incl, off);
-    if ((lane & 31) >= off) incl += t;
-  }
-  uint64_t hit = __ballot(lane < 32 && (uint32_t)incl > k);
-  if (hit == 0) return P;
-  int r = __ffsll((unsigned long long)hit) - 1;
-  uint32_t row = __builtin_amdgcn_readlane(valid, r);
-  uint32_t before = (uint32_t)__builtin_amdgcn_readlane(incl, r) - (uint32_t)__popc(row);
-  uint32_t t = k - before;
-  for (uint32_t i = 0; i < t; ++i) row &= row - 1;
-  return r * N + (__ffs(row) - 1);
-}
-
 // GoEnv.uniform_random_action (gym_go/envs/go_env.py:78-81) for every game: one draw of the per-game generator, the
-// k-th valid action of plane 3 (every action once the game has ended: gogame.invalid_moves, gym_go/gogame.py:155-156).
+// k-th valid action of plane 3 in ascending order, k == count: the pass (every point once the game has ended:
+// gogame.invalid_moves, gym_go/gogame.py:155-156).  Sixteen boards per wavefront: all loads of the group up front (plane 3
+// as aligned 16-byte vectors, one game-over byte and one generator word per board), one row of one board packed per lane,
+// then the sampler of the multi-ply kernel - four lanes per board, RPL rows each, a quad scan over the row counts.
 template <int R>
-__global__ __launch_bounds__(kWave) void k_sample(const uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
-                                                  int32_t *__restrict__ actions, int64_t B, int N) {
-  __shared__ __attribute__((aligned(16))) uint8_t iobuf[Cfg<R>::kIoBytes];
+struct LdsSample {
+  static constexpr int kRS = Cfg<R>::kRowStride, kBoards = 16;
+  static constexpr int kVec = (R * R + 15 + 15) / 16 + 1;        // 16-byte vectors covering one plane at any alignment
+  static constexpr int kStageBoard = kVec * 16;
+  static constexpr int kPerLane = (kBoards * kVec + kWave - 1) / kWave;
+  static constexpr int kRows = (kBoards * kStageBoard + 3) / 4;  // words: [16][kRS] rows of plane 3
+  static constexpr int kMeta = kRows + kBoards * kRS;            // words: done[16], rng[32]
+  static constexpr int kTotal = kMeta + 3 * kBoards;
+};
+
+template <int R>
+__global__ __launch_bounds__(kWave) void k_sample16(const uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+                                                    int32_t *__restrict__ actions, int64_t B, int N) {
+  using L = LdsSample<R>;
+  constexpr int RS = L::kRS, RPL = (R + 3) / 4;
+  static_assert(4 * RPL <= RS, "four lanes cover the rows of a board");
+  __shared__ __attribute__((aligned(16))) uint32_t lds[L::kTotal];
+  uint8_t *stage = reinterpret_cast<uint8_t *>(lds);
+  uint32_t *rows = lds + L::kRows, *donev = lds + L::kMeta, *rngv = lds + L::kMeta + L::kBoards;
   const int lane = threadIdx.x;
   const int P = N * N, S = 6 * P;
-  const uint32_t full_l1 = lane < N ? (1u << N) - 1u : 0u;
-  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
-    const uint8_t *gs = states + b * (int64_t)S;
-    uint32_t flags = load_flags(gs, P, 0, lane);
-    WAVE_SYNC();
-    const uint32_t mi = stage_in(gs + 3 * P, P, iobuf, lane);
-    WAVE_SYNC();
-    uint32_t invalid = plane_to_row<R>(iobuf + mi, N, lane);
-    if (flags & 8u) invalid = 0;
-    uint32_t valid = full_l1 & ~invalid;
-    int cnt = __popc(valid);
+  const int64_t b_first = (int64_t)blockIdx.x * L::kBoards;
+  uint4 v[L::kPerLane];
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-    cnt = __builtin_amdgcn_readfirstlane(cnt);
-    uint64_t x = uniform64(rng[b]);
-    uint64_t u = splitmix_next(x);
-    uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(cnt + 1)) >> 32);
-    int a = pick_action(valid, k, N, P, lane);
-    if (lane == 0) {
-      rng[b] = x;
-      actions[b] = a;
-    }
+  for (int k = 0; k < L::kPerLane; ++k) {
+    const int j = lane + kWave * k, i = j / L::kVec, w = j - i * L::kVec;
+    int64_t b = b_first + i;
+    if (b >= B) b = B - 1;
+    const uint8_t *g = states + b * (int64_t)S + 3 * P;
+    const uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
+    const bool need = i < L::kBoards && 16 * w < (int)mis + P;
+    v[k] = need ? reinterpret_cast<const uint4 *>(g - mis)[w] : make_uint4(0u, 0u, 0u, 0u);
+  }
+  uint32_t done_b = 0;
+  uint64_t x0 = 0;
+  if (lane < L::kBoards) {
+    const int64_t b = b_first + lane < B ? b_first + lane : B - 1;
+    done_b = states[b * (int64_t)S + 5 * P];
+    x0 = rng[b];
+  }
+#pragma unroll
+  for (int k = 0; k < L::kPerLane; ++k) {
+    const int j = lane + kWave * k, i = j / L::kVec, w = j - i * L::kVec;
+    if (i < L::kBoards) *reinterpret_cast<uint4 *>(stage + i * L::kStageBoard + 16 * w) = v[k];
+  }
+  for (int u = lane; u < L::kBoards * RS; u += kWave) rows[u] = 0;   // rows N .. RS-1: nothing to play there
+  if (lane < L::kBoards) {
+    donev[lane] = done_b;
+    rngv[2 * lane] = (uint32_t)x0;
+    rngv[2 * lane + 1] = (uint32_t)(x0 >> 32);
+  }
+  WAVE_SYNC();
+  for (int u = lane; u < L::kBoards * N; u += kWave) {
+    const int i = u / N, r = u - i * N;
+    const int64_t b = b_first + i < B ? b_first + i : B - 1;
+    const uint32_t mis = (uint32_t)((uintptr_t)(states + b * (int64_t)S + 3 * P) & 15u);
+    rows[i * RS + r] = plane_to_row<R>(stage + i * L::kStageBoard + mis, N, r);
+  }
+  WAVE_SYNC();
+  // ---- four lanes per board
+  const int q = lane >> 2, t = lane & 3, r0 = RPL * t;
+  const uint32_t keep = donev[q] ? 0u : ~0u;
+  uint32_t vr_[RPL], p[RPL];
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    const uint32_t full = (r0 + r < N) ? (1u << N) - 1u : 0u;
+    vr_[r] = full & ~(rows[q * RS + r0 + r] & keep);
+    p[r] = (uint32_t)__popc(vr_[r]) + (r ? p[r - 1] : 0u);
+  }
+  const uint32_t T = p[RPL - 1];
+  // (the DPP moves are evaluated by every lane, THEN masked: inside a conditional the source lanes would be off)
+  const uint32_t sh1 = dpp0<QP_SHR1>(T);
+  const uint32_t x1 = T + (t >= 1 ? sh1 : 0u);
+  const uint32_t sh2 = dpp0<QP_SHR2>(x1);
+  const uint32_t Sx = x1 + (t >= 2 ? sh2 : 0u);
+  const uint32_t n = dpp0<QP_B3>(Sx), before = Sx - T;
+  uint64_t x = ((uint64_t)rngv[2 * q + 1] << 32) | rngv[2 * q];
+  const uint64_t u64 = splitmix_next(x);
+  const uint32_t k = (uint32_t)(((u64 >> 32) * (uint64_t)(n + 1)) >> 32);   // k == n: the pass
+  const bool hit = k >= before && k < before + T;
+  uint32_t tt = k - before, vr = vr_[0], base = 0, pos = 0;
+  int rr = 0;
+#pragma unroll
+  for (int r = 1; r < RPL; ++r)
+    if (tt >= p[r - 1]) { rr = r; vr = vr_[r]; base = p[r - 1]; }
+  tt -= base;
+#pragma unroll
+  for (int sh = 16; sh >= 1; sh >>= 1) {   // the tt-th set bit of vr
+    const uint32_t c = (uint32_t)__popc((vr >> pos) & ((1u << sh) - 1u));
+    if (tt >= c) { tt -= c; pos += sh; }
+  }
+  const int64_t b = b_first + q;
+  if (b < B) {
+    if (k < n ? hit : t == 0) actions[b] = k < n ? (r0 + rr) * N + (int)pos : P;
+    if (t == 0) rng[b] = x;
   }
 }
 

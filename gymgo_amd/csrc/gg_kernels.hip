@@ -300,10 +300,12 @@ int32_t gg_batch_sample_actions(const uint8_t *states, uint64_t *rng, int32_t *a
                                 void *hip_stream) {
   GG_ENTER(states);
   if (!rng || !actions) return GG_E_NULLPTR;
-  const int grid = grid_for(cus, B);
-  GG_DISPATCH(N, (k_sample<9><<<grid, kWave, 0, s>>>(states, rng, actions, B, N)),
-              (k_sample<13><<<grid, kWave, 0, s>>>(states, rng, actions, B, N)),
-              (k_sample<19><<<grid, kWave, 0, s>>>(states, rng, actions, B, N)));
+  const int64_t groups = (B + LdsSample<19>::kBoards - 1) / LdsSample<19>::kBoards;   // one wave per sixteen boards
+  if (groups > 0x7FFFFFFF) return GG_E_BADSIZE;
+  const int grid = (int)groups;
+  GG_DISPATCH(N, (k_sample16<9><<<grid, kWave, 0, s>>>(states, rng, actions, B, N)),
+              (k_sample16<13><<<grid, kWave, 0, s>>>(states, rng, actions, B, N)),
+              (k_sample16<19><<<grid, kWave, 0, s>>>(states, rng, actions, B, N)));
   return (int32_t)hipGetLastError();
 }
 
