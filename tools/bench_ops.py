@@ -73,7 +73,9 @@ def main():
         out['gg_batch_next_states_canonical_%dx%d_B%d' % (N, N, B)] = {'steps_per_s': B / t}
         t = timed(lambda: gogame.batch_areas(st2), 50)
         out['gg_batch_areas_%dx%d_B%d' % (N, N, B)] = {
-            'boards_per_s': B / t, 'algorithmic_GBps': B * (S + 8) / t / 1e9, 'roofline_frac': B * (S + 8) / t / PEAK}
+            'boards_per_s': B / t, 'bytes_per_board': 2 * N * N + 8, 'moved_GBps': B * (2 * N * N + 8) / t / 1e9,
+            'roofline_frac': B * (2 * N * N + 8) / t / PEAK,
+            'note': 'the kernel reads planes 0 / 1 only (2 N^2 of the 6 N^2 bytes of a state) and writes two int32 per board'}
         t = timed(lambda: state_utils.batch_compute_invalid_moves(st2, None, None), 50)
         out['gg_batch_invalid_mask_%dx%d_B%d' % (N, N, B)] = {'boards_per_s': B / t}
         r2 = gogame.rng_seed(B, 11)
