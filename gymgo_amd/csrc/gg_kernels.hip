@@ -504,8 +504,9 @@ int32_t gg_batch_play_moves_tracked(uint32_t *tracked, const int32_t *moves, int
 }
 
 int32_t gg_batch_env_step_tracked(uint32_t *tracked, const int32_t *actions, uint64_t *rng, float *rewards, uint8_t *dones,
-                                  int32_t *status, int32_t *taken_actions, uint8_t *states_out, int64_t B, int32_t N,
-                                  float komi, int32_t reward_method, int32_t auto_reset, void *hip_stream) {
+                                  int32_t *status, int32_t *taken_actions, uint8_t *states_out, int64_t *steps_done,
+                                  int64_t B, int32_t N, float komi, int32_t reward_method, int32_t auto_reset,
+                                  void *hip_stream) {
   if (reward_method != GG_REWARD_REAL && reward_method != GG_REWARD_HEURISTIC) return GG_E_BADARG;
   GG_ENTER(tracked);
   if (!actions && !rng) return GG_E_NULLPTR;
@@ -517,9 +518,9 @@ int32_t gg_batch_env_step_tracked(uint32_t *tracked, const int32_t *actions, uin
   env.states_out = states_out; env.komi = komi; env.heuristic = reward_method == GG_REWARD_HEURISTIC;
   env.ws = nullptr; env.canonical = 0;
   if (actions) {
-    GG_DISPATCH4E(N, true, grid, st, nullptr, nullptr, nullptr, B, N, inv, 1, auto_reset, nb, actions, nullptr, env);
+    GG_DISPATCH4E(N, true, grid, st, nullptr, nullptr, steps_done, B, N, inv, 1, auto_reset, nb, actions, nullptr, env);
   } else {
-    GG_DISPATCH4E(N, false, grid, st, rng, nullptr, nullptr, B, N, inv, 1, auto_reset, nb, nullptr, nullptr, env);
+    GG_DISPATCH4E(N, false, grid, st, rng, nullptr, steps_done, B, N, inv, 1, auto_reset, nb, nullptr, nullptr, env);
   }
   return (int32_t)hipGetLastError();
 }

@@ -106,9 +106,11 @@ class GoVecEnv:
         if self.layout == 'tracked':
             rewards, dones, status, taken = gogame.batch_env_step_tracked(
                 self.tracked, actions, self.rng, self.komi, self.reward_method, self.auto_reset, out=self._step_out,
-                states_out=self._obs)
+                states_out=self._obs, steps_done=self.steps_done)      # the launch counts the played steps itself
             self._obs_fresh = True
-            obs = self._obs
+            if check and bool((status != 0).any()):
+                raise AssertionError('illegal move in batch')
+            return self._obs, rewards, dones, status
         else:
             fn, store = ((gogame.batch_env_step_packed, self.packed_states) if self.packed
                          else (gogame.batch_env_step, self._states))

@@ -684,10 +684,11 @@ def batch_play_moves_tracked(tracked, moves, played=None):
 
 
 def batch_env_step_tracked(tracked, actions=None, rng=None, komi=0.0, reward_method='real', auto_reset=True, out=None,
-                           states_out=None):
+                           states_out=None, steps_done=None):
     """IN PLACE GoEnv.step (gym_go/envs/go_env.py:49-76) of every game on TRACKED boards in ONE launch
     (gg_batch_env_step_tracked): no per-ply analysis.  -> (rewards, dones, status, taken) like batch_env_step;
-    states_out: a uint8 [B,6,N,N] device tensor that receives the byte-plane observation of every game (optional)."""
+    states_out: a uint8 [B,6,N,N] device tensor that receives the byte-plane observation of every game (optional);
+    steps_done: an int64 [B] device tensor, += 1 for every game whose step was played (optional)."""
     N = _tracked_size(tracked)
     B = tracked.shape[0]
     dev = tracked.device
@@ -702,7 +703,8 @@ def batch_env_step_tracked(tracked, actions=None, rng=None, komi=0.0, reward_met
     code = _lib.lib().gg_batch_env_step_tracked(
         _lib.dev_ptr(tracked, _I32, 'tracked'), _lib.dev_ptr(actions, _I32, 'actions'), _lib.dev_ptr(rng, _I64, 'rng'),
         _lib.dev_ptr(rewards, torch.float32, 'rewards'), _lib.dev_ptr(dones, _U8, 'dones'), _lib.dev_ptr(status, _I32, 'status'),
-        _lib.dev_ptr(taken, _I32, 'taken'), _lib.dev_ptr(states_out, _U8, 'states_out'), B, N, float(komi),
+        _lib.dev_ptr(taken, _I32, 'taken'), _lib.dev_ptr(states_out, _U8, 'states_out'),
+        _lib.dev_ptr(steps_done, _I64, 'steps_done'), B, N, float(komi),
         REWARD_METHODS[reward_method], int(bool(auto_reset)), _lib.stream_ptr(dev))
     _lib.check(code, 'gg_batch_env_step_tracked')
     return out

@@ -228,11 +228,13 @@ int32_t gg_batch_play_moves_tracked(uint32_t *tracked, const int32_t *moves, int
  * their liberty classes - no per-ply analysis, so a policy-driven env steps at the multi-ply kernel's per-ply rate.
  * states_out (nullable): uint8 [B][6][N][N], the resulting position of EVERY game as byte planes - the observation
  * GoEnv.step returns (:66), written by the same launch (pass NULL to keep only the tracked boards current).
+ * steps_done (nullable): int64 [B], += 1 for every game whose step was played (status GG_STATUS_OK).
  * GG_REWARD_REAL scores a game only when it ends (a rare path); GG_REWARD_HEURISTIC scores every game every step.
  */
 int32_t gg_batch_env_step_tracked(uint32_t *tracked, const int32_t *actions, uint64_t *rng, float *rewards, uint8_t *dones,
-                                  int32_t *status, int32_t *taken_actions, uint8_t *states_out, int64_t B, int32_t N,
-                                  float komi, int32_t reward_method, int32_t auto_reset, void *hip_stream);
+                                  int32_t *status, int32_t *taken_actions, uint8_t *states_out, int64_t *steps_done,
+                                  int64_t B, int32_t N, float komi, int32_t reward_method, int32_t auto_reset,
+                                  void *hip_stream);
 
 /* rng[b] = initial generator state for (base_seed, game index first_game + b). */
 int32_t gg_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B, void *hip_stream);

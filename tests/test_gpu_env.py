@@ -160,7 +160,9 @@ def test_fused_env_step_refuses_illegal_and_frozen(layout):
         if in_range[i] and acts[i] < N * N and inval[i, acts[i]]:
             bad[i] = True
     assert bad.any() and (~bad).any()
+    n0 = env.steps_done.clone()
     states, rewards, dones, status = env.step(torch.from_numpy(acts).cuda())
+    assert np.array_equal((env.steps_done - n0).cpu().numpy(), (~bad).astype(np.int64))   # refused steps are not counted
     want = host.copy()
     ok = np.flatnonzero(~bad)
     want[ok] = c_oracle.batch_next_states(host[ok], acts[ok])[0]
