@@ -1,5 +1,4 @@
-"""gg_batch_areas: rate at the config sizes + (with an argument) an oracle check on mid-game boards of every size
-(odd batches, unaligned views)."""
+"""gg_batch_areas: rate at the config sizes (the oracle comparison for every N lives in tests/test_gpu_parity.py)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -18,16 +17,3 @@ for N, B in ((19, 65536), (19, 8192), (13, 65536), (9, 4096), (9, 65536), (5, 10
     b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) / 20 * 1e3
     print('%2dx%-2d B %6d  %.1f us  %.3e boards/s  planes 0/1 at %.2f TB/s' % (N, N, B, us, B / us * 1e6, B * 2 * N * N / us / 1e6), flush=True)
-if len(sys.argv) > 1:
-    from oracle import c_oracle
-    for N in range(2, 20):
-        B = 1000 + N
-        st = gogame.batch_init_state(B, N, device='cuda'); rng = gogame.rng_seed(B, N)
-        for g in range(4):
-            hi = (g + 1) * 250 + (N if g == 3 else 0)
-            gogame.batch_rollout(st[g * 250:hi], rng[g * 250:hi], 3 + g * (N * N) // 3, False)
-        view = st[3:]                                   # an unaligned view
-        bk, wh = gogame.batch_areas(view)
-        ob, ow = c_oracle.batch_areas_mt(view.cpu().numpy())
-        assert np.array_equal(bk.cpu().numpy(), ob) and np.array_equal(wh.cpu().numpy(), ow), N
-    print('areas vs oracle: every N = 2 .. 19, odd batches, unaligned views: exact')
