@@ -408,6 +408,20 @@ def extras(dev, back, opts):
         'steps_per_s': round(n_steps / (time.perf_counter() - t0), 1),
         'note': 'one H2D action + two launches + one D2H record per step; latency-bound plumbing by construction'}
     out['configs'] = configs
+    # --- what this box streams ("also report against a measured device-copy bandwidth on the box")
+    big = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(big)
+    r_fill, _ = event_rate(torch, dev, lambda: big.zero_(), float(1 << 30), 5)
+    r_copy, _ = event_rate(torch, dev, lambda: dst.copy_(big), float(2 << 30), 5)
+    del big, dst
+    out['box_bandwidth'] = {'fill_GBps': round(r_fill / 1e9, 1), 'copy_read_plus_write_GBps': round(r_copy / 1e9, 1),
+                            'note': '1 GiB torch fill / copy on this box; the per-ply fractions above are against the 8 TB/s vendor peak',
+                            # next_states reads a board and writes a board, like a copy; the tracked env step really
+                            # moves 5 (5N+1) + 12 B in and the same + the 6 N^2 B observation + 13 B out, 7/8 of it writes
+                            'gg_batch_next_states_frac_of_copy': round(algo * out['gg_batch_next_states_steps_per_s'] / r_copy, 4),
+                            'gg_batch_env_step_bytes_moved_per_step': 8 * (5 * N + 1) + 6 * N * N + 25,
+                            'gg_batch_env_step_frac_of_fill': round((8 * (5 * N + 1) + 6 * N * N + 25)
+                                                                    * out['gg_batch_env_step_steps_per_s'] / r_fill, 4)}
     out['note'] = ('per-ply rates: HIP events over back-to-back calls through the Python API on the resident config-3 batch; '
                    'configs: one driver-timed number per BASELINE config that is not the headline')
     return out, per_ply
