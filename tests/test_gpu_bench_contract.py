@@ -13,6 +13,15 @@ REQUIRED = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step
             'vs_baseline', 'dtype', 'data', 'config', 'roofline')
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def _run(cmd, timeout=420):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
@@ -62,7 +71,7 @@ def test_bench_two_ranks(launcher):
         cmd = [sys.executable] + tail
     else:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-               '--master-port', '29541'] + tail
+               '--master-port', str(_free_port())] + tail
     line = _run(cmd)
     _check(line, 2, 2, 1)
     assert line['config']['games'] == 32768 and line['config']['games_per_gpu'] == 16384
