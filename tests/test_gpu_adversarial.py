@@ -169,6 +169,59 @@ def test_full_size_properties_and_shard_invariance():
     assert np.array_equal(s[torch.as_tensor(idx, device='cuda')].cpu().numpy(), want)
 
 
+def _sym(t, k):
+    """The k-th of the 8 board symmetries on the last two dims of a tensor: k & 3 quarter turns, then a flip if k & 4."""
+    t = torch.rot90(t, k & 3, dims=(-2, -1))
+    return torch.flip(t, dims=(-1,)) if k & 4 else t
+
+
+def test_full_size_symmetry_equivariance():
+    """BASELINE config 3 size, a property that needs no oracle: the rules of Go commute with the 8 symmetries of the
+    board.  For 65 536 mid-game boards of every phase and one sampled legal move each:
+    next_state(sym(s), sym(a)) == sym(next_state(s, a)) for the byte-plane kernel AND for the workspace / multi-ply path,
+    areas are invariant, and the padded children of a sub-batch are the permuted, transformed children."""
+    from gymgo_amd import gogame
+    B, N = 65536, 19
+    P = N * N
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, 77)
+    for g in range(16):
+        gogame.batch_rollout(st[g * 4096:(g + 1) * 4096], rng[g * 4096:(g + 1) * 4096], 20 + 24 * g, auto_reset=False)
+    gogame.batch_reset_finished(st)
+    acts = gogame.batch_sample_actions(st, rng)
+    base, status = gogame.batch_next_states(st, acts, check=False)
+    assert int(status.sum()) == 0
+    b0, w0 = gogame.batch_areas(base)
+    # where each point goes under symmetry k: transform the index grid itself
+    grid = torch.arange(P, dtype=torch.int32, device='cuda').reshape(N, N)
+    ws = gogame.next_states_workspace(B, N, 'cuda')
+    out = torch.empty_like(st)
+    st_flag = torch.empty(B, dtype=torch.int32, device='cuda')
+    for k in range(1, 8):
+        moved = _sym(grid, k).reshape(-1)                  # moved[j] = the old index now at position j
+        where = torch.empty(P + 1, dtype=torch.int32, device='cuda')
+        where[moved.long()] = torch.arange(P, dtype=torch.int32, device='cuda')
+        where[P] = P                                         # the pass stays the pass
+        s_k = _sym(st, k).contiguous()
+        a_k = where[acts.long()].contiguous()
+        got, status = gogame.batch_next_states(s_k, a_k, check=False)
+        assert int(status.sum()) == 0
+        want = _sym(base, k)
+        assert torch.equal(got, want), k
+        # the same through the multi-ply kernel's one-ply path (every board misses the workspace: analysed from scratch
+        # at load, then stepped by the quad-per-board ply)
+        gogame.batch_next_states(s_k, a_k, check=False, out=out, status=st_flag, workspace=ws)
+        assert torch.equal(out, want) and int(st_flag.sum()) == 0, ('workspace', k)
+        bk, wk = gogame.batch_areas(got)
+        assert torch.equal(bk, b0) and torch.equal(wk, w0), ('areas', k)
+        if k in (3, 6):                                      # children of a sub-batch: slots permuted, boards transformed
+            sub = slice(0, 65536, 257)
+            kids = gogame.batch_children(st[sub].contiguous())
+            kids_k = gogame.batch_children(s_k[sub].contiguous())
+            perm = torch.cat([moved.long(), torch.tensor([P], device='cuda')])     # slot j of the transformed parent = old slot perm[j]
+            assert torch.equal(kids_k, _sym(kids[:, perm], k)), ('children', k)
+
+
 @pytest.mark.parametrize('N,B,plies', [(19, 96, (30, 120, 250, 330)), (13, 64, (20, 90, 150)), (9, 128, (10, 40, 70)),
                                         (5, 64, (6, 14, 22)), (3, 32, (3, 7)), (2, 16, (1, 3))])
 def test_children_many_positions(N, B, plies):
