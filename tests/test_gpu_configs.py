@@ -113,7 +113,7 @@ def test_config4_one_rank_shard_of_1048576_games_vs_oracle():
     """BASELINE config 4: 19x19, 1 048 576 games as 8 shards of 131 072 (one per GPU, no collective).  This is rank 5's
     shard exactly as bench.py runs it (generator seeded by GLOBAL game index): 131 072 games, launches of 40 + 56 plies;
     ORACLE: 2 048 games of the shard (every 64th) replayed by global index; and the shard equals the same index range
-    computed inside a larger single-rank batch (shard invariance, HIP-vs-HIP)."""
+    computed inside a larger single-rank batch (shard invariance, HIP-vs-HIP); packed / tracked round trips of the shard."""
     from gymgo_amd import gogame
     from gymgo_amd.envs.vec_env import shard
     from oracle import c_oracle
@@ -137,6 +137,15 @@ def test_config4_one_rank_shard_of_1048576_games_vs_oracle():
     gogame.batch_rollout(wide, wide_rng, 40, True)
     gogame.batch_rollout(wide, wide_rng, 56, True)
     assert torch.equal(wide[4096:], st[:20480])
+    # format round trips at the shard's size: packed and tracked boards hold exactly the byte planes
+    assert torch.equal(gogame.batch_unpack(gogame.batch_pack(st), N), st)
+    tracked = gogame.batch_track(st)
+    assert torch.equal(gogame.batch_untrack(tracked), st)
+    rng_t = rng.clone()                                           # and stepping either form keeps them equal
+    gogame.batch_rollout_tracked(tracked, rng_t, 24, True)
+    gogame.batch_rollout(st, rng, 24, True)
+    assert torch.equal(gogame.batch_untrack(tracked), st) and torch.equal(rng_t, rng)
+    assert torch.equal(tracked, gogame.batch_track(st))            # the carried liberty classes == a fresh analysis
 
 
 def test_config1_7x7_single_game_goenv_step_vs_oracle():
