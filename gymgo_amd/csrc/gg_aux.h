@@ -94,17 +94,9 @@ __global__ __launch_bounds__(kWave) void k_sample16(const uint8_t *__restrict__ 
   const uint64_t u64 = splitmix_next(x);
   const uint32_t k = (uint32_t)(((u64 >> 32) * (uint64_t)(n + 1)) >> 32);   // k == n: the pass
   const bool hit = k >= before && k < before + T;
-  uint32_t tt = k - before, vr = vr_[0], base = 0, pos = 0;
-  int rr = 0;
-#pragma unroll
-  for (int r = 1; r < RPL; ++r)
-    if (tt >= p[r - 1]) { rr = r; vr = vr_[r]; base = p[r - 1]; }
-  tt -= base;
-#pragma unroll
-  for (int sh = 16; sh >= 1; sh >>= 1) {   // the tt-th set bit of vr
-    const uint32_t c = (uint32_t)__popc((vr >> pos) & ((1u << sh) - 1u));
-    if (tt >= c) { tt -= c; pos += sh; }
-  }
+  int rr;
+  uint32_t pos;
+  kth_set_bit<RPL>(vr_, p, (k - before) & 0x3FFu, rr, pos);   // (only the hit lane's result is used)
   const int64_t b = b_first + q;
   if (b < B) {
     if (k < n ? hit : t == 0) actions[b] = k < n ? (r0 + rr) * N + (int)pos : P;

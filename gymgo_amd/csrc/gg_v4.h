@@ -89,6 +89,35 @@ constexpr int QP_X1 = 0xB1, QP_X2 = 0x4E;   // [1,0,3,2] / [2,3,0,1]: butterfly
 __device__ __forceinline__ uint32_t quad_or(uint32_t x) { x |= dpp0<QP_X1>(x); return x | dpp0<QP_X2>(x); }
 __device__ __forceinline__ uint32_t quad_sum(uint32_t x) { x += dpp0<QP_X1>(x); return x + dpp0<QP_X2>(x); }
 
+// The tt-th (0-based) set bit among the RPL row words v[] of a lane, p[] = their inclusive prefix counts (tt < p[RPL-1]):
+// row index and bit position.  Branch-free on 0 / ~0 masks made by arithmetic shifts: a v_cmp + v_cndmask pair costs
+// 8 issue cycles, sub + ashr + bitop3 costs 6 and needs no VCC round trip.
+template <int RPL>
+__device__ __forceinline__ void kth_set_bit(const uint32_t (&v)[RPL], const uint32_t (&p)[RPL], uint32_t tt, int &rr,
+                                            uint32_t &pos) {
+  const uint32_t ntt = ~tt;
+  uint32_t vr = v[0], base = 0, row = 0;
+#pragma unroll
+  for (int r = 1; r < RPL; ++r) {
+    const uint32_t ge = (uint32_t)((int32_t)(p[r - 1] + ntt) >> 31);   // p[r-1] - 1 - tt < 0  <=>  tt >= p[r-1]
+    vr = B3(ge, v[r], vr, T_SEL);
+    base = B3(ge, p[r - 1], base, T_SEL);
+    row -= ge;
+  }
+  tt -= base;
+  uint32_t ps = 0;
+#pragma unroll
+  for (int sh = 16; sh >= 1; sh >>= 1) {
+    const uint32_t c = (uint32_t)__popc((vr >> ps) & ((1u << sh) - 1u));
+    const uint32_t d = tt - c;
+    const uint32_t lt = (uint32_t)((int32_t)d >> 31);                   // tt < c: the bit is in the lower half
+    tt = B3(lt, tt, d, T_SEL);
+    ps = B3(ps, (uint32_t)sh, lt, TA | (TB & ~TC & 0xFF));              // ps | (sh & ~lt)
+  }
+  rr = (int)row;
+  pos = ps;
+}
+
 // 4-neighbourhood dilation of the RPL adjacent rows of a lane: the row above x[0] / below x[RPL-1] sits in the
 // neighbouring lane (a non-existent row of a quad's last lane is zero in every set that is dilated, so nothing leaks
 // from the previous board; what leaks into such a row from the next board is masked by the caller).  The centre point
@@ -502,17 +531,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
           const uint64_t u = splitmix_next(x);
           const uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(n + 1)) >> 32);   // k == n: the pass
           const bool hit = k >= P && k < P + T;        // this lane holds the k-th valid point
-          uint32_t tt = k - P, vr = v[0], base = 0;
-          int rr = 0;
-#pragma unroll
-          for (int r = 1; r < RPL; ++r)
-            if (tt >= p[r - 1]) { rr = r; vr = v[r]; base = p[r - 1]; }
-          tt -= base;
-#pragma unroll
-          for (int sh = 16; sh >= 1; sh >>= 1) {   // the tt-th set bit of vr
-            const uint32_t c = (uint32_t)__popc((vr >> pos) & ((1u << sh) - 1u));
-            if (tt >= c) { tt -= c; pos += sh; }
-          }
+          int rr;
+          kth_set_bit<RPL>(v, p, (k - P) & 0x3FFu, rr, pos);   // (only the hit lane's result is used; the mask keeps tt small elsewhere)
           rabs = r0 + rr;
           // -1: the board does not move this ply.  The lane with the point announces it; a pass / an idle board is
           // announced by the board's first lane
