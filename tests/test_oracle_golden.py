@@ -145,3 +145,30 @@ def test_update_pieces_arbitrary_positions(golden):
         after, killed, groups = c_oracle.update_pieces(state, adj[:, 0] * state.shape[-1] + adj[:, 1], player)
         assert np.array_equal(after, z[k + 'after']) and np.array_equal(killed, z[k + 'killed']), i
         assert groups == int(z[k + 'groups']), i
+
+
+@pytest.mark.parametrize('size,depths', [(3, (2, 5, 9)), (5, (4, 12, 22, 30)), (9, (10, 35, 60, 85)), (13, (30, 90, 150)),
+                                         (19, (60, 180, 300))])
+def test_c_restatement_vs_scipy_port_on_every_child(size, depths):
+    """Differential pinning beyond the recorded goldens: the C restatement (the oracle the GPU tests use) against the
+    NumPy / SciPy port (same scipy.ndimage call structure as gym_go/state_utils.py, itself pinned to the reference by the
+    goldens above) on EVERY action of positions from every game phase - each legal move's successor incl. captures, ko and
+    the suicide boundary, canonical form on and off, and the areas of every successor."""
+    for depth in depths:
+        rng = c_oracle.rng_seed(1000 + depth, 4)
+        states, rng, _ = c_oracle.batch_rollout(np.zeros((4, 6, size, size), np.uint8), rng, depth, False)
+        for s in states:
+            if s[5, 0, 0]:
+                continue                                   # children of a finished game: undefined in the reference
+            for canon in (False, True):
+                kids = c_oracle.batch_children(s[None], canon)[0]
+                for a in range(size * size + 1):
+                    if a < size * size and s[3].reshape(-1)[a]:
+                        assert not kids[a].any()
+                        continue
+                    want = np_oracle.next_state(s.astype(float), a, canon)
+                    assert np.array_equal(kids[a], want.astype(np.uint8)), (size, depth, a, canon)
+                    if not canon and a % 7 == 0:
+                        b, w = c_oracle.batch_areas(kids[a][None])
+                        nb, nw = np_oracle.areas(want)
+                        assert (int(b[0]), int(w[0])) == (int(nb), int(nw)), (size, depth, a)
