@@ -45,6 +45,12 @@ def fused_bytes_per_game(n):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
+# oracle/ref_harness/pin_oracle.py, run where /root/reference exists (the build container, 8 vCPU Xeon @ 2.1 GHz), times the
+# real reference and the port on the same positions: the reference cannot travel to the GPU box, its ratio to the port can
+REFERENCE_STEPS_PER_S_PER_CORE_BUILD_BOX = 1217.0
+PORT_STEPS_PER_S_PER_CORE_BUILD_BOX = 1618.0
+
+
 def _cpu_worker(args):
     size, seconds, seed = args
     sys.path.insert(0, ROOT)
@@ -52,21 +58,32 @@ def _cpu_worker(args):
     return np_oracle.random_rollout_steps(size, seconds, seed)
 
 
-def cpu_baseline(size, seconds_per_worker=6.0, max_workers=64):
+def cpu_baseline(size, seconds_per_worker=6.0, max_workers=None):
     """The NumPy/SciPy port of the reference's next_state (oracle/np_oracle.py: the same scipy.ndimage calls per step,
-    pinned bit-exact and speed-calibrated against the real reference) on this box's host cores: one worker process per
-    core (capped at `max_workers`), each playing uniform-random games with auto-reset for a fixed wall time."""
+    pinned bit-exact and speed-calibrated against the real reference) on this box's host cores: one single-threaded
+    worker process per USABLE core (sched_getaffinity; `max_workers` caps it), each playing uniform-random games with
+    auto-reset for a fixed wall time.  Runs on rank 0 at every world size, before the GPU context / process group exist."""
     import multiprocessing as mp
     host = os.cpu_count() or 1
     try:
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = host
-    cores = max(1, min(usable, max_workers))
+    cores = max(1, min(usable, max_workers or usable))
     ctx = mp.get_context('spawn')
+    one_thread = {k: '1' for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS', 'NUMEXPR_NUM_THREADS')}
+    saved = {k: os.environ.get(k) for k in one_thread}
+    os.environ.update(one_thread)          # inherited by the spawned workers: one worker = one core
     t0 = time.perf_counter()
-    with ctx.Pool(cores) as pool:
-        steps = pool.map(_cpu_worker, [(size, seconds_per_worker, 1000 + i) for i in range(cores)])
+    try:
+        with ctx.Pool(cores) as pool:
+            steps = pool.map(_cpu_worker, [(size, seconds_per_worker, 1000 + i) for i in range(cores)])
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     wall = time.perf_counter() - t0
     c_rate = None   # the build's own C restatement, one thread: reported next to the baseline, it is not the baseline
     try:
@@ -81,10 +98,17 @@ def cpu_baseline(size, seconds_per_worker=6.0, max_workers=64):
     except Exception:
         c_rate = None
     total = float(sum(steps))
+    ratio = PORT_STEPS_PER_S_PER_CORE_BUILD_BOX / REFERENCE_STEPS_PER_S_PER_CORE_BUILD_BOX
     return {
         'value': round(total / seconds_per_worker, 1), 'unit': 'env steps/s', 'cores': cores, 'kind': 'port',
         'host_cpu_count': host, 'usable_cpus': usable, 'per_core': round(total / seconds_per_worker / cores, 1),
         'c_restatement_steps_per_s_one_core': c_rate,
+        # the port is FASTER than the reference it restates: divide by this to estimate the reference on this box
+        'port_vs_reference_speed': round(ratio, 3),
+        'reference_estimate_steps_per_s': round(total / seconds_per_worker / ratio, 1),
+        'port_vs_reference_note': 'oracle/ref_harness/pin_oracle.py in the build container (where /root/reference exists): '
+                                  'reference %.0f, port %.0f steps/s/core on the same positions'
+                                  % (REFERENCE_STEPS_PER_S_PER_CORE_BUILD_BOX, PORT_STEPS_PER_S_PER_CORE_BUILD_BOX),
         'sample': '%d worker processes (os.cpu_count() = %d, usable %d) x %.1f s of %dx%d uniform-random self-play with '
                   'auto-reset (oracle/np_oracle.py, same scipy.ndimage calls per step as the reference); %d steps total, '
                   'pool wall %.1f s' % (cores, host, usable, seconds_per_worker, size, size, int(total), wall),
@@ -129,9 +153,58 @@ class HipBackend:
     def comm_tensor(self, values):
         return self.torch.tensor(values, dtype=self.torch.float64, device=self.device)
 
+    def clock_sampler(self):
+        return ClockSampler(self.torch, self.device)
+
     def state_digest(self):
         import hashlib
         return hashlib.sha256(self.states.cpu().numpy().tobytes()).hexdigest()
+
+
+class ClockSampler:
+    """Shader clock / board power of the run, sampled from a host thread through amdsmi (torch.cuda.clock_rate /
+    power_draw) while the warm-up and timed launches are in flight: a VALU-bound number moves with the clock the box
+    happens to hold (DESIGN 5 records a lease that ran 45 % slower), so the line says which clock it was measured at."""
+
+    def __init__(self, torch, device, period_s=0.004):
+        import threading
+        self.torch, self.device, self.period = torch, device, period_s
+        self.mhz, self.watts, self.error = [], [], None
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        t = self.torch
+        while not self._stop.is_set():
+            try:
+                self.mhz.append(float(t.cuda.clock_rate(self.device)))
+                try:
+                    self.watts.append(float(t.cuda.power_draw(self.device)) / 1e3)
+                except Exception:
+                    pass
+            except Exception as e:       # no amdsmi on this box: the line says so
+                self.error = '%s: %s' % (type(e).__name__, str(e)[:120])
+                return
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=2.0)
+
+    def record(self):
+        if not self.mhz:
+            return {'sclk_mhz': None, 'note': 'amdsmi clock query unavailable (%s)' % (self.error or 'no samples')}
+        m = sorted(self.mhz)
+        rec = {'sclk_mhz': {'min': m[0], 'median': m[len(m) // 2], 'max': m[-1], 'samples': len(m)},
+               'note': 'torch.cuda.clock_rate (amdsmi current gfx clock) polled from a host thread during warm-up + timed launches'}
+        if self.watts:
+            w = sorted(self.watts)
+            rec['power_w'] = {'min': round(w[0], 1), 'median': round(w[len(w) // 2], 1), 'max': round(w[-1], 1)}
+        return rec
 
 
 def shard(total_games, rank, world_size):
@@ -162,6 +235,9 @@ def run_rank(rank, world, backend, opts, dist=None):
                 backend.rollout(g * opts['desync'] // 16, lo, hi)
     for _ in range(opts['burn_in_steps']):      # same launch shape as the timed ones (rocprof averages then agree)
         backend.rollout(F, count_steps=False)
+    sampler = backend.clock_sampler() if hasattr(backend, 'clock_sampler') else None
+    if sampler is not None:
+        sampler.__enter__()
     for _ in range(W):
         backend.rollout(F, count_steps=False)
 
@@ -181,23 +257,37 @@ def run_rank(rank, world, backend, opts, dist=None):
     stop()
     fence()
     wall = time.perf_counter() - t0
+    if sampler is not None:
+        sampler.__exit__(None, None, None)
     kernel_ms = elapsed_ms()
     played = backend.played() - before
     assert played == K * F * count, 'work was skipped inside the timed region (%d != %d)' % (played, K * F * count)
     red = backend.comm_tensor([wall, float(played)])
+    comm = {'backend': None, 'world_size': 1, 'ranks_counted': 1}
+    per_rank_ms = [kernel_ms / K]
     if dist is not None:
         tmax = red[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = red[1:].clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         wall_max, played_all = float(tmax[0]), int(tsum[0])
+        # what the communicator itself saw: an all-reduce of ones counts the ranks, every rank's own launch time lands in
+        # its slot of a zero vector (sum all-reduce = gather)
+        slots = [0.0] * (world + 1)
+        slots[rank], slots[world] = kernel_ms / K, 1.0
+        gathered = backend.comm_tensor(slots)
+        dist.all_reduce(gathered, op=dist.ReduceOp.SUM)
+        per_rank_ms = [float(x) for x in gathered[:world]]
+        comm = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'ranks_counted': int(round(float(gathered[world])))}
     else:
         wall_max, played_all = wall, played
     assert played_all == K * F * total_games
+    assert comm['ranks_counted'] == world
     if rank != 0:
         return None
     return {'value': played_all / wall_max, 'wall_s': wall_max, 'kernel_ms': kernel_ms, 'total_games': total_games,
-            'games_per_gpu': per_gpu, 'count': count, 'first': first, 'steps_played': played_all}
+            'games_per_gpu': per_gpu, 'count': count, 'first': first, 'steps_played': played_all,
+            'per_rank_launch_ms': per_rank_ms, 'comm': comm, 'clocks': sampler.record() if sampler is not None else None}
 
 
 # ------------------------------------------------------------------------------------------------ roofline records
@@ -236,7 +326,7 @@ def load_pmc(kernel, n, plies, games):
     return None
 
 
-def roofline_record(dev, n, games, plies, launch_ms, per_ply):
+def roofline_record(dev, n, games, plies, launch_ms, per_ply, clocks=None):
     import torch
     props = torch.cuda.get_device_properties(dev)
     cus = props.multi_processor_count
@@ -271,6 +361,15 @@ def roofline_record(dev, n, games, plies, launch_ms, per_ply):
     else:
         rec.update({'achieved': None, 'frac': None, 'traffic': None,
                     'pmc_source': 'no PMC pass for this launch shape under profiles/ (tools/profile_round.sh collects one)'})
+    # the same fraction against the clock the run actually held (median of the amdsmi samples), next to the nominal one
+    mhz = ((clocks or {}).get('sclk_mhz') or {}).get('median') if clocks else None
+    if mhz:
+        peak_m = cus * 4 * mhz * 1e6 / 2.0 / 1e9
+        rec['measured_clock'] = {'sclk_mhz_median': mhz, 'peak': round(peak_m, 2),
+                                 'frac': round(rec['achieved'] / peak_m, 4) if rec.get('achieved') else None,
+                                 'note': 'peak and frac recomputed with the shader clock sampled during the run'}
+    else:
+        rec['measured_clock'] = None
     rec['hbm'] = {
         'note': 'fused launch: board in + board out + generator per game per LAUNCH, whatever the ply count',
         'algorithmic_bytes_per_launch': fused_bytes, 'achieved': round(fused_bytes / (launch_ms * 1e-3) / 1e9, 2),
@@ -342,10 +441,17 @@ def extras(dev, back, opts):
     obs = torch.empty_like(states)
     r, ms = event_rate(torch, dev, lambda: gogame.batch_env_step_tracked(tracked, None, rng, 7.5, 'real', True, out=env_out,
                                                                          states_out=obs), count, 32)
+    moved = 8 * (5 * N + 1) + 6 * N * N + 25      # tracked board in + out, generator, per-game outputs, the observation
     out['gg_batch_env_step_steps_per_s'] = round(r, 1)
-    out['gg_batch_env_step_hbm_frac'] = round(algo * r / 1e9 / HBM_PEAK_GBS, 4)
+    out['gg_batch_env_step_launch_us'] = round(ms * 1e3, 2)
+    out['gg_batch_env_step_bytes_moved_per_step'] = moved
+    out['gg_batch_env_step_hbm_frac'] = round(moved * r / 1e9 / HBM_PEAK_GBS, 4)
+    out['gg_batch_env_step_x_byte_plane_step_roofline'] = round(algo * r / 1e9 / HBM_PEAK_GBS, 4)
     out['gg_batch_env_step_note'] = ('GoVecEnv.step (layout tracked): gg_batch_env_step_tracked incl. the byte-plane observation; '
-                                     'the fraction prices the SURVEY 8(d) per-step bytes (4 336 B) against 8 TB/s')
+                                     'hbm_frac = the bytes this launch really moves (%d B per step: 384 B tracked board in and out, '
+                                     'generator, outputs, the 2 166 B observation) against 8 TB/s; x_byte_plane_step_roofline = its '
+                                     'rate relative to the roofline of an out-of-place byte-plane step (4 336 B, SURVEY 8d), which '
+                                     'it is not bound by' % moved)
     r, _ = event_rate(torch, dev, lambda: gogame.batch_env_step_tracked(tracked, None, rng, 7.5, 'real', True, out=env_out), count, 32)
     out['gg_batch_env_step_no_observation_steps_per_s'] = round(r, 1)
     del tracked, obs
@@ -436,11 +542,12 @@ def parse_args(argv=None):
     ap.add_argument('--size', type=int, default=19)
     ap.add_argument('--games-per-gpu', type=int, default=0, help='0 = 65536 at 1 GPU, 131072 per GPU otherwise')
     ap.add_argument('--plies-per-step', '--fuse', dest='plies_per_step', type=int,
-                    default=int(os.environ.get('GG_BENCH_PLIES', '256')), help='plies per kernel launch (= per bench step)')
+                    default=256, help='plies per kernel launch (= per bench step)')
     ap.add_argument('--burn-in', type=int, default=1, help='untimed launches before warm-up (same shape as the timed ones)')
     ap.add_argument('--desync', type=int, default=640, help='spread of extra burn-in plies across the batch (0 = lock-step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=6.0, help='wall seconds per CPU-baseline worker')
+    ap.add_argument('--cpu-workers', type=int, default=0, help='CPU-baseline worker processes (0 = every usable core)')
     ap.add_argument('--no-also', action='store_true', help='skip the untimed extras (clean profiling passes)')
     ap.add_argument('--comm', choices=('nccl', 'gloo'), default='nccl',
                     help='process-group backend for barrier + reductions (gloo: rehearse the N > 1 path on a box with fewer '
@@ -488,8 +595,10 @@ def main(argv=None):
     args.gpus = world
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.size, args.cpu_seconds)   # before the GPU context exists (spawned workers)
+    if rank == 0 and not args.no_cpu_baseline:
+        # every world size carries the CPU path of the same box in the same run (north_star); on rank 0, before the GPU
+        # context and the process group exist (spawned workers) - the other ranks wait for it at the rendezvous
+        cpu = cpu_baseline(args.size, args.cpu_seconds, args.cpu_workers or None)
 
     import torch
     import torch.distributed as dist
@@ -532,10 +641,25 @@ def main(argv=None):
                 'env_steps_per_bench_step': F * res['total_games'], 'burn_in_steps': opts['burn_in_steps'],
                 'desync_plies': opts['desync'], 'sharding': 'batch split across ranks by global game index, no collective',
             },
-            'roofline': roofline_record(dev, N, res['count'], F, launch_ms, per_ply),
+            'roofline': roofline_record(dev, N, res['count'], F, launch_ms, per_ply, res.get('clocks')),
+            'clocks': res.get('clocks'),
+            # what the communicator saw (None at a plain one-process run): backend, its world size, the ranks an
+            # all-reduce of ones counted; and every rank's own average launch time (HIP events on its stream)
+            'comm': res['comm'], 'rccl_world_size': res['comm']['world_size'] if res['comm']['backend'] else None,
+            'per_rank_launch_ms': [round(x, 5) for x in res['per_rank_launch_ms']],
+            'per_gpu_steps_per_s': [round(F * res['games_per_gpu'] / (x * 1e-3), 1) for x in res['per_rank_launch_ms']],
         }
         if cpu is not None:
             line['cpu_baseline'] = cpu
+        base = (also.get('configs') or {}).get('config4_per_gpu_batch_131072_games_on_one_gpu') if also else None
+        if world == 1 and base:
+            # weak-scaling base: the per-GPU batch of the N > 1 lines (131 072 games) on ONE GPU, same launch shape -
+            # efficiency at N GPUs = value(N) / (N x this)
+            line['weak_scaling_base'] = {'games': 131072, 'steps_per_s_one_gpu': base['fused_rollout_steps_per_s'],
+                                         'launch_ms': base['launch_ms']}
+        elif world == 1 and res['games_per_gpu'] == 131072:
+            line['weak_scaling_base'] = {'games': 131072, 'steps_per_s_one_gpu': round(res['value'], 1),
+                                         'launch_ms': round(launch_ms, 5)}
         line['also'] = also
     if use_dist:
         dist.barrier()

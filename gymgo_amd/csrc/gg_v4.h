@@ -543,8 +543,11 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         }
         if (wr_act) actv[s4] = a;
         if (!MOVES && bl && t5 == 0 && live) { rngv[2 * s4] = (uint32_t)x; rngv[2 * s4 + 1] = (uint32_t)(x >> 32); }
-        if (__ballot(live) == 0) break;
+        // (a finished game whose move is refused is still reset when auto_reset - GoEnv.reset comes before the action
+        // check - also when no board of the wave moves: the resets are applied before the early exit)
         uint64_t resetm = __ballot(reset && t5 == 0);
+        const bool none_live = __ballot(live) == 0;
+        if (none_live && resetm == 0) break;
         if (resetm) {   // rare
           if (reset) {
 #pragma unroll
@@ -556,6 +559,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
             for (int i = hf.lane; i < 2 * RS; i += kWave) st[(i / RS) * PL + s * RS + (i % RS)] = 0;
             if (hf.lane == 0) flagsv[s] = (flagsv[s] & 16u) | 8u | 32u;   // on, reset (written back even if nothing is played)
           }
+          if (none_live) break;
         }
         WAVE_SYNC();
         // the new stone goes into the mover's plane right away: every later phase sees the position with it

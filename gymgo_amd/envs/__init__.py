@@ -20,17 +20,47 @@ def make(spec, **kwargs):
     return ENV_IDS[env_id](**kwargs)
 
 
+ENTRY_POINT = 'gymgo_amd.envs:GoEnv'
+GYM_IDS = ('go-v0', 'gymgo_amd/go-v0')     # the reference's bare id + one that cannot collide with `import gym_go`
+
+
+def _registered_entry_point(env_id):
+    """The entry point gym / gymnasium currently holds for `env_id` (None if unknown)."""
+    try:
+        registry = __import__(spaces.gym.__name__ + '.envs.registration', fromlist=['registry']).registry
+        spec = registry.get(env_id) if hasattr(registry, 'get') else registry.env_specs.get(env_id)   # old gym: EnvRegistry
+        return spec if spec is None or isinstance(spec, str) else getattr(spec, 'entry_point', None)
+    except Exception:
+        return None
+
+
 def register_gym():
-    """Register 'go-v0' with gym / gymnasium (gym_go/__init__.py:3-6); False when neither is installed (they are
-    not in the MI355X image) or the id is registered already.  Runs once on import."""
+    """Register 'go-v0' (gym_go/__init__.py:3-6) and the collision-free 'gymgo_amd/go-v0' with gym / gymnasium.  Returns
+    False when neither is installed (they are not in the MI355X image).  The bare id is shared with the reference
+    package: if `gym_go` was imported first (or the registry refuses to re-register) the registry keeps ITS entry
+    point, and `gym.make('gymgo_amd:go-v0')` would then build the CPU reference env - that is checked and reported
+    (RuntimeWarning + GYM_REGISTRATION['go-v0'] = False) instead of silently swallowed; 'gymgo_amd/go-v0' and
+    gymgo_amd.envs.make() always give this package's GoEnv.  Runs once on import."""
+    import warnings
     if spaces.gym is None:
         return False
     try:
         registration = __import__(spaces.gym.__name__ + '.envs.registration', fromlist=['register'])
-        registration.register(id='go-v0', entry_point='gymgo_amd.envs:GoEnv')
-        return True
-    except Exception:   # e.g. gym's "Cannot re-register id" when imported twice under different names
+    except Exception:
         return False
+    for env_id in GYM_IDS:
+        try:
+            registration.register(id=env_id, entry_point=ENTRY_POINT)
+        except Exception:   # e.g. gym's "Cannot re-register id": decided by the check below
+            pass
+        held = _registered_entry_point(env_id)
+        ok = held == ENTRY_POINT or held is GoEnv
+        GYM_REGISTRATION[env_id] = ok
+        if not ok and env_id == 'go-v0':
+            warnings.warn("gym id 'go-v0' is held by %r, not by gymgo_amd (was gym_go imported first?): "
+                          "use gym.make('gymgo_amd/go-v0') or gymgo_amd.envs.make('go-v0')" % (held,), RuntimeWarning)
+    return GYM_REGISTRATION.get('go-v0', False) or GYM_REGISTRATION.get('gymgo_amd/go-v0', False)
 
 
+GYM_REGISTRATION = {}
 REGISTERED_WITH_GYM = register_gym()

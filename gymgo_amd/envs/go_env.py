@@ -39,9 +39,19 @@ class GoEnv(spaces.Env):
                                             shape=(govars.NUM_CHNLS, size, size))
         self.action_space = spaces.Discrete(gogame.action_size(self.state_))
         self.done = False
-        self._areas, self._areas_of = (0.0, 0.0), self.state_    # the score of `_areas_of` (identity)
+        # `state_` is a public attribute in the reference, and callers both REPLACE it (`env.state_ = x`) and EDIT it in
+        # place (`env.state_[0, 1, 1] = 1`); the reference recomputes from it on every call.  The device copy and the cached
+        # score therefore remember the exact bytes they belong to (a uint8 snapshot, 6 N^2 bytes) and are refreshed
+        # whenever `state_` no longer matches it.
+        self._areas, self._areas_of = (0.0, 0.0), self._snapshot()
         self._dev = None          # device record, allocated on the first step
-        self._dev_of = None       # the host state the device copy mirrors (identity): `env.state_ = x` re-uploads
+        self._dev_of = None       # snapshot of the host state the device copy mirrors
+
+    def _snapshot(self):
+        return np.ascontiguousarray(self.state_).astype(np.uint8)
+
+    def _same(self, snap):
+        return snap is not None and snap.shape == np.shape(self.state_) and np.array_equal(snap, self.state_)
 
     # ---- the resident device record: [state 6 N^2 | pad | black i32 | white i32 | status i32 | done u8 ...]
     def _record(self):
@@ -56,16 +66,16 @@ class GoEnv(spaces.Env):
                 'black': buf[off:off + 4].view(torch.int32), 'white': buf[off + 4:off + 8].view(torch.int32),
                 'status': buf[off + 8:off + 12].view(torch.int32), 'done': buf[off + 12:off + 13],
             }
-        if self._dev_of is not self.state_:
-            self._dev['states'].copy_(torch.from_numpy(np.ascontiguousarray(self.state_).astype(np.uint8)).view(
-                1, govars.NUM_CHNLS, self.size, self.size))
-            self._dev_of = self.state_
+        if not self._same(self._dev_of):      # replaced or edited in place by the caller: upload it
+            snap = self._snapshot()
+            self._dev['states'].copy_(torch.from_numpy(snap).view(1, govars.NUM_CHNLS, self.size, self.size))
+            self._dev_of = snap
         return self._dev
 
     def reset(self):
         self.state_ = gogame.init_state(self.size)
         self.done = False
-        self._areas, self._areas_of = (0.0, 0.0), self.state_
+        self._areas, self._areas_of = (0.0, 0.0), self._snapshot()
         return np.copy(self.state_)
 
     def step(self, action):
@@ -95,9 +105,10 @@ class GoEnv(spaces.Env):
         if status != 0:                           # gym_go/gogame.py:59: the position is unchanged
             a = int(action)
             raise AssertionError(('Invalid move', (a // n, a % n)))
-        self.state_ = host[:off][:govars.NUM_CHNLS * n * n].reshape(govars.NUM_CHNLS, n, n).astype(np.float64)
-        self._dev_of = self.state_
-        self._areas, self._areas_of = (float(black), float(white)), self.state_
+        snap = host[:off][:govars.NUM_CHNLS * n * n].reshape(govars.NUM_CHNLS, n, n).copy()
+        self.state_ = snap.astype(np.float64)
+        self._dev_of = snap
+        self._areas, self._areas_of = (float(black), float(white)), snap
         self.done = int(host[off + 12])
         return np.copy(self.state_), self.reward(), self.done, self.info()
 
@@ -140,8 +151,8 @@ class GoEnv(spaces.Env):
         return gogame.children(self.state_, canonical, padded)
 
     def _score(self):
-        if self._areas_of is not self.state_:     # state replaced by the caller: score it afresh
-            self._areas, self._areas_of = tuple(float(x) for x in gogame.areas(self.state_)), self.state_
+        if not self._same(self._areas_of):     # state replaced or edited by the caller: score it afresh
+            self._areas, self._areas_of = tuple(float(x) for x in gogame.areas(self.state_)), self._snapshot()
         return self._areas
 
     def winning(self):

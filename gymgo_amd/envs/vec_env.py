@@ -31,6 +31,8 @@ class GoVecEnv:
         self.reward_method = reward_method
         self.device = torch.device(device) if device is not None else gogame._device()
         self.auto_reset = auto_reset
+        if packed and layout not in (None, 'packed'):
+            raise ValueError("packed=True is the legacy spelling of layout='packed'; it contradicts layout=%r" % (layout,))
         self.layout = layout or ('packed' if packed else 'tracked')
         if self.layout not in ('tracked', 'bytes', 'packed'):
             raise ValueError("layout must be 'tracked', 'bytes' or 'packed'")
@@ -138,7 +140,9 @@ class GoVecEnv:
         return self.states, self.rewards(dones), dones, status
 
     def rollout(self, plies):
-        """`plies` uniform-random steps per game, fused on the device (boards stay on-chip)."""
+        """`plies` uniform-random steps per game, fused on the device (boards stay on-chip).  Returns the RESIDENT store in
+        its own layout (uint8 [B,6,N,N] for 'bytes', int32 [B,3N+1] for 'packed', int32 [B,5N+1] for 'tracked') - no
+        conversion is run; read `env.states` for the uint8 observation (unlike step(), which always returns it)."""
         if self.layout == 'packed':
             gogame.batch_rollout_packed(self.packed_states, self.rng, plies, self.auto_reset, self.last_actions, self.steps_done)
             return self.packed_states

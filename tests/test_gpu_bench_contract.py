@@ -52,21 +52,28 @@ def _check(line, n_gpus, steps, warmup):
 
 
 def test_bench_one_gpu_plain_invocation():
-    line = _run([sys.executable, 'bench.py', '--gpus', '1', '--steps', '3', '--warmup', '1', '--cpu-seconds', '0.5'])
+    line = _run([sys.executable, 'bench.py', '--gpus', '1', '--steps', '3', '--warmup', '1', '--cpu-seconds', '0.5',
+                 '--cpu-workers', '8'])
     _check(line, 1, 3, 1)
+    assert line['comm']['backend'] is None and line['rccl_world_size'] is None and len(line['per_rank_launch_ms']) == 1
+    assert line['weak_scaling_base']['games'] == 131072 and line['weak_scaling_base']['steps_per_s_one_gpu'] > 1e8
+    assert 'clocks' in line and 'measured_clock' in line['roofline']
     assert line['config']['games'] == 65536 and line['config']['board'] == 19 and line['config']['plies_per_step'] == 256
     assert line['roofline']['frac'] is not None                       # the committed PMC record matches the default shape
     assert 0 < line['roofline']['per_ply']['frac'] <= 1
     cpu = line['cpu_baseline']
-    assert cpu['kind'] == 'port' and cpu['cores'] >= 1 and cpu['value'] > 0 and cpu['unit'] == line['unit']
+    assert cpu['kind'] == 'port' and cpu['cores'] == 8 and cpu['value'] > 0 and cpu['unit'] == line['unit']
+    assert cpu['port_vs_reference_speed'] > 1 and cpu['reference_estimate_steps_per_s'] < cpu['value']
     also = line['also']
+    assert also['gg_batch_env_step_hbm_frac'] < also['gg_batch_env_step_x_byte_plane_step_roofline'] <= 1.2
     assert also['gg_batch_env_step_steps_per_s'] > 0 and set(also['configs']) >= {
         'config2_9x9_4096_games', 'config5_children_8192_parents', 'config1_7x7_single_game_GoEnv_step'}
 
 
 @pytest.mark.parametrize('launcher', ['torch.distributed.run', 'self-spawn'])
 def test_bench_two_ranks(launcher):
-    tail = ['bench.py', '--gpus', '2', '--comm', 'gloo', '--games-per-gpu', '16384', '--steps', '2', '--warmup', '1', '--no-also']
+    tail = ['bench.py', '--gpus', '2', '--comm', 'gloo', '--games-per-gpu', '16384', '--steps', '2', '--warmup', '1', '--no-also',
+            '--cpu-seconds', '0.5', '--cpu-workers', '4']
     if launcher == 'self-spawn':
         cmd = [sys.executable] + tail
     else:
@@ -75,4 +82,10 @@ def test_bench_two_ranks(launcher):
     line = _run(cmd)
     _check(line, 2, 2, 1)
     assert line['config']['games'] == 32768 and line['config']['games_per_gpu'] == 16384
-    assert 'cpu_baseline' not in line                                   # rank 0 at N = 1 only
+    # the N > 1 line is complete and self-evidencing: the CPU path of the same box in the same run (rank 0), the world
+    # size as the communicator counted it (an all-reduce of ones), every rank's own launch time
+    assert line['cpu_baseline']['kind'] == 'port' and line['cpu_baseline']['cores'] == 4 and line['cpu_baseline']['value'] > 0
+    assert line['comm'] == {'backend': 'gloo', 'world_size': 2, 'ranks_counted': 2} and line['rccl_world_size'] == 2
+    assert len(line['per_rank_launch_ms']) == 2 and all(x > 0 for x in line['per_rank_launch_ms'])
+    assert len(line['per_gpu_steps_per_s']) == 2
+    assert line['value'] <= sum(line['per_gpu_steps_per_s']) * 1.001    # the whole job cannot beat the sum of its ranks

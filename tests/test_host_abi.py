@@ -11,9 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope='module')
-def built():
-    import __graft_entry__
-    __graft_entry__.build()
+def built(native_built):
+    # (conftest.native_built builds the library when it is missing or stale and skips on a box without hipcc / torch)
     from gymgo_amd import _lib
     return _lib
 
@@ -184,3 +183,30 @@ def test_host_side_argument_checks_without_device(built):
             gogame.batch_rollout_packed(torch.zeros((2, 28), dtype=torch.int32), torch.zeros(2, dtype=torch.int64), 3)
         with pytest.raises(built.GymGoNativeError):
             gogame.batch_track(torch.zeros((2, 6, 9, 9), dtype=torch.uint8))
+
+
+def test_gym_registration_is_checked_not_assumed(tmp_path):
+    """'go-v0' is shared with the reference package.  With a gym whose registry already holds the
+    reference's entry point (and refuses to re-register), importing gymgo_amd.envs must WARN and record that the bare id
+    is not ours, while the namespaced id and envs.make() still resolve to this package's GoEnv.  Run in subprocesses
+    against the import stub of gym under oracle/ref_harness/stubs (gym itself is not in the image)."""
+    import subprocess
+    import sys
+    stubs = os.path.join(ROOT, 'oracle', 'ref_harness', 'stubs')
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([stubs, ROOT]))
+    clean = ("import gymgo_amd.envs as e; from gym.envs import registration as r; "
+             "assert e.REGISTERED_WITH_GYM and e.GYM_REGISTRATION == {'go-v0': True, 'gymgo_amd/go-v0': True}, e.GYM_REGISTRATION; "
+             "assert r.registry['go-v0'] == 'gymgo_amd.envs:GoEnv'")
+    taken = ("import warnings; from gym.envs import registration as r; r.registry['go-v0'] = 'gym_go.envs:GoEnv'\n"
+             "def strict(id, entry_point, **kw):\n"
+             "    if id in r.registry: raise RuntimeError('Cannot re-register id: ' + id)\n"
+             "    r.registry[id] = entry_point\n"
+             "r.register = strict\n"
+             "with warnings.catch_warnings(record=True) as w:\n"
+             "    warnings.simplefilter('always'); import gymgo_amd.envs as e\n"
+             "assert e.GYM_REGISTRATION == {'go-v0': False, 'gymgo_amd/go-v0': True}, e.GYM_REGISTRATION\n"
+             "assert any('go-v0' in str(x.message) and issubclass(x.category, RuntimeWarning) for x in w)\n"
+             "assert r.registry['go-v0'] == 'gym_go.envs:GoEnv' and type(e.make('go-v0', size=5)).__module__ == 'gymgo_amd.envs.go_env'")
+    for code in (clean, taken):
+        res = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-1500:]

@@ -92,6 +92,10 @@ def test_bench_run_rank_two_ranks_over_gloo(tmp_path):
     assert res['total_games'] == total and res['count'] == OPTS['games_per_gpu'] and res['first'] == 0
     assert res['steps_played'] == OPTS['steps'] * OPTS['plies_per_step'] * total           # summed over BOTH ranks
     assert res['value'] == pytest.approx(res['steps_played'] / res['wall_s']) and res['wall_s'] > 0
+    # the communicator's own evidence: its backend and world size, the ranks an all-reduce of ones counted, one launch
+    # time per rank (each written by its own rank into its slot)
+    assert res['comm'] == {'backend': 'gloo', 'world_size': 2, 'ranks_counted': 2}
+    assert len(res['per_rank_launch_ms']) == 2 and all(x > 0 for x in res['per_rank_launch_ms'])
     # the union of the shards == bench's own driver at world 1 over the whole batch with the same schedule per game:
     # rank r's games get the schedule of a 24-game shard (de-sync slices are per shard), so rebuild it shard by shard
     got = np.concatenate([np.load(tmp_path / ('states_%d.npy' % r)) for r in range(world)])

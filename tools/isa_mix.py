@@ -7,7 +7,7 @@ rest: v_bfrev, v_bcnt, v_cndmask, v_cmp, v_lshlrev, three-operand ops, DPP moves
 
 The ply loop is the code between the two `v_mbcnt_lo` markers of k_rollout4<19, 0, false, true, false> (the kernel reads
 its lane id afresh at the top of every ply and once more before the write-back).  Inner loops are weighted by the trip
-counts measured on mid-game boards (tests/dbg_flood_stats.py: 3.07 flood sweeps per wave-ply on average; a capture on
+counts measured on mid-game boards (tests/devtools/flood_stats.py: 3.07 flood sweeps per wave-ply on average; a capture on
 some board of the wave on 85 % of the plies; the auto-reset block is rare)."""
 import collections
 import re
