@@ -97,11 +97,16 @@ def cpu_baseline(size, seconds_per_worker=6.0, max_workers=None):
         c_rate = round(32 * 600 / (time.perf_counter() - c0), 1)
     except Exception:
         c_rate = None
+    try:      # a container may own fewer CPUs' worth of time than it can see
+        quota = open('/sys/fs/cgroup/cpu.max').read().split()
+        cgroup = None if quota[0] == 'max' else round(float(quota[0]) / float(quota[1]), 2)
+    except Exception:
+        cgroup = None
     total = float(sum(steps))
     ratio = PORT_STEPS_PER_S_PER_CORE_BUILD_BOX / REFERENCE_STEPS_PER_S_PER_CORE_BUILD_BOX
     return {
         'value': round(total / seconds_per_worker, 1), 'unit': 'env steps/s', 'cores': cores, 'kind': 'port',
-        'host_cpu_count': host, 'usable_cpus': usable, 'per_core': round(total / seconds_per_worker / cores, 1),
+        'host_cpu_count': host, 'usable_cpus': usable, 'cgroup_cpu_quota_cores': cgroup, 'per_core': round(total / seconds_per_worker / cores, 1),
         'c_restatement_steps_per_s_one_core': c_rate,
         # the port is FASTER than the reference it restates: divide by this to estimate the reference on this box
         'port_vs_reference_speed': round(ratio, 3),
@@ -179,7 +184,7 @@ class ClockSampler:
             try:
                 self.mhz.append(float(t.cuda.clock_rate(self.device)))
                 try:
-                    self.watts.append(float(t.cuda.power_draw(self.device)) / 1e3)
+                    self.watts.append(float(t.cuda.power_draw(self.device)))
                 except Exception:
                     pass
             except Exception as e:       # no amdsmi on this box: the line says so
@@ -203,7 +208,9 @@ class ClockSampler:
                'note': 'torch.cuda.clock_rate (amdsmi current gfx clock) polled from a host thread during warm-up + timed launches'}
         if self.watts:
             w = sorted(self.watts)
-            rec['power_w'] = {'min': round(w[0], 1), 'median': round(w[len(w) // 2], 1), 'max': round(w[-1], 1)}
+            # torch documents milliwatts, amdsmi's socket power comes back in watts on this stack: raw values, unit unresolved
+            rec['power_raw'] = {'min': round(w[0], 1), 'median': round(w[len(w) // 2], 1), 'max': round(w[-1], 1),
+                                'unit': 'as returned by torch.cuda.power_draw (mW per its doc; W if amdsmi reports socket power)'}
         return rec
 
 
@@ -454,7 +461,19 @@ def extras(dev, back, opts):
                                      'it is not bound by' % moved)
     r, _ = event_rate(torch, dev, lambda: gogame.batch_env_step_tracked(tracked, None, rng, 7.5, 'real', True, out=env_out), count, 32)
     out['gg_batch_env_step_no_observation_steps_per_s'] = round(r, 1)
-    del tracked, obs
+    # the same step with the move of every game drawn from policy weights (float32 [B, N^2+1]: 1 448 B more to read per
+    # game) by the launch itself - what a self-play loop with a policy network runs per ply
+    probs = torch.rand((count, N * N + 1), dtype=torch.float32, device=dev)
+    r_w, ms_w = event_rate(torch, dev, lambda: gogame.batch_env_step_tracked(tracked, None, rng, 7.5, 'real', True, out=env_out,
+                                                                             states_out=obs, weights=probs), count, 32)
+    out['gg_batch_env_step_policy_weighted_steps_per_s'] = round(r_w, 1)
+    out['gg_batch_env_step_policy_weighted_launch_us'] = round(ms_w * 1e3, 2)
+    out['gg_batch_env_step_policy_weighted_vs_uniform'] = round(r_w / out['gg_batch_env_step_steps_per_s'], 4)
+    acts_w = torch.empty(count, dtype=torch.int32, device=dev)
+    r_s, ms_s = event_rate(torch, dev, lambda: gogame.batch_sample_weighted(states, probs, rng), count, 32)
+    out['gg_batch_sample_weighted_boards_per_s'] = round(r_s, 1)
+    out['gg_batch_sample_weighted_launch_us'] = round(ms_s * 1e3, 2)
+    del tracked, obs, probs, acts_w
     configs = {}
     F = opts['plies_per_step']
     # --- config 2: 9x9, 4 096 games
@@ -528,6 +547,17 @@ def extras(dev, back, opts):
                             'gg_batch_env_step_bytes_moved_per_step': 8 * (5 * N + 1) + 6 * N * N + 25,
                             'gg_batch_env_step_frac_of_fill': round((8 * (5 * N + 1) + 6 * N * N + 25)
                                                                     * out['gg_batch_env_step_steps_per_s'] / r_fill, 4)}
+    # --- the shader clock over a LONGER busy stretch than the timed region (K launches are ~50 ms: shorter than the
+    # smoothing of the SMU's clock read-out): ~0.3 s of back-to-back launches of the timed shape, sampled the same way
+    with ClockSampler(torch, dev, 0.01) as probe:
+        r_probe, ms_probe = event_rate(torch, dev, lambda: back.rollout(F, count_steps=False), count * F, max(8, int(300.0 / max(0.05, opts.get('launch_ms_hint', 2.5)))))
+    rec = probe.record()
+    rec['steps_per_s_during_probe'] = round(r_probe, 1)
+    rec['launch_ms_during_probe'] = round(ms_probe, 5)
+    if probe.mhz:
+        tail = probe.mhz[len(probe.mhz) // 2:]
+        rec['sclk_mhz_second_half_mean'] = round(sum(tail) / len(tail), 1)
+    out['clock_probe'] = rec
     out['note'] = ('per-ply rates: HIP events over back-to-back calls through the Python API on the resident config-3 batch; '
                    'configs: one driver-timed number per BASELINE config that is not the headline')
     return out, per_ply

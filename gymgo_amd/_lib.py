@@ -11,7 +11,7 @@ import torch  # must be imported before the library so both share ONE HIP runtim
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgymgo_amd.so')   # always the in-tree build: no override, no search path
-ABI_VERSION = 2                                      # GG_ABI_VERSION of include/gymgo_amd.h
+ABI_VERSION = 3                                      # GG_ABI_VERSION of include/gymgo_amd.h
 
 EXPORTS = (
     'gg_version', 'gg_device_cus', 'gg_batch_next_states', 'gg_batch_next_states_ws', 'gg_batch_invalid_mask', 'gg_batch_areas',
@@ -19,7 +19,8 @@ EXPORTS = (
     'gg_batch_unpack_states', 'gg_batch_next_states_packed', 'gg_batch_rollout_packed', 'gg_batch_env_step_packed',
     'gg_batch_children_packed', 'gg_batch_play_moves', 'gg_batch_play_moves_packed', 'gg_tracked_words', 'gg_batch_track_states',
     'gg_batch_untrack_states', 'gg_batch_rollout_tracked', 'gg_batch_play_moves_tracked', 'gg_batch_env_step_tracked',
-    'gg_rng_seed',
+    'gg_rng_seed', 'gg_batch_env_step_tracked_weighted', 'gg_batch_sample_weighted', 'gg_batch_sample_weighted_rows',
+    'gg_batch_symmetry', 'gg_batch_symmetry_rows',
 )
 
 _vp, _i64, _i32, _u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64
@@ -52,6 +53,11 @@ _SIGNATURES = {
     'gg_batch_play_moves_tracked': ([_vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
     'gg_batch_env_step_tracked': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_float, _i32, _i32, _vp], _i32),
     'gg_rng_seed': ([_vp, _u64, _i64, _i64, _vp], _i32),
+    'gg_batch_env_step_tracked_weighted': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_float, _i32, _i32, _vp], _i32),
+    'gg_batch_sample_weighted': ([_vp, _vp, _vp, _vp, _i64, _i32, _vp], _i32),
+    'gg_batch_sample_weighted_rows': ([_vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp], _i32),
+    'gg_batch_symmetry': ([_vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
+    'gg_batch_symmetry_rows': ([_vp, _i32, _vp, _vp, _i64, _i32, _vp], _i32),
 }
 
 _lib = None

@@ -1,8 +1,8 @@
 // gg_kernels.hip - C-ABI (include/gymgo_amd.h) of the MI355X batched Go step path: argument checks, device selection,
 // grid sizing and dispatch on the board-size template.  The kernels live in gg_common.h (shared building blocks),
 // gg_v2.h (per-ply kernels: two boards per wavefront, every liberty class from scratch), gg_v4.h (multi-ply kernels:
-// sixteen boards per wavefront, liberty classes carried from ply to ply) and gg_aux.h (stand-alone sampler and capture
-// resolution).  Which kernel serves an entry point depends on the arguments only (batch size, plies per launch): there
+// sixteen boards per wavefront, liberty classes carried from ply to ply), gg_aux.h (stand-alone sampler and capture
+// resolution), gg_ws.h (policy-weighted sampling) and gg_sym.h (batched symmetries).  Which kernel serves an entry point depends on the arguments only (batch size, plies per launch): there
 // are no environment switches and no mutable global state besides the per-device CU-count cache below.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -14,6 +14,8 @@
 #include "gg_v2.h"
 #include "gg_v4.h"
 #include "gg_aux.h"
+#include "gg_ws.h"
+#include "gg_sym.h"
 #include "gymgo_amd.h"
 
 namespace {
@@ -123,6 +125,17 @@ uint32_t recip16(int32_t N) {
     else if ((N) < 13) { k_rollout4<13, 2, MOVES, false, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
     else if ((N) == 19) { k_rollout4<19, 2, MOVES, true, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
     else { k_rollout4<19, 2, MOVES, false, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }               \
+  } while (0)
+
+// ... with the moves drawn from policy weights by the kernel
+#define GG_DISPATCH4W(N, GRID, ...)                                                                        \
+  do {                                                                                                     \
+    if ((N) == 9) { k_rollout4<9, 2, true, true, true, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }        \
+    else if ((N) < 9) { k_rollout4<9, 2, true, false, true, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }   \
+    else if ((N) == 13) { k_rollout4<13, 2, true, true, true, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
+    else if ((N) < 13) { k_rollout4<13, 2, true, false, true, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
+    else if ((N) == 19) { k_rollout4<19, 2, true, true, true, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); } \
+    else { k_rollout4<19, 2, true, false, true, true><<<GRID, kWave, 0, s>>>(__VA_ARGS__); }               \
   } while (0)
 
 #define GG_DISPATCH(N, CALL9, CALL13, CALL19) \
@@ -516,12 +529,76 @@ int32_t gg_batch_env_step_tracked(uint32_t *tracked, const int32_t *actions, uin
   EnvArgs env;
   env.actions = actions; env.rewards = rewards; env.dones = dones; env.status = status; env.taken = taken_actions;
   env.states_out = states_out; env.komi = komi; env.heuristic = reward_method == GG_REWARD_HEURISTIC;
-  env.ws = nullptr; env.canonical = 0;
+  env.ws = nullptr; env.canonical = 0; env.weights = nullptr;
   if (actions) {
     GG_DISPATCH4E(N, true, grid, st, nullptr, nullptr, steps_done, B, N, inv, 1, auto_reset, nb, actions, nullptr, env);
   } else {
     GG_DISPATCH4E(N, false, grid, st, rng, nullptr, steps_done, B, N, inv, 1, auto_reset, nb, nullptr, nullptr, env);
   }
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_env_step_tracked_weighted(uint32_t *tracked, const float *weights, uint64_t *rng, float *rewards,
+                                           uint8_t *dones, int32_t *status, int32_t *taken_actions, uint8_t *states_out,
+                                           int64_t *steps_done, int64_t B, int32_t N, float komi, int32_t reward_method,
+                                           int32_t auto_reset, void *hip_stream) {
+  if (reward_method != GG_REWARD_REAL && reward_method != GG_REWARD_HEURISTIC) return GG_E_BADARG;
+  GG_ENTER(tracked);
+  if (!weights || !rng) return GG_E_NULLPTR;
+  uint8_t *st = reinterpret_cast<uint8_t *>(tracked);
+  int grid;
+  const int nb = boards_per_wave(cus, B, grid);
+  EnvArgs env = EnvArgs();
+  env.rewards = rewards; env.dones = dones; env.status = status; env.taken = taken_actions;
+  env.states_out = states_out; env.komi = komi; env.heuristic = reward_method == GG_REWARD_HEURISTIC;
+  env.weights = weights;
+  // the given-moves instantiation, with the move of every game drawn from its weights by the kernel itself
+  GG_DISPATCH4W(N, grid, st, rng, nullptr, steps_done, B, N, inv, 1, auto_reset, nb, nullptr, nullptr, env);
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_sample_weighted(const uint8_t *states, const float *weights, uint64_t *rng, int32_t *actions, int64_t B,
+                                 int32_t N, void *hip_stream) {
+  GG_ENTER(weights);
+  if (!rng || !actions) return GG_E_NULLPTR;   // states may be NULL: nothing is masked
+  const int grid = grid_for(cus, (B + 3) / 4);
+  GG_DISPATCH(N, (k_sample_weighted<9><<<grid, kWave, 0, s>>>(states, weights, rng, actions, B, N)),
+              (k_sample_weighted<13><<<grid, kWave, 0, s>>>(states, weights, rng, actions, B, N)),
+              (k_sample_weighted<19><<<grid, kWave, 0, s>>>(states, weights, rng, actions, B, N)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_sample_weighted_rows(const uint32_t *boards, int32_t planes, const float *weights, uint64_t *rng,
+                                      int32_t *actions, int64_t B, int32_t N, void *hip_stream) {
+  if (planes != 3 && planes != 5) return GG_E_BADARG;
+  GG_ENTER(boards);
+  if (!weights || !rng || !actions) return GG_E_NULLPTR;
+  const int grid = grid_for(cus, (B + 3) / 4);
+  const int W = planes * N + 1;
+  GG_DISPATCH(N, (k_sample_weighted_rows<9><<<grid, kWave, 0, s>>>(boards, W, weights, rng, actions, B, N)),
+              (k_sample_weighted_rows<13><<<grid, kWave, 0, s>>>(boards, W, weights, rng, actions, B, N)),
+              (k_sample_weighted_rows<19><<<grid, kWave, 0, s>>>(boards, W, weights, rng, actions, B, N)));
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_symmetry(const uint8_t *in, const int32_t *orient, uint8_t *out, int64_t B, int32_t C, int32_t N,
+                          void *hip_stream) {
+  if (C < 1 || (int64_t)C * N * N > 8192) return GG_E_BADARG;
+  GG_ENTER(in);
+  if (!out) return GG_E_NULLPTR;
+  const int grid = grid_for(cus, B);
+  if (C * N * N <= 2304) k_symmetry_bytes<2304><<<grid, kWave, 0, s>>>(in, orient, out, B, C, N);
+  else k_symmetry_bytes<8192><<<grid, kWave, 0, s>>>(in, orient, out, B, C, N);
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_symmetry_rows(const uint32_t *in, int32_t planes, const int32_t *orient, uint32_t *out, int64_t B,
+                               int32_t N, void *hip_stream) {
+  if (planes != 3 && planes != 5) return GG_E_BADARG;
+  GG_ENTER(in);
+  if (!out) return GG_E_NULLPTR;
+  const int grid = grid_for(cus, (B + 1) / 2);
+  k_symmetry_rows<<<grid, kWave, 0, s>>>(in, orient, out, B, N, planes);
   return (int32_t)hipGetLastError();
 }
 

@@ -37,6 +37,11 @@ namespace gg {
 // bit-string and table (the limit for four waves per SIMD is 10 240 B).
 constexpr int kNB4 = 16;
 
+// gg_ws.h (policy-weighted sampling, one DPP row of 16 lanes per board); used by the weighted env step below
+template <int NJ> __device__ __forceinline__ int wsample_row(const uint32_t (&bits)[NJ], const uint32_t (&vm)[NJ], uint32_t uhi, int lane);
+template <int NJ> __device__ __forceinline__ void wload_row(const float *__restrict__ wrow, int A, bool on, int lane, uint32_t (&bits)[NJ]);
+template <int NJ> __device__ __forceinline__ void wmask_from_bits(const uint32_t *vw, int lane, uint32_t (&vm)[NJ]);
+
 #ifdef GG_AB_PROF
 // A/B builds only: shader-clock time of the phases of a ply as one wave experiences them (incl. waiting for the SIMD)
 __device__ unsigned long long gg_prof[8];
@@ -230,9 +235,14 @@ struct EnvArgs {
   int heuristic;
   uint32_t *ws;             // IO == 3 only: the caller's workspace, uint32 [B][5N+1] (tracked boards of the last outputs)
   int canonical;            // IO == 3 only
+  // WTS instantiation: the move of every game is DRAWN from these policy weights (float32
+  // [B][N*N+1], gg_ws.h: masked by the game's invalid-move rows, exact fixed-point inverse CDF, the game's generator)
+  // instead of read from `actions` - gogame.random_weighted_action (gym_go/gogame.py:385-392) fused into the step
+  const float *weights;
 };
 
-template <int R, int IO, bool MOVES = false, bool FULLN = false, bool ENV = false>
+// WTS (ENV + MOVES): the move of every game is drawn from env.weights by the kernel (gg_ws.h) instead of read from env.actions
+template <int R, int IO, bool MOVES = false, bool FULLN = false, bool ENV = false, bool WTS = false>
 __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                        int32_t *__restrict__ last_actions, int64_t *__restrict__ steps_done,
                                                        int64_t B, int N, uint32_t inv, int plies, int auto_reset,
@@ -240,6 +250,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
                                                        int32_t *__restrict__ played_out = nullptr, EnvArgs env = EnvArgs()) {
   static_assert(!ENV || IO == 2, "the env step runs on tracked boards");
   static_assert(IO != 3 || (MOVES && !ENV), "the workspace step replays one given move per game");
+  static_assert(!WTS || (ENV && MOVES), "policy-weighted moves belong to the env step's given-moves form");
   constexpr int RS = Lds4<R>::RS;
   constexpr int RV = (R + 3) / 4;
   constexpr int RPL = Lds4<R>::RPL;
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         if (!on) flagsv[sb] = 0;
         lastv[sb] = -1;
         playedv[sb] = 0;
-        if (!MOVES) {
+        if (!MOVES || WTS) {
           const uint64_t x = rng[on ? b_first + sb : B - 1];
           rngv[2 * sb] = (uint32_t)x;
           rngv[2 * sb + 1] = (uint32_t)(x >> 32);
@@ -455,6 +466,74 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
     }
 #undef GG_ISSUE_PAIR
 
+    // ---------------------------------------------------------------- policy-weighted moves (ENV + MOVES + weights)
+    int *wact = reinterpret_cast<int *>(tmp);   // [16] the drawn moves (tmp is free on tracked boards)
+    if (WTS) {
+      constexpr int NJ = (R * R + 1 + 15) / 16;
+      const int A = hf.P + 1;
+      uint32_t *vb = sc;        // [16][16]: the boards' valid-action bit-strings (the flood blocks are free before the ply)
+      uint32_t *uh = clsv;      // [16] draws, [16 .. 31] "this game draws"
+      WAVE_SYNC();
+      for (int i = hf.lane; i < kNB4 * 16; i += kWave) vb[i] = 0;
+      if (hf.lane < kNB4) {
+        const uint32_t fl = flagsv[hf.lane];
+        const bool draws = ((fl >> 3) & 1u) && !(((fl >> 2) & 1u) && !auto_reset);   // a frozen game keeps its generator
+        uint32_t hi = 0;
+        if (draws) {
+          uint64_t x = ((uint64_t)rngv[2 * hf.lane + 1] << 32) | rngv[2 * hf.lane];
+          hi = (uint32_t)(splitmix_next(x) >> 32);
+          rngv[2 * hf.lane] = (uint32_t)x;
+          rngv[2 * hf.lane + 1] = (uint32_t)(x >> 32);
+        }
+        uh[hf.lane] = hi;
+        uh[kNB4 + hf.lane] = draws ? 1u : 0u;
+        wact[hf.lane] = -1;
+      }
+      WAVE_SYNC();
+      {   // every quad ORs the playable points of its rows into its board's string (a game being reset plays on the empty board)
+        const uint32_t fl = flagsv[q4];
+        const bool resets = ((fl >> 2) & 1u) && auto_reset;
+        const uint32_t fullrow = (1u << N) - 1u;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          const int rr = r04 + r;
+          if (rr < N) {
+            const uint32_t ok = resets ? fullrow : (fullrow & ~inv_r[r]);
+            const uint32_t q = (uint32_t)(rr * N);
+            const uint64_t sh = (uint64_t)ok << (q & 31u);
+            atomicOr(vb + 16 * q4 + (q >> 5), (uint32_t)sh);
+            if ((uint32_t)(sh >> 32)) atomicOr(vb + 16 * q4 + (q >> 5) + 1, (uint32_t)(sh >> 32));
+          }
+        }
+        if (t4 == 0) atomicOr(vb + 16 * q4 + (hf.P >> 5), 1u << (hf.P & 31));   // the pass
+      }
+      WAVE_SYNC();
+      // four boards per pass, one DPP row each; the weights of the next pass are in flight while this one is drawn
+      const int rw = hf.lane >> 4;
+      uint32_t nbits[NJ];
+      {
+        const int s0 = rw;
+        const int64_t b0 = (b_first + s0 < B) ? b_first + s0 : B - 1;
+        wload_row<NJ>(env.weights + b0 * (int64_t)A, A, s0 < nb && b_first + s0 < B && uh[kNB4 + s0] != 0u, hf.lane, nbits);
+      }
+#pragma unroll 1
+      for (int ps = 0; ps < 4; ++ps) {
+        uint32_t bits[NJ], vm[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bits[j] = nbits[j];
+        const int s = 4 * ps + rw;
+        if (ps + 1 < 4) {
+          const int s1 = s + 4;
+          const int64_t b1 = (b_first + s1 < B) ? b_first + s1 : B - 1;
+          wload_row<NJ>(env.weights + b1 * (int64_t)A, A, s1 < nb && b_first + s1 < B && uh[kNB4 + s1] != 0u, hf.lane, nbits);
+        }
+        wmask_from_bits<NJ>(vb + 16 * s, hf.lane, vm);
+        const int a = wsample_row<NJ>(bits, vm, uh[s], hf.lane);
+        if (a != -2 && s < nb && b_first + s < B && uh[kNB4 + s] != 0u) wact[s] = a;
+      }
+      WAVE_SYNC();
+    }
+
     // ---------------------------------------------------------------- the plies
     GG_PROF(6);   // load
     int mv_next = 0;
@@ -484,8 +563,9 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         if (MOVES) {
           // the move of this ply was fetched during the previous one (mv_next), the next one is requested now
           const int64_t bm = (b_first + s4 < B) ? b_first + s4 : B - 1;
-          const int mv = t == 0 ? moves[bm * (int64_t)plies] : mv_next;
-          if (t + 1 < plies) mv_next = moves[bm * (int64_t)plies + t + 1];
+          constexpr bool drawn = WTS;   // the move was drawn from the policy weights above
+          const int mv = drawn ? wact[s4] : (t == 0 ? moves[bm * (int64_t)plies] : mv_next);
+          if (!drawn && t + 1 < plies) mv_next = moves[bm * (int64_t)plies + t + 1];
           // (gg_batch_play_moves passes auto_reset = 0: a finished game stops; the env step may reset it first, and the
           // reset stands even when the move is then refused - GoEnv.reset comes before the action check)
           reset = !CACHED && on && done && auto_reset != 0 && !((fl >> 4) & 1u);
@@ -857,7 +937,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         if (CACHED) {
           if (env.status) env.status[b] = played ? GG_STATUS_OK : GG_STATUS_ILLEGAL;
         } else {
-          if (!MOVES) rng[b] = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
+          if (!MOVES || WTS) rng[b] = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
           if (last_actions) last_actions[b] = lastv[sb];
           if (steps_done) steps_done[b] += played;
           if (MOVES && played_out) played_out[b] = played;
@@ -910,7 +990,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         if (env.rewards) env.rewards[b] = rwd;
         if (env.dones) env.dones[b] = (uint8_t)doneb;
         if (env.status) env.status[b] = ((fl >> 4) & 1u) ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
-        if (env.taken) env.taken[b] = MOVES ? env.actions[b] : lastv[q4s];
+        if (env.taken) env.taken[b] = MOVES ? (WTS ? wact[q4s] : env.actions[b]) : lastv[q4s];
       }
       if (env.states_out) {
         // the observation: every board of the group as byte planes, one contiguous write

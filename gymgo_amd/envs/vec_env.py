@@ -80,6 +80,12 @@ class GoVecEnv:
     def _store(self):
         return {'packed': lambda: self.packed_states, 'tracked': lambda: self.tracked, 'bytes': lambda: self._states}[self.layout]()
 
+    def _store_done(self):
+        """bool [B]: the game-over flag of every resident game."""
+        if self.layout == 'bytes':
+            return self._states[:, govars.DONE_CHNL, 0, 0] != 0
+        return (self._store()[:, -1] & 4) != 0
+
     def reset(self, mask=None):
         store = self._store()
         if mask is None:
@@ -97,18 +103,31 @@ class GoVecEnv:
         """Uniform over valid actions incl. pass, per game, on the device."""
         return gogame.batch_sample_actions(self.states, self.rng)
 
-    def step(self, actions=None, check=False):
+    def step(self, actions=None, check=False, probs=None):
         """One GoEnv.step per game in ONE launch -> (states, rewards, dones, status); `states` is the uint8 observation
         (layout 'tracked': written by the step itself; 'bytes': the resident tensor; 'packed': the packed tensor).
         actions=None draws a uniform-random valid action per game on the device (it is left in self.last_actions).
+        probs = float32 [B, N*N+1] policy weights (need not be normalised): the move of every game is drawn from them,
+        masked by the game's invalid moves, on the device (gogame.random_weighted_action, gym_go/gogame.py:385-392) - by
+        the step launch itself with layout 'tracked', by one sampling launch before it otherwise; the drawn moves are
+        left in self.last_actions, a game without a positive playable weight is refused (status 1).
         Finished games are reset first when auto_reset; rewards are float32, black's perspective
         (gym_go/envs/go_env.py:128-149).  The returned tensors are fixed buffers, overwritten by the next step()."""
+        if actions is not None and probs is not None:
+            raise ValueError('give actions OR probs, not both')
         if actions is not None:
             actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        if probs is not None and self.layout != 'tracked':
+            # (a finished game is reset by the step before the move is checked, so it is drawn for on the empty board)
+            if self.auto_reset:
+                self.reset(self._store_done())
+            actions = (gogame.batch_sample_weighted(self._states, probs, self.rng) if self.layout == 'bytes' else
+                       gogame.batch_sample_weighted_rows(self.packed_states, self.size, probs, self.rng))
+            probs = None
         if self.layout == 'tracked':
             rewards, dones, status, taken = gogame.batch_env_step_tracked(
                 self.tracked, actions, self.rng, self.komi, self.reward_method, self.auto_reset, out=self._step_out,
-                states_out=self._obs, steps_done=self.steps_done)      # the launch counts the played steps itself
+                states_out=self._obs, steps_done=self.steps_done, weights=probs)   # the launch counts the played steps itself
             self._obs_fresh = True
             if check and bool((status != 0).any()):
                 raise AssertionError('illegal move in batch')

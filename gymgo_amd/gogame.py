@@ -684,14 +684,23 @@ def batch_play_moves_tracked(tracked, moves, played=None):
 
 
 def batch_env_step_tracked(tracked, actions=None, rng=None, komi=0.0, reward_method='real', auto_reset=True, out=None,
-                           states_out=None, steps_done=None):
+                           states_out=None, steps_done=None, weights=None):
     """IN PLACE GoEnv.step (gym_go/envs/go_env.py:49-76) of every game on TRACKED boards in ONE launch
     (gg_batch_env_step_tracked): no per-ply analysis.  -> (rewards, dones, status, taken) like batch_env_step;
     states_out: a uint8 [B,6,N,N] device tensor that receives the byte-plane observation of every game (optional);
-    steps_done: an int64 [B] device tensor, += 1 for every game whose step was played (optional)."""
+    steps_done: an int64 [B] device tensor, += 1 for every game whose step was played (optional).
+    weights: float32 [B, N*N+1] policy weights - the move of every game is then DRAWN from them by the same launch
+    (gg_batch_env_step_tracked_weighted: gogame.random_weighted_action, gym_go/gogame.py:385-392, masked by the game's
+    invalid moves, with `rng`); `taken` receives the drawn moves, a game without a positive playable weight is refused."""
     N = _tracked_size(tracked)
     B = tracked.shape[0]
     dev = tracked.device
+    if weights is not None:
+        if actions is not None:
+            raise ValueError('give actions OR weights, not both')
+        if rng is None:
+            raise ValueError('drawing from weights needs the rng state')
+        weights = _weights_tensor(weights, B, N, dev)
     if actions is None and rng is None:
         raise ValueError('batch_env_step_tracked needs actions or an rng state to draw them with')
     if out is None:
@@ -700,6 +709,15 @@ def batch_env_step_tracked(tracked, actions=None, rng=None, komi=0.0, reward_met
     if states_out is not None and tuple(states_out.shape) != (B, govars.NUM_CHNLS, N, N):
         raise ValueError('states_out must be uint8 [B, 6, N, N]')
     rewards, dones, status, taken = out
+    if weights is not None:
+        code = _lib.lib().gg_batch_env_step_tracked_weighted(
+            _lib.dev_ptr(tracked, _I32, 'tracked'), _lib.dev_ptr(weights, torch.float32, 'weights'), _lib.dev_ptr(rng, _I64, 'rng'),
+            _lib.dev_ptr(rewards, torch.float32, 'rewards'), _lib.dev_ptr(dones, _U8, 'dones'), _lib.dev_ptr(status, _I32, 'status'),
+            _lib.dev_ptr(taken, _I32, 'taken'), _lib.dev_ptr(states_out, _U8, 'states_out'),
+            _lib.dev_ptr(steps_done, _I64, 'steps_done'), B, N, float(komi),
+            REWARD_METHODS[reward_method], int(bool(auto_reset)), _lib.stream_ptr(dev))
+        _lib.check(code, 'gg_batch_env_step_tracked_weighted')
+        return out
     code = _lib.lib().gg_batch_env_step_tracked(
         _lib.dev_ptr(tracked, _I32, 'tracked'), _lib.dev_ptr(actions, _I32, 'actions'), _lib.dev_ptr(rng, _I64, 'rng'),
         _lib.dev_ptr(rewards, torch.float32, 'rewards'), _lib.dev_ptr(dones, _U8, 'dones'), _lib.dev_ptr(status, _I32, 'status'),
@@ -708,3 +726,136 @@ def batch_env_step_tracked(tracked, actions=None, rng=None, komi=0.0, reward_met
         REWARD_METHODS[reward_method], int(bool(auto_reset)), _lib.stream_ptr(dev))
     _lib.check(code, 'gg_batch_env_step_tracked')
     return out
+
+
+# ---------------------------------------------------------------- policy-weighted sampling on the device
+# gogame.random_weighted_action / random_action (gym_go/gogame.py:385-404) for every game of a batch: what a self-play loop
+# with a policy network calls after the forward pass.  The draw is defined in integers (include/gymgo_amd.h,
+# gg_batch_sample_weighted) so that device and CPU restatement agree bit for bit; P(a) = w[a] / sum(w) over the playable
+# actions up to 22-bit fixed point relative to the largest weight.
+
+def _weights_tensor(weights, B, N, device):
+    if not isinstance(weights, torch.Tensor):
+        weights = torch.as_tensor(np.asarray(weights, dtype=np.float32))
+    w = weights.to(device=device, dtype=torch.float32).contiguous()
+    if tuple(w.shape) != (B, N * N + 1):
+        raise ValueError('weights must be float32 [B, N*N+1] = [%d, %d] (got %s)' % (B, N * N + 1, tuple(w.shape)))
+    return w
+
+
+def _check_drawn(actions, check):
+    if check and bool((actions < 0).any()):
+        raise ValueError('no positive weight on a playable action for some game (np.random.choice raises here too)')
+    return actions
+
+
+def batch_sample_weighted(batch_states, weights, rng, check=False):
+    """actions[b] ~ weights[b] / sum(weights[b]) over the actions plane 3 of batch_states[b] allows (the pass always;
+    a finished game allows everything) - gogame.random_weighted_action (gym_go/gogame.py:385-392) per game, on the device,
+    with the per-game generator `rng` (advanced once).  batch_states=None: nothing is masked (the reference "assumes all
+    invalid moves have weight 0").  A game without a positive playable weight gets -1 (check=True: ValueError)."""
+    if batch_states is not None:
+        B, C, N, _ = batch_states.shape
+        dev = batch_states.device
+    else:
+        if not isinstance(weights, torch.Tensor):
+            raise ValueError('without states the weights must be a device tensor')
+        B, dev = weights.shape[0], weights.device
+        N = int(round((weights.shape[1] - 1) ** 0.5))
+    w = _weights_tensor(weights, B, N, dev)
+    actions = torch.empty(B, dtype=_I32, device=dev)
+    code = _lib.lib().gg_batch_sample_weighted(
+        _lib.dev_ptr(batch_states, _U8, 'states'), _lib.dev_ptr(w, torch.float32, 'weights'), _lib.dev_ptr(rng, _I64, 'rng'),
+        _lib.dev_ptr(actions, _I32, 'actions'), B, N, _lib.stream_ptr(dev))
+    _lib.check(code, 'gg_batch_sample_weighted')
+    return _check_drawn(actions, check)
+
+
+def batch_sample_weighted_rows(boards, board_size, weights, rng, check=False):
+    """The same draw for packed (int32 [B, 3N+1]) or tracked (int32 [B, 5N+1]) boards."""
+    B, W = boards.shape
+    N = int(board_size)
+    planes = (W - 1) // N if N > 0 else 0
+    if boards.dtype != _I32 or planes * N + 1 != W or planes not in (3, 5):
+        raise ValueError('boards must be packed [B, 3N+1] or tracked [B, 5N+1] int32 for N = %d (got %s)' % (N, tuple(boards.shape)))
+    w = _weights_tensor(weights, B, N, boards.device)
+    actions = torch.empty(B, dtype=_I32, device=boards.device)
+    code = _lib.lib().gg_batch_sample_weighted_rows(
+        _lib.dev_ptr(boards, _I32, 'boards'), planes, _lib.dev_ptr(w, torch.float32, 'weights'), _lib.dev_ptr(rng, _I64, 'rng'),
+        _lib.dev_ptr(actions, _I32, 'actions'), B, N, _lib.stream_ptr(boards.device))
+    _lib.check(code, 'gg_batch_sample_weighted_rows')
+    return _check_drawn(actions, check)
+
+
+def batch_random_action(batch_states, rng):
+    """gogame.random_action (gym_go/gogame.py:395-404) per game: weights 1 - invalid_moves, i.e. uniform over the playable
+    actions, through the weighted sampler (batch_sample_actions draws the same distribution with a cheaper kernel)."""
+    B, C, N, _ = batch_states.shape
+    ones = torch.ones((B, N * N + 1), dtype=torch.float32, device=batch_states.device)
+    return batch_sample_weighted(batch_states, ones, rng)
+
+
+# ---------------------------------------------------------------- batched symmetries on the device
+# gogame.all_symmetries / random_symmetry (gym_go/gogame.py:340-382) for whole batches: one orientation per game or all
+# eight, on byte planes (any channel count) and on packed / tracked boards.
+
+def batch_symmetry(batch_images, orient=None, out=None):
+    """uint8 [B, C, N, N] device tensor -> the view `orient[b]` (int32 [B], 0..7, composed as the reference does: bit 0
+    flip the columns, bit 1 flip the rows, bit 2 rot90) of every image: [B, C, N, N]; orient=None: all eight views,
+    [B, 8, C, N, N] in the order of all_symmetries (gg_batch_symmetry)."""
+    B, C, N, N2 = batch_images.shape
+    if N != N2:
+        raise ValueError('images must be [B, C, N, N]')
+    dev = batch_images.device
+    shape = (B, C, N, N) if orient is not None else (B, 8, C, N, N)
+    if out is None:
+        out = torch.empty(shape, dtype=_U8, device=dev)
+    elif tuple(out.shape) != shape:
+        raise ValueError('out must be uint8 %s' % (shape,))
+    if orient is not None:
+        orient = _actions_tensor(orient, B, dev)
+    code = _lib.lib().gg_batch_symmetry(_lib.dev_ptr(batch_images, _U8, 'images'), _lib.dev_ptr(orient, _I32, 'orient'),
+                                        _lib.dev_ptr(out, _U8, 'out'), B, C, N, _lib.stream_ptr(dev))
+    _lib.check(code, 'gg_batch_symmetry')
+    return out
+
+
+def batch_symmetry_rows(boards, board_size, orient=None):
+    """The same on packed (int32 [B, 3N+1]) / tracked (int32 [B, 5N+1]) boards: -> [B, W], or [B, 8, W] for all eight
+    views (gg_batch_symmetry_rows).  A transformed tracked board is a valid tracked board."""
+    B, W = boards.shape
+    N = int(board_size)
+    planes = (W - 1) // N if N > 0 else 0
+    if boards.dtype != _I32 or planes * N + 1 != W or planes not in (3, 5):
+        raise ValueError('boards must be packed [B, 3N+1] or tracked [B, 5N+1] int32 for N = %d (got %s)' % (N, tuple(boards.shape)))
+    out = torch.empty((B, W) if orient is not None else (B, 8, W), dtype=_I32, device=boards.device)
+    if orient is not None:
+        orient = _actions_tensor(orient, B, boards.device)
+    code = _lib.lib().gg_batch_symmetry_rows(_lib.dev_ptr(boards, _I32, 'boards'), planes, _lib.dev_ptr(orient, _I32, 'orient'),
+                                             _lib.dev_ptr(out, _I32, 'out'), B, N, _lib.stream_ptr(boards.device))
+    _lib.check(code, 'gg_batch_symmetry_rows')
+    return out
+
+
+def batch_random_symmetry(batch_images, generator=None):
+    """gogame.random_symmetry (gym_go/gogame.py:340-359) per game: -> (views [B, C, N, N], orient int32 [B]); the
+    orientations come from torch's device generator (pass `generator` for reproducibility)."""
+    B = batch_images.shape[0]
+    orient = torch.randint(0, 8, (B,), dtype=_I32, device=batch_images.device, generator=generator)
+    return batch_symmetry(batch_images, orient), orient
+
+
+def symmetry_actions(actions, orient, board_size):
+    """Where a move lands under the views above: action a of the ORIGINAL board -> the action that marks the same point
+    on the view `orient` (the pass stays the pass).  int tensors / arrays [B] -> int32 tensor [B] on actions' device."""
+    N = int(board_size)
+    a = actions if isinstance(actions, torch.Tensor) else torch.as_tensor(np.asarray(actions))
+    o = orient if isinstance(orient, torch.Tensor) else torch.as_tensor(np.asarray(orient))
+    a = a.to(torch.int64)
+    o = o.to(device=a.device, dtype=torch.int64)
+    sr, sc = torch.div(a, N, rounding_mode='floor'), a % N
+    r1 = torch.where((o & 2) != 0, N - 1 - sr, sr)
+    c1 = torch.where((o & 1) != 0, N - 1 - sc, sc)
+    r = torch.where((o & 4) != 0, N - 1 - c1, r1)
+    c = torch.where((o & 4) != 0, r1, c1)
+    return torch.where(a >= N * N, a, r * N + c).to(_I32)

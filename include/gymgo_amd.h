@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 2
+#define GG_ABI_VERSION 3
 #define GG_MAX_BOARD 19
 #define GG_NUM_CHNLS 6
 
@@ -235,6 +235,60 @@ int32_t gg_batch_env_step_tracked(uint32_t *tracked, const int32_t *actions, uin
                                   int32_t *status, int32_t *taken_actions, uint8_t *states_out, int64_t *steps_done,
                                   int64_t B, int32_t N, float komi, int32_t reward_method, int32_t auto_reset,
                                   void *hip_stream);
+
+/*
+ * gg_batch_env_step_tracked with the move of every game DRAWN FROM POLICY WEIGHTS by the same launch:
+ * gogame.random_weighted_action (gym_go/gogame.py:385-392) fused into GoEnv.step (gym_go/envs/go_env.py:49-76).
+ * weights: float32 [B][N*N+1] (one weight per action, the pass last).  Per game: a finished game is reset first when
+ * auto_reset; the weights are masked by the game's invalid-move rows (the pass is always playable), L1-normalised and
+ * drawn from as gg_batch_sample_weighted describes, with rng[b] (which advances once; a frozen game - finished,
+ * auto_reset == 0 - draws nothing and is refused).  A game whose playable weights are all zero is refused
+ * (status GG_STATUS_ILLEGAL, taken action -1) - np.random.choice raises for such a vector.  Other arguments and
+ * outputs as gg_batch_env_step_tracked; taken_actions receives the drawn moves.
+ */
+int32_t gg_batch_env_step_tracked_weighted(uint32_t *tracked, const float *weights, uint64_t *rng, float *rewards,
+                                           uint8_t *dones, int32_t *status, int32_t *taken_actions, uint8_t *states_out,
+                                           int64_t *steps_done, int64_t B, int32_t N, float komi, int32_t reward_method,
+                                           int32_t auto_reset, void *hip_stream);
+
+/*
+ * gogame.random_weighted_action(move_weights)                           gym_go/gogame.py:385-392
+ * gogame.random_action(state) = the same with weights 1 - invalid       gym_go/gogame.py:395-404
+ * for every game: actions[b] ~ weights[b] / sum(weights[b]) over the playable actions.  The reference normalises in
+ * float64 and draws from NumPy's global generator; so that device and oracle agree bit for bit the draw is defined in
+ * integers: (1) each float32 weight is clamped to [+0, FLT_MAX] on its bit pattern (negative -> 0, NaN / inf -> FLT_MAX)
+ * and zeroed where plane 3 of states[b] is set (the reference ASSUMES invalid moves have weight 0, :387; the pass is
+ * never masked, a finished game masks nothing, gym_go/gogame.py:155-156; states == NULL: no mask); (2) with E = max(the
+ * largest weight's biased exponent, 24), q[a] = trunc(w[a] * 2^(148 - E)) < 2^22: the weights as 22-bit fixed point
+ * relative to the largest; (3) T = sum q, k = floor((u >> 32) * T / 2^32) with u the next output of rng[b]
+ * (gg_rng_seed's generator, advanced once per game per call); (4) the action is the first one, in the interleaved order
+ * a = i + 16 j (i = 0..15 outer), whose running sum of q exceeds k, so P(a) = q[a] / T.  T == 0 gives actions[b] = -1.
+ */
+int32_t gg_batch_sample_weighted(const uint8_t *states, const float *weights, uint64_t *rng, int32_t *actions, int64_t B,
+                                 int32_t N, void *hip_stream);
+
+/* The same draw for row-mask boards: planes = 3 (packed, gg_batch_pack_states) or 5 (tracked, gg_batch_track_states). */
+int32_t gg_batch_sample_weighted_rows(const uint32_t *boards, int32_t planes, const float *weights, uint64_t *rng,
+                                      int32_t *actions, int64_t B, int32_t N, void *hip_stream);
+
+/*
+ * gogame.all_symmetries(image) / gogame.random_symmetry(image)          gym_go/gogame.py:340-382
+ * for a batch: in is uint8 [B][C][N][N] (any C >= 1 with C*N*N <= 8192: states, observations, per-point targets).
+ * orient: int32 [B], the orientation of each game in 0..7 composed exactly as the reference does (bit 0 flip the columns,
+ * then bit 1 flip the rows, then bit 2 np.rot90 over the board axes) -> out is [B][C][N][N]; orient == NULL: all eight
+ * views of every game, out is [B][8][C][N][N] in the order of all_symmetries.  in and out must not overlap.
+ */
+int32_t gg_batch_symmetry(const uint8_t *in, const int32_t *orient, uint8_t *out, int64_t B, int32_t C, int32_t N,
+                          void *hip_stream);
+
+/*
+ * The same on row-mask boards (planes = 3 packed / 5 tracked; uint32 [B][planes*N+1]): every row plane is transformed
+ * (a column flip is a bit reversal, a row flip a row permutation, the rotation a bit transpose), the flag word copied -
+ * liberty classes and the invalid-move rows (ko point included) are geometric, so the result is a valid board of the
+ * same format.  out is [B][W] (orient given) or [B][8][W].
+ */
+int32_t gg_batch_symmetry_rows(const uint32_t *in, int32_t planes, const int32_t *orient, uint32_t *out, int64_t B,
+                               int32_t N, void *hip_stream);
 
 /* rng[b] = initial generator state for (base_seed, game index first_game + b). */
 int32_t gg_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B, void *hip_stream);

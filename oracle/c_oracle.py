@@ -50,6 +50,9 @@ def lib():
                                               ctypes.c_int32]
         L.gg_oracle_update_pieces.restype = ctypes.c_int32
         L.gg_oracle_update_pieces.argtypes = [_u8p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _u8p]
+        L.gg_oracle_batch_sample_weighted.restype = None
+        L.gg_oracle_batch_sample_weighted.argtypes = [_u8p, ctypes.POINTER(ctypes.c_float), _u64p, _i32p, ctypes.c_int64,
+                                                      ctypes.c_int32]
         _lib = L
     return _lib
 
@@ -123,6 +126,25 @@ def batch_rollout(states, rng, plies, auto_reset=True):
     lib().gg_oracle_batch_rollout(states.ctypes.data_as(_u8p), rng.ctypes.data_as(_u64p),
                                   last.ctypes.data_as(_i32p), B, N, int(plies), int(bool(auto_reset)))
     return states, rng, last
+
+
+def batch_sample_weighted(states, weights, rng):
+    """Policy-weighted draw per game (see gg_oracle_sample_weighted): states [B,6,N,N] (plane 3 masks) or None,
+    weights float32 [B,N*N+1], rng uint64 [B] -> (actions int32 [B], rng after)."""
+    weights = np.ascontiguousarray(weights, dtype=np.float32)
+    B = weights.shape[0]
+    N = int(round((weights.shape[1] - 1) ** 0.5))
+    assert N * N + 1 == weights.shape[1]
+    rng = np.array(rng, dtype=np.uint64, copy=True)
+    actions = np.empty(B, dtype=np.int32)
+    if states is None:
+        sp = None
+    else:
+        states, sp = _u8(states)
+        assert states.shape == (B, 6, N, N)
+    lib().gg_oracle_batch_sample_weighted(sp, weights.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                          rng.ctypes.data_as(_u64p), actions.ctypes.data_as(_i32p), B, N)
+    return actions, rng
 
 
 def update_pieces(state, adj_flat, player):

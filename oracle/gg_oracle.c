@@ -393,4 +393,69 @@ void gg_oracle_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actio
     }
 }
 
-int32_t gg_oracle_version(void) { return 1; }
+/* ---- policy-weighted action sampling: gogame.random_weighted_action (gym_go/gogame.py:385-392: L1-normalise the move
+ * weights, draw from them) and gogame.random_action (:395-404: the same with weights 1 - invalid_moves).  The reference
+ * normalises in float64 and draws from NumPy's global generator; the build defines an EXACT integer form so that the
+ * device and this oracle pick identical actions from identical weights:
+ *   1. v[a] = the float32 weight clamped to [+0, FLT_MAX] on its bit pattern (negative -> 0, NaN / +inf -> FLT_MAX),
+ *      and 0 where plane 3 marks the point invalid (a < N*N; "assumes all invalid moves have weight 0", :387 - here
+ *      enforced); the pass (a = N*N) is never masked;
+ *   2. E = max(biased exponent of max v, 24), S = 2^(148 - E) (bits (275 - E) << 23), q[a] = trunc(v[a] * S) < 2^22:
+ *      an exact power-of-two scaling, i.e. the weights as 22-bit fixed point relative to the largest one
+ *      (weights below 2^-22 of the largest, or below 2^-103, count as 0);
+ *   3. T = sum q (< 2^31); one draw of the game's generator: k = floor((u >> 32) * T / 2^32), uniform on [0, T);
+ *   4. inverse CDF in the INTERLEAVED action order a = i + 16 j (i = 0..15 outer, j inner - one 16-lane DPP row per
+ *      board on the device): the first a of that order whose running sum of q exceeds k.  Any fixed order gives
+ *      P(a) = q[a] / T.
+ * T == 0 (no positive weight on a valid action) returns -1: np.random.choice raises for such a vector.
+ * The generator advances exactly once per call. ---- */
+int32_t gg_oracle_sample_weighted(const uint8_t *invalid, const float *w, uint64_t *rng, int32_t N)
+{
+    int P = N * N, A = P + 1;
+    uint32_t v[GG_MAXP + 1], q[GG_MAXP + 1], mx = 0;
+    for (int a = 0; a < A; ++a) {
+        int32_t bits;
+        memcpy(&bits, &w[a], 4);
+        if (bits < 0) bits = 0;
+        if (bits > 0x7F7FFFFF) bits = 0x7F7FFFFF;
+        if (a < P && invalid && invalid[a]) bits = 0;
+        v[a] = (uint32_t)bits;
+        if (v[a] > mx) mx = v[a];
+    }
+    uint32_t E = mx >> 23;
+    if (E < 24) E = 24;
+    uint32_t sbits = (275u - E) << 23;
+    float S;
+    memcpy(&S, &sbits, 4);
+    uint32_t T = 0;
+    for (int a = 0; a < A; ++a) {
+        float f;
+        memcpy(&f, &v[a], 4);
+        volatile float prod = f * S; /* one IEEE single-precision product (exact: S is a power of two) */
+        q[a] = (uint32_t)prod;
+        T += q[a];
+    }
+    uint64_t u = splitmix_next(rng);
+    if (T == 0) return -1;
+    uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)T) >> 32);
+    uint32_t run = 0;
+    for (int i = 0; i < 16; ++i)
+        for (int a = i; a < A; a += 16) {
+            run += q[a];
+            if (run > k) return a;
+        }
+    return -1; /* unreachable: run reaches T > k */
+}
+
+/* actions[b] = gg_oracle_sample_weighted(plane 3 of states[b], weights[b], &rng[b]); weights float32 [B][N*N+1].
+ * A finished game masks nothing (gogame.invalid_moves returns zeros once the game has ended, gym_go/gogame.py:155-156). */
+void gg_oracle_batch_sample_weighted(const uint8_t *states, const float *weights, uint64_t *rng, int32_t *actions,
+                                     int64_t B, int32_t N)
+{
+    size_t P = (size_t)N * N, S = (size_t)NUM_CHNLS * P;
+    for (int64_t b = 0; b < B; ++b)
+        actions[b] = gg_oracle_sample_weighted((states && !game_ended(states + b * S, N)) ? states + b * S + (size_t)INVD_CHNL * P : NULL,
+                                               weights + b * (P + 1), rng + b, N);
+}
+
+int32_t gg_oracle_version(void) { return 2; }

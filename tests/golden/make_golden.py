@@ -14,6 +14,13 @@ Outputs (committed; data only - inputs and expected outputs, no reference source
                  views of a [C,N,N] image), state_utils.update_pieces on ARBITRARY (not legally reachable) positions
                  incl. every corner / edge, with the location lists the reference's callers pass and longer ones.
 
+  policy.npz     gogame.random_weighted_action / random_action (gym_go/gogame.py:385-404): for several weight vectors (with
+                 and without an invalid-move mask) the probability vector the REFERENCE draws from (its own
+                 sklearn l1-normalisation) and the histogram of 20 000 seeded draws of the reference itself; plus
+                 mid-game states whose plane 3 masks the weights, and the actions the build's exact sampler
+                 (oracle/gg_oracle.c, gg_oracle_sample_weighted) draws for them (these pin kernel == oracle on the
+                 GPU box; the reference pins the DISTRIBUTION).
+
   python tests/golden/make_golden.py [name ...]     (no name = all of them)
 """
 import hashlib
@@ -306,6 +313,82 @@ def extras(gogame, govars, state_utils):
     print('extras: %d texts, 4 symmetry images, %d update_pieces cases (%d with captures)' % (len(texts), len(cases), n_kill))
 
 
+def policy(gogame, govars):
+    from sklearn import preprocessing
+    rng = np.random.default_rng(23)
+    out = {}
+    cases = []
+    for size in (2, 5, 9, 19):
+        A = size * size + 1
+        # a mid-game position of the reference itself: its plane 3 is the mask
+        s = gogame.init_state(size)
+        for _ in range(int(1.2 * size * size)):
+            if gogame.game_ended(s):
+                break
+            valid = np.flatnonzero(np.append(s[govars.INVD_CHNL].ravel(), 0) == 0)
+            s = gogame.next_state(s, int(rng.choice(valid)))
+        if gogame.game_ended(s):
+            s = gogame.init_state(size)
+        invalid = np.append(s[govars.INVD_CHNL].ravel(), 0)
+        for kind in ('uniform_valid', 'softmax', 'peaked', 'sparse'):
+            if kind == 'uniform_valid':      # gogame.random_action's own weights
+                w = 1 - invalid
+            elif kind == 'softmax':
+                z = rng.normal(0, 2.0, A)
+                w = np.exp(z - z.max()) * (1 - invalid)
+            elif kind == 'peaked':
+                w = (rng.random(A) ** 8) * (1 - invalid)
+                w[int(np.flatnonzero(1 - invalid)[0])] = 40.0
+            else:
+                w = np.where(rng.random(A) < 0.2, rng.random(A), 0.0) * (1 - invalid)
+                w[A - 1] = 0.05
+            w = w.astype(np.float32)
+            p = preprocessing.normalize(w.astype(np.float64)[np.newaxis], norm='l1')[0]   # gym_go/gogame.py:391
+            np.random.seed(1000 + len(cases))
+            draws = np.array([gogame.random_weighted_action(w.astype(np.float64)) for _ in range(20000)])
+            cases.append((size, kind))
+            k = 'case/%d/' % (len(cases) - 1)
+            out[k + 'size'] = np.array(size, dtype=np.int32)
+            out[k + 'kind'] = np.array(kind)
+            out[k + 'state'] = u8(s)
+            out[k + 'weights'] = w
+            out[k + 'p_reference'] = p
+            out[k + 'hist_reference'] = np.bincount(draws, minlength=A).astype(np.int32)
+        # gogame.random_action on the same state: its histogram
+        np.random.seed(77 + size)
+        ra = np.array([gogame.random_action(s) for _ in range(20000)])
+        out['random_action/%d/state' % size] = u8(s)
+        out['random_action/%d/hist_reference' % size] = np.bincount(ra, minlength=A).astype(np.int32)
+    out['case/count'] = np.array(len(cases), dtype=np.int32)
+    # the build's exact sampler on batches of reference-made states: (states, weights, rng) -> actions
+    for size in (5, 9, 19):
+        A = size * size + 1
+        B = 64
+        states = []
+        for b in range(B):
+            s = gogame.init_state(size)
+            for _ in range(int(rng.integers(0, 2 * size * size))):
+                if gogame.game_ended(s):
+                    break
+                valid = np.flatnonzero(np.append(s[govars.INVD_CHNL].ravel(), 0) == 0)
+                s = gogame.next_state(s, int(rng.choice(valid)))
+            states.append(u8(s))
+        states = np.stack(states)
+        w = (rng.random((B, A)) ** 3).astype(np.float32)
+        w[::7] *= 1e-30
+        w[3::11, : A // 2] = 0
+        w[5] = 0                      # nothing playable has weight: -1
+        w[6, :-1] = 0
+        w[6, -1] = 1e-3               # only the pass
+        w[9, 0] = -4.0                # a negative weight counts as 0
+        rng0 = c_oracle.rng_seed(31 + size, B)
+        acts, rng1 = c_oracle.batch_sample_weighted(states, w, rng0)
+        k = 'exact/%d/' % size
+        out[k + 'states'], out[k + 'weights'], out[k + 'rng0'], out[k + 'rng1'], out[k + 'actions'] = states, w, rng0, rng1, acts
+    np.savez_compressed(os.path.join(HERE, 'policy.npz'), **out)
+    print('policy: %d weight vectors x 20 000 reference draws, exact-sampler batches at 5 / 9 / 19' % len(cases))
+
+
 def main():
     gym, gogame, govars, state_utils = refimport.load()
     jobs = {
@@ -315,6 +398,7 @@ def main():
         'batch_passes': lambda: batch_passes(gogame, govars),
         'rollout': lambda: rollout(gogame, govars),
         'extras': lambda: extras(gogame, govars, state_utils),
+        'policy': lambda: policy(gogame, govars),
     }
     for name in (sys.argv[1:] or list(jobs)):
         jobs[name]()

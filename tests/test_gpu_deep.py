@@ -158,8 +158,8 @@ def test_tracked_env_step_resets_finished_games_whose_move_is_refused(B):
     rng = gogame.rng_seed(B, 3)
     gogame.batch_rollout(st, rng, 30, False)
     passes = torch.full((B,), N * N, dtype=torch.int32, device='cuda')
-    st, _ = gogame.batch_next_states(st, passes)
-    st, _ = gogame.batch_next_states(st, passes)
+    st = gogame.batch_next_states(st, passes)
+    st = gogame.batch_next_states(st, passes)
     assert bool((st[:, 5, 0, 0] == 1).all()) and int(st[:, 0].sum()) > 0
     bad = torch.full((B,), N * N + 1, dtype=torch.int32, device='cuda')
     bad[B // 2:] = -7

@@ -172,3 +172,36 @@ def test_c_restatement_vs_scipy_port_on_every_child(size, depths):
                         b, w = c_oracle.batch_areas(kids[a][None])
                         nb, nw = np_oracle.areas(want)
                         assert (int(b[0]), int(w[0])) == (int(nb), int(nw)), (size, depth, a)
+
+
+def test_weighted_sampler_oracle_distribution_matches_the_reference(golden):
+    """CPU: the exact integer sampler of oracle/gg_oracle.c (gg_oracle_sample_weighted) draws from the distribution the
+    REFERENCE draws from - its own sklearn l1-normalisation of the weights (gym_go/gogame.py:391), recorded per weight
+    vector in tests/golden/policy.npz together with 20 000 of the reference's own seeded draws; and the committed
+    (states, weights, generator) -> actions vectors reproduce."""
+    from oracle import c_oracle
+    z = golden('policy')
+    n = 20000
+    for c in range(int(z['case/count'])):
+        k = 'case/%d/' % c
+        N = int(z[k + 'size'])
+        state, w, p, href = z[k + 'state'], z[k + 'weights'], z[k + 'p_reference'], z[k + 'hist_reference']
+        assert abs(p.sum() - 1) < 1e-9 and not p[np.append(state[3].ravel(), 0) == 1].any()
+        acts, _ = c_oracle.batch_sample_weighted(np.broadcast_to(state, (n,) + state.shape), np.broadcast_to(w, (n, len(w))),
+                                                 c_oracle.rng_seed(500 + c, n))
+        hist = np.bincount(acts, minlength=N * N + 1)
+        sigma = np.sqrt(n * p * (1 - p))
+        assert np.all(np.abs(hist - n * p) <= 5 * sigma + 1.5), (c, str(z[k + 'kind']))
+        assert not hist[p == 0].any()
+        both = (hist + href) > 0
+        chi2 = float((((hist - href) ** 2)[both] / (hist + href)[both]).sum())
+        dof = int(both.sum()) - 1
+        assert chi2 < dof + 6 * np.sqrt(2 * max(dof, 1)) + 10, (c, chi2, dof)
+    for N in (5, 9, 19):
+        k = 'exact/%d/' % N
+        acts, rng1 = c_oracle.batch_sample_weighted(z[k + 'states'], z[k + 'weights'], z[k + 'rng0'])
+        assert np.array_equal(acts, z[k + 'actions']) and np.array_equal(rng1, z[k + 'rng1'])
+        # the quantisation is monotone and scale-free: multiplying a row by a power of two never changes the draw
+        acts2, _ = c_oracle.batch_sample_weighted(z[k + 'states'], z[k + 'weights'] * np.float32(2.0 ** 20), z[k + 'rng0'])
+        big = np.abs(z[k + 'weights']).max(axis=1) > 1e-20      # (rows scaled by 1e-30 leave the normal range when un-scaled)
+        assert np.array_equal(acts2[big], z[k + 'actions'][big])
