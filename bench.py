@@ -69,7 +69,13 @@ def cpu_baseline(size, seconds_per_worker=6.0, max_workers=None):
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = host
-    cores = max(1, min(usable, max_workers or usable))
+    try:      # a container may own fewer CPUs' worth of time than it can see: more workers than that only contend
+        quota = open('/sys/fs/cgroup/cpu.max').read().split()
+        cgroup = None if quota[0] == 'max' else float(quota[0]) / float(quota[1])
+    except Exception:
+        cgroup = None
+    granted = usable if not cgroup else max(1, min(usable, int(cgroup + 0.999)))
+    cores = max(1, min(granted, max_workers or granted))
     ctx = mp.get_context('spawn')
     one_thread = {k: '1' for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS', 'NUMEXPR_NUM_THREADS')}
     saved = {k: os.environ.get(k) for k in one_thread}
@@ -97,16 +103,11 @@ def cpu_baseline(size, seconds_per_worker=6.0, max_workers=None):
         c_rate = round(32 * 600 / (time.perf_counter() - c0), 1)
     except Exception:
         c_rate = None
-    try:      # a container may own fewer CPUs' worth of time than it can see
-        quota = open('/sys/fs/cgroup/cpu.max').read().split()
-        cgroup = None if quota[0] == 'max' else round(float(quota[0]) / float(quota[1]), 2)
-    except Exception:
-        cgroup = None
     total = float(sum(steps))
     ratio = PORT_STEPS_PER_S_PER_CORE_BUILD_BOX / REFERENCE_STEPS_PER_S_PER_CORE_BUILD_BOX
     return {
         'value': round(total / seconds_per_worker, 1), 'unit': 'env steps/s', 'cores': cores, 'kind': 'port',
-        'host_cpu_count': host, 'usable_cpus': usable, 'cgroup_cpu_quota_cores': cgroup, 'per_core': round(total / seconds_per_worker / cores, 1),
+        'host_cpu_count': host, 'usable_cpus': usable, 'cgroup_cpu_quota_cores': None if cgroup is None else round(cgroup, 2), 'per_core': round(total / seconds_per_worker / cores, 1),
         'c_restatement_steps_per_s_one_core': c_rate,
         # the port is FASTER than the reference it restates: divide by this to estimate the reference on this box
         'port_vs_reference_speed': round(ratio, 3),
@@ -114,9 +115,10 @@ def cpu_baseline(size, seconds_per_worker=6.0, max_workers=None):
         'port_vs_reference_note': 'oracle/ref_harness/pin_oracle.py in the build container (where /root/reference exists): '
                                   'reference %.0f, port %.0f steps/s/core on the same positions'
                                   % (REFERENCE_STEPS_PER_S_PER_CORE_BUILD_BOX, PORT_STEPS_PER_S_PER_CORE_BUILD_BOX),
-        'sample': '%d worker processes (os.cpu_count() = %d, usable %d) x %.1f s of %dx%d uniform-random self-play with '
+        'sample': '%d worker processes (os.cpu_count() = %d, usable %d, cgroup quota %s cores) x %.1f s of %dx%d uniform-random self-play with '
                   'auto-reset (oracle/np_oracle.py, same scipy.ndimage calls per step as the reference); %d steps total, '
-                  'pool wall %.1f s' % (cores, host, usable, seconds_per_worker, size, size, int(total), wall),
+                  'pool wall %.1f s' % (cores, host, usable, 'none' if cgroup is None else '%.1f' % cgroup, seconds_per_worker,
+                                        size, size, int(total), wall),
     }
 
 
@@ -369,12 +371,16 @@ def roofline_record(dev, n, games, plies, launch_ms, per_ply, clocks=None):
         rec.update({'achieved': None, 'frac': None, 'traffic': None,
                     'pmc_source': 'no PMC pass for this launch shape under profiles/ (tools/profile_round.sh collects one)'})
     # the same fraction against the clock the run actually held (median of the amdsmi samples), next to the nominal one
-    mhz = ((clocks or {}).get('sclk_mhz') or {}).get('median') if clocks else None
+    mhz = None
+    if clocks:
+        mhz = clocks.get('sclk_mhz_second_half_mean') or ((clocks.get('sclk_mhz') or {}).get('median'))
     if mhz:
         peak_m = cus * 4 * mhz * 1e6 / 2.0 / 1e9
-        rec['measured_clock'] = {'sclk_mhz_median': mhz, 'peak': round(peak_m, 2),
+        rec['measured_clock'] = {'sclk_mhz': mhz, 'peak': round(peak_m, 2),
                                  'frac': round(rec['achieved'] / peak_m, 4) if rec.get('achieved') else None,
-                                 'note': 'peak and frac recomputed with the shader clock sampled during the run'}
+                                 'note': 'peak and frac recomputed with the shader clock sampled over ~0.3 s of back-to-back '
+                                         'launches of the timed shape (also.clock_probe; the SMU read-out is smoothed over '
+                                         'tens of ms, so the samples inside the ~50 ms timed region lag - see `clocks`)'}
     else:
         rec['measured_clock'] = None
     rec['hbm'] = {
@@ -671,7 +677,7 @@ def main(argv=None):
                 'env_steps_per_bench_step': F * res['total_games'], 'burn_in_steps': opts['burn_in_steps'],
                 'desync_plies': opts['desync'], 'sharding': 'batch split across ranks by global game index, no collective',
             },
-            'roofline': roofline_record(dev, N, res['count'], F, launch_ms, per_ply, res.get('clocks')),
+            'roofline': roofline_record(dev, N, res['count'], F, launch_ms, per_ply, (also or {}).get('clock_probe') or res.get('clocks')),
             'clocks': res.get('clocks'),
             # what the communicator saw (None at a plain one-process run): backend, its world size, the ranks an
             # all-reduce of ones counted; and every rank's own average launch time (HIP events on its stream)

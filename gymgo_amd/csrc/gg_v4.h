@@ -39,7 +39,7 @@ constexpr int kNB4 = 16;
 
 // gg_ws.h (policy-weighted sampling, one DPP row of 16 lanes per board); used by the weighted env step below
 template <int NJ> __device__ __forceinline__ int wsample_row(const uint32_t (&bits)[NJ], const uint32_t (&vm)[NJ], uint32_t uhi, int lane);
-template <int NJ> __device__ __forceinline__ void wload_row(const float *__restrict__ wrow, int A, bool on, int lane, uint32_t (&bits)[NJ]);
+template <int NJ> __device__ __forceinline__ void wload_row(const float *__restrict__ wrow, int A, int lane, uint32_t (&bits)[NJ]);
 template <int NJ> __device__ __forceinline__ void wmask_from_bits(const uint32_t *vw, int lane, uint32_t (&vm)[NJ]);
 
 #ifdef GG_AB_PROF
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       {
         const int s0 = rw;
         const int64_t b0 = (b_first + s0 < B) ? b_first + s0 : B - 1;
-        wload_row<NJ>(env.weights + b0 * (int64_t)A, A, s0 < nb && b_first + s0 < B && uh[kNB4 + s0] != 0u, hf.lane, nbits);
+        wload_row<NJ>(env.weights + b0 * (int64_t)A, A, hf.lane, nbits);
       }
 #pragma unroll 1
       for (int ps = 0; ps < 4; ++ps) {
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         if (ps + 1 < 4) {
           const int s1 = s + 4;
           const int64_t b1 = (b_first + s1 < B) ? b_first + s1 : B - 1;
-          wload_row<NJ>(env.weights + b1 * (int64_t)A, A, s1 < nb && b_first + s1 < B && uh[kNB4 + s1] != 0u, hf.lane, nbits);
+          wload_row<NJ>(env.weights + b1 * (int64_t)A, A, hf.lane, nbits);
         }
         wmask_from_bits<NJ>(vb + 16 * s, hf.lane, vm);
         const int a = wsample_row<NJ>(bits, vm, uh[s], hf.lane);

@@ -80,14 +80,17 @@ __device__ __forceinline__ int wsample_row(const uint32_t (&bits)[NJ], const uin
   return (T == 0u && i == 0) ? -1 : -2;
 }
 
-// weights of the row's board -> registers (contiguous 64-byte segments per load instruction and row)
+// weights of the row's board -> registers (contiguous 64-byte segments per load instruction and row).  The loads are
+// UNCONDITIONAL on a clamped index (the caller hands over a readable row also for an absent board; what lies beyond the
+// action range is masked by vm[]): a load under a per-element condition is a branch whose join waits for the data, i.e.
+// NJ dependent memory round trips instead of NJ loads in flight (measured: 64 -> 26 us per 65 536 boards).
 template <int NJ>
-__device__ __forceinline__ void wload_row(const float *__restrict__ wrow, int A, bool on, int lane, uint32_t (&bits)[NJ]) {
+__device__ __forceinline__ void wload_row(const float *__restrict__ wrow, int A, int lane, uint32_t (&bits)[NJ]) {
   const int i = lane & 15;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int a = i + 16 * j;
-    bits[j] = (on && a < A) ? __float_as_uint(wrow[a]) : 0u;
+    bits[j] = __float_as_uint(wrow[a < A ? a : A - 1]);
   }
 }
 
@@ -113,22 +116,25 @@ __global__ __launch_bounds__(kWave) void k_sample_weighted(const uint8_t *__rest
     const bool on = b0 + row < B;
     const int64_t b = on ? b0 + row : B - 1;
     uint32_t bits[NJ], vm[NJ];
-    wload_row<NJ>(weights + b * (int64_t)A, A, on, lane, bits);
+    wload_row<NJ>(weights + b * (int64_t)A, A, lane, bits);
     uint64_t x = rng[b];
     if (states) {
       const uint8_t *gs = states + b * (int64_t)S;
       const uint32_t ended = gs[5 * P];
       uint32_t inv[NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
+      for (int j = 0; j < NJ; ++j) {   // (unconditional loads on a clamped index, see wload_row)
         const int a = i + 16 * j;
-        inv[j] = a < P ? gs[3 * P + a] : 0u;
+        inv[j] = gs[3 * P + (a < P ? a : P - 1)];
       }
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) vm[j] = (i + 16 * j < A && (ended || inv[j] == 0u)) ? ~0u : 0u;
+      for (int j = 0; j < NJ; ++j) {
+        const int a = i + 16 * j;
+        vm[j] = (on && a < A && (a == P || ended || inv[j] == 0u)) ? ~0u : 0u;
+      }
     } else {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) vm[j] = (i + 16 * j < A) ? ~0u : 0u;
+      for (int j = 0; j < NJ; ++j) vm[j] = (on && i + 16 * j < A) ? ~0u : 0u;
     }
     const uint64_t u = splitmix_next(x);
     const int a = wsample_row<NJ>(bits, vm, (uint32_t)(u >> 32), lane);
@@ -152,11 +158,11 @@ __global__ __launch_bounds__(kWave) void k_sample_weighted_rows(const uint32_t *
     const bool on = b0 + row < B;
     const int64_t b = on ? b0 + row : B - 1;
     uint32_t bits[NJ], vm[NJ];
-    wload_row<NJ>(weights + b * (int64_t)A, A, on, lane, bits);
+    wload_row<NJ>(weights + b * (int64_t)A, A, lane, bits);
     uint64_t x = rng[b];
     const uint32_t *gb = boards + b * (int64_t)W;
     const uint32_t ended = (gb[W - 1] >> 2) & 1u;
-    uint32_t r0v = i < N ? gb[2 * N + i] : 0u, r1v = i + 16 < N ? gb[2 * N + i + 16] : 0u;
+    const uint32_t r0v = gb[2 * N + (i < N ? i : N - 1)], r1v = gb[2 * N + (i + 16 < N ? i + 16 : N - 1)];
     WAVE_SYNC();
     for (int w = i; w < VW + 2; w += 16) vbits[row][w] = 0;
     WAVE_SYNC();
