@@ -1,0 +1,33 @@
+"""k_next_states32 taken apart (A/B build): GG_AB_V5_DBG bit 0 no stores, bit 1 one flood pass, bit 2 no plane loads"""
+import os, sys, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) == 1:
+    for early in ('0', '1'):
+        for dbg in ('0', '1', '2', '3', '4', '5', '7'):
+            env = dict(os.environ, GG_AB_V5_DBG=dbg, GG_AB_V5_EARLY=early, LIB='libgymgo_ab.so')
+            out = subprocess.run([sys.executable, __file__, 'run'], env=env, capture_output=True, text=True).stdout.strip()
+            print('early %s dbg %s  %s' % (early, dbg, out), flush=True)
+    sys.exit(0)
+sys.path.insert(0, ROOT)
+import torch
+from gymgo_amd import _lib
+_lib.LIB_PATH = os.path.join(ROOT, 'tools', 'exp', os.environ['LIB'])
+from gymgo_amd import gogame
+N, B = 19, 65536
+st = gogame.batch_init_state(B, N, device='cuda'); rng = gogame.rng_seed(B, 20260927)
+ch = B // 16
+dbg = os.environ.pop('GG_AB_V5_DBG')
+os.environ['GG_AB_V5_DBG'] = '0'
+for g in range(1, 16):
+    gogame.batch_rollout(st[g*ch:(g+1)*ch], rng[g*ch:(g+1)*ch], g * 40, True)
+gogame.batch_rollout(st, rng, 256 * 7, True)
+acts = gogame.batch_sample_actions(st, rng)
+nxt, status = torch.empty_like(st), torch.empty(B, dtype=torch.int32, device='cuda')
+os.environ['GG_AB_V5_DBG'] = dbg
+fn = lambda: gogame.batch_next_states(st, acts, check=False, out=nxt, status=status)
+fn(); torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(32): fn()
+b.record(); torch.cuda.synchronize()
+print('%.1f us' % (a.elapsed_time(b) / 32 * 1e3))
