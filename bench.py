@@ -475,6 +475,12 @@ def extras(dev, back, opts):
     out['gg_batch_env_step_policy_weighted_steps_per_s'] = round(r_w, 1)
     out['gg_batch_env_step_policy_weighted_launch_us'] = round(ms_w * 1e3, 2)
     out['gg_batch_env_step_policy_weighted_vs_uniform'] = round(r_w / out['gg_batch_env_step_steps_per_s'], 4)
+    moved_w = moved + 4 * (N * N + 1)          # + the float32 weights of the game
+    out['gg_batch_env_step_policy_weighted_bytes_moved_per_step'] = moved_w
+    out['gg_batch_env_step_policy_weighted_hbm_frac'] = round(moved_w * r_w / 1e9 / HBM_PEAK_GBS, 4)
+    out['gg_batch_env_step_policy_weighted_note'] = ('reads 1.49x the bytes of the uniform-draw step (%d vs %d B per game): at the '
+                                                     'same achieved bandwidth it cannot be faster than %.2fx the uniform rate'
+                                                     % (moved_w, moved, moved / float(moved_w)))
     acts_w = torch.empty(count, dtype=torch.int32, device=dev)
     r_s, ms_s = event_rate(torch, dev, lambda: gogame.batch_sample_weighted(states, probs, rng), count, 32)
     out['gg_batch_sample_weighted_boards_per_s'] = round(r_s, 1)

@@ -140,7 +140,8 @@ __device__ __forceinline__ void flood2_dual(const uint32_t (&m)[R], const uint32
 // `out` = this lane's row of the L2 -> L1 transpose buffer: the converged fill is stored there in normal bit order
 // (the normal-order copy made for the closure test is the result, so it never has to stay live across sweeps).
 // PREREV: the caller hands the odd rows of the seeds over bit-reversed already
-template <int R, bool PREREV = false>
+// OUT128: `out` is 16-byte aligned with room for (R + 3) & ~3 words; the copy is written four rows at a time
+template <int R, bool PREREV = false, bool OUT128 = false>
 __device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R],
                                               uint32_t *out) {
   if (!PREREV) {
@@ -154,10 +155,16 @@ __device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint
     if (it > 0) {
       // normal-order copy streamed into `out` (speculatively: it is the result if the test passes)
       uint32_t open = 0, above = 0;  // a filled stone whose upper neighbour is fillable but not filled
+      uint32_t q[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int r = R - 1; r >= 0; --r) {
         const uint32_t g = ((r + 1) & 1) ? __brev(f[r]) : f[r];
-        out[r] = g;
+        if (OUT128) {   // four rows per ds_write_b128: a lane's rows are RS (a multiple of 4) words apart, so 32-bit
+          q[r & 3] = g; // stores of one row hit every fourth bank only (4-way conflict), 16-byte stores do not
+          if ((r & 3) == 0) *reinterpret_cast<uint4 *>(out + r) = make_uint4(q[0], q[1], q[2], q[3]);
+        } else {
+          out[r] = g;
+        }
         if (r < R - 1) open |= B3(above, m[r], g, T_AND_ANDN);
         above = g;
       }
@@ -167,10 +174,19 @@ __device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint
     for (int r = R - 1; r >= 0; --r) FLOOD_VISIT(r, r + 1, ((r + 1) & 1) != 0);  // up: domain ((r+1)&1) -> (r&1)
     if (it > 0) {
       uint32_t open = 0, below = 0;
+      uint32_t q[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const uint32_t g = (r & 1) ? __brev(f[r]) : f[r];
-        out[r] = g;
+        if (OUT128) {
+          q[r & 3] = g;
+          if ((r & 3) == 3 || r == R - 1) {
+            if ((r & 3) != 3) { for (int z = (r & 3) + 1; z < 4; ++z) q[z] = 0u; }
+            *reinterpret_cast<uint4 *>(out + (r & ~3)) = make_uint4(q[0], q[1], q[2], q[3]);
+          }
+        } else {
+          out[r] = g;
+        }
         if (r > 0) open |= B3(below, m[r], g, T_AND_ANDN);
         below = g;
       }

@@ -1007,6 +1007,7 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
   __shared__ __attribute__((aligned(16))) uint32_t planes[4 * 32]; // rows: mover, opponent, both bit-reversed
   __shared__ __attribute__((aligned(16))) uint32_t ring[kRingWords];  // output bit-stream window (1 bit per output byte)
   __shared__ uint16_t elist[R * R + 2];                            // action index of the t-th empty point
+  __shared__ uint16_t alist[R * R + 2];                            // index t of the u-th empty point NEXT TO A STONE
   __shared__ uint2 lut[256];
   const Half hf = make_half(threadIdx.x, N, inv);
   load_spread_lut(lut, hf.lane);
@@ -1049,9 +1050,18 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
     // empty points: total, list, and the index range [t0, t1) of those inside the chunk
     const uint32_t ecnt = (uint32_t)__popc(e);
     const uint32_t eincl = half_scan(ecnt);
-    const int E = __builtin_amdgcn_readlane((int)eincl, 31);
     const int t0 = __builtin_amdgcn_readlane((int)half_scan((uint32_t)__popc(e & below_lo)), 31);
     const int t1 = __builtin_amdgcn_readlane((int)half_scan((uint32_t)__popc(e & below_hi)), 31);
+    // Only an empty point NEXT TO A STONE can be a liberty, capture anything or join a group: the floods (pass 1 and
+    // pass 2) run over those points only; a child on any other empty point is the parent plus a lone stone with >= 2
+    // liberties.  Early-game parents (350 empty points, a few dozen next to stones) need 1-2 flood batches instead of 11.
+    const uint32_t stn = mine | opp;
+    const uint32_t ea = e & (B3(shl1(stn), stn >> 1, dpp0<0x138>(stn), T_OR3) | dpp0<0x130>(stn));
+    const uint32_t acnt = (uint32_t)__popc(ea);
+    const uint32_t aincl = half_scan(acnt);
+    const int EA = __builtin_amdgcn_readlane((int)aincl, 31);
+    const int u0 = __builtin_amdgcn_readlane((int)half_scan((uint32_t)__popc(ea & below_lo)), 31);   // ... inside the chunk: [u0, u1)
+    const int u1 = __builtin_amdgcn_readlane((int)half_scan((uint32_t)__popc(ea & below_hi)), 31);
     WAVE_SYNC();  // staging buffer read out
     if (hf.h == 0) {
       planes[hf.hl] = mine;
@@ -1059,21 +1069,25 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
       planes[64 + hf.hl] = __brev(mine);
       planes[96 + hf.hl] = __brev(opp);
       if (hf.hl < N) {
-        const uint32_t off = eincl - ecnt;
+        const uint32_t off = eincl - ecnt, aoff = aincl - acnt;
 #pragma unroll
         for (int c = 0; c < R; ++c)
-          if (c < N && ((e >> c) & 1u)) elist[off + (uint32_t)__popc(e & ((1u << c) - 1u))] = (uint16_t)(base + c);
+          if (c < N && ((e >> c) & 1u)) {
+            const uint32_t t = off + (uint32_t)__popc(e & ((1u << c) - 1u));
+            elist[t] = (uint16_t)(base + c);
+            if ((ea >> c) & 1u) alist[aoff + (uint32_t)__popc(ea & ((1u << c) - 1u))] = (uint16_t)t;
+          }
       }
     }
     WAVE_SYNC();
 
-    // lane (h, l): flood colour h from the stones adjacent to empty point #(tbase + l); result -> sc[lane][row].
-    // Returns the lane's point (action index), -1 if there is none.
-    auto flood_batch = [&](int tbase) -> int {
+    // lane (h, l): flood colour h from the stones adjacent to the (ubase + l)-th empty point next to a stone; result ->
+    // sc[lane][row].  Returns the lane's point (action index), -1 if there is none.
+    auto flood_batch = [&](int ubase) -> int {
       uint32_t m[R], mrev[R], f[R];
-      const int t = tbase + hf.hl;
-      const bool have = t < E;
-      const int x = have ? (int)elist[t] : 0;
+      const int u = ubase + hf.hl;
+      const bool have = u < EA;
+      const int x = have ? (int)elist[alist[u]] : 0;
       int xr, xc;
       split_action(x, N, hf.inv, xr, xc);
       const uint32_t bit = have ? (1u << xc) : 0u, hb = (bit << 1) | (bit >> 1);
@@ -1103,11 +1117,11 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
 
     // pass 1: exact liberty counts (saturated at 3) - half 0 counts for the mover's stones, half 1 for the opponent's
     uint32_t ge1 = 0, ge2 = 0, ge3 = 0;
-    const int nbatch = (E + 31) >> 5;
+    const int nbatch = (EA + 31) >> 5;
 #pragma unroll 1
     for (int i = 0; i < nbatch; ++i) {
       flood_batch(32 * i);
-      const int cnt = min(32, E - 32 * i);
+      const int cnt = min(32, EA - 32 * i);
       if (hf.hl < R) {
         const uint32_t *col = sc + (32 * hf.h) * RS + hf.hl;
 #pragma unroll 4
@@ -1182,16 +1196,17 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       WAVE_SYNC();
     }
-    // one child per half: `a` = its action, `tj` = flood lane of its point inside the current batch (-1: pass)
+    // one child per half: `a` = its action, `tj` = flood lane of its point inside the current batch (-1: pass, -2: an
+    // empty point with no stone next to it - no group is touched, nothing to look up)
     auto child = [&](int a, int tj, bool on) {
-      const bool is_pass = tj < 0;
+      const bool is_pass = tj == -1;
       uint32_t nmine = mine, nopp = opp, invalid;
       if (__ballot(on && !is_pass) == 0) {
         invalid = invalid_from2(opp, mine, Mo, Mm, hf);
       } else {
-        const int tl = is_pass ? 0 : tj;
+        const int tl = tj < 0 ? 0 : tj;
         uint32_t Rm = 0, Ro = 0;
-        if (hf.hl < R && !is_pass) {
+        if (hf.hl < R && tj >= 0) {
           Rm = sc[tl * RS + hf.hl];
           Ro = sc[(32 + tl) * RS + hf.hl];
         }
@@ -1278,31 +1293,44 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
       }
     };
 
-    // pass 2: the chunk's empty points, 32 per flood batch, two legal children per L1 pass
+    // pass 2: the chunk's empty points in slot order.  Window i = the i-th batch of 32 stone-adjacent points of the chunk
+    // (one flood batch) together with every free point up to the next window; its points are taken 32 at a time (one per
+    // lane of the lower half), two legal children per L1 pass.
+    {
+      const int nwin = u1 > u0 ? (u1 - u0 + 31) >> 5 : 1;
 #pragma unroll 1
-    for (int tb = t0; tb < t1; tb += 32) {
-      int x;
-      if (nbatch == 1 && tb == 0) {   // pass 1's only batch is still in sc
-        const int t = hf.hl;
-        x = t < E ? (int)elist[t] : -1;
-      } else {
-        x = flood_batch(tb);
-      }
-      int xr, xc;
-      split_action(x < 0 ? 0 : x, N, hf.inv, xr, xc);
-      const uint32_t irow = __shfl(invd, xr);   // every lane executes the exchange (a masked-off source lane reads as 0)
-      const bool legal = x >= 0 && tb + hf.hl < t1 && ((irow >> xc) & 1u) == 0;
-      uint32_t lm = (uint32_t)__ballot(legal);   // low half: lanes 0-31 carry the 32 points of the batch
+      for (int wi = 0; wi < nwin; ++wi) {
+        const int ub = u0 + 32 * wi;
+        if (ub < u1 && !(nbatch == 1 && ub == 0)) flood_batch(ub);   // (pass 1's only batch is still in sc)
+        const int tlo = wi == 0 ? t0 : (int)alist[ub];
+        const int thi = (wi + 1 < nwin) ? (int)alist[ub + 32] : t1;
 #pragma unroll 1
-      while (lm) {
-        const int j0 = __ffs(lm) - 1;
-        lm &= lm - 1u;
-        const int j1 = lm ? __ffs(lm) - 1 : -1;
-        lm &= lm - 1u;
-        const int tj = hf.h ? j1 : j0;
-        const bool on = tj >= 0;
-        const int a = __shfl(x, on ? tj : j0);
-        child(a, on ? tj : j0, on);
+        for (int tb = tlo; tb < thi; tb += 32) {
+          const int t = tb + hf.hl;
+          const int x = t < thi ? (int)elist[t] : -1;
+          int xr, xc;
+          split_action(x < 0 ? 0 : x, N, hf.inv, xr, xc);
+          const uint32_t irow = __shfl(invd, xr);   // every lane executes the exchanges (a masked-off source lane reads as 0)
+          const uint32_t arow = __shfl(ea, xr);
+          const uint32_t apre = __shfl(aincl - acnt, xr);
+          const bool legal = x >= 0 && ((irow >> xc) & 1u) == 0;
+          // flood lane of the point inside the window's batch, or -2 for a free point
+          const int fl = ((arow >> xc) & 1u) ? (int)(apre + (uint32_t)__popc(arow & ((1u << xc) - 1u))) - ub : -2;
+          uint32_t lm = (uint32_t)__ballot(legal);   // low half: lanes 0-31 carry the 32 points of the round
+#pragma unroll 1
+          while (lm) {
+            const int j0 = __ffs(lm) - 1;
+            lm &= lm - 1u;
+            const int j1 = lm ? __ffs(lm) - 1 : -1;
+            lm &= lm - 1u;
+            const int js = hf.h ? j1 : j0;
+            const bool on = js >= 0;
+            const int src = on ? js : j0;
+            const int a = __shfl(x, src);
+            const int tj = __shfl(fl, src);
+            child(a, tj, on);
+          }
+        }
       }
     }
     if (a1 == A) child(hf.P, -1, hf.h == 0);

@@ -711,7 +711,10 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
             // (measured on this kernel, 65 536 games x 256 plies: the two-chain flood2_dual 2.78 ms against 2.33 ms, a first
             // closure test already after the second sweep 2.43 ms)
             GG_PROF(1);
-            flood2_serial<R, true>(m, mrev, f, sc + ln * RS);
+            // (the closure test's copy of the fill goes to LDS four rows per ds_write_b128: 32-bit stores of one row
+            // from lanes RS = 20 words apart are a 4-way bank conflict - removing it measured 2.327 vs 2.327 ms per
+            // 256-ply launch: the LDS is not on this kernel's critical path)
+            flood2_serial<R, true, true>(m, mrev, f, sc + ln * RS);
             GG_PROF(2);
           }
           // liberties of this lane's group on the position with the new stone (captures not yet removed); m[] still

@@ -7,7 +7,7 @@ if os.environ.get('LIB'):
     _lib.LIB_PATH = os.path.join(ROOT, 'tools', 'exp', os.environ['LIB'])
 from gymgo_amd import gogame
 B, N = 8192, 19
-for plies in (60, 250, 400):
+for plies in (6, 20, 60, 250, 400):
     st = gogame.batch_init_state(B, N, device='cuda'); rng = gogame.rng_seed(B, 7)
     gogame.batch_rollout(st, rng, plies, True)
     kids = torch.empty((B, N * N + 1, 6, N, N), dtype=torch.uint8, device='cuda')
