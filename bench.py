@@ -305,7 +305,7 @@ def rollout_kernel_name(n, games, plies, cus):
     rcap = 9 if n <= 9 else 13 if n <= 13 else 19
     full = 'true' if n == rcap else 'false'
     if plies >= 2 and games >= 32 * cus:
-        return 'k_rollout4<%d, 0, false, %s, false>' % (rcap, full)
+        return 'k_rollout4<%d, 0, false, %s, false, false>' % (rcap, full)
     return 'k_rollout2<%d, %s, false, %s>' % (rcap, 'true' if plies <= 2 else 'false', full)
 
 
@@ -519,17 +519,30 @@ def extras(dev, back, opts):
         kids = torch.empty((8192, N * N + 1, 6, N, N), dtype=torch.uint8, device=dev)
         lib = _lib.lib()
 
-        def expand():
+        def expand():   # (reads `parents` at call time)
             _lib.check(lib.gg_batch_children(_lib.dev_ptr(parents, torch.uint8, 'states'), _lib.dev_ptr(kids, torch.uint8, 'children'),
                                              8192, N, 0, _lib.stream_ptr(dev)), 'gg_batch_children')
         r, ms = event_rate(torch, dev, expand, 8192, 8)
         bytes_per_parent = 6 * N * N + (N * N + 1) * 6 * N * N
         configs['config5_children_8192_parents'] = {
+            'parents': 'the first 8 192 games of the resident batch (stationary mix: every game phase)',
             'parents_per_s': round(r, 1), 'child_states_per_s': round(r * (N * N + 1), 1), 'launch_ms': round(ms, 4),
             'roofline': {'bound': 'hbm', 'kernel': 'k_children3<19, false>', 'algorithmic_bytes_per_parent': bytes_per_parent,
                          'achieved': round(bytes_per_parent * r / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(bytes_per_parent * r / 1e9 / HBM_PEAK_GBS, 4)}}
-        del kids
+        # the same expansion for parents of ONE game phase each (the floods run over the empty points next to a stone,
+        # the 362 slots are written whatever the position: the rate barely depends on the phase)
+        by_phase = {}
+        for phase, plies in (('early_20_plies', 20), ('mid_150_plies', 150), ('late_400_plies', 400)):
+            ph = gogame.batch_init_state(8192, N, device=dev)
+            gogame.batch_rollout(ph, gogame.rng_seed(8192, 77, 0, dev), plies, False)
+            parents = ph
+            rp, msp = event_rate(torch, dev, expand, 8192, 6)
+            by_phase[phase] = {'parents_per_s': round(rp, 1), 'launch_ms': round(msp, 4),
+                               'mean_stones': round(float((ph[:, 0] | ph[:, 1]).sum()) / 8192, 1),
+                               'hbm_frac': round(bytes_per_parent * rp / 1e9 / HBM_PEAK_GBS, 4)}
+        configs['config5_children_8192_parents']['by_game_phase'] = by_phase
+        del kids, parents
     # --- config 1: one 7x7 game through GoEnv.step (device round trip per step: plumbing, not a throughput path)
     import numpy as np
     env = make('gym_go:go-v0', size=7)

@@ -68,7 +68,8 @@ struct Lds4 {
   // ply loop: per flood lane its result word (liberty class, size, role, seed) + the transpose buffer of the group masks
   static constexpr int kCls = kUnion;
   static constexpr int kSc = kCls + kWave;
-  static constexpr int kLoopEnd = kSc + kWave * RS;
+  static constexpr int kScPad = 4;                               // words of padding per board between its four flood blocks and the next board's
+  static constexpr int kLoopEnd = kSc + kWave * RS + kNB4 * kScPad;
   // load / store: the v2 analysis in its compact form (region 0 only: staging / transpose buffer); at store time the
   // emitter's scratch (2 x 128 words) and the spread table (uint2[256]); tracked boards: the parked mask / class rows
   static constexpr int kV2 = kUnion;
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
   constexpr int RV = (R + 3) / 4;
   constexpr int RPL = Lds4<R>::RPL;
   constexpr int PL = kNB4 * RS;   // words per plane of all boards
+  constexpr int SCP = Lds4<R>::kScPad;
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds4<R>::kTotal];
   if (FULLN) N = R;   // a compile-time constant from here on: row masks, r * N + c and the "row exists" tests fold
   const Half hf = make_half(threadIdx.x, N, inv);
@@ -714,13 +716,13 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
             // (the closure test's copy of the fill goes to LDS four rows per ds_write_b128: 32-bit stores of one row
             // from lanes RS = 20 words apart are a 4-way bank conflict - removing it measured 2.327 vs 2.327 ms per
             // 256-ply launch: the LDS is not on this kernel's critical path)
-            flood2_serial<R, true, true>(m, mrev, f, sc + ln * RS);
+            flood2_serial<R, true, true>(m, mrev, f, sc + ln * RS + (ln >> 2) * SCP);
             GG_PROF(2);
           }
           // liberties of this lane's group on the position with the new stone (captures not yet removed); m[] still
           // holds the flooded colour's rows
           uint32_t gt[RV * 4], ot[RV * 4];
-          const uint4 *pg = reinterpret_cast<const uint4 *>(sc + ln * RS);
+          const uint4 *pg = reinterpret_cast<const uint4 *>(sc + ln * RS + (ln >> 2) * SCP);
           const uint4 *pov = reinterpret_cast<const uint4 *>(oth);
 #pragma unroll
           for (int i = 0; i < RV; ++i) {
@@ -743,7 +745,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
                    (isG ? CL_G : 0u) | ((uint32_t)(sr & 0xFF) << 8) | ((uint32_t)(scol & 0xFF) << 16);
         // an opponent group that keeps >= 2 liberties keeps its class: phase 3 must not see it
         if (!isG && cnt >= 2u) {
-          uint4 *pz = reinterpret_cast<uint4 *>(sc + ln * RS);
+          uint4 *pz = reinterpret_cast<uint4 *>(sc + ln * RS + (ln >> 2) * SCP);
 #pragma unroll
           for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
         }
@@ -766,7 +768,9 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         const int turn0 = fl & 1u;
         uint32_t *pmine = st + turn0 * PL + s4 * RS + r0;
         uint32_t *popp = st + (1 - turn0) * PL + s4 * RS + r0;
-        const uint32_t *gr = sc + (4 * s4) * RS + r0;   // block j: gr[j * RS + r]
+        // (a board's four flood blocks are 4 RS + 4 words from the next board's: with a stride of exactly 4 RS = 80 words
+        // the 32-bit reads below hit every sixteenth bank only - a 4-way conflict on all twenty of them)
+        const uint32_t *gr = sc + (4 * s4) * RS + s4 * SCP + r0;   // block j: gr[j * RS + r]
         uint32_t mine1[RPL], opp0[RPL], b0[RPL], b1[RPL], b2[RPL], b3[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {

@@ -21,7 +21,7 @@ def _seeds(c_oracle, base, idx):
 def test_bench_trajectory_subsample_vs_oracle():
     """The bench's own driver on the bench's own workload: every launch bench.run_rank issues (15 de-synchronising
     slice launches of 40 ... 600 plies, 1 burn-in + 5 warm-up + 4 timed launches of 256 plies over all 65 536 games -
-    k_rollout4<19, 0, false, true, false>) is followed by an oracle replay of 512 games chosen by global game index
+    k_rollout4<19, 0, false, true, false, false>) is followed by an oracle replay of 512 games chosen by global game index
     (every 128th, offset 5: all 16 slices); states, generator states and the kernel's own step counters must agree
     after each of the 25 launches, i.e. up to ~3 160 plies into a slot's life (mean game length ~640)."""
     import bench

@@ -134,6 +134,6 @@ def test_bench_argument_plumbing():
     a = bench.parse_args(['--fuse', '64'])
     assert a.plies_per_step == 64 and a.gpus == 1
     assert bench.algo_bytes_per_step(19) == 4336 and bench.fused_bytes_per_game(19) == 4348
-    assert bench.rollout_kernel_name(19, 65536, 256, 256) == 'k_rollout4<19, 0, false, true, false>'
+    assert bench.rollout_kernel_name(19, 65536, 256, 256) == 'k_rollout4<19, 0, false, true, false, false>'
     assert bench.rollout_kernel_name(9, 4096, 256, 256) == 'k_rollout2<9, false, false, true>'
     assert bench.rollout_kernel_name(19, 65536, 1, 256) == 'k_rollout2<19, true, false, true>'

@@ -92,6 +92,12 @@ def main():
         out['gg_batch_children_19x19_B8192%s' % ('_canonical' if canon else '')] = {
             'parents_per_s': B / t, 'child_states_per_s': B * (N * N + 1) / t, 'ms_per_batch': t * 1e3,
             'algorithmic_GBps': nbytes / t / 1e9, 'roofline_frac': nbytes / t / PEAK, 'mean_valid_children': valid}
+    for phase, plies in (('early', 20), ('mid', 150), ('late', 400)):
+        ph = gogame.batch_init_state(B, N, device='cuda')
+        gogame.batch_rollout(ph, gogame.rng_seed(B, 77), plies, False)
+        t = timed(lambda: gogame.batch_children(ph), 5)
+        out['gg_batch_children_19x19_B8192_%s_parents_%d_plies' % (phase, plies)] = {
+            'parents_per_s': B / t, 'ms_per_batch': t * 1e3, 'roofline_frac': B * (S + (N * N + 1) * S) / t / PEAK}
     # the same parents as packed boards: 362 x 232 B per parent
     pk = gogame.batch_pack(st)
     t = timed(lambda: gogame.batch_children_packed(pk), 10)
@@ -135,6 +141,37 @@ def main():
     out['gg_batch_track_states_19x19_B65536'] = {'boards_per_s': B2 / t}
     t = timed(lambda: gogame.batch_untrack(tr), 20)
     out['gg_batch_untrack_states_19x19_B65536'] = {'boards_per_s': B2 / t}
+    # policy-weighted sampling (gogame.random_weighted_action per game) and the env step that draws from weights itself
+    probs = torch.rand((B2, N * N + 1), dtype=torch.float32, device='cuda')
+    WB = 4 * (N * N + 1)
+    t = timed(lambda: gogame.batch_sample_weighted(st2, probs, rt), 30)
+    out['gg_batch_sample_weighted_19x19_B65536'] = {'boards_per_s': B2 / t, 'moved_GBps': B2 * (WB + N * N + 13) / t / 1e9}
+    t = timed(lambda: gogame.batch_sample_weighted_rows(tr, N, probs, rt), 30)
+    out['gg_batch_sample_weighted_rows_tracked_19x19_B65536'] = {'boards_per_s': B2 / t, 'moved_GBps': B2 * (WB + 4 * N + 16) / t / 1e9}
+    obs = torch.empty_like(st2)
+    ebuf = None
+
+    def wstep(w):
+        nonlocal ebuf
+        ebuf = gogame.batch_env_step_tracked(tr, None, rt, 7.5, 'real', True, out=ebuf, states_out=obs, weights=w)
+    t = timed(lambda: wstep(None), 30)
+    t_w = timed(lambda: wstep(probs), 30)
+    moved = 8 * (5 * N + 1) + S + 25
+    out['gg_batch_env_step_tracked_19x19_B65536'] = {'steps_per_s': B2 / t, 'moved_GBps': B2 * moved / t / 1e9}
+    out['gg_batch_env_step_tracked_weighted_19x19_B65536'] = {'steps_per_s': B2 / t_w, 'moved_GBps': B2 * (moved + WB) / t_w / 1e9,
+                                                              'vs_uniform_draws': t / t_w}
+    # batched symmetries: one view per game / all eight, byte planes and tracked boards
+    orient = torch.randint(0, 8, (B2,), dtype=torch.int32, device='cuda')
+    v1 = torch.empty_like(st2)
+    t = timed(lambda: gogame.batch_symmetry(st2, orient, out=v1), 20)
+    out['gg_batch_symmetry_one_view_19x19_B65536'] = {'boards_per_s': B2 / t, 'moved_GBps': B2 * 2 * S / t / 1e9}
+    B3 = 8192
+    v8 = torch.empty((B3, 8, 6, N, N), dtype=torch.uint8, device='cuda')
+    t = timed(lambda: gogame.batch_symmetry(st2[:B3], None, out=v8), 20)
+    out['gg_batch_symmetry_all_eight_19x19_B8192'] = {'boards_per_s': B3 / t, 'moved_GBps': B3 * 9 * S / t / 1e9}
+    t = timed(lambda: gogame.batch_symmetry_rows(tr, N, orient), 20)
+    out['gg_batch_symmetry_rows_tracked_19x19_B65536'] = {'boards_per_s': B2 / t, 'moved_GBps': B2 * 8 * (5 * N + 1) / t / 1e9}
+    del probs, obs, v1, v8
     # replay of recorded move sequences (64 moves per game in one launch)
     T = 64
     rec = torch.empty((B2, T), dtype=torch.int32, device='cuda')
