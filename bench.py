@@ -481,11 +481,18 @@ def extras(dev, back, opts):
     out['gg_batch_env_step_policy_weighted_note'] = ('reads 1.49x the bytes of the uniform-draw step (%d vs %d B per game): at the '
                                                      'same achieved bandwidth it cannot be faster than %.2fx the uniform rate'
                                                      % (moved_w, moved, moved / float(moved_w)))
+    probs16 = probs.to(torch.bfloat16)      # what a bf16 policy head hands over: widened exactly, half the bytes
+    r_h, ms_h = event_rate(torch, dev, lambda: gogame.batch_env_step_tracked(tracked, None, rng, 7.5, 'real', True, out=env_out,
+                                                                             states_out=obs, weights=probs16), count, 32)
+    out['gg_batch_env_step_policy_weighted_bf16_steps_per_s'] = round(r_h, 1)
+    out['gg_batch_env_step_policy_weighted_bf16_launch_us'] = round(ms_h * 1e3, 2)
+    out['gg_batch_env_step_policy_weighted_bf16_vs_uniform'] = round(r_h / out['gg_batch_env_step_steps_per_s'], 4)
+    out['gg_batch_env_step_policy_weighted_bf16_hbm_frac'] = round((moved + 2 * (N * N + 1)) * r_h / 1e9 / HBM_PEAK_GBS, 4)
     acts_w = torch.empty(count, dtype=torch.int32, device=dev)
     r_s, ms_s = event_rate(torch, dev, lambda: gogame.batch_sample_weighted(states, probs, rng), count, 32)
     out['gg_batch_sample_weighted_boards_per_s'] = round(r_s, 1)
     out['gg_batch_sample_weighted_launch_us'] = round(ms_s * 1e3, 2)
-    del tracked, obs, probs, acts_w
+    del tracked, obs, probs, probs16, acts_w
     configs = {}
     F = opts['plies_per_step']
     # --- config 2: 9x9, 4 096 games

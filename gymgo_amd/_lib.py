@@ -53,9 +53,9 @@ _SIGNATURES = {
     'gg_batch_play_moves_tracked': ([_vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
     'gg_batch_env_step_tracked': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_float, _i32, _i32, _vp], _i32),
     'gg_rng_seed': ([_vp, _u64, _i64, _i64, _vp], _i32),
-    'gg_batch_env_step_tracked_weighted': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_float, _i32, _i32, _vp], _i32),
-    'gg_batch_sample_weighted': ([_vp, _vp, _vp, _vp, _i64, _i32, _vp], _i32),
-    'gg_batch_sample_weighted_rows': ([_vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp], _i32),
+    'gg_batch_env_step_tracked_weighted': ([_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_float, _i32, _i32, _vp], _i32),
+    'gg_batch_sample_weighted': ([_vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp], _i32),
+    'gg_batch_sample_weighted_rows': ([_vp, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _vp], _i32),
     'gg_batch_symmetry': ([_vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
     'gg_batch_symmetry_rows': ([_vp, _i32, _vp, _vp, _i64, _i32, _vp], _i32),
 }

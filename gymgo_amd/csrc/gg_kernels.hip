@@ -538,11 +538,12 @@ int32_t gg_batch_env_step_tracked(uint32_t *tracked, const int32_t *actions, uin
   return (int32_t)hipGetLastError();
 }
 
-int32_t gg_batch_env_step_tracked_weighted(uint32_t *tracked, const float *weights, uint64_t *rng, float *rewards,
+int32_t gg_batch_env_step_tracked_weighted(uint32_t *tracked, const void *weights, int32_t weight_dtype, uint64_t *rng, float *rewards,
                                            uint8_t *dones, int32_t *status, int32_t *taken_actions, uint8_t *states_out,
                                            int64_t *steps_done, int64_t B, int32_t N, float komi, int32_t reward_method,
                                            int32_t auto_reset, void *hip_stream) {
   if (reward_method != GG_REWARD_REAL && reward_method != GG_REWARD_HEURISTIC) return GG_E_BADARG;
+  if (weight_dtype < GG_W_F32 || weight_dtype > GG_W_F16) return GG_E_BADARG;
   GG_ENTER(tracked);
   if (!weights || !rng) return GG_E_NULLPTR;
   uint8_t *st = reinterpret_cast<uint8_t *>(tracked);
@@ -551,33 +552,35 @@ int32_t gg_batch_env_step_tracked_weighted(uint32_t *tracked, const float *weigh
   EnvArgs env = EnvArgs();
   env.rewards = rewards; env.dones = dones; env.status = status; env.taken = taken_actions;
   env.states_out = states_out; env.komi = komi; env.heuristic = reward_method == GG_REWARD_HEURISTIC;
-  env.weights = weights;
+  env.weights = weights; env.wdtype = weight_dtype;
   // the given-moves instantiation, with the move of every game drawn from its weights by the kernel itself
   GG_DISPATCH4W(N, grid, st, rng, nullptr, steps_done, B, N, inv, 1, auto_reset, nb, nullptr, nullptr, env);
   return (int32_t)hipGetLastError();
 }
 
-int32_t gg_batch_sample_weighted(const uint8_t *states, const float *weights, uint64_t *rng, int32_t *actions, int64_t B,
-                                 int32_t N, void *hip_stream) {
+int32_t gg_batch_sample_weighted(const uint8_t *states, const void *weights, int32_t weight_dtype, uint64_t *rng,
+                                 int32_t *actions, int64_t B, int32_t N, void *hip_stream) {
+  if (weight_dtype < GG_W_F32 || weight_dtype > GG_W_F16) return GG_E_BADARG;
   GG_ENTER(weights);
   if (!rng || !actions) return GG_E_NULLPTR;   // states may be NULL: nothing is masked
   const int grid = grid_for(cus, (B + 3) / 4);
-  GG_DISPATCH(N, (k_sample_weighted<9><<<grid, kWave, 0, s>>>(states, weights, rng, actions, B, N)),
-              (k_sample_weighted<13><<<grid, kWave, 0, s>>>(states, weights, rng, actions, B, N)),
-              (k_sample_weighted<19><<<grid, kWave, 0, s>>>(states, weights, rng, actions, B, N)));
+  GG_DISPATCH(N, (k_sample_weighted<9><<<grid, kWave, 0, s>>>(states, weights, weight_dtype, rng, actions, B, N)),
+              (k_sample_weighted<13><<<grid, kWave, 0, s>>>(states, weights, weight_dtype, rng, actions, B, N)),
+              (k_sample_weighted<19><<<grid, kWave, 0, s>>>(states, weights, weight_dtype, rng, actions, B, N)));
   return (int32_t)hipGetLastError();
 }
 
-int32_t gg_batch_sample_weighted_rows(const uint32_t *boards, int32_t planes, const float *weights, uint64_t *rng,
-                                      int32_t *actions, int64_t B, int32_t N, void *hip_stream) {
+int32_t gg_batch_sample_weighted_rows(const uint32_t *boards, int32_t planes, const void *weights, int32_t weight_dtype,
+                                      uint64_t *rng, int32_t *actions, int64_t B, int32_t N, void *hip_stream) {
   if (planes != 3 && planes != 5) return GG_E_BADARG;
+  if (weight_dtype < GG_W_F32 || weight_dtype > GG_W_F16) return GG_E_BADARG;
   GG_ENTER(boards);
   if (!weights || !rng || !actions) return GG_E_NULLPTR;
   const int grid = grid_for(cus, (B + 3) / 4);
   const int W = planes * N + 1;
-  GG_DISPATCH(N, (k_sample_weighted_rows<9><<<grid, kWave, 0, s>>>(boards, W, weights, rng, actions, B, N)),
-              (k_sample_weighted_rows<13><<<grid, kWave, 0, s>>>(boards, W, weights, rng, actions, B, N)),
-              (k_sample_weighted_rows<19><<<grid, kWave, 0, s>>>(boards, W, weights, rng, actions, B, N)));
+  GG_DISPATCH(N, (k_sample_weighted_rows<9><<<grid, kWave, 0, s>>>(boards, W, weights, weight_dtype, rng, actions, B, N)),
+              (k_sample_weighted_rows<13><<<grid, kWave, 0, s>>>(boards, W, weights, weight_dtype, rng, actions, B, N)),
+              (k_sample_weighted_rows<19><<<grid, kWave, 0, s>>>(boards, W, weights, weight_dtype, rng, actions, B, N)));
   return (int32_t)hipGetLastError();
 }
 

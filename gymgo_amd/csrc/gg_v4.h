@@ -39,7 +39,7 @@ constexpr int kNB4 = 16;
 
 // gg_ws.h (policy-weighted sampling, one DPP row of 16 lanes per board); used by the weighted env step below
 template <int NJ> __device__ __forceinline__ int wsample_row(const uint32_t (&bits)[NJ], const uint32_t (&vm)[NJ], uint32_t uhi, int lane);
-template <int NJ> __device__ __forceinline__ void wload_row(const float *__restrict__ wrow, int A, int lane, uint32_t (&bits)[NJ]);
+template <int NJ, int AMIN> __device__ __forceinline__ void wload_row(const void *__restrict__ wbase, int64_t board, int wt, int A, int lane, uint32_t (&bits)[NJ]);
 template <int NJ> __device__ __forceinline__ void wmask_from_bits(const uint32_t *vw, int lane, uint32_t (&vm)[NJ]);
 
 #ifdef GG_AB_PROF
@@ -236,10 +236,11 @@ struct EnvArgs {
   int heuristic;
   uint32_t *ws;             // IO == 3 only: the caller's workspace, uint32 [B][5N+1] (tracked boards of the last outputs)
   int canonical;            // IO == 3 only
-  // WTS instantiation: the move of every game is DRAWN from these policy weights (float32
+  // WTS instantiation: the move of every game is DRAWN from these policy weights (float32 / bfloat16 / float16
   // [B][N*N+1], gg_ws.h: masked by the game's invalid-move rows, exact fixed-point inverse CDF, the game's generator)
   // instead of read from `actions` - gogame.random_weighted_action (gym_go/gogame.py:385-392) fused into the step
-  const float *weights;
+  const void *weights;
+  int wdtype;               // GG_W_F32 / GG_W_BF16 / GG_W_F16
 };
 
 // WTS (ENV + MOVES): the move of every game is drawn from env.weights by the kernel (gg_ws.h) instead of read from env.actions
@@ -471,53 +472,55 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
     // ---------------------------------------------------------------- policy-weighted moves (ENV + MOVES + weights)
     int *wact = reinterpret_cast<int *>(tmp);   // [16] the drawn moves (tmp is free on tracked boards)
     if (WTS) {
-      constexpr int NJ = (R * R + 1 + 15) / 16;
-      const int A = hf.P + 1;
+      constexpr int NJ = (R * R + 1 + 15) / 16, AMIN = FULLN ? R * R + 1 : 5;
+      // every lane-derived value of this block comes from a FRESH lane id (volatile asm: neither hoisted nor merged).
+      // Derived from the ids computed before the group loop they are spilled across it, and each reload is a scratch
+      // round trip that also waits for the weight loads in flight: 25 dependent round trips, +12 us on the launch.
+      int lw;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lw));
+      const int q4w = lw >> 2, t4w = lw & 3, r04w = RPL * t4w, rw = lw >> 4;
+      const int Pw = N * N, A = Pw + 1;
       uint32_t *vb = sc;        // [16][16]: the boards' valid-action bit-strings (the flood blocks are free before the ply)
       uint32_t *uh = clsv;      // [16] draws, [16 .. 31] "this game draws"
       WAVE_SYNC();
-      for (int i = hf.lane; i < kNB4 * 16; i += kWave) vb[i] = 0;
-      if (hf.lane < kNB4) {
-        const uint32_t fl = flagsv[hf.lane];
+      for (int i = lw; i < kNB4 * 16; i += kWave) vb[i] = 0;
+      if (lw < kNB4) {
+        const uint32_t fl = flagsv[lw];
         const bool draws = ((fl >> 3) & 1u) && !(((fl >> 2) & 1u) && !auto_reset);   // a frozen game keeps its generator
         uint32_t hi = 0;
         if (draws) {
-          uint64_t x = ((uint64_t)rngv[2 * hf.lane + 1] << 32) | rngv[2 * hf.lane];
+          uint64_t x = ((uint64_t)rngv[2 * lw + 1] << 32) | rngv[2 * lw];
           hi = (uint32_t)(splitmix_next(x) >> 32);
-          rngv[2 * hf.lane] = (uint32_t)x;
-          rngv[2 * hf.lane + 1] = (uint32_t)(x >> 32);
+          rngv[2 * lw] = (uint32_t)x;
+          rngv[2 * lw + 1] = (uint32_t)(x >> 32);
         }
-        uh[hf.lane] = hi;
-        uh[kNB4 + hf.lane] = draws ? 1u : 0u;
-        wact[hf.lane] = -1;
+        uh[lw] = hi;
+        uh[kNB4 + lw] = draws ? 1u : 0u;
+        wact[lw] = -1;
       }
+      // the weights of the first four boards: in flight while the bit-strings are built
+      uint32_t nbits[NJ];
+      wload_row<NJ, AMIN>(env.weights, (b_first + rw < B) ? b_first + rw : B - 1, env.wdtype, A, lw, nbits);
       WAVE_SYNC();
       {   // every quad ORs the playable points of its rows into its board's string (a game being reset plays on the empty board)
-        const uint32_t fl = flagsv[q4];
+        const uint32_t fl = flagsv[q4w];
         const bool resets = ((fl >> 2) & 1u) && auto_reset;
         const uint32_t fullrow = (1u << N) - 1u;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-          const int rr = r04 + r;
+          const int rr = r04w + r;
           if (rr < N) {
             const uint32_t ok = resets ? fullrow : (fullrow & ~inv_r[r]);
             const uint32_t q = (uint32_t)(rr * N);
             const uint64_t sh = (uint64_t)ok << (q & 31u);
-            atomicOr(vb + 16 * q4 + (q >> 5), (uint32_t)sh);
-            if ((uint32_t)(sh >> 32)) atomicOr(vb + 16 * q4 + (q >> 5) + 1, (uint32_t)(sh >> 32));
+            atomicOr(vb + 16 * q4w + (q >> 5), (uint32_t)sh);
+            if ((uint32_t)(sh >> 32)) atomicOr(vb + 16 * q4w + (q >> 5) + 1, (uint32_t)(sh >> 32));
           }
         }
-        if (t4 == 0) atomicOr(vb + 16 * q4 + (hf.P >> 5), 1u << (hf.P & 31));   // the pass
+        if (t4w == 0) atomicOr(vb + 16 * q4w + (Pw >> 5), 1u << (Pw & 31));   // the pass
       }
       WAVE_SYNC();
       // four boards per pass, one DPP row each; the weights of the next pass are in flight while this one is drawn
-      const int rw = hf.lane >> 4;
-      uint32_t nbits[NJ];
-      {
-        const int s0 = rw;
-        const int64_t b0 = (b_first + s0 < B) ? b_first + s0 : B - 1;
-        wload_row<NJ>(env.weights + b0 * (int64_t)A, A, hf.lane, nbits);
-      }
 #pragma unroll 1
       for (int ps = 0; ps < 4; ++ps) {
         uint32_t bits[NJ], vm[NJ];
@@ -526,11 +529,10 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         const int s = 4 * ps + rw;
         if (ps + 1 < 4) {
           const int s1 = s + 4;
-          const int64_t b1 = (b_first + s1 < B) ? b_first + s1 : B - 1;
-          wload_row<NJ>(env.weights + b1 * (int64_t)A, A, hf.lane, nbits);
+          wload_row<NJ, AMIN>(env.weights, (b_first + s1 < B) ? b_first + s1 : B - 1, env.wdtype, A, lw, nbits);
         }
-        wmask_from_bits<NJ>(vb + 16 * s, hf.lane, vm);
-        const int a = wsample_row<NJ>(bits, vm, uh[s], hf.lane);
+        wmask_from_bits<NJ>(vb + 16 * s, lw, vm);
+        const int a = wsample_row<NJ>(bits, vm, uh[s], lw);
         if (a != -2 && s < nb && b_first + s < B && uh[kNB4 + s] != 0u) wact[s] = a;
       }
       WAVE_SYNC();

@@ -53,9 +53,8 @@ __device__ __forceinline__ int wsample_row(const uint32_t (&bits)[NJ], const uin
   uint32_t v[NJ], mx = 0;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    int32_t s = (int32_t)bits[j];
-    s = s < 0 ? 0 : s;
-    s = s > 0x7F7FFFFF ? 0x7F7FFFFF : s;
+    int32_t s;   // clamp to [+0, FLT_MAX] on the bit pattern: one v_med3_i32
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(s) : "v"((int32_t)bits[j]), "v"(0x7F7FFFFF));
     v[j] = (uint32_t)s & vm[j];
     mx = v[j] > mx ? v[j] : mx;
   }
@@ -80,17 +79,45 @@ __device__ __forceinline__ int wsample_row(const uint32_t (&bits)[NJ], const uin
   return (T == 0u && i == 0) ? -1 : -2;
 }
 
-// weights of the row's board -> registers (contiguous 64-byte segments per load instruction and row).  The loads are
+// weights of the row's board -> registers as float32 bit patterns (contiguous 64- / 32-byte segments per load
+// instruction and row).  wt: GG_W_F32 float32, GG_W_BF16 bfloat16, GG_W_F16 float16 - the 16-bit forms are widened
+// exactly, so the draw is the one of the float32 weights with the same values at half the HBM traffic.  The loads are
 // UNCONDITIONAL on a clamped index (the caller hands over a readable row also for an absent board; what lies beyond the
 // action range is masked by vm[]): a load under a per-element condition is a branch whose join waits for the data, i.e.
 // NJ dependent memory round trips instead of NJ loads in flight (measured: 64 -> 26 us per 65 536 boards).
-template <int NJ>
-__device__ __forceinline__ void wload_row(const float *__restrict__ wrow, int A, int lane, uint32_t (&bits)[NJ]) {
+// AMIN: a compile-time lower bound of A (the exact value when the board fills its row capacity): elements below it
+// are addressed as base + constant (one address computation, immediate offsets), only the rest through a clamped index.
+template <int NJ, int AMIN = 5>
+__device__ __forceinline__ void wload_row(const void *__restrict__ wbase, int64_t board, int wt, int A, int lane, uint32_t (&bits)[NJ]) {
   const int i = lane & 15;
+  if (wt == GG_W_F32) {
+    const float *wrow = reinterpret_cast<const float *>(wbase) + board * (int64_t)A;
+    const float *wl = wrow + i;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int a = i + 16 * j;
-    bits[j] = __float_as_uint(wrow[a < A ? a : A - 1]);
+    for (int j = 0; j < NJ; ++j) {
+      const int a = i + 16 * j;
+      bits[j] = __float_as_uint(16 * j + 15 < AMIN ? wl[16 * j] : wrow[a < A ? a : A - 1]);
+    }
+  } else {
+    const uint16_t *wrow = reinterpret_cast<const uint16_t *>(wbase) + board * (int64_t)A;
+    const uint16_t *wl = wrow + i;
+    uint32_t h[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int a = i + 16 * j;
+      h[j] = 16 * j + 15 < AMIN ? wl[16 * j] : wrow[a < A ? a : A - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (wt == GG_W_BF16) {
+        bits[j] = h[j] << 16;
+      } else {
+        _Float16 x;
+        const uint16_t hv = (uint16_t)h[j];
+        __builtin_memcpy(&x, &hv, 2);
+        bits[j] = __float_as_uint((float)x);
+      }
+    }
   }
 }
 
@@ -106,7 +133,7 @@ __device__ __forceinline__ void wmask_from_bits(const uint32_t *vw, int lane, ui
 // The validity of an action is read straight from plane 3 (one byte per action, the same interleaved pattern as the
 // weights); states == nullptr: nothing is masked.
 template <int R>
-__global__ __launch_bounds__(kWave) void k_sample_weighted(const uint8_t *__restrict__ states, const float *__restrict__ weights,
+__global__ __launch_bounds__(kWave) void k_sample_weighted(const uint8_t *__restrict__ states, const void *__restrict__ weights, int wt,
                                                            uint64_t *__restrict__ rng, int32_t *__restrict__ actions,
                                                            int64_t B, int N) {
   constexpr int NJ = WsCfg<R>::kNJ;
@@ -116,7 +143,7 @@ __global__ __launch_bounds__(kWave) void k_sample_weighted(const uint8_t *__rest
     const bool on = b0 + row < B;
     const int64_t b = on ? b0 + row : B - 1;
     uint32_t bits[NJ], vm[NJ];
-    wload_row<NJ>(weights + b * (int64_t)A, A, lane, bits);
+    wload_row<NJ>(weights, b, wt, A, lane, bits);
     uint64_t x = rng[b];
     if (states) {
       const uint8_t *gs = states + b * (int64_t)S;
@@ -147,7 +174,7 @@ __global__ __launch_bounds__(kWave) void k_sample_weighted(const uint8_t *__rest
 // 2 N .. 3 N - 1 of a board, the flag word (bit 2: game over) its last one.  The rows become a valid-action bit-string in LDS.
 template <int R>
 __global__ __launch_bounds__(kWave) void k_sample_weighted_rows(const uint32_t *__restrict__ boards, int W,
-                                                                const float *__restrict__ weights, uint64_t *__restrict__ rng,
+                                                                const void *__restrict__ weights, int wt, uint64_t *__restrict__ rng,
                                                                 int32_t *__restrict__ actions, int64_t B, int N) {
   constexpr int NJ = WsCfg<R>::kNJ, VW = (WsCfg<R>::kVW + 1) & ~1;
   __shared__ uint32_t vbits[4][VW + 2];
@@ -158,7 +185,7 @@ __global__ __launch_bounds__(kWave) void k_sample_weighted_rows(const uint32_t *
     const bool on = b0 + row < B;
     const int64_t b = on ? b0 + row : B - 1;
     uint32_t bits[NJ], vm[NJ];
-    wload_row<NJ>(weights + b * (int64_t)A, A, lane, bits);
+    wload_row<NJ>(weights, b, wt, A, lane, bits);
     uint64_t x = rng[b];
     const uint32_t *gb = boards + b * (int64_t)W;
     const uint32_t ended = (gb[W - 1] >> 2) & 1u;

@@ -700,7 +700,7 @@ def batch_env_step_tracked(tracked, actions=None, rng=None, komi=0.0, reward_met
             raise ValueError('give actions OR weights, not both')
         if rng is None:
             raise ValueError('drawing from weights needs the rng state')
-        weights = _weights_tensor(weights, B, N, dev)
+        weights, wcode = _weights_tensor(weights, B, N, dev)
     if actions is None and rng is None:
         raise ValueError('batch_env_step_tracked needs actions or an rng state to draw them with')
     if out is None:
@@ -711,7 +711,7 @@ def batch_env_step_tracked(tracked, actions=None, rng=None, komi=0.0, reward_met
     rewards, dones, status, taken = out
     if weights is not None:
         code = _lib.lib().gg_batch_env_step_tracked_weighted(
-            _lib.dev_ptr(tracked, _I32, 'tracked'), _lib.dev_ptr(weights, torch.float32, 'weights'), _lib.dev_ptr(rng, _I64, 'rng'),
+            _lib.dev_ptr(tracked, _I32, 'tracked'), _lib.dev_ptr(weights, weights.dtype, 'weights'), wcode, _lib.dev_ptr(rng, _I64, 'rng'),
             _lib.dev_ptr(rewards, torch.float32, 'rewards'), _lib.dev_ptr(dones, _U8, 'dones'), _lib.dev_ptr(status, _I32, 'status'),
             _lib.dev_ptr(taken, _I32, 'taken'), _lib.dev_ptr(states_out, _U8, 'states_out'),
             _lib.dev_ptr(steps_done, _I64, 'steps_done'), B, N, float(komi),
@@ -734,13 +734,20 @@ def batch_env_step_tracked(tracked, actions=None, rng=None, komi=0.0, reward_met
 # gg_batch_sample_weighted) so that device and CPU restatement agree bit for bit; P(a) = w[a] / sum(w) over the playable
 # actions up to 22-bit fixed point relative to the largest weight.
 
+WEIGHT_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}   # GG_W_* of include/gymgo_amd.h
+
+
 def _weights_tensor(weights, B, N, device):
+    """-> (contiguous device tensor in its own dtype if that is float32 / bfloat16 / float16 - anything else becomes
+    float32 - and the GG_W_* code).  The 16-bit forms are widened exactly by the kernels: half the bytes, the same draw."""
     if not isinstance(weights, torch.Tensor):
         weights = torch.as_tensor(np.asarray(weights, dtype=np.float32))
-    w = weights.to(device=device, dtype=torch.float32).contiguous()
+    if weights.dtype not in WEIGHT_DTYPES:
+        weights = weights.to(torch.float32)
+    w = weights.to(device=device).contiguous()
     if tuple(w.shape) != (B, N * N + 1):
-        raise ValueError('weights must be float32 [B, N*N+1] = [%d, %d] (got %s)' % (B, N * N + 1, tuple(w.shape)))
-    return w
+        raise ValueError('weights must be [B, N*N+1] = [%d, %d] (got %s)' % (B, N * N + 1, tuple(w.shape)))
+    return w, WEIGHT_DTYPES[w.dtype]
 
 
 def _check_drawn(actions, check):
@@ -762,10 +769,10 @@ def batch_sample_weighted(batch_states, weights, rng, check=False):
             raise ValueError('without states the weights must be a device tensor')
         B, dev = weights.shape[0], weights.device
         N = int(round((weights.shape[1] - 1) ** 0.5))
-    w = _weights_tensor(weights, B, N, dev)
+    w, wcode = _weights_tensor(weights, B, N, dev)
     actions = torch.empty(B, dtype=_I32, device=dev)
     code = _lib.lib().gg_batch_sample_weighted(
-        _lib.dev_ptr(batch_states, _U8, 'states'), _lib.dev_ptr(w, torch.float32, 'weights'), _lib.dev_ptr(rng, _I64, 'rng'),
+        _lib.dev_ptr(batch_states, _U8, 'states'), _lib.dev_ptr(w, w.dtype, 'weights'), wcode, _lib.dev_ptr(rng, _I64, 'rng'),
         _lib.dev_ptr(actions, _I32, 'actions'), B, N, _lib.stream_ptr(dev))
     _lib.check(code, 'gg_batch_sample_weighted')
     return _check_drawn(actions, check)
@@ -778,10 +785,10 @@ def batch_sample_weighted_rows(boards, board_size, weights, rng, check=False):
     planes = (W - 1) // N if N > 0 else 0
     if boards.dtype != _I32 or planes * N + 1 != W or planes not in (3, 5):
         raise ValueError('boards must be packed [B, 3N+1] or tracked [B, 5N+1] int32 for N = %d (got %s)' % (N, tuple(boards.shape)))
-    w = _weights_tensor(weights, B, N, boards.device)
+    w, wcode = _weights_tensor(weights, B, N, boards.device)
     actions = torch.empty(B, dtype=_I32, device=boards.device)
     code = _lib.lib().gg_batch_sample_weighted_rows(
-        _lib.dev_ptr(boards, _I32, 'boards'), planes, _lib.dev_ptr(w, torch.float32, 'weights'), _lib.dev_ptr(rng, _I64, 'rng'),
+        _lib.dev_ptr(boards, _I32, 'boards'), planes, _lib.dev_ptr(w, w.dtype, 'weights'), wcode, _lib.dev_ptr(rng, _I64, 'rng'),
         _lib.dev_ptr(actions, _I32, 'actions'), B, N, _lib.stream_ptr(boards.device))
     _lib.check(code, 'gg_batch_sample_weighted_rows')
     return _check_drawn(actions, check)

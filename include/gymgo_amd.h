@@ -38,6 +38,11 @@ extern "C" {
 #define GG_E_NULLPTR (-2)  /* a required pointer is NULL */
 #define GG_E_BADARG (-3)   /* other argument out of range */
 
+/* element type of policy weights (gg_batch_sample_weighted*, gg_batch_env_step_tracked_weighted) */
+#define GG_W_F32 0  /* float32 */
+#define GG_W_BF16 1 /* bfloat16: the upper half of a float32 */
+#define GG_W_F16 2  /* IEEE float16 */
+
 /* per-game status written by gg_batch_next_states */
 #define GG_STATUS_OK 0
 #define GG_STATUS_ILLEGAL 1 /* point has INVD set / action out of range: the reference raises
@@ -239,14 +244,15 @@ int32_t gg_batch_env_step_tracked(uint32_t *tracked, const int32_t *actions, uin
 /*
  * gg_batch_env_step_tracked with the move of every game DRAWN FROM POLICY WEIGHTS by the same launch:
  * gogame.random_weighted_action (gym_go/gogame.py:385-392) fused into GoEnv.step (gym_go/envs/go_env.py:49-76).
- * weights: float32 [B][N*N+1] (one weight per action, the pass last).  Per game: a finished game is reset first when
+ * weights: [B][N*N+1] of float32 / bfloat16 / float16 (weight_dtype = GG_W_*; one weight per action, the pass last; the
+ * 16-bit forms are widened exactly and halve the bytes this launch reads).  Per game: a finished game is reset first when
  * auto_reset; the weights are masked by the game's invalid-move rows (the pass is always playable), L1-normalised and
  * drawn from as gg_batch_sample_weighted describes, with rng[b] (which advances once; a frozen game - finished,
  * auto_reset == 0 - draws nothing and is refused).  A game whose playable weights are all zero is refused
  * (status GG_STATUS_ILLEGAL, taken action -1) - np.random.choice raises for such a vector.  Other arguments and
  * outputs as gg_batch_env_step_tracked; taken_actions receives the drawn moves.
  */
-int32_t gg_batch_env_step_tracked_weighted(uint32_t *tracked, const float *weights, uint64_t *rng, float *rewards,
+int32_t gg_batch_env_step_tracked_weighted(uint32_t *tracked, const void *weights, int32_t weight_dtype, uint64_t *rng, float *rewards,
                                            uint8_t *dones, int32_t *status, int32_t *taken_actions, uint8_t *states_out,
                                            int64_t *steps_done, int64_t B, int32_t N, float komi, int32_t reward_method,
                                            int32_t auto_reset, void *hip_stream);
@@ -256,7 +262,8 @@ int32_t gg_batch_env_step_tracked_weighted(uint32_t *tracked, const float *weigh
  * gogame.random_action(state) = the same with weights 1 - invalid       gym_go/gogame.py:395-404
  * for every game: actions[b] ~ weights[b] / sum(weights[b]) over the playable actions.  The reference normalises in
  * float64 and draws from NumPy's global generator; so that device and oracle agree bit for bit the draw is defined in
- * integers: (1) each float32 weight is clamped to [+0, FLT_MAX] on its bit pattern (negative -> 0, NaN / inf -> FLT_MAX)
+ * integers: (1) each weight (float32, or bfloat16 / float16 widened exactly: weight_dtype = GG_W_*) is clamped to
+ * [+0, FLT_MAX] on its float32 bit pattern (negative -> 0, NaN / inf -> FLT_MAX)
  * and zeroed where plane 3 of states[b] is set (the reference ASSUMES invalid moves have weight 0, :387; the pass is
  * never masked, a finished game masks nothing, gym_go/gogame.py:155-156; states == NULL: no mask); (2) with E = max(the
  * largest weight's biased exponent, 24), q[a] = trunc(w[a] * 2^(148 - E)) < 2^22: the weights as 22-bit fixed point
@@ -264,12 +271,12 @@ int32_t gg_batch_env_step_tracked_weighted(uint32_t *tracked, const float *weigh
  * (gg_rng_seed's generator, advanced once per game per call); (4) the action is the first one, in the interleaved order
  * a = i + 16 j (i = 0..15 outer), whose running sum of q exceeds k, so P(a) = q[a] / T.  T == 0 gives actions[b] = -1.
  */
-int32_t gg_batch_sample_weighted(const uint8_t *states, const float *weights, uint64_t *rng, int32_t *actions, int64_t B,
-                                 int32_t N, void *hip_stream);
+int32_t gg_batch_sample_weighted(const uint8_t *states, const void *weights, int32_t weight_dtype, uint64_t *rng,
+                                 int32_t *actions, int64_t B, int32_t N, void *hip_stream);
 
 /* The same draw for row-mask boards: planes = 3 (packed, gg_batch_pack_states) or 5 (tracked, gg_batch_track_states). */
-int32_t gg_batch_sample_weighted_rows(const uint32_t *boards, int32_t planes, const float *weights, uint64_t *rng,
-                                      int32_t *actions, int64_t B, int32_t N, void *hip_stream);
+int32_t gg_batch_sample_weighted_rows(const uint32_t *boards, int32_t planes, const void *weights, int32_t weight_dtype,
+                                      uint64_t *rng, int32_t *actions, int64_t B, int32_t N, void *hip_stream);
 
 /*
  * gogame.all_symmetries(image) / gogame.random_symmetry(image)          gym_go/gogame.py:340-382

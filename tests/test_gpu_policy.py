@@ -298,3 +298,48 @@ def test_symmetry_of_packed_and_tracked_boards_is_geometric(N, B):
     assert np.array_equal(got[live], want[live])
     with pytest.raises(ValueError):
         gogame.batch_symmetry_rows(gogame.batch_pack(st), N + 1, orient)
+
+
+@pytest.mark.parametrize('dtype', ['bfloat16', 'float16'])
+def test_half_precision_weights_draw_like_their_float32_values(dtype):
+    """bfloat16 / float16 policy weights (GG_W_BF16 / GG_W_F16) are widened exactly by the kernels: the draw is the
+    oracle's draw on the same values as float32 - stand-alone on byte planes / packed / tracked boards and fused into
+    the tracked env step; half the bytes read."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    tdt = getattr(torch, dtype)
+    B, N = 3000, 19
+    gen = np.random.default_rng(5)
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, 12)
+    for g in range(8):
+        lo, hi = g * B // 8, (g + 1) * B // 8
+        gogame.batch_rollout(st[lo:hi], rng[lo:hi], g * 45, False)
+    w32 = (gen.random((B, N * N + 1)) ** 5).astype(np.float32)
+    w32 *= (10.0 ** gen.integers(-4, 3, size=(B, 1))).astype(np.float32)
+    w32[gen.random(w32.shape) < 0.4] = 0
+    w32[7] = 0
+    wh = torch.from_numpy(w32).cuda().to(tdt)                  # what a bf16 / fp16 policy head hands over
+    exact = wh.float().cpu().numpy()                           # ... and its exact float32 values
+    assert (exact != w32).any()
+    host = st.cpu().numpy()
+    rng0 = _rng_np(rng).copy()
+    want, rng1 = c_oracle.batch_sample_weighted(host, exact, rng0)
+    for draw in (lambda r: gogame.batch_sample_weighted(st, wh, r),
+                 lambda r: gogame.batch_sample_weighted_rows(gogame.batch_pack(st), N, wh, r),
+                 lambda r: gogame.batch_sample_weighted_rows(gogame.batch_track(st), N, wh, r)):
+        r = _rng_t(rng0)
+        assert np.array_equal(draw(r).cpu().numpy(), want)
+        assert np.array_equal(_rng_np(r), rng1)
+    assert want[7] == -1 and (want >= 0).sum() > B - 50
+    # fused into the env step
+    tracked = gogame.batch_track(st)
+    obs = torch.empty_like(st)
+    r = _rng_t(rng0)
+    w_want, w_acts, w_status, w_rng1 = _oracle_weighted_step(c_oracle, host, exact, rng0, True)
+    rewards, dones, status, taken = gogame.batch_env_step_tracked(tracked, None, r, 0.0, 'real', True, states_out=obs, weights=wh)
+    assert np.array_equal(taken.cpu().numpy(), w_acts) and np.array_equal(status.cpu().numpy(), w_status)
+    assert np.array_equal(obs.cpu().numpy(), w_want) and np.array_equal(_rng_np(r), w_rng1)
+    # float64 weights are converted to float32 by the wrapper
+    got64 = gogame.batch_sample_weighted(st, torch.from_numpy(exact.astype(np.float64)).cuda(), _rng_t(rng0))
+    assert np.array_equal(got64.cpu().numpy(), want)
