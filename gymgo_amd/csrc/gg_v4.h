@@ -260,7 +260,6 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
   constexpr int SCP = Lds4<R>::kScPad;
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds4<R>::kTotal];
   if (FULLN) N = R;   // a compile-time constant from here on: row masks, r * N + c and the "row exists" tests fold
-  const Half hf = make_half(threadIdx.x, N, inv);
   uint32_t *st = lds + Lds4<R>::kState;     // st[colour * PL + board * RS + row]
   uint32_t *flagsv = lds + Lds4<R>::kMeta;  // bit 0 turn, 1 passed, 2 done, 3 on, 4 stopped / refused, 5 reset (dirty), 6 illegal move (IO 3)
   int *actv = reinterpret_cast<int *>(lds + Lds4<R>::kMeta + kNB4);
@@ -275,14 +274,21 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
   uint32_t *park = lds + Lds4<R>::kV2;      // tracked I/O: park[set * PL + board * RS + row], set 0 invalid, 1 mb, 2 mw
   uint2 *lut = reinterpret_cast<uint2 *>(lds + Lds4<R>::kLut);
   constexpr bool PACKED = IO == 1, TRACKED = IO == 2, CACHED = IO == 3;
-  const int S = 6 * hf.P, W = ((TRACKED || CACHED) ? 5 : 3) * N + 1;
-  const bool row = hf.hl < RS;
+  const int S = 6 * N * N, W = ((TRACKED || CACHED) ? 5 : 3) * N + 1;
   // nb (even, <= kNB4) boards per wave: the host picks it so that the groups fill the resident waves evenly
   const int64_t ngroups = (B + nb - 1) / nb;
-  const int q4 = hf.lane >> 2, t4 = hf.lane & 3, r04 = RPL * t4;   // outside the ply loop: board / first row of this lane
 
   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const int64_t b_first = g * nb;
+    // The lane-derived values of the load phase are computed from a fresh lane id INSIDE the group loop (volatile asm:
+    // not hoisted).  Computed once before the loop the compiler spills some of them across the first analysis and
+    // reloads them one by one - each reload a scratch round trip behind a full `s_waitcnt vmcnt(0)` on the head of a
+    // launch that, for the one-ply entry points, is one iteration long.
+    int ln0;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln0));
+    const Half hf = make_half(ln0, N, inv);
+    const bool row = hf.hl < RS;
+    const int q4 = hf.lane >> 2, t4 = hf.lane & 3, r04 = RPL * t4;   // outside the ply loop: board / first row of this lane
     // the next mover's invalid-move mask and the stones of groups with >= 2 liberties, rows r04 .. r04 + RPL - 1 of
     // board q4: in registers from here to the write-back
     uint32_t inv_r[RPL], M[RPL];
