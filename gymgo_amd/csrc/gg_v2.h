@@ -772,7 +772,7 @@ __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_
     if (on && hf.hl == 0) {
       rng[b] = hf.h ? xb : xa;
       if (last_actions) last_actions[b] = last;
-      if (steps_done) steps_done[b] += played;
+      if (steps_done && played) atomicAdd(reinterpret_cast<unsigned long long *>(steps_done) + b, (unsigned long long)played);
     }
   }
 }

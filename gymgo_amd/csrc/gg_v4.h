@@ -36,6 +36,9 @@ namespace gg {
 // flood results and a few words per board: 8 704 B per wave at 19x19 in the ply loop, 9 728 B with the write-back's group
 // bit-string and table (the limit for four waves per SIMD is 10 240 B).
 constexpr int kNB4 = 16;
+#ifndef GG_KLD
+#define GG_KLD 8   // loads of a tracked block in flight per lane
+#endif
 
 // gg_ws.h (policy-weighted sampling, one DPP row of 16 lanes per board); used by the weighted env step below
 template <int NJ> __device__ __forceinline__ int wsample_row(const uint32_t (&bits)[NJ], const uint32_t (&vm)[NJ], uint32_t uhi, int lane);
@@ -307,19 +310,22 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       for (int i = hf.lane; i < 2 * PL; i += kWave) st[i] = 0;      // rows N .. RS-1 and absent boards read as zero
       for (int i = hf.lane; i < 3 * PL; i += kWave) park[i] = 0;
       const uint32_t invW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;   // i / W exactly for i < 16 * 96
+      // the generator states of the group: requested before the block, so that they do not cost a round trip of their own
+      uint64_t xg = 0;
+      if ((!MOVES || WTS) && hf.lane < kNB4) xg = rng[(hf.lane < nb && b_first + hf.lane < B) ? b_first + hf.lane : B - 1];
       // eight loads of the block are in flight at a time (a plain copy loop waits for each load in turn: 24 dependent
       // round trips on the head of a launch; all 24 at once cost 47 spilled registers)
       WAVE_SYNC();
 #pragma unroll 1
-      for (int i0 = 0; i0 < nw; i0 += 8 * kWave) {
-        uint32_t buf[8];
+      for (int i0 = 0; i0 < nw; i0 += GG_KLD * kWave) {
+        uint32_t buf[GG_KLD];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < GG_KLD; ++k) {
           const int i = i0 + hf.lane + kWave * k;
           buf[k] = gp[i < nw ? i : nw - 1];
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < GG_KLD; ++k) {
           const int i = i0 + hf.lane + kWave * k;
           if (i < nw) {
             const uint32_t v = buf[k];
@@ -341,9 +347,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         lastv[sb] = -1;
         playedv[sb] = 0;
         if (!MOVES || WTS) {
-          const uint64_t x = rng[on ? b_first + sb : B - 1];
-          rngv[2 * sb] = (uint32_t)x;
-          rngv[2 * sb + 1] = (uint32_t)(x >> 32);
+          rngv[2 * sb] = (uint32_t)xg;
+          rngv[2 * sb + 1] = (uint32_t)(xg >> 32);
         }
       }
       WAVE_SYNC();
@@ -954,7 +959,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         } else {
           if (!MOVES || WTS) rng[b] = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
           if (last_actions) last_actions[b] = lastv[sb];
-          if (steps_done) steps_done[b] += played;
+          if (steps_done && played) atomicAdd(reinterpret_cast<unsigned long long *>(steps_done) + b, (unsigned long long)played);   // (no read-back: nothing to wait for)
           if (MOVES && played_out) played_out[b] = played;
         }
       }
@@ -1029,7 +1034,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         const int played = playedv[sb];
         if (!MOVES) rng[b] = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
         if (last_actions) last_actions[b] = lastv[sb];
-        if (steps_done) steps_done[b] += played;
+        if (steps_done && played) atomicAdd(reinterpret_cast<unsigned long long *>(steps_done) + b, (unsigned long long)played);
         if (MOVES && played_out) played_out[b] = played;
       }
       WAVE_SYNC();
@@ -1064,7 +1069,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       if (on && hs.hl == 0) {
         if (!MOVES) rng[b] = ((uint64_t)rngv[2 * s + 1] << 32) | rngv[2 * s];
         if (last_actions) last_actions[b] = lastv[s];
-        if (steps_done) steps_done[b] += played;
+        if (steps_done && played) atomicAdd(reinterpret_cast<unsigned long long *>(steps_done) + b, (unsigned long long)played);
         if (MOVES && played_out) played_out[b] = played;
       }
       WAVE_SYNC();

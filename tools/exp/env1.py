@@ -5,6 +5,8 @@ import torch
 from gymgo_amd import _lib
 if os.environ.get('USE_AB'):
     _lib.LIB_PATH = os.path.join(ROOT, 'tools', 'exp', 'libgymgo_ab.so')
+if os.environ.get('LIB'):
+    _lib.LIB_PATH = os.path.join(ROOT, 'tools', 'exp', os.environ['LIB'])
 from gymgo_amd import gogame
 B, N = 65536, 19
 st = gogame.batch_init_state(B, N, device='cuda'); rng = gogame.rng_seed(B, 3)
@@ -22,7 +24,7 @@ def ev(fn, reps=40):
     return a.elapsed_time(b) / reps * 1e3
 acts = gogame.batch_sample_actions(st, rng).reshape(B, 1).contiguous()
 pl = torch.empty(B, dtype=torch.int32, device='cuda')
-tag = 'NB=%s' % os.environ.get('GG_AB_NB', 'auto')
+tag = '%s NB=%s' % (os.environ.get('LIB', '-'), os.environ.get('GG_AB_NB', 'auto'))
 print(tag, 'play_moves_tracked T=1   %.1f us' % ev(lambda: gogame.batch_play_moves_tracked(tr, acts, pl)))
 print(tag, 'rollout_tracked F=1      %.1f us' % ev(lambda: gogame.batch_rollout_tracked(tr, rng, 1, True)))
 print(tag, 'env sampled, no obs      %.1f us' % ev(lambda: gogame.batch_env_step_tracked(tr, None, rng, 7.5, 'real', True, out=out)))
