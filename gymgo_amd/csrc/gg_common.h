@@ -344,6 +344,72 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
   return ((uint64_t)hi << 32) | (uint64_t)lo;
 }
 
+// ---------------------------------------------------------------- a fair share of the SIMD for long-running waves
+// The instruction arbiter of a SIMD serves its OLDEST wave first.  Four waves that each run 256 plies on one SIMD therefore
+// do not advance together: the oldest runs at the speed of a wave that is alone (3.4 us per ply), the youngest gets what
+// is left, and they finish at 0.40 / 0.59 / 0.79 / 1.00 of the launch - its second half runs at three, two and finally one
+// wave per SIMD, where the issue port is idle most of the time (measured per workgroup with `s_getreg HW_ID` +
+// wall_clock64: tools/exp/where.py).  Nothing a wave computes depends on another wave, so the cure is pure scheduling:
+// every wave publishes how far it is (one word per hardware wave slot in a board in device memory), reads the words of
+// the other slots of its SIMD, and sets its own issue priority (`s_setprio`, 0..3) by how many of its mates are at least
+// `lag` units behind it - the leader yields, the stragglers catch up, all finish within microseconds of each other and
+// the SIMD keeps four waves to the end: 2.33 -> 2.03 ms per 256-ply launch of the fused rollout (7.2 -> 8.3e9 steps/s).
+// A hysteresis (`lag` = 8 plies, checked every fourth ply) beats strict equality: the waves then hold DISTINCT priorities
+// for long stretches, and four strictly ordered waves issue more per cycle than four that keep overtaking each other.
+// The mates' words travel global -> LDS by LDS-DMA and are read at the NEXT check: no register is held and nothing
+// waits for the load.  The board carries no result: stale or foreign entries (another stream's kernel) only shift
+// priorities.  It is the one piece of mutable device-global state of the library (512 KB per device).
+__device__ unsigned int gg_fair_board[8 * 8 * 2 * 16 * 4 * 16];   // [XCC][SE][SH][CU][SIMD][wave slot]: progress + 1, 0 / ~0 = free
+
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // M0 is written and consumed inside one asm statement (clang warns that it is reserved)
+struct FairShare {
+  unsigned int *row;      // this SIMD's 16 wave slots on the board (wave-uniform)
+  unsigned int slot;      // this wave's slot
+  uint32_t *mates;        // 16 words of LDS: the row as it was at the previous check
+  uint32_t mates_lds;
+  __device__ __forceinline__ explicit FairShare(uint32_t *lds16) : mates(lds16), mates_lds(lds_addr_of(lds16)) {
+    unsigned int hw, xc;
+    asm volatile("s_getreg_b32 %0, hwreg(4)" : "=s"(hw));    // HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]
+    asm volatile("s_getreg_b32 %0, hwreg(20)" : "=s"(xc));   // XCC_ID
+    const unsigned int simd = ((((xc & 7u) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 15u)) * 4u + ((hw >> 4) & 3u);
+    row = gg_fair_board + simd * 16u;
+    slot = hw & 15u;
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    if (ln < 16) lds16[ln] = 0u;   // nobody seen yet
+  }
+  // progress: any monotone counter (plies, iterations); lag: how far behind a mate must be to count
+  __device__ __forceinline__ void update(uint32_t progress, uint32_t lag) {
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row requested at the previous check has landed long ago
+    const uint32_t mate = ln < 16 ? mates[ln] : 0u;
+    const uint32_t behind = (uint32_t)__popcll(__ballot(mate != 0u && mate != 0xFFFFFFFFu && mate + lag <= progress + 1u));
+    if (behind >= 3u) __builtin_amdgcn_s_setprio(0);
+    else if (behind == 2u) __builtin_amdgcn_s_setprio(1);
+    else if (behind == 1u) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+    if (ln == 0) __hip_atomic_store(row + slot, progress + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS words are in registers before the DMA may overwrite them
+    if (ln < 16) {   // next check's view of the row: global -> LDS directly (no VGPR is held while it flies)
+      const unsigned int *src = row + ln;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc0 sc1" ::"s"(mates_lds), "v"(src) : "memory", "m0");
+    }
+  }
+  __device__ __forceinline__ void release() {
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    if (ln == 0) __hip_atomic_store(row + slot, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_setprio(0);
+  }
+};
+#pragma clang diagnostic pop
+
 // ---- sampler shared by the rollout kernels (mirrors oracle/gg_oracle.c splitmix_next / rollout_ply)
 __device__ __forceinline__ uint64_t splitmix_next(uint64_t &x) {
   uint64_t z = (x += 0x9E3779B97F4A7C15ull);

@@ -171,6 +171,13 @@ int32_t gg_ab_prof_read(unsigned long long *out8) {
 }
 #endif
 
+#ifdef GG_AB_WHERE
+int32_t gg_ab_where_read(unsigned int *out, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(gg::gg_where), sizeof(unsigned int) * 3 * n) == hipSuccess ? 0 : 2;
+}
+#endif
+
 int32_t gg_version(void) { return GG_ABI_VERSION; }
 
 int32_t gg_device_cus(void) {
@@ -197,7 +204,10 @@ int32_t gg_batch_next_states(const uint8_t *in, const int32_t *actions, uint8_t 
                              int32_t N, int32_t canonical, void *hip_stream) {
   GG_ENTER(in);
   if (!actions || !out) return GG_E_NULLPTR;
-  const int grid = grid_resident(cus, (B + 1) / 2, GG_LB_PLY);
+  int grid = grid_resident(cus, (B + 1) / 2, GG_LB_PLY);
+#ifdef GG_AB
+  if (const char *e = getenv("GG_AB_NS_GRID")) grid = atoi(e);
+#endif
   GG_DISPATCH(N, (k_next_states2<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
               (k_next_states2<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
               (k_next_states2<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));

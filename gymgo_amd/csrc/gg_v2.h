@@ -694,6 +694,7 @@ __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_
                                                     int plies, int auto_reset) {
   if (FULLN) { N = R; inv = (65536u + R - 1u) / R; }   // N == R: compile-time constants (see k_env_step2)
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
+  __shared__ uint32_t fair_mates[16];
   const Half hf = make_half(threadIdx.x, N, inv);
   __shared__ uint2 lut[256];
   load_cw_table<R>(lds, hf.lane);
@@ -727,8 +728,10 @@ __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_
     int last = -1, played = 0;
     uint32_t atari = 0;   // next mover's opponents in atari, known from the previous ply of this launch
     bool have_atari = false;
+    FairShare fair(fair_mates);   // a fused launch: the waves of a SIMD advance together (gg_common.h)
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
+      if (!PERPLY && (t & 3) == 0 && plies >= 8) fair.update((uint32_t)t, 8u);
       const bool live = on && !(done && !auto_reset);
       const uint64_t lv = __ballot(live);
       if (lv == 0) break;
@@ -763,6 +766,7 @@ __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_
         ++played;
       }
     }
+    if (!PERPLY && plies >= 8) fair.release();
     if (PACKED) {
       store_packed_h(gp, N, hf, black, white, invalid, (uint32_t)turn, (uint32_t)passed, (uint32_t)done, on && played != 0);
     } else if (__ballot(played != 0)) {

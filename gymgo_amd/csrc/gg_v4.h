@@ -45,6 +45,18 @@ template <int NJ> __device__ __forceinline__ int wsample_row(const uint32_t (&bi
 template <int NJ, int AMIN> __device__ __forceinline__ void wload_row(const void *__restrict__ wbase, int64_t board, int wt, int A, int lane, uint32_t (&bits)[NJ]);
 template <int NJ> __device__ __forceinline__ void wmask_from_bits(const uint32_t *vw, int lane, uint32_t (&vm)[NJ]);
 
+#ifdef GG_AB_WHERE
+// A/B builds only: per workgroup (XCC, HW_ID, duration in 100 MHz ticks) of k_rollout4 - how fast is each part of the chip?
+__device__ unsigned int gg_where[3 * 16384];
+#define GG_WHERE_BEGIN const long long tw0_ = wall_clock64()
+#define GG_WHERE_END do { if (threadIdx.x == 0 && blockIdx.x < 16384) { unsigned int hw_, xc_; \
+    asm volatile("s_getreg_b32 %0, hwreg(4)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(20)" : "=s"(xc_)); \
+    gg_where[3 * blockIdx.x] = xc_; gg_where[3 * blockIdx.x + 1] = hw_; gg_where[3 * blockIdx.x + 2] = (unsigned int)(wall_clock64() - tw0_); } } while (0)
+#else
+#define GG_WHERE_BEGIN do {} while (0)
+#define GG_WHERE_END do {} while (0)
+#endif
+
 #ifdef GG_AB_PROF
 // A/B builds only: shader-clock time of the phases of a ply as one wave experiences them (incl. waiting for the SIMD)
 __device__ unsigned long long gg_prof[8];
@@ -65,7 +77,8 @@ struct Lds4 {
   static_assert(4 * RPL <= RS, "a quad's rows must fit the row stride");
   static constexpr int kState = 0;                               // [2][kNB4][RS]: black, white
   static constexpr int kMeta = kState + 2 * kNB4 * RS;           // flags[16], act[16], last[16], played[16], rng[32]
-  static constexpr int kInfo = kMeta + 6 * kNB4;                 // per board: what phase 2 learnt about q's neighbours
+  static constexpr int kFair = kMeta + 6 * kNB4;                 // [16]: the progress words of this SIMD's wave slots (FairShare)
+  static constexpr int kInfo = kFair + 16;                       // per board: what phase 2 learnt about q's neighbours
   static constexpr int kTmp = kInfo + kNB4;                      // [2][2][RS]: layout change of one pair at load / store
   static constexpr int kUnion = kTmp + 4 * RS;
   // ply loop: per flood lane its result word (liberty class, size, role, seed) + the transpose buffer of the group masks
@@ -281,6 +294,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
   // nb (even, <= kNB4) boards per wave: the host picks it so that the groups fill the resident waves evenly
   const int64_t ngroups = (B + nb - 1) / nb;
 
+  GG_WHERE_BEGIN;
   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const int64_t b_first = g * nb;
     // The lane-derived values of the load phase are computed from a fresh lane id INSIDE the group loop (volatile asm:
@@ -551,9 +565,13 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
 
     // ---------------------------------------------------------------- the plies
     GG_PROF(6);   // load
+    FairShare fair(lds + Lds4<R>::kFair);
     int mv_next = 0;
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
+      // fair share of the SIMD (gg_common.h): every fourth ply the wave publishes the ply it has reached and sets its issue
+      // priority by how many of its SIMD-mates are >= 8 plies behind it
+      if ((t & 3) == 0 && plies >= 8) fair.update((uint32_t)t, 8u);
       // the lane-derived indices of the three phases are recomputed every ply (a few VALU ops) instead of being hoisted
       // out of the loop, where they end up in scratch: a reload is a vector-memory round trip at the top of each phase
       // (volatile asm: neither hoisted nor merged)
@@ -895,6 +913,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       WAVE_SYNC();
       GG_PROF(4);
     }
+    if (plies >= 8) fair.release();
     GG_PROF(5);   // (nothing between the last ply and the write-back)
 
     // ---------------------------------------------------------------- store
@@ -1077,6 +1096,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
     GG_PROF(7);   // write-back
     GG_PROF_FLUSH;
   }
+  GG_WHERE_END;
 }
 
 // byte planes -> tracked boards: the rows of planes 0 / 1 / 3 and the liberty classes of one v2 analysis
