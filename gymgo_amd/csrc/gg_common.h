@@ -354,7 +354,7 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 // the other slots of its SIMD, and sets its own issue priority (`s_setprio`, 0..3) by how many of its mates are at least
 // `lag` units behind it - the leader yields, the stragglers catch up, all finish within microseconds of each other and
 // the SIMD keeps four waves to the end: 2.33 -> 2.03 ms per 256-ply launch of the fused rollout (7.2 -> 8.3e9 steps/s).
-// A hysteresis (`lag` = 8 plies, checked every fourth ply) beats strict equality: the waves then hold DISTINCT priorities
+// A hysteresis (`lag` = an eighth of the launch, at most 24 plies, checked every fourth ply) beats strict equality: the waves then hold DISTINCT priorities
 // for long stretches, and four strictly ordered waves issue more per cycle than four that keep overtaking each other.
 // The mates' words travel global -> LDS by LDS-DMA and are read at the NEXT check: no register is held and nothing
 // waits for the load.  The board carries no result: stale or foreign entries (another stream's kernel) only shift

@@ -204,13 +204,22 @@ int32_t gg_batch_next_states(const uint8_t *in, const int32_t *actions, uint8_t 
                              int32_t N, int32_t canonical, void *hip_stream) {
   GG_ENTER(in);
   if (!actions || !out) return GG_E_NULLPTR;
-  int grid = grid_resident(cus, (B + 1) / 2, GG_LB_PLY);
+  const int64_t npairs = (B + 1) / 2;
+  int grid = grid_resident(cus, npairs, GG_LB_PLY);
+  // from six pairs per resident wave on, the three waves of a SIMD share its pairs unevenly (k_next_states2): fractions
+  // of a SIMD's pairs taken by its oldest / by its two oldest waves, 16.16 fixed point
+  int cols = npairs >= (int64_t)cus * 4 * GG_LB_PLY * 2 ? cus * 4 : 0;
+  uint32_t share1 = (uint32_t)(0.45 * 65536), share2 = (uint32_t)(0.79 * 65536);   // (14 / 11 / 7 of 32 pairs: 65.5 -> 61.6 us per 65 536 boards)
 #ifdef GG_AB
-  if (const char *e = getenv("GG_AB_NS_GRID")) grid = atoi(e);
+  if (const char *e = getenv("GG_AB_NS_GRID")) { grid = atoi(e); cols = 0; }
+  if (const char *e = getenv("GG_AB_NS_S1")) share1 = (uint32_t)(atof(e) * 65536);
+  if (const char *e = getenv("GG_AB_NS_S2")) share2 = (uint32_t)(atof(e) * 65536);
+  if (getenv("GG_AB_NS_EVEN")) cols = 0;
 #endif
-  GG_DISPATCH(N, (k_next_states2<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
-              (k_next_states2<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
-              (k_next_states2<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
+  if (cols) grid = cols * GG_LB_PLY;
+  GG_DISPATCH(N, (k_next_states2<9><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical, cols, share1, share2)),
+              (k_next_states2<13><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical, cols, share1, share2)),
+              (k_next_states2<19><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical, cols, share1, share2)));
   return (int32_t)hipGetLastError();
 }
 

@@ -19,6 +19,11 @@ namespace gg {
 // The flood variants, the 2-cycle op spelling (bitop3 / add-for-shift) and the staging helpers are in gg_common.h.
 constexpr int kCwClasses = 11, kCwWeight = 5, kCwLanes = 2 * kCwClasses;
 
+#ifdef GG_AB_WHERE
+// A/B builds only: per workgroup (XCC, HW_ID, duration in 100 MHz ticks) - how evenly do the waves of a launch finish?
+__device__ unsigned int gg_where[3 * 16384];
+#endif
+
 struct CwTable { uint32_t m[kCwClasses + 1][20]; };  // [class][row] -> columns of the class; last row = zeros
 
 constexpr CwTable make_cw_table() {
@@ -579,7 +584,8 @@ template <int R>
 __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_next_states2(const uint8_t *__restrict__ in,
                                                         const int32_t *__restrict__ actions,
                                                         uint8_t *__restrict__ out, int32_t *__restrict__ status,
-                                                        int64_t B, int N, uint32_t inv, int canonical) {
+                                                        int64_t B, int N, uint32_t inv, int canonical,
+                                                        int cols, uint32_t share1, uint32_t share2) {
   constexpr int kRounds = 2;   // 2 planes + misalignment <= 47 vectors
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   __shared__ __attribute__((aligned(16))) uint8_t stage[2 * kRounds * 512];
@@ -590,7 +596,28 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_next_states2(const uint8_t
   load_spread_lut(lut, hf.lane);
   const int S = 6 * hf.P;
   const int64_t npairs = (B + 1) >> 1;
-  const int64_t G = gridDim.x;
+  // Which pairs a wave takes.  The grid is the resident set: `cols` SIMDs x 3 waves, and the dispatcher places workgroups
+  // c, c + cols, c + 2 cols on the same SIMD in that order (tools/exp/where_ns.py: on all 1 024 SIMDs).  The arbiter serves
+  // the oldest wave first, so with equal shares the three finish at 0.69 / 0.86 / 1.00 of the launch and the SIMD idles
+  // towards the end.  The pairs of a column (c, c + cols, c + 2 cols ...) are therefore split UNEVENLY among its three
+  // waves - the oldest takes the fraction share1, the next share2 - share1, the youngest the rest - so that they finish
+  // together.  cols == 0 (small batches): one wave per pair stride, as before.
+  int64_t p, G, pend;
+  if (cols > 0) {
+    const int c = (int)(blockIdx.x % (unsigned)cols), r = (int)(blockIdx.x / (unsigned)cols);
+    const int64_t K = (npairs - c + cols - 1) / cols;                 // pairs of this column
+    const int64_t k1 = (K * share1) >> 16, k2 = (K * share2) >> 16;
+    const int64_t a0 = r == 0 ? 0 : r == 1 ? k1 : k2, a1 = r == 0 ? k1 : r == 1 ? k2 : K;
+    if (a0 >= a1) return;
+    G = cols;
+    p = c + G * a0;
+    pend = c + G * a1;
+    if (pend > npairs) pend = npairs;
+  } else {
+    G = gridDim.x;
+    p = blockIdx.x;
+    pend = npairs;
+  }
   const uint32_t stage_lds = lds_addr(stage), meta_lds = lds_addr(meta);
   const uint8_t *sh = stage + hf.h * (kRounds * 512);
   uint32_t *work = lds + hf.h * 128;   // emit_store_h scratch (free outside the analysis)
@@ -605,13 +632,15 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_next_states2(const uint8_t
     dma_stage_h<kRounds>(gi, 2 * hf.P, stage_lds, hf);
     const int64_t p2 = p + G;
     const uint8_t *fa = gi + flag_off(a);
-    const void *src = hf.hl == 4 ? (const void *)(actions + board_of(p2 < npairs ? p2 : p))
+    const void *src = hf.hl == 4 ? (const void *)(actions + board_of(p2 < pend ? p2 : p))
                                  : (const void *)(fa - ((uintptr_t)fa & 3u));
     if (hf.hl < 5) dma4(src, meta_lds);
   };
 
-  int64_t p = blockIdx.x;
-  if (p >= npairs) return;
+  if (p >= pend) return;
+#ifdef GG_AB_WHERE
+  const long long tw0_ = wall_clock64();
+#endif
   int a = actions[board_of(p)];
   issue(p, a);
   bool have_prev = false;
@@ -633,7 +662,7 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_next_states2(const uint8_t
     lds_drain();
     WAVE_SYNC();
     const int64_t pn = p + G;
-    if (pn < npairs) issue(pn, a_next);
+    if (pn < pend) issue(pn, a_next);
     if (have_prev) {   // stores of the previous pair fly during this pair's analysis
       const int64_t q0 = 2 * (p - G) + hf.h;
       const bool qon = q0 < B;
@@ -668,7 +697,7 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_next_states2(const uint8_t
     pm = (uint32_t)nturn | (passed << 1) | (done << 2) | ((illegal ? 1u : 0u) << 3);
     have_prev = true;
     a = a_next;
-    if (pn >= npairs) break;
+    if (pn >= pend) break;
     p = pn;
   }
   {
@@ -682,6 +711,14 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_next_states2(const uint8_t
     if (ill) copy_row_h(in + q * (int64_t)S, out + q * (int64_t)S, S, hf.hl, qon);
     if (status && qon && hf.hl == 0) status[q] = ill ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
   }
+#ifdef GG_AB_WHERE
+  if (threadIdx.x == 0 && blockIdx.x < 16384) {
+    unsigned int hw_, xc_;
+    asm volatile("s_getreg_b32 %0, hwreg(4)" : "=s"(hw_));
+    asm volatile("s_getreg_b32 %0, hwreg(20)" : "=s"(xc_));
+    gg_where[3 * blockIdx.x] = xc_; gg_where[3 * blockIdx.x + 1] = hw_; gg_where[3 * blockIdx.x + 2] = (unsigned int)(wall_clock64() - tw0_);
+  }
+#endif
 }
 
 // PERPLY = instantiation for 1-2 plies per launch: the board I/O dominates there and the kernel runs best spill-free
@@ -731,7 +768,7 @@ __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_
     FairShare fair(fair_mates);   // a fused launch: the waves of a SIMD advance together (gg_common.h)
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
-      if (!PERPLY && (t & 3) == 0 && plies >= 8) fair.update((uint32_t)t, 8u);
+      if (!PERPLY && (t & 3) == 0 && plies >= 8) fair.update((uint32_t)t, plies >= 192 ? 24u : (plies >= 16 ? (uint32_t)plies >> 3 : 2u));
       const bool live = on && !(done && !auto_reset);
       const uint64_t lv = __ballot(live);
       if (lv == 0) break;

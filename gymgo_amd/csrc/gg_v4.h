@@ -46,8 +46,7 @@ template <int NJ, int AMIN> __device__ __forceinline__ void wload_row(const void
 template <int NJ> __device__ __forceinline__ void wmask_from_bits(const uint32_t *vw, int lane, uint32_t (&vm)[NJ]);
 
 #ifdef GG_AB_WHERE
-// A/B builds only: per workgroup (XCC, HW_ID, duration in 100 MHz ticks) of k_rollout4 - how fast is each part of the chip?
-__device__ unsigned int gg_where[3 * 16384];
+// A/B builds only: per workgroup (XCC, HW_ID, duration in 100 MHz ticks) of k_rollout4 (the array lives in gg_v2.h)
 #define GG_WHERE_BEGIN const long long tw0_ = wall_clock64()
 #define GG_WHERE_END do { if (threadIdx.x == 0 && blockIdx.x < 16384) { unsigned int hw_, xc_; \
     asm volatile("s_getreg_b32 %0, hwreg(4)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(20)" : "=s"(xc_)); \
@@ -566,12 +565,15 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
     // ---------------------------------------------------------------- the plies
     GG_PROF(6);   // load
     FairShare fair(lds + Lds4<R>::kFair);
+    // (a wide band - an eighth of the launch, at most 24 plies: measured 4 / 8 / 16 / 24 / 32 plies at 256 plies per launch:
+    // 2.076 / 2.062 / 2.049 / 2.042 / 2.046 ms)
+    const uint32_t fair_lag = plies >= 192 ? 24u : (plies >= 16 ? (uint32_t)plies >> 3 : 2u);
     int mv_next = 0;
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
       // fair share of the SIMD (gg_common.h): every fourth ply the wave publishes the ply it has reached and sets its issue
-      // priority by how many of its SIMD-mates are >= 8 plies behind it
-      if ((t & 3) == 0 && plies >= 8) fair.update((uint32_t)t, 8u);
+      // priority by how many of its SIMD-mates are >= fair_lag plies behind it
+      if ((t & 3) == 0 && plies >= 8) fair.update((uint32_t)t, fair_lag);
       // the lane-derived indices of the three phases are recomputed every ply (a few VALU ops) instead of being hoisted
       // out of the loop, where they end up in scratch: a reload is a vector-memory round trip at the top of each phase
       // (volatile asm: neither hoisted nor merged)

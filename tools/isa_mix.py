@@ -5,7 +5,7 @@ rest: v_bfrev, v_bcnt, v_cndmask, v_cmp, v_lshlrev, three-operand ops, DPP moves
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -S --cuda-device-only -o /tmp/gg.s gymgo_amd/csrc/gg_kernels.hip
     python tools/isa_mix.py /tmp/gg.s > profiles/rNN_isa_mix.txt
 
-The ply loop is the code between the last two `v_mbcnt_lo` markers of k_rollout4<19, 0, false, true, false, false> (the kernel reads
+The ply loop is the longest stretch between two consecutive `v_mbcnt_lo` markers of k_rollout4<19, 0, false, true, false, false> (the kernel reads
 its lane id afresh at the top of every ply and once more before the write-back).  Inner loops are weighted by the trip
 counts measured on mid-game boards (tests/devtools/flood_stats.py: 3.07 flood sweeps per wave-ply on average; a capture on
 some board of the wave on 85 % of the plies; the auto-reset block is rare)."""
@@ -24,8 +24,12 @@ def main(path):
     end = next(i for i in range(start, len(text)) if 's_endpgm' in text[i])
     body = text[start:end]
     marks = [i for i, l in enumerate(body) if 'v_mbcnt_lo_u32_b32' in l]
-    assert len(marks) >= 2, marks   # (a third one at the top of the group loop since round 3: the ply loop lies between the last two)
-    marks = marks[-2:]
+    assert len(marks) >= 2, marks
+    # the kernel reads its lane id afresh in several places (group loop, FairShare, ply, write-back): the ply body is the
+    # longest stretch between two consecutive reads
+    gaps = [(marks[i + 1] - marks[i], i) for i in range(len(marks) - 1)]
+    i = max(gaps)[1]
+    marks = [marks[i], marks[i + 1]]
     loop = body[marks[0]:marks[1]]
     # blocks of the loop in program order: (first line, label, depth)
     depth, blocks = 2, []
