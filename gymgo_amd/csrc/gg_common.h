@@ -344,6 +344,39 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
   return ((uint64_t)hi << 32) | (uint64_t)lo;
 }
 
+// ---------------------------------------------------------------- which pairs of boards a wave of a persistent grid takes
+// A persistent per-pair kernel runs the resident set: `cols` SIMDs x W waves, and the dispatcher places workgroups c,
+// c + cols, c + 2 cols ... on the same SIMD in that order (tools/ubench/placement.hip, tools/exp/where_ns.py).  The arbiter
+// of a SIMD serves its oldest wave first, so W waves with equal shares finish one after the other and the SIMD idles
+// towards the end of the launch.  The pairs of a column (c, c + cols, c + 2 cols ...) are therefore split UNEVENLY by
+// age: wave r of the column takes the pairs [cut[r-1], cut[r]) of it (cumulative 16.16 fractions; cut[-1] = 0, the
+// youngest runs to the end).  cols == 0 (small batches, or a kernel whose occupancy is not known): pair p0 + k * grid.
+struct AgeSplit {
+  int cols;
+  uint32_t cut[3];
+};
+struct PairSpan {
+  int64_t first, stride, end;
+};
+__device__ __forceinline__ PairSpan pair_span(int64_t npairs, const AgeSplit &as) {
+  PairSpan sp;
+  if (as.cols > 0) {
+    const int c = (int)(blockIdx.x % (unsigned)as.cols), r = (int)(blockIdx.x / (unsigned)as.cols);
+    const int64_t K = (npairs - c + as.cols - 1) / as.cols;   // pairs of this column
+    const int64_t a0 = r == 0 ? 0 : (K * as.cut[r - 1]) >> 16;
+    const int64_t a1 = r >= 3 ? K : (K * as.cut[r]) >> 16;
+    sp.stride = as.cols;
+    sp.first = c + sp.stride * a0;
+    sp.end = c + sp.stride * a1;
+    if (sp.end > npairs) sp.end = npairs;
+  } else {
+    sp.first = blockIdx.x;
+    sp.stride = gridDim.x;
+    sp.end = npairs;
+  }
+  return sp;
+}
+
 // ---------------------------------------------------------------- a fair share of the SIMD for long-running waves
 // The instruction arbiter of a SIMD serves its OLDEST wave first.  Four waves that each run 256 plies on one SIMD therefore
 // do not advance together: the oldest runs at the speed of a wave that is alone (3.4 us per ply), the youngest gets what

@@ -6,6 +6,8 @@
 // are no environment switches and no mutable global state besides the per-device CU-count cache below.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
+#include <unordered_map>
 #ifdef GG_AB
 #include <stdlib.h>   // A/B builds only (make ab): tuning overrides read from the environment; never in the shipped library
 #endif
@@ -57,6 +59,9 @@ struct OnDeviceOf {
 // persistent grid: enough single-wave workgroups to fill every SIMD several times over
 int grid_for(int cus, int64_t work) {
   int64_t cap = (int64_t)cus * 32;
+#ifdef GG_AB
+  if (const char *e = getenv("GG_AB_GRID_CAP")) cap = atoll(e);
+#endif
   return (int)(work < cap ? (work > 0 ? work : 1) : cap);
 }
 
@@ -65,6 +70,54 @@ int grid_for(int cus, int64_t work) {
 int grid_resident(int cus, int64_t work, int waves_per_simd) {
   int64_t cap = (int64_t)cus * 4 * waves_per_simd;
   return (int)(work < cap ? (work > 0 ? work : 1) : cap);
+}
+
+// Persistent per-pair kernels (pair_span, gg_common.h): from two pairs per resident wave on, the grid is exactly the
+// resident set of THIS kernel (its occupancy, asked of the runtime once per kernel) and the pairs of a SIMD are split by
+// wave age.  Cumulative shares from sweeps on 65 536 boards (tools/exp/age_split.py; 32 pairs per SIMD): three waves
+// 0.40 / 0.74 (12 / 11 / 9 pairs: gg_batch_env_step 81.0 -> 73 us, the one-ply gg_batch_rollout 77.4 -> 69.5 us), four
+// waves 0.39 / 0.665 / 0.86 (12 / 9 / 6 / 5: invalid mask 50.9 -> 47, track 50.4 -> 45, packed next states 42.8 -> 41,
+// packed env step 52.3 -> 47.5 us).  Equal shares on the same resident grid gain nothing or lose (tools/exp/grid_cap.py).
+// Anything smaller, or an occupancy the split has no shares for: one wave per pair, at most 32 per CU, as before.
+int waves_per_simd_of(const void *kern) {
+  static std::mutex mu;
+  static std::unordered_map<const void *, int> known;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = known.find(kern);
+  if (it != known.end()) return it->second;
+  int blocks = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, kWave, 0) != hipSuccess) { (void)hipGetLastError(); blocks = 0; }
+  const int w = blocks / 4;
+  known.emplace(kern, w);
+  return w;
+}
+
+AgeSplit age_split(const void *kern, int cus, int64_t npairs, bool split, int &grid) {
+  AgeSplit as = {0, {0, 0, 0}};
+  grid = grid_for(cus, npairs);
+  int w = split ? waves_per_simd_of(kern) : 0;
+  double c[3] = {0, 0, 0};
+  if (w == 2) { c[0] = 0.58; c[1] = c[2] = 1.0; }
+  else if (w == 3) { c[0] = 0.40; c[1] = 0.74; c[2] = 1.0; }
+  else if (w == 4) { c[0] = 0.39; c[1] = 0.665; c[2] = 0.86; }
+  else w = 0;
+#ifdef GG_AB
+  if (getenv("GG_AB_EVEN")) w = 0;
+  if (const char *e = getenv(w == 4 ? "GG_AB_CUT4" : w == 3 ? "GG_AB_CUT3" : "GG_AB_CUT2")) sscanf(e, "%lf,%lf,%lf", &c[0], &c[1], &c[2]);
+#endif
+  if (w && npairs >= (int64_t)cus * 4 * w * 2) {
+    as.cols = cus * 4;
+    for (int i = 0; i < 3; ++i) as.cut[i] = (uint32_t)(c[i] * 65536.0);
+    grid = as.cols * w;
+  }
+  return as;
+}
+
+template <typename... KArgs, typename... Args>
+void launch_pairs(void (*kern)(KArgs...), int cus, int64_t npairs, bool split, hipStream_t s, Args... args) {
+  int grid;
+  const AgeSplit as = age_split(reinterpret_cast<const void *>(kern), cus, npairs, split, grid);
+  kern<<<grid, kWave, 0, s>>>(args..., as);
 }
 
 // multi-ply kernel: boards per wave (even, <= kNB4 = 16).  The flood batch of a ply costs the same for 2 or 16 boards, so
@@ -239,8 +292,8 @@ int32_t gg_batch_invalid_mask(const uint8_t *states, const int32_t *ko, uint8_t 
                               void *hip_stream) {
   GG_ENTER(states);
   if (!mask) return GG_E_NULLPTR;
-  const int grid = grid_for(cus, (B + 1) / 2);
-#define GG_K(R, F) k_invalid_mask2<R, F><<<grid, kWave, 0, s>>>(states, ko, mask, B, N, inv)
+  const int64_t npairs = (B + 1) / 2;
+#define GG_K(R, F) launch_pairs(k_invalid_mask2<R, F>, cus, npairs, true, s, states, ko, mask, B, N, inv)
   GG_DISPATCH_N(N);
 #undef GG_K
   return (int32_t)hipGetLastError();
@@ -296,13 +349,13 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
     GG_DISPATCH4(N, 0, false, grid, states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
     return (int32_t)hipGetLastError();
   }
-  const int grid = grid_for(cus, (B + 1) / 2);
+  const int64_t npairs = (B + 1) / 2;
   if (plies <= 2) {
-#define GG_K(R, F) k_rollout2<R, true, false, F><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
+#define GG_K(R, F) launch_pairs(k_rollout2<R, true, false, F>, cus, npairs, true, s, states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
     GG_DISPATCH_N(N);
 #undef GG_K
   } else {
-#define GG_K(R, F) k_rollout2<R, false, false, F><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
+#define GG_K(R, F) launch_pairs(k_rollout2<R, false, false, F>, cus, npairs, plies < 8, s, states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
     GG_DISPATCH_N(N);
 #undef GG_K
   }
@@ -315,13 +368,13 @@ int32_t gg_batch_env_step(uint8_t *states, const int32_t *actions, uint64_t *rng
   if (reward_method != GG_REWARD_REAL && reward_method != GG_REWARD_HEURISTIC) return GG_E_BADARG;
   GG_ENTER(states);
   if (!actions && !rng) return GG_E_NULLPTR;
-  const int grid = grid_for(cus, (B + 1) / 2);
+  const int64_t npairs = (B + 1) / 2;
   if (reward_method == GG_REWARD_HEURISTIC) {
-#define GG_K(R, F) k_env_step2<R, true, false, F><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
+#define GG_K(R, F) launch_pairs(k_env_step2<R, true, false, F>, cus, npairs, true, s, states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
     GG_DISPATCH_N(N);
 #undef GG_K
   } else {
-#define GG_K(R, F) k_env_step2<R, false, false, F><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
+#define GG_K(R, F) launch_pairs(k_env_step2<R, false, false, F>, cus, npairs, true, s, states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
     GG_DISPATCH_N(N);
 #undef GG_K
   }
@@ -389,8 +442,8 @@ int32_t gg_batch_next_states_packed(const uint32_t *in, const int32_t *actions, 
                                     int32_t N, int32_t canonical, void *hip_stream) {
   GG_ENTER(in);
   if (!actions || !out) return GG_E_NULLPTR;
-  const int grid = grid_for(cus, (B + 1) / 2);
-#define GG_K(R, F) k_next_states_p<R, F><<<grid, kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)
+  const int64_t npairs = (B + 1) / 2;
+#define GG_K(R, F) launch_pairs(k_next_states_p<R, F>, cus, npairs, true, s, in, actions, out, status, B, N, inv, canonical)
   GG_DISPATCH_N(N);
 #undef GG_K
   return (int32_t)hipGetLastError();
@@ -409,8 +462,8 @@ int32_t gg_batch_rollout_packed(uint32_t *packed, uint64_t *rng, int32_t *last_a
     GG_DISPATCH4(N, 1, false, grid3, st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
     return (int32_t)hipGetLastError();
   }
-  const int grid = grid_for(cus, (B + 1) / 2);
-#define GG_K(R, F) k_rollout2<R, false, true, F><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
+  const int64_t npairs = (B + 1) / 2;
+#define GG_K(R, F) launch_pairs(k_rollout2<R, false, true, F>, cus, npairs, plies < 8, s, st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
   GG_DISPATCH_N(N);
 #undef GG_K
   return (int32_t)hipGetLastError();
@@ -422,14 +475,14 @@ int32_t gg_batch_env_step_packed(uint32_t *packed, const int32_t *actions, uint6
   if (reward_method != GG_REWARD_REAL && reward_method != GG_REWARD_HEURISTIC) return GG_E_BADARG;
   GG_ENTER(packed);
   if (!actions && !rng) return GG_E_NULLPTR;
-  const int grid = grid_for(cus, (B + 1) / 2);
+  const int64_t npairs = (B + 1) / 2;
   uint8_t *st = reinterpret_cast<uint8_t *>(packed);
   if (reward_method == GG_REWARD_HEURISTIC) {
-#define GG_K(R, F) k_env_step2<R, true, true, F><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
+#define GG_K(R, F) launch_pairs(k_env_step2<R, true, true, F>, cus, npairs, true, s, st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
     GG_DISPATCH_N(N);
 #undef GG_K
   } else {
-#define GG_K(R, F) k_env_step2<R, false, true, F><<<grid, kWave, 0, s>>>(st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
+#define GG_K(R, F) launch_pairs(k_env_step2<R, false, true, F>, cus, npairs, true, s, st, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
     GG_DISPATCH_N(N);
 #undef GG_K
   }
@@ -461,10 +514,10 @@ int32_t gg_batch_play_moves(uint8_t *states, const int32_t *moves, int32_t *play
     GG_DISPATCH4(N, 0, true, grid3, states, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played);
     return (int32_t)hipGetLastError();
   }
-  const int grid = grid_for(cus, (B + 1) / 2);
-  GG_DISPATCH(N, (k_play_moves2<9, false><<<grid, kWave, 0, s>>>(states, moves, played, B, N, inv, T)),
-              (k_play_moves2<13, false><<<grid, kWave, 0, s>>>(states, moves, played, B, N, inv, T)),
-              (k_play_moves2<19, false><<<grid, kWave, 0, s>>>(states, moves, played, B, N, inv, T)));
+  const int64_t npairs = (B + 1) / 2;
+  GG_DISPATCH(N, (launch_pairs(k_play_moves2<9, false>, cus, npairs, true, s, states, moves, played, B, N, inv, T)),
+              (launch_pairs(k_play_moves2<13, false>, cus, npairs, true, s, states, moves, played, B, N, inv, T)),
+              (launch_pairs(k_play_moves2<19, false>, cus, npairs, true, s, states, moves, played, B, N, inv, T)));
   return (int32_t)hipGetLastError();
 }
 
@@ -480,10 +533,10 @@ int32_t gg_batch_play_moves_packed(uint32_t *packed, const int32_t *moves, int32
     GG_DISPATCH4(N, 1, true, grid3, st, nullptr, nullptr, nullptr, B, N, inv, T, 0, nb, moves, played);
     return (int32_t)hipGetLastError();
   }
-  const int grid = grid_for(cus, (B + 1) / 2);
-  GG_DISPATCH(N, (k_play_moves2<9, true><<<grid, kWave, 0, s>>>(st, moves, played, B, N, inv, T)),
-              (k_play_moves2<13, true><<<grid, kWave, 0, s>>>(st, moves, played, B, N, inv, T)),
-              (k_play_moves2<19, true><<<grid, kWave, 0, s>>>(st, moves, played, B, N, inv, T)));
+  const int64_t npairs = (B + 1) / 2;
+  GG_DISPATCH(N, (launch_pairs(k_play_moves2<9, true>, cus, npairs, true, s, st, moves, played, B, N, inv, T)),
+              (launch_pairs(k_play_moves2<13, true>, cus, npairs, true, s, st, moves, played, B, N, inv, T)),
+              (launch_pairs(k_play_moves2<19, true>, cus, npairs, true, s, st, moves, played, B, N, inv, T)));
   return (int32_t)hipGetLastError();
 }
 
@@ -493,10 +546,10 @@ int32_t gg_tracked_words(int32_t N) { return (N < 2 || N > GG_MAX_BOARD) ? GG_E_
 int32_t gg_batch_track_states(const uint8_t *states, uint32_t *tracked, int64_t B, int32_t N, void *hip_stream) {
   GG_ENTER(states);
   if (!tracked) return GG_E_NULLPTR;
-  const int grid = grid_for(cus, (B + 1) / 2);
-  GG_DISPATCH(N, (k_track<9><<<grid, kWave, 0, s>>>(states, tracked, B, N, inv)),
-              (k_track<13><<<grid, kWave, 0, s>>>(states, tracked, B, N, inv)),
-              (k_track<19><<<grid, kWave, 0, s>>>(states, tracked, B, N, inv)));
+  const int64_t npairs = (B + 1) / 2;
+  GG_DISPATCH(N, (launch_pairs(k_track<9>, cus, npairs, true, s, states, tracked, B, N, inv)),
+              (launch_pairs(k_track<13>, cus, npairs, true, s, states, tracked, B, N, inv)),
+              (launch_pairs(k_track<19>, cus, npairs, true, s, states, tracked, B, N, inv)));
   return (int32_t)hipGetLastError();
 }
 

@@ -491,14 +491,15 @@ __device__ __forceinline__ void store_packed_h(uint32_t *gp, int N, const Half &
 template <int R, bool FULLN = false>
 __global__ __launch_bounds__(kWave, 4) void k_next_states_p(const uint32_t *__restrict__ in, const int32_t *__restrict__ actions,
                                                             uint32_t *__restrict__ out, int32_t *__restrict__ status,
-                                                            int64_t B, int N, uint32_t inv, int canonical) {
+                                                            int64_t B, int N, uint32_t inv, int canonical, AgeSplit age) {
   if (FULLN) { N = R; inv = (65536u + R - 1u) / R; }   // N == R: compile-time constants (see k_env_step2)
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv);
   load_cw_table<R>(lds, hf.lane);
   const int W = 3 * N + 1;
   const int64_t npairs = (B + 1) >> 1;
-  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+  const PairSpan span = pair_span(npairs, age);
+  for (int64_t p = span.first; p < span.end; p += span.stride) {
     const int64_t b0 = 2 * p + hf.h;
     const bool on = b0 < B;
     const int64_t b = on ? b0 : B - 1;
@@ -728,7 +729,7 @@ template <int R, bool PERPLY, bool PACKED = false, bool FULLN = false>
 __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_rollout2(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                     int32_t *__restrict__ last_actions,
                                                     int64_t *__restrict__ steps_done, int64_t B, int N, uint32_t inv,
-                                                    int plies, int auto_reset) {
+                                                    int plies, int auto_reset, AgeSplit age) {
   if (FULLN) { N = R; inv = (65536u + R - 1u) / R; }   // N == R: compile-time constants (see k_env_step2)
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   __shared__ uint32_t fair_mates[16];
@@ -739,7 +740,8 @@ __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_
   const int S = 6 * hf.P;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
-  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+  const PairSpan span = pair_span(npairs, age);
+  for (int64_t p = span.first; p < span.end; p += span.stride) {
     const int64_t bA = 2 * p, bB = (2 * p + 1 < B) ? 2 * p + 1 : B - 1;
     const bool on = 2 * p + hf.h < B;
     const int64_t b = hf.h ? bB : bA;
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_
 template <int R, bool PACKED>
 __global__ __launch_bounds__(kWave, 4) void k_play_moves2(uint8_t *__restrict__ states, const int32_t *__restrict__ moves,
                                                           int32_t *__restrict__ played_out, int64_t B, int N, uint32_t inv,
-                                                          int T) {
+                                                          int T, AgeSplit age) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv);
   __shared__ uint2 lut[256];
@@ -834,7 +836,8 @@ __global__ __launch_bounds__(kWave, 4) void k_play_moves2(uint8_t *__restrict__ 
   const int S = 6 * hf.P;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
-  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+  const PairSpan span = pair_span(npairs, age);
+  for (int64_t p = span.first; p < span.end; p += span.stride) {
     const bool on = 2 * p + hf.h < B;
     const int64_t b = on ? 2 * p + hf.h : B - 1;
     uint8_t *gs = states + b * (int64_t)S;
@@ -914,7 +917,7 @@ __global__ __launch_bounds__(kWave, PACKED ? 4 : GG_LB_PLY) void k_env_step2(uin
                                                         uint64_t *__restrict__ rng, float *__restrict__ rewards,
                                                         uint8_t *__restrict__ dones, int32_t *__restrict__ status,
                                                         int32_t *__restrict__ taken, int64_t B, int N, uint32_t inv,
-                                                        float komi, int auto_reset) {
+                                                        float komi, int auto_reset, AgeSplit age) {
   // FULLN: the board fills the row capacity (N == R) - N, N * N and the reciprocal become compile-time constants
   // (GoVecEnv.step 19x19: 7.9e8 against 7.6e8 steps/s; the same on k_next_states2 costs registers: 7.0e8 against 1.0e9)
   if (FULLN) { N = R; inv = (65536u + R - 1u) / R; }
@@ -927,7 +930,8 @@ __global__ __launch_bounds__(kWave, PACKED ? 4 : GG_LB_PLY) void k_env_step2(uin
   const int S = 6 * hf.P;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
-  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+  const PairSpan span = pair_span(npairs, age);
+  for (int64_t p = span.first; p < span.end; p += span.stride) {
     const int64_t bA = 2 * p, bB = (2 * p + 1 < B) ? 2 * p + 1 : B - 1;
     const bool on = 2 * p + hf.h < B;
     const int64_t b = hf.h ? bB : bA;
@@ -1388,7 +1392,7 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
 template <int R, bool FULLN = false>
 __global__ __launch_bounds__(kWave, 4) void k_invalid_mask2(const uint8_t *__restrict__ states,
                                                             const int32_t *__restrict__ ko, uint8_t *__restrict__ mask,
-                                                            int64_t B, int N, uint32_t inv) {
+                                                            int64_t B, int N, uint32_t inv, AgeSplit age) {
   if (FULLN) { N = R; inv = (65536u + R - 1u) / R; }   // N == R: compile-time constants (see k_env_step2)
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv);
@@ -1396,7 +1400,8 @@ __global__ __launch_bounds__(kWave, 4) void k_invalid_mask2(const uint8_t *__res
   const int S = 6 * hf.P;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
-  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+  const PairSpan span = pair_span(npairs, age);
+  for (int64_t p = span.first; p < span.end; p += span.stride) {
     const bool on = 2 * p + hf.h < B;
     const int64_t b = on ? 2 * p + hf.h : B - 1;
     const uint8_t *gi = states + b * (int64_t)S;

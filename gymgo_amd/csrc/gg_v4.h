@@ -1104,14 +1104,15 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
 // byte planes -> tracked boards: the rows of planes 0 / 1 / 3 and the liberty classes of one v2 analysis
 template <int R>
 __global__ __launch_bounds__(kWave, 4) void k_track(const uint8_t *__restrict__ states, uint32_t *__restrict__ tracked,
-                                                     int64_t B, int N, uint32_t inv) {
+                                                     int64_t B, int N, uint32_t inv, AgeSplit age) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv);
   load_cw_table<R>(lds, hf.lane);
   const int S = 6 * hf.P, W = 5 * N + 1;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
-  for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+  const PairSpan span = pair_span(npairs, age);
+  for (int64_t p = span.first; p < span.end; p += span.stride) {
     const bool on = 2 * p + hf.h < B;
     const int64_t b = on ? 2 * p + hf.h : B - 1;
     const uint8_t *gs = states + b * (int64_t)S;
