@@ -349,11 +349,12 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 // c + cols, c + 2 cols ... on the same SIMD in that order (tools/ubench/placement.hip, tools/exp/where_ns.py).  The arbiter
 // of a SIMD serves its oldest wave first, so W waves with equal shares finish one after the other and the SIMD idles
 // towards the end of the launch.  The pairs of a column (c, c + cols, c + 2 cols ...) are therefore split UNEVENLY by
-// age: wave r of the column takes the pairs [cut[r-1], cut[r]) of it (cumulative 16.16 fractions; cut[-1] = 0, the
-// youngest runs to the end).  cols == 0 (small batches, or a kernel whose occupancy is not known): pair p0 + k * grid.
+// age: wave r of the column takes the pairs [cut[r-1], cut[r]) of it (cumulative 16.16 fractions; cut[-1] = 0, unused
+// ranks hold 1.0, the youngest runs to the end).  cols == 0 (small batches, or a kernel whose occupancy is not known): pair p0 + k * grid.
+constexpr int kAgeRanks = 4;   // waves per SIMD the split has (measured) shares for
 struct AgeSplit {
   int cols;
-  uint32_t cut[3];
+  uint32_t cut[kAgeRanks - 1];
 };
 struct PairSpan {
   int64_t first, stride, end;
@@ -363,8 +364,8 @@ __device__ __forceinline__ PairSpan pair_span(int64_t npairs, const AgeSplit &as
   if (as.cols > 0) {
     const int c = (int)(blockIdx.x % (unsigned)as.cols), r = (int)(blockIdx.x / (unsigned)as.cols);
     const int64_t K = (npairs - c + as.cols - 1) / as.cols;   // pairs of this column
-    const int64_t a0 = r == 0 ? 0 : (K * as.cut[r - 1]) >> 16;
-    const int64_t a1 = r >= 3 ? K : (K * as.cut[r]) >> 16;
+    const int64_t a0 = r == 0 ? 0 : (K * as.cut[r - 1 < kAgeRanks - 1 ? r - 1 : kAgeRanks - 2]) >> 16;
+    const int64_t a1 = r >= kAgeRanks - 1 ? K : (K * as.cut[r]) >> 16;
     sp.stride = as.cols;
     sp.first = c + sp.stride * a0;
     sp.end = c + sp.stride * a1;

@@ -9,6 +9,7 @@
 #include <mutex>
 #include <unordered_map>
 #ifdef GG_AB
+#include <stdio.h>
 #include <stdlib.h>   // A/B builds only (make ab): tuning overrides read from the environment; never in the shipped library
 #endif
 
@@ -96,18 +97,26 @@ AgeSplit age_split(const void *kern, int cus, int64_t npairs, bool split, int &g
   AgeSplit as = {0, {0, 0, 0}};
   grid = grid_for(cus, npairs);
   int w = split ? waves_per_simd_of(kern) : 0;
-  double c[3] = {0, 0, 0};
-  if (w == 2) { c[0] = 0.58; c[1] = c[2] = 1.0; }
-  else if (w == 3) { c[0] = 0.40; c[1] = 0.74; c[2] = 1.0; }
-  else if (w == 4) { c[0] = 0.39; c[1] = 0.665; c[2] = 0.86; }
-  else w = 0;
+  if (w < 3 || w > kAgeRanks) w = 0;   // measured: three and four waves per SIMD
+  // the share of the wave of age rank r (oldest first).  More than four waves per SIMD (9x9 boards: 5-7) keep equal
+  // shares: a geometric fall-off extrapolated from these was measured slower than even (9x9 x 65 536: 51.3 vs 49.6 us)
+  static const double kShare[kAgeRanks + 1][kAgeRanks] = {
+      {0}, {0}, {0}, {0.40, 0.34, 0.26}, {0.39, 0.275, 0.195, 0.14}};
+  double c[kAgeRanks - 1];
+  double acc = 0;
+  for (int i = 0; i < kAgeRanks - 1; ++i) {
+    acc += i < w ? kShare[w][i] : 0.0;
+    c[i] = i < w - 1 ? acc : 1.0;
+  }
 #ifdef GG_AB
   if (getenv("GG_AB_EVEN")) w = 0;
-  if (const char *e = getenv(w == 4 ? "GG_AB_CUT4" : w == 3 ? "GG_AB_CUT3" : "GG_AB_CUT2")) sscanf(e, "%lf,%lf,%lf", &c[0], &c[1], &c[2]);
+  char name[16];
+  snprintf(name, sizeof name, "GG_AB_CUT%d", w);
+  if (const char *e = getenv(name)) sscanf(e, "%lf,%lf,%lf", &c[0], &c[1], &c[2]);
 #endif
   if (w && npairs >= (int64_t)cus * 4 * w * 2) {
     as.cols = cus * 4;
-    for (int i = 0; i < 3; ++i) as.cut[i] = (uint32_t)(c[i] * 65536.0);
+    for (int i = 0; i < kAgeRanks - 1; ++i) as.cut[i] = (uint32_t)(c[i] * 65536.0);
     grid = as.cols * w;
   }
   return as;

@@ -3,30 +3,28 @@
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CONFIGS = [
-    {'GG_AB_CUT3': '0.41,0.72,1', 'GG_AB_CUT4': '0.41,0.69,0.88'},
-    {'GG_AB_CUT3': '0.38,0.72,1', 'GG_AB_CUT4': '0.44,0.72,0.88'},
-    {'GG_AB_CUT3': '0.44,0.76,1', 'GG_AB_CUT4': '0.44,0.69,0.85'},
-    {'GG_AB_CUT3': '0.44,0.79,1', 'GG_AB_CUT4': '0.41,0.66,0.85'},
-    {'GG_AB_CUT3': '0.41,0.79,1', 'GG_AB_CUT4': '0.38,0.66,0.85'},
-    {'GG_AB_CUT3': '0.38,0.76,1', 'GG_AB_CUT4': '0.47,0.75,0.91'},
+    {'GG_AB_EVEN': '1'},
+    {},
 ]
+SIZES = os.environ.get('GGN', '19').split(',')
 if len(sys.argv) == 1:
-    for cfg in CONFIGS:
-        env = dict(os.environ, LIB='libgymgo_ab.so', **cfg)
-        r = subprocess.run([sys.executable, __file__, 'run'], env=env, capture_output=True, text=True)
-        print(cfg, '\n   ', r.stdout.strip() or r.stderr[-800:], flush=True)
+    for n in SIZES:
+        for cfg in CONFIGS:
+            env = dict(os.environ, LIB='libgymgo_ab.so', GGN=n, **cfg)
+            r = subprocess.run([sys.executable, __file__, 'run'], env=env, capture_output=True, text=True)
+            print(n, cfg, '\n   ', r.stdout.strip() or r.stderr[-800:], flush=True)
     sys.exit(0)
 sys.path.insert(0, ROOT)
 import torch
 from gymgo_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, 'tools', 'exp', os.environ['LIB'])
 from gymgo_amd import gogame, state_utils
-N, B = 19, 65536
+N, B = int(os.environ.get('GGN', '19')), 65536
 held = {k: os.environ.pop(k) for k in list(os.environ) if k.startswith('GG_AB_')}
 st = gogame.batch_init_state(B, N, device='cuda'); rng = gogame.rng_seed(B, 20260927)
 ch = B // 16
 for g in range(1, 16):
-    gogame.batch_rollout(st[g*ch:(g+1)*ch], rng[g*ch:(g+1)*ch], g * 40, True)
+    gogame.batch_rollout(st[g*ch:(g+1)*ch], rng[g*ch:(g+1)*ch], g * (N * N // 9), True)
 gogame.batch_rollout(st, rng, 256 * 7, True)
 os.environ.update(held)
 def ev(fn, reps=24):
