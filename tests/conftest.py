@@ -13,7 +13,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 # 65 536 rollouts), config 2 (9x9 x 4 096), config 5 (children), then every other oracle / golden comparison, then the
 # env and host-surface tests.  Within a file the source order is kept.
 GPU_ORDER = ('test_gpu_configs.py', 'test_gpu_deep.py', 'test_gpu_parity.py', 'test_gpu_adversarial.py', 'test_gpu_packed.py',
-             'test_gpu_extras.py', 'test_gpu_env.py')
+             'test_gpu_extras.py', 'test_gpu_env.py', 'test_gpu_split.py')
 
 
 def pytest_configure(config):

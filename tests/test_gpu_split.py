@@ -1,0 +1,118 @@
+"""-m gpu: the persistent per-pair kernels on batches large enough for the resident grid split by wave age
+(gg_kernels.hip age_split / gg_common.h pair_span: from two pairs per resident wave on, 12 288 - 16 384 boards on 256
+CUs).  Which wave steps which pair must not matter: the whole batch in one call equals the same batch in chunks small
+enough for the plain grid (pinned to the oracle by the other suites), bit for bit, odd batch sizes and a sub-sample
+against the oracle included."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+CHUNK = 3000   # 1 500 pairs: below the split threshold of every device with >= 47 CUs
+
+
+def _mixed(B, N, seed):
+    """every game phase: stripe g of 16 has played g * N*N/9 plies, finished games are kept (auto_reset off on odd stripes)"""
+    from gymgo_amd import gogame
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, seed)
+    ch = (B + 15) // 16
+    for g in range(1, 16):
+        lo, hi = g * ch, min(B, (g + 1) * ch)
+        if lo < hi:
+            gogame.batch_rollout(st[lo:hi], rng[lo:hi], g * (N * N // 9), g % 2 == 0)
+    return st, rng
+
+
+def _chunks(B):
+    return [(lo, min(B, lo + CHUNK)) for lo in range(0, B, CHUNK)]
+
+
+@pytest.mark.parametrize('N,B', [(19, 40001), (13, 36865), (9, 33000)])
+def test_whole_batch_equals_chunks(N, B):
+    from gymgo_amd import gogame, state_utils
+    st, rng = _mixed(B, N, 31 + N)
+    cuts = _chunks(B)
+
+    def both(fn_whole, fn_chunk):
+        """fn_whole() -> tensors; fn_chunk(lo, hi) -> tensors of the slice; compared along dim 0"""
+        whole = fn_whole()
+        parts = [fn_chunk(lo, hi) for lo, hi in cuts]
+        for i, w in enumerate(whole):
+            got = torch.cat([p[i] for p in parts], 0)
+            assert torch.equal(w, got), (N, B, i)
+        return whole
+
+    # gg_batch_invalid_mask (with a ko point on every third board), gg_batch_track_states
+    ko = torch.full((B,), -1, dtype=torch.int32, device='cuda')
+    ko[::3] = torch.arange(B, device='cuda', dtype=torch.int32)[::3] % (N * N)
+    both(lambda: (gogame._invalid_mask_dev(st, ko),), lambda lo, hi: (gogame._invalid_mask_dev(st[lo:hi], ko[lo:hi]),))
+    tracked, = both(lambda: (gogame.batch_track(st),), lambda lo, hi: (gogame.batch_track(st[lo:hi]),))
+    assert torch.equal(gogame.batch_untrack(tracked), st)
+
+    # gg_batch_env_step on byte planes and on packed boards: drawn moves, both reward methods, in place
+    for method in ('real', 'heuristic'):
+        for packed in (False, True):
+            step = gogame.batch_env_step_packed if packed else gogame.batch_env_step
+            base = gogame.batch_pack(st) if packed else st
+            a, ra = base.clone(), rng.clone()
+            b, rb = base.clone(), rng.clone()
+            wa = step(a, None, ra, 5.5, method, True)
+            wb = [step(b[lo:hi], None, rb[lo:hi], 5.5, method, True) for lo, hi in cuts]
+            for i in range(4):
+                assert torch.equal(wa[i], torch.cat([w[i] for w in wb], 0)), (N, method, packed, i)
+            assert torch.equal(a, b) and torch.equal(ra, rb), (N, method, packed)
+            if not packed and method == 'real':
+                stepped, taken = a, wa[3]
+
+    # ... and given moves (some illegal / out of range): the drawn ones of above, perturbed
+    acts = taken.clone()
+    acts[::7] = (acts[::7] * 5 + 3) % (N * N + 3) - 1
+    for packed in (False, True):
+        step = gogame.batch_env_step_packed if packed else gogame.batch_env_step
+        base = gogame.batch_pack(st) if packed else st
+        a, b = base.clone(), base.clone()
+        wa = step(a, acts, None, 0.0, 'real', False)
+        wb = [step(b[lo:hi], acts[lo:hi], None, 0.0, 'real', False) for lo, hi in cuts]
+        for i in range(4):
+            assert torch.equal(wa[i], torch.cat([w[i] for w in wb], 0)), (N, packed, i)
+        assert torch.equal(a, b)
+
+    # the one- and two-ply rollouts (per-ply kernel), packed next states, given move lists
+    for plies in (1, 2):
+        for packed in (False, True):
+            roll = gogame.batch_rollout_packed if packed else gogame.batch_rollout
+            base = gogame.batch_pack(st) if packed else st
+            a, ra, b, rb = base.clone(), rng.clone(), base.clone(), rng.clone()
+            la, lb = (torch.full((B,), -9, dtype=torch.int32, device='cuda') for _ in range(2))
+            sa, sb = (torch.zeros(B, dtype=torch.int64, device='cuda') for _ in range(2))
+            roll(a, ra, plies, True, la, sa)
+            for lo, hi in cuts:
+                roll(b[lo:hi], rb[lo:hi], plies, True, lb[lo:hi], sb[lo:hi])
+            assert torch.equal(a, b) and torch.equal(ra, rb) and torch.equal(la, lb) and torch.equal(sa, sb), (N, plies, packed)
+    pk = gogame.batch_pack(st)
+    both(lambda: gogame.batch_next_states_packed(pk, acts, check=False),
+         lambda lo, hi: gogame.batch_next_states_packed(pk[lo:hi], acts[lo:hi], check=False))
+    both(lambda: gogame.batch_next_states(st, acts, check=False),
+         lambda lo, hi: gogame.batch_next_states(st[lo:hi], acts[lo:hi], check=False))
+    moves = torch.stack([acts, taken, acts], 1).contiguous()
+    for packed in (False, True):
+        base = gogame.batch_pack(st) if packed else st
+        a, b = base.clone(), base.clone()
+        pa = gogame.batch_play_moves(a, moves)
+        pb = torch.cat([gogame.batch_play_moves(b[lo:hi], moves[lo:hi]) for lo, hi in cuts], 0)
+        assert torch.equal(a, b) and torch.equal(pa, pb), (N, packed)
+
+    # a strided sub-sample of the big env step against the oracle (gym_go/envs/go_env.py:49-76 via gogame.next_state)
+    from oracle import c_oracle
+    idx = np.arange(0, B, 97)
+    before = st.cpu().numpy()[idx]
+    tk = taken.cpu().numpy()[idx]
+    after = stepped.cpu().numpy()[idx]
+    for j in range(len(idx)):
+        s0 = before[j]
+        if s0[5].any():   # a finished game was reset first (auto_reset)
+            s0 = np.zeros_like(s0)
+        want = c_oracle.batch_next_states(s0[None], tk[j:j + 1], False)[0][0]
+        assert np.array_equal(after[j], want), (N, int(idx[j]))
