@@ -58,8 +58,8 @@ struct OnDeviceOf {
 };
 
 // persistent grid: enough single-wave workgroups to fill every SIMD several times over
-int grid_for(int cus, int64_t work) {
-  int64_t cap = (int64_t)cus * 32;
+int grid_for(int cus, int64_t work, int per_cu = 32) {
+  int64_t cap = (int64_t)cus * per_cu;
 #ifdef GG_AB
   if (const char *e = getenv("GG_AB_GRID_CAP")) cap = atoll(e);
 #endif
@@ -681,7 +681,7 @@ int32_t gg_batch_symmetry_rows(const uint32_t *in, int32_t planes, const int32_t
   if (planes != 3 && planes != 5) return GG_E_BADARG;
   GG_ENTER(in);
   if (!out) return GG_E_NULLPTR;
-  const int grid = grid_for(cus, (B + 1) / 2);
+  const int grid = grid_for(cus, (B + 1) / 2, 128);   // short iterations: 54 -> 47 us per 65 536 tracked boards with 4x the workgroups
   k_symmetry_rows<<<grid, kWave, 0, s>>>(in, orient, out, B, N, planes);
   return (int32_t)hipGetLastError();
 }
