@@ -111,9 +111,11 @@ def test_config5_children_of_8192_midgame_parents_vs_oracle():
 
 def test_config4_one_rank_shard_of_1048576_games_vs_oracle():
     """BASELINE config 4: 19x19, 1 048 576 games as 8 shards of 131 072 (one per GPU, no collective).  This is rank 5's
-    shard exactly as bench.py runs it (generator seeded by GLOBAL game index): 131 072 games, launches of 40 + 56 plies;
-    ORACLE: 2 048 games of the shard (every 64th) replayed by global index; and the shard equals the same index range
-    computed inside a larger single-rank batch (shard invariance, HIP-vs-HIP); packed / tracked round trips of the shard."""
+    shard exactly as bench.py runs it (generator seeded by GLOBAL game index): 131 072 games, launches of 40 + 56 plies
+    (shard invariance is checked there) and then three bench-sized launches of 256 plies - 864 plies per game, through
+    game ends and auto-resets; ORACLE: 4 096 games of the shard (every 32nd) replayed by global index after every
+    launch; and the shard equals the same index range computed inside a larger single-rank batch (shard invariance,
+    HIP-vs-HIP); packed / tracked round trips of the shard."""
     from gymgo_amd import gogame
     from gymgo_amd.envs.vec_env import shard
     from oracle import c_oracle
@@ -123,7 +125,7 @@ def test_config4_one_rank_shard_of_1048576_games_vs_oracle():
     st = gogame.batch_init_state(count, N, device='cuda')
     rng = gogame.rng_seed(count, SEED, first)
     sd = torch.zeros(count, dtype=torch.int64, device='cuda')
-    idx = np.arange(0, count, 64)
+    idx = np.arange(0, count, 32)
     want = np.zeros((len(idx), 6, N, N), np.uint8)
     want_rng = _oracle_rng(c_oracle, first + idx)
     for plies in (40, 56):
@@ -146,6 +148,15 @@ def test_config4_one_rank_shard_of_1048576_games_vs_oracle():
     gogame.batch_rollout(st, rng, 24, True)
     assert torch.equal(gogame.batch_untrack(tracked), st) and torch.equal(rng_t, rng)
     assert torch.equal(tracked, gogame.batch_track(st))            # the carried liberty classes == a fresh analysis
+    # ... and on through whole games at the bench's launch length (the oracle's copy follows the 24 plies above first)
+    want, want_rng, _ = c_oracle.batch_rollout_mt(want, want_rng, 24, True)
+    gix = torch.as_tensor(idx, device='cuda')
+    for launch in range(3):
+        gogame.batch_rollout(st, rng, 256, True, None, sd)
+        want, want_rng, _ = c_oracle.batch_rollout_mt(want, want_rng, 256, True)
+        assert np.array_equal(st[gix].cpu().numpy(), want), launch
+        assert np.array_equal(rng[gix].cpu().numpy().view(np.uint64), np.asarray(want_rng).view(np.uint64)), launch
+    assert int(sd.min()) == 96 + 3 * 256 and int(sd.max()) == 96 + 3 * 256
 
 
 def test_config1_7x7_single_game_goenv_step_vs_oracle():
