@@ -770,7 +770,10 @@ __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_
     FairShare fair(fair_mates);   // a fused launch: the waves of a SIMD advance together (gg_common.h)
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
-      if (!PERPLY && (t & 3) == 0 && plies >= 8) fair.update((uint32_t)t, plies >= 192 ? 24u : (plies >= 16 ? (uint32_t)plies >> 3 : 2u));
+      if (!PERPLY && (t & 3) == 0 && plies >= 8) {   // (the band of k_rollout4: never wider than the plies that are left)
+        const uint32_t band = plies >= 192 ? 24u : (plies >= 16 ? (uint32_t)plies >> 3 : 2u), left = (uint32_t)(plies - t);
+        fair.update((uint32_t)t, left < band ? (left > 2u ? left : 2u) : band);
+      }
       const bool live = on && !(done && !auto_reset);
       const uint64_t lv = __ballot(live);
       if (lv == 0) break;

@@ -573,7 +573,13 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
     for (int t = 0; t < plies; ++t) {
       // fair share of the SIMD (gg_common.h): every fourth ply the wave publishes the ply it has reached and sets its issue
       // priority by how many of its SIMD-mates are >= fair_lag plies behind it
-      if ((t & 3) == 0 && plies >= 8) fair.update((uint32_t)t, fair_lag);
+      if ((t & 3) == 0 && plies >= 8) {
+        // ... and the band never exceeds the plies that are left: towards the end of the launch the stragglers are let
+        // through, the four waves of a SIMD reach their write-back together (2.046 -> 2.022 ms per 256-ply launch;
+        // half / a quarter / an eighth of the plies left: 2.027 / 2.032 / 2.040; checks every 2 / 8 plies: 2.05 / 2.09)
+        const uint32_t left = (uint32_t)(plies - t);
+        fair.update((uint32_t)t, left < fair_lag ? (left > 2u ? left : 2u) : fair_lag);
+      }
       // the lane-derived indices of the three phases are recomputed every ply (a few VALU ops) instead of being hoisted
       // out of the loop, where they end up in scratch: a reload is a vector-memory round trip at the top of each phase
       // (volatile asm: neither hoisted nor merged)
