@@ -467,6 +467,14 @@ def extras(dev, back, opts):
                                      'it is not bound by' % moved)
     r, _ = event_rate(torch, dev, lambda: gogame.batch_env_step_tracked(tracked, None, rng, 7.5, 'real', True, out=env_out), count, 32)
     out['gg_batch_env_step_no_observation_steps_per_s'] = round(r, 1)
+    # the headline's launch on boards that STAY in the tracked format (GoVecEnv.rollout, gg_batch_rollout_tracked): no first
+    # analysis and no byte-plane write-back per launch - what the byte-plane boundary costs the headline
+    tr2, rng2 = tracked.clone(), rng.clone()
+    plies = opts['plies_per_step']
+    r, ms = event_rate(torch, dev, lambda: gogame.batch_rollout_tracked(tr2, rng2, plies, True), count * plies, 6)
+    out['fused_rollout_tracked_boards_steps_per_s'] = round(r, 1)
+    out['fused_rollout_tracked_boards_launch_ms'] = round(ms, 4)
+    del tr2, rng2
     # the same step with the move of every game drawn from policy weights (float32 [B, N^2+1]: 1 448 B more to read per
     # game) by the launch itself - what a self-play loop with a policy network runs per ply
     probs = torch.rand((count, N * N + 1), dtype=torch.float32, device=dev)

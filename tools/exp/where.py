@@ -8,7 +8,7 @@ from gymgo_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, 'tools', 'exp', os.environ.get('LIB', 'libgymgo_where.so'))
 from gymgo_amd import gogame
 L = ctypes.CDLL(_lib.LIB_PATH)
-N, F, B = 19, 1024, int(os.environ.get('B', '65536'))
+N, F, B = 19, int(os.environ.get("F", "1024")), int(os.environ.get('B', '65536'))
 st = gogame.batch_init_state(B, N, device='cuda'); rng = gogame.rng_seed(B, 20260927)
 ch = B // 16
 for g in range(1, 16):
