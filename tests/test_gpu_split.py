@@ -116,3 +116,32 @@ def test_whole_batch_equals_chunks(N, B):
             s0 = np.zeros_like(s0)
         want = c_oracle.batch_next_states(s0[None], tk[j:j + 1], False)[0][0]
         assert np.array_equal(after[j], want), (N, int(idx[j]))
+
+
+def test_first_use_inside_a_hipgraph_capture():
+    """The host side asks the runtime for a kernel's occupancy the first time it launches it (age_split); that first
+    time may be inside a stream capture (a GoVecEnv step loop captured as a hipGraph): a fresh process captures
+    gg_batch_env_step on a batch large enough for the split, replays it, and gets the eager result."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys, torch
+sys.path.insert(0, %r)
+from gymgo_amd import gogame
+B, N = 16385, 19
+st = gogame.batch_init_state(B, N, device='cuda'); rng = gogame.rng_seed(B, 7)
+out = (torch.empty(B, dtype=torch.float32, device='cuda'), torch.empty(B, dtype=torch.uint8, device='cuda'),
+       torch.empty(B, dtype=torch.int32, device='cuda'), torch.empty(B, dtype=torch.int32, device='cuda'))
+ref, rref = st.clone(), rng.clone()
+g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+with torch.cuda.stream(s):
+    with torch.cuda.graph(g, stream=s):
+        gogame.batch_env_step(st, None, rng, 7.5, 'real', True, out=out)
+for _ in range(5): g.replay()
+torch.cuda.synchronize()
+for _ in range(5): gogame.batch_env_step(ref, None, rref, 7.5, 'real', True)
+assert torch.equal(st, ref) and torch.equal(rng, rref)
+print('SAME')
+''' % root
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'SAME' in r.stdout, r.stderr[-2000:]
