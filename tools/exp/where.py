@@ -35,3 +35,12 @@ per = collections.defaultdict(list)
 for k, d in zip(skey, dur): per[k].append(d)
 rows = np.array([sorted(v)[:4] + [np.nan] * (4 - len(v[:4])) for v in per.values() if len(v) >= 4 and B == 65536] or [[0, 0, 0, 0]])
 print('  per SIMD, the four workgroups sorted by duration (mean over SIMDs): %s us' % np.round(np.nanmean(rows, axis=0)).tolist())
+if os.environ.get('DUMP'):
+    # several consecutive launches: is a workgroup's duration predictable from its group index / from the previous launch?
+    durs = [dur.copy()]
+    for _ in range(int(os.environ.get('LAUNCHES', '5'))):
+        gogame.batch_rollout(st, rng, F, True)
+        L.gg_ab_where_read(buf, n)
+        durs.append(np.frombuffer(buf, dtype=np.uint32).reshape(n, 3)[:, 2].astype(np.float64) / 100.0)
+    stones = (st[:, 0].sum(dim=(1, 2)) + st[:, 1].sum(dim=(1, 2))).reshape(n, 16).float().mean(dim=1).cpu().numpy()
+    np.savez(os.path.join(ROOT, 'gpurun_out', os.environ['DUMP']), dur=np.stack(durs), hw=hw, xcc=xcc, stones=stones)
