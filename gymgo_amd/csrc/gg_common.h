@@ -141,7 +141,10 @@ __device__ __forceinline__ void flood2_dual(const uint32_t (&m)[R], const uint32
 // (the normal-order copy made for the closure test is the result, so it never has to stay live across sweeps).
 // PREREV: the caller hands the odd rows of the seeds over bit-reversed already
 // OUT128: `out` is 16-byte aligned with room for (R + 3) & ~3 words; the copy is written four rows at a time
-template <int R, bool PREREV = false, bool OUT128 = false>
+// EARLY: the first closure test already after the second sweep (down, up).  It pays on 9x9 boards in the from-scratch
+// analysis (groups are small: config 2 fused 2.32 -> 2.38e9 steps/s, the 9x9 per-ply kernels -3 %) and nowhere else
+// (13x13: -3 % in the fused rollout; 19x19: 2.33 -> 2.43 ms; the multi-ply kernel's floods at 9x9: -1.5 %)
+template <int R, bool PREREV = false, bool OUT128 = false, bool EARLY = false>
 __device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R],
                                               uint32_t *out) {
   if (!PREREV) {
@@ -172,7 +175,7 @@ __device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint
     }
 #pragma unroll
     for (int r = R - 1; r >= 0; --r) FLOOD_VISIT(r, r + 1, ((r + 1) & 1) != 0);  // up: domain ((r+1)&1) -> (r&1)
-    if (it > 0) {
+    if (it > 0 || EARLY) {
       uint32_t open = 0, below = 0;
       uint32_t q[4] = {0u, 0u, 0u, 0u};
 #pragma unroll

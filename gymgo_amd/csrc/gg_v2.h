@@ -152,7 +152,7 @@ __device__ __forceinline__ void analyze2(uint32_t c0, uint32_t c1, uint32_t e, c
     }
   }
   if (DUAL) flood2_dual<R>(m, mrev, f, sc + hf.lane * RS);
-  else flood2_serial<R>(m, mrev, f, sc + hf.lane * RS);
+  else flood2_serial<R, false, false, (R <= 9)>(m, mrev, f, sc + hf.lane * RS);
   WAVE_SYNC();
   multi0 = 0; multi1 = 0; alive0 = 0;
   if (alive1_out) *alive1_out = 0;
