@@ -9,7 +9,7 @@
 // Two forms: byte planes uint8 [B][C][N][N] (any C: states, observations, per-point targets), staged through LDS with
 // aligned vector accesses only; and row-mask boards (packed 3 N + 1 / tracked 5 N + 1 words, gg_batch_pack_states /
 // gg_batch_track_states), where a column flip is a bit reversal of the row masks, a row flip a lane permutation and
-// the rotation a transpose made of N wave ballots - liberty classes and the invalid-move rows (ko point included) are
+// the rotation a 32 x 32 bit-matrix transpose across the lanes of a half-wave - liberty classes and the invalid-move rows (ko point included) are
 // geometric, so a transformed tracked board is a valid tracked board.
 #pragma once
 #include "gg_common.h"
@@ -79,13 +79,24 @@ __global__ __launch_bounds__(kWave) void k_symmetry_rows(const uint32_t *__restr
     const uint32_t fw = gi[W - 1];
     for (int pl = 0; pl < planes; ++pl) {
       const uint32_t x = hl < N ? gi[pl * N + hl] : 0u;
-      // the transpose of the plane, once: bit c of row r <- bit r of row c (a ballot per column; both halves at once)
-      uint32_t xt = 0;
-      for (int k = 0; k < N; ++k) {
-        const uint64_t bal = __ballot((x >> k) & 1u);
-        const uint32_t col = h ? (uint32_t)(bal >> 32) : (uint32_t)bal;   // bit c = x[c] bit k
-        if (hl == k) xt = col;
+      // the transpose of the plane, once: bit c of row r <- bit r of row c.  Five block-swap stages over the 32 lanes of
+      // the half (lane = row of a 32 x 32 bit matrix): at distance j the lanes without bit j take their partner's low
+      // column blocks into their high ones, the lanes with bit j the partner's high blocks into their low ones
+      // (N ballots + N selects per plane before: 48 -> 26.6 us per 65 536 tracked boards)
+      uint32_t xt = x;
+#define GG_TSTAGE(J, LOWM)                                                       \
+      {                                                                          \
+        const uint32_t y_ = (uint32_t)__shfl_xor((int)xt, J);                    \
+        const uint32_t up_ = (xt & (LOWM)) | ((y_ & (LOWM)) << (J));      /* (lane & J) == 0 */ \
+        const uint32_t dn_ = (xt & ~(LOWM)) | ((y_ & ~(LOWM)) >> (J));    /* (lane & J) != 0 */ \
+        xt = (hl & (J)) ? dn_ : up_;                                             \
       }
+      GG_TSTAGE(16, 0x0000FFFFu)
+      GG_TSTAGE(8, 0x00FF00FFu)
+      GG_TSTAGE(4, 0x0F0F0F0Fu)
+      GG_TSTAGE(2, 0x33333333u)
+      GG_TSTAGE(1, 0x55555555u)
+#undef GG_TSTAGE
       for (int v = 0; v < views; ++v) {
         const int o = orient ? (orient[b] & 7) : v;
         // out[r][c] = y[sr][sc]; with the rotation, (r', c') = (c, N-1-r): out[r] bit c = X[c'' ...]: work on the

@@ -10,7 +10,8 @@ if len(sys.argv) == 1:
 sys.path.insert(0, ROOT)
 import torch
 from gymgo_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, 'tools', 'exp', os.environ['LIB'])
+if os.environ.get('LIB', 'shipped') != 'shipped':
+    _lib.LIB_PATH = os.path.join(ROOT, 'tools', 'exp', os.environ['LIB'])
 from gymgo_amd import gogame
 N, B = 19, 65536
 cap = os.environ.pop('GG_AB_GRID_CAP', None)
