@@ -19,6 +19,7 @@
 #include "gg_aux.h"
 #include "gg_ws.h"
 #include "gg_sym.h"
+#include "gg_ns16.h"
 #include "gymgo_amd.h"
 
 namespace {
@@ -266,6 +267,36 @@ int32_t gg_batch_next_states(const uint8_t *in, const int32_t *actions, uint8_t 
                              int32_t N, int32_t canonical, void *hip_stream) {
   GG_ENTER(in);
   if (!actions || !out) return GG_E_NULLPTR;
+  // Big batches of full-size boards: sixteen boards per wave, floods class-major (gg_ns16.h), from four groups per SIMD on
+  // (65 536 boards on 256 CUs; at 49 152 - one group per wave of 19x19's three per SIMD, a single lock-step round - the
+  // two-board kernel is still ahead: 46 against 47 us).  19x19 runs the resident set with a SIMD's groups split 2 : 1 : 1
+  // by wave age (58.6 us per 65 536 boards against 60.0 with one workgroup per group; 1 : 1 : 2 70.6), the smaller
+  // boards (four waves per SIMD) one workgroup per group.
+  {
+    const int64_t ngroups = (B + kNB16 - 1) / kNB16;
+    bool big = (N == 9 || N == 13 || N == 19) && ngroups >= (int64_t)cus * 4 * 4 && ngroups <= 0x7FFFFFFF;
+    double c1 = 0.5, c2 = 0.75;
+#ifdef GG_AB
+    if (const char *e = getenv("GG_AB_NS16")) big = big && atoi(e) != 0;
+    if (const char *e = getenv("GG_AB_NS16_CUT")) sscanf(e, "%lf,%lf", &c1, &c2);
+#endif
+    if (big) {
+      AgeSplit as = {cus * 4, {(uint32_t)(c1 * 65536.0), (uint32_t)(c2 * 65536.0), 65536u}};
+      int grid16 = as.cols * 3;
+      if (N != 19) { as.cols = 0; grid16 = (int)ngroups; }
+#ifdef GG_AB
+      if (const char *e = getenv("GG_AB_NS16_GRID")) { grid16 = atoi(e); as.cols = 0; }
+      {
+        const int dbg = getenv("GG_AB_NS16_DBG") ? atoi(getenv("GG_AB_NS16_DBG")) : 0;
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(gg::gg_ns16_dbg), &dbg, sizeof dbg, 0, hipMemcpyHostToDevice, s);
+      }
+#endif
+      GG_DISPATCH(N, (k_next_states16<9><<<grid16, kWave, 0, s>>>(in, actions, out, status, B, canonical, as)),
+                  (k_next_states16<13><<<grid16, kWave, 0, s>>>(in, actions, out, status, B, canonical, as)),
+                  (k_next_states16<19><<<grid16, kWave, 0, s>>>(in, actions, out, status, B, canonical, as)));
+      return (int32_t)hipGetLastError();
+    }
+  }
   const int64_t npairs = (B + 1) / 2;
   int grid = grid_resident(cus, npairs, GG_LB_PLY);
   // from six pairs per resident wave on, the three waves of a SIMD share its pairs unevenly (k_next_states2): fractions

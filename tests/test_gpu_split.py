@@ -145,3 +145,36 @@ print('SAME')
 ''' % root
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'SAME' in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize('N,B', [(19, 53001), (13, 50003), (9, 70001)])
+def test_next_states_sixteen_boards_per_wave_equals_two_board_kernel(N, B):
+    """gg_batch_next_states takes the sixteen-boards-per-wave kernel (k_next_states16, gg_ns16.h) from one group per
+    resident wave on (49 152 boards on 256 CUs) for 9x9 / 13x13 / 19x19: the whole batch - every game phase, legal moves,
+    passes, moves on occupied / suicide / ko points, out-of-range actions, finished games, both `canonical` settings,
+    a ragged last group - equals the same batch in chunks that take the two-board kernel, and a sub-sample the oracle
+    (gym_go/gogame.py:34-87)."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    st, rng = _mixed(B, N, 77 + N)
+    acts = gogame.batch_sample_actions(st, rng)
+    gen = torch.Generator(device='cuda'); gen.manual_seed(N)
+    wild = torch.rand(B, device='cuda', generator=gen) < 0.3
+    rnd = torch.randint(-2, N * N + 3, (B,), device='cuda', generator=gen, dtype=torch.int32)
+    acts = torch.where(wild, rnd, acts)
+    for canon in (False, True):
+        out, status = gogame.batch_next_states(st, acts, canonical=canon, check=False)
+        parts = [gogame.batch_next_states(st[lo:hi], acts[lo:hi], canonical=canon, check=False) for lo, hi in _chunks(B)]
+        assert torch.equal(status, torch.cat([p[1] for p in parts], 0)), (N, canon)
+        assert torch.equal(out, torch.cat([p[0] for p in parts], 0)), (N, canon)
+        assert int((status != 0).sum()) > B // 20   # the refused moves are there
+        idx = np.arange(0, B, 131)
+        ok = idx[status.cpu().numpy()[idx] == 0]
+        host = st.cpu().numpy()[ok]
+        want = c_oracle.batch_next_states(host, acts.cpu().numpy()[ok], canon)[0]
+        assert np.array_equal(out.cpu().numpy()[ok], want), (N, canon)
+    # unaligned views (a batch that starts in the middle of another: the group's byte range starts at any address mod 16)
+    sub = st[7:7 + 50000 + (N == 9) * 20000]
+    o1, s1 = gogame.batch_next_states(sub, acts[7:7 + len(sub)], check=False)
+    o2, s2 = gogame.batch_next_states(sub.clone(), acts[7:7 + len(sub)].clone(), check=False)
+    assert torch.equal(o1, o2) and torch.equal(s1, s2)
