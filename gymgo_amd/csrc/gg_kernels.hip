@@ -332,6 +332,23 @@ int32_t gg_batch_invalid_mask(const uint8_t *states, const int32_t *ko, uint8_t 
                               void *hip_stream) {
   GG_ENTER(states);
   if (!mask) return GG_E_NULLPTR;
+  {   // big batches of 9x9 / 13x13 boards: the class-major analysis, sixteen boards per wave (as gg_batch_next_states;
+      // per 65 536 boards 33.3 -> 28.6 us at 13x13, 29.1 -> 18.8 us at 9x9.  At 19x19 - three waves per SIMD - it is no
+      // faster than the two-board kernel at four, 47 us both, and stays out: what it gains gg_batch_next_states is the
+      // write-back, which the mask does not have)
+    const int64_t ngroups = (B + kNB16 - 1) / kNB16;
+    bool big = (N == 9 || N == 13) && ngroups >= (int64_t)cus * 4 * 4 && ngroups <= 0x7FFFFFFF;
+#ifdef GG_AB
+    if (const char *e = getenv("GG_AB_NS16")) big = big && atoi(e) != 0;
+#endif
+    if (big) {
+      const AgeSplit as = {0, {0u, 0u, 0u}};   // one workgroup per group
+      const int grid16 = (int)ngroups;
+      if (N == 9) k_invalid_mask16<9><<<grid16, kWave, 0, s>>>(states, ko, mask, B, as);
+      else k_invalid_mask16<13><<<grid16, kWave, 0, s>>>(states, ko, mask, B, as);
+      return (int32_t)hipGetLastError();
+    }
+  }
   const int64_t npairs = (B + 1) / 2;
 #define GG_K(R, F) launch_pairs(k_invalid_mask2<R, F>, cus, npairs, true, s, states, ko, mask, B, N, inv)
   GG_DISPATCH_N(N);

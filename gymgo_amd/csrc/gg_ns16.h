@@ -143,17 +143,18 @@ __device__ __forceinline__ void load_plane_rows(const uint8_t *g, uint32_t (&m)[
 // rows[p * PL + board * RS + r] (p = 0 black, 1 white, 2 invalid; word R of a black block = the flags), and leaves as aligned 16-byte
 // vectors, 64 lanes x 16 B = 1 KB per instruction, through the 8 bits -> 8 bytes table (emit_group of gg_v4.h with the
 // mask rows read from LDS instead of the quad layout's registers).
-template <int R>
+// NP = 6: whole states; NP = 1: one plane per board, its rows in rows[0 * PL ...] (the invalid-move masks of a group)
+template <int R, int NP = 6>
 __device__ __forceinline__ void emit_rows16(uint8_t *g, int nbrd, const uint32_t *rows, int PL, int RS,
                                             uint32_t *bs, const uint2 *lut, int lane, bool nostore = false) {
-  constexpr int N = R, P = R * R, S = 6 * P, RPL = (R + 3) / 4;
+  constexpr int N = R, P = R * R, S = NP * P, RPL = (R + 3) / 4;
   const uint32_t mo = (uint32_t)((uintptr_t)g & 15u);
   const int nbits = (int)mo + nbrd * S;
   const int q4 = lane >> 2, r04 = RPL * (lane & 3);
   for (int i = lane; i < (nbits + 31) / 32 + 1; i += kWave) bs[i] = 0;
   WAVE_SYNC();
   if (q4 < nbrd) {
-    const uint32_t fl = rows[q4 * RS + R];
+    const uint32_t fl = NP == 6 ? rows[q4 * RS + R] : 0u;
     constexpr uint32_t fullrow = (1u << N) - 1u;
     const uint32_t tp = (fl & 1u) ? fullrow : 0u, pp = (fl & 2u) ? fullrow : 0u, dp = (fl & 4u) ? fullrow : 0u;
     const uint32_t base = mo + (uint32_t)(q4 * S);
@@ -161,9 +162,10 @@ __device__ __forceinline__ void emit_rows16(uint8_t *g, int nbrd, const uint32_t
     for (int r = 0; r < RPL; ++r) {
       const int rr = r04 + r;
       if (rr < N) {
-        const uint32_t rw[6] = {rows[0 * PL + q4 * RS + rr], rows[1 * PL + q4 * RS + rr], tp, rows[2 * PL + q4 * RS + rr], pp, dp};
+        const uint32_t rw[6] = {rows[0 * PL + q4 * RS + rr], NP == 6 ? rows[1 * PL + q4 * RS + rr] : 0u, tp,
+                                NP == 6 ? rows[2 * PL + q4 * RS + rr] : 0u, pp, dp};
 #pragma unroll
-        for (int p = 0; p < 6; ++p) {
+        for (int p = 0; p < NP; ++p) {
           if (rw[p]) {
             const uint32_t q = base + (uint32_t)(p * P + rr * N);
             const uint64_t x = (uint64_t)rw[p] << (q & 31u);
@@ -436,6 +438,124 @@ __global__ __launch_bounds__(kWave, Ns16Waves<R>::value) void k_next_states16(co
       }
     }
     if (status && on && (lane & 3) == 0) status[b] = illegal ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
+    WAVE_SYNC();
+  }
+}
+
+// state_utils.batch_compute_invalid_moves (gym_go/state_utils.py:86-156; per game :24-83) for big batches, the same
+// class-major analysis without a move: the lanes of the colour to move (plane 2) derive the mask, `ko` (int32 [B] or
+// nullptr: the point a ko forbids, -1 = none) is added as in gg_batch_invalid_mask's two-board kernel.
+template <int R>
+__global__ __launch_bounds__(kWave, Ns16Waves<R>::value) void k_invalid_mask16(const uint8_t *__restrict__ states,
+                                                                               const int32_t *__restrict__ ko,
+                                                                               uint8_t *__restrict__ mask, int64_t B, AgeSplit age) {
+  constexpr int N = R, P = R * R, S = 6 * P, RS = Lds16<R>::RS, PL = kNB16 * RS;
+  constexpr uint32_t full = (1u << R) - 1u;
+  constexpr uint32_t inv16 = (65536u + R - 1u) / R;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds16<R>::kTotal];
+  uint32_t *rows = lds + Lds16<R>::kRows;
+  uint32_t *cwt = lds + Lds16<R>::kCwt;
+  uint2 *lut = reinterpret_cast<uint2 *>(lds + Lds16<R>::kGrpLut);
+  {
+    const int l0 = threadIdx.x;
+    for (int i = l0; i < (kCwClasses + 1) * 20; i += kWave) cwt[i] = kCw.m[i / 20][i % 20];
+    for (int e_ = l0; e_ < 256; e_ += kWave)
+      lut[e_] = make_uint2(__umul24((uint32_t)e_ & 15u, 0x204081u) & 0x01010101u, __umul24((uint32_t)e_ >> 4, 0x204081u) & 0x01010101u);
+  }
+  WAVE_SYNC();
+  const int64_t ngroups = (B + kNB16 - 1) / kNB16;
+  const PairSpan span = pair_span(ngroups, age);
+  for (int64_t grp = span.first; grp < span.end; grp += span.stride) {
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    const int c = lane & 1, h = (lane >> 1) & 1, bl = lane >> 2;
+    const int64_t b_first = grp * kNB16;
+    const bool on = b_first + bl < B;
+    const int64_t b = on ? b_first + bl : B - 1;
+    const uint8_t *gi = states + b * (int64_t)S;
+    uint32_t m[R];
+    load_plane_rows<R>(gi + c * P, m);
+    uint32_t multi[R];
+    {
+      uint32_t c0[R], c1[R], c2[R], mrev[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        c0[r] = c1[r] = c2[r] = 0u;
+        mrev[r] = __brev(m[r]);
+      }
+#pragma unroll 1
+      for (int j = 0; j < (kCwClasses + 1) / 2; ++j) {
+        uint32_t f[R], g[R];
+        {
+          uint32_t ee[R + 1];
+          const uint4 *pc = reinterpret_cast<const uint4 *>(cwt + (2 * j + h) * 20);
+#pragma unroll
+          for (int i = 0; i < (R + 3) / 4; ++i) {
+            const uint4 d = pc[i];
+            if (4 * i < R) ee[4 * i] = d.x;
+            if (4 * i + 1 < R) ee[4 * i + 1] = d.y;
+            if (4 * i + 2 < R) ee[4 * i + 2] = d.z;
+            if (4 * i + 3 < R) ee[4 * i + 3] = d.w;
+          }
+#pragma unroll
+          for (int r = 0; r < R; ++r) ee[r] = B3(ee[r], m[r], dpp0<QP_COLOUR>(m[r]), TA & ~(TB | TC) & 0xFF) & full;
+          ee[R] = 0;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const uint32_t x = r > 0 ? B3(shl1(ee[r]), ee[r] >> 1, ee[r - 1], T_OR3) : (shl1(ee[r]) | (ee[r] >> 1));
+            f[r] = B3(m[r], x, ee[r + 1], T_AND_OR2);
+          }
+        }
+        flood2_serial_regs<R>(m, mrev, f, g);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint32_t k0 = c0[r] & g[r];
+          c0[r] ^= g[r];
+          const uint32_t k1 = c1[r] & k0;
+          c1[r] ^= k0;
+          c2[r] |= k1;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t p0 = dpp0<QP_HALF>(c0[r]), p1 = dpp0<QP_HALF>(c1[r]), p2 = dpp0<QP_HALF>(c2[r]);
+        const uint32_t k0 = c0[r] & p0;
+        const uint32_t s1 = B3(c1[r], p1, k0, TA ^ TB ^ TC);
+        const uint32_t k1 = B3(c1[r], p1, k0, (TA & TB) | (TA & TC) | (TB & TC));
+        const uint32_t s2 = B3(c2[r], p2, k1, TA ^ TB ^ TC);
+        const uint32_t s3 = B3(c2[r], p2, k1, (TA & TB) | (TA & TC) | (TB & TC));
+        multi[r] = B3(s3, s2, s1, T_OR_AND);          // >= 6 floods: two or more liberties
+      }
+    }
+    // the mask, on the lanes of the colour to move (invalid_from2 of gg_v2.h, point-wise): a point is playable iff it is
+    // empty and next to an empty point, to one of the mover's groups with >= 2 liberties or to an opponent group in atari
+    // (the turn byte and the ko point are fetched here, after the passes: held across them they cost scratch)
+    WAVE_SYNC();
+    const int nbrd = (int)((B - b_first) < kNB16 ? (B - b_first) : kNB16);
+    {
+      const uint32_t f_turn = gi[2 * P];
+      const int k = ko ? ko[b] : -1;
+      const bool owner = (uint32_t)c == (f_turn & 1u);
+      int kr = -1, kc = 0;
+      if (k >= 0 && k < P) split_action(k, N, inv16, kr, kc);
+      const uint32_t kohot = kr >= 0 ? (1u << kr) : 0u, kbit = 1u << kc;
+      uint32_t x[R], e2[R], nb[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t pm = dpp0<QP_COLOUR>(m[r]), pmulti = dpp0<QP_COLOUR>(multi[r]);
+        e2[r] = full & ~(m[r] | pm);
+        x[r] = B3(e2[r], m[r] & multi[r], pm & ~pmulti, T_OR3);
+      }
+      dilate_regs<R>(x, nb);
+      if (h == 0 && owner) {
+        uint32_t *pi = rows + bl * RS;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          pi[r] = (full & ~(e2[r] & nb[r])) | ((uint32_t)__builtin_amdgcn_sbfe((int)kohot, r, 1) & kbit);
+      }
+    }
+    WAVE_SYNC();
+    emit_rows16<R, 1>(mask + b_first * (int64_t)P, nbrd, rows, PL, RS, lds + Lds16<R>::kGrpBits, lut, lane);
     WAVE_SYNC();
   }
 }

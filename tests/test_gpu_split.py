@@ -178,3 +178,27 @@ def test_next_states_sixteen_boards_per_wave_equals_two_board_kernel(N, B):
     o1, s1 = gogame.batch_next_states(sub, acts[7:7 + len(sub)], check=False)
     o2, s2 = gogame.batch_next_states(sub.clone(), acts[7:7 + len(sub)].clone(), check=False)
     assert torch.equal(o1, o2) and torch.equal(s1, s2)
+
+
+@pytest.mark.parametrize('N,B', [(19, 65553), (13, 66001), (9, 70003)])
+def test_invalid_mask_sixteen_boards_per_wave(N, B):
+    """gg_batch_invalid_mask on big batches (k_invalid_mask16): equal to the same batch in chunks that take the two-board
+    kernel, with and without ko points, every game phase, finished games included; a sub-sample against the oracle's
+    state_utils.compute_invalid_moves (gym_go/state_utils.py:24-83)."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    st, _ = _mixed(B, N, 5 + N)
+    ko = torch.full((B,), -1, dtype=torch.int32, device='cuda')
+    ko[::3] = torch.arange(B, device='cuda', dtype=torch.int32)[::3] % (N * N)
+    for kk in (None, ko):
+        whole = gogame._invalid_mask_dev(st, kk)
+        parts = torch.cat([gogame._invalid_mask_dev(st[lo:hi], None if kk is None else kk[lo:hi]) for lo, hi in _chunks(B)], 0)
+        assert torch.equal(whole, parts), (N, kk is None)
+    idx = np.arange(0, B, 257)
+    host = st.cpu().numpy()[idx]
+    got = gogame._invalid_mask_dev(st, None).cpu().numpy()[idx]
+    for j in range(len(idx)):
+        want = c_oracle.compute_invalid_moves(host[j], 1 - int(host[j][2, 0, 0]), -1)   # (the mask is for the opponent of `player`)
+        assert np.array_equal(got[j], want), (N, int(idx[j]))
+    sub = st[5:5 + 65536 + 16]
+    assert torch.equal(gogame._invalid_mask_dev(sub, None), gogame._invalid_mask_dev(sub.clone(), None))
