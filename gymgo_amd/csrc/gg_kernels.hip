@@ -425,6 +425,28 @@ int32_t gg_batch_env_step(uint8_t *states, const int32_t *actions, uint64_t *rng
   if (reward_method != GG_REWARD_REAL && reward_method != GG_REWARD_HEURISTIC) return GG_E_BADARG;
   GG_ENTER(states);
   if (!actions && !rng) return GG_E_NULLPTR;
+  {   // big batches of full-size boards: the class-major analysis, sixteen boards per wave (as gg_batch_next_states)
+    const int64_t ngroups = (B + kNB16 - 1) / kNB16;
+    bool big = (N == 9 || N == 13 || N == 19) && ngroups >= (int64_t)cus * 4 * 4 && ngroups <= 0x7FFFFFFF;
+#ifdef GG_AB
+    if (const char *e = getenv("GG_AB_NS16")) big = big && atoi(e) != 0;
+#endif
+    if (big) {
+      AgeSplit as = {cus * 4, {32768u, 49152u, 65536u}};   // 19x19: a SIMD's groups 2 : 1 : 1 by wave age
+      int grid16 = as.cols * 3;
+      if (N != 19) { as.cols = 0; grid16 = (int)ngroups; }
+      if (reward_method == GG_REWARD_HEURISTIC) {
+        GG_DISPATCH(N, (k_env_step16<9, true><<<grid16, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, komi, auto_reset, as)),
+                    (k_env_step16<13, true><<<grid16, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, komi, auto_reset, as)),
+                    (k_env_step16<19, true><<<grid16, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, komi, auto_reset, as)));
+      } else {
+        GG_DISPATCH(N, (k_env_step16<9, false><<<grid16, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, komi, auto_reset, as)),
+                    (k_env_step16<13, false><<<grid16, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, komi, auto_reset, as)),
+                    (k_env_step16<19, false><<<grid16, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, komi, auto_reset, as)));
+      }
+      return (int32_t)hipGetLastError();
+    }
+  }
   const int64_t npairs = (B + 1) / 2;
   if (reward_method == GG_REWARD_HEURISTIC) {
 #define GG_K(R, F) launch_pairs(k_env_step2<R, true, false, F>, cus, npairs, true, s, states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)

@@ -560,4 +560,298 @@ __global__ __launch_bounds__(kWave, Ns16Waves<R>::value) void k_invalid_mask16(c
   }
 }
 
+// One GoEnv.step for every game of a batched env on byte planes, in place (gym_go/envs/go_env.py:49-76; the contract of
+// k_env_step2, gg_v2.h: auto-reset or refusal of finished games, the action given or drawn uniformly among the valid
+// moves, legality, next_state, game_ended, GoEnv.reward :128-149), for big batches: the class-major analysis of
+// k_next_states16.  The spare class-half lanes (h = 1) load the invalid-move plane instead of a second copy of their
+// colour's stones: they draw the move (valid points, prefix counts and the k-th set bit, all in one lane) or test the
+// given one, hand the verdict to their unit, and only then take the stone rows over from the h = 0 lanes.  The
+// Tromp-Taylor areas (gym_go/gogame.py:275-300) are one more flood pass of the empty points, seeded next to the lane's
+// colour - every step for the heuristic reward (HEUR), only in a wave where a game has just ended for the real one.
+template <int R, bool HEUR>
+__global__ __launch_bounds__(kWave, Ns16Waves<R>::value) void k_env_step16(uint8_t *__restrict__ states, const int32_t *__restrict__ actions,
+                                                                           uint64_t *__restrict__ rng, float *__restrict__ rewards,
+                                                                           uint8_t *__restrict__ dones, int32_t *__restrict__ status,
+                                                                           int32_t *__restrict__ taken, int64_t B, float komi,
+                                                                           int auto_reset, AgeSplit age) {
+  constexpr int N = R, P = R * R, S = 6 * P, RS = Lds16<R>::RS, PL = kNB16 * RS;
+  constexpr uint32_t full = (1u << R) - 1u;
+  constexpr uint32_t inv16 = (65536u + R - 1u) / R;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds16<R>::kTotal];
+  uint32_t *rows = lds + Lds16<R>::kRows;
+  uint32_t *cwt = lds + Lds16<R>::kCwt;
+  uint2 *lut = reinterpret_cast<uint2 *>(lds + Lds16<R>::kGrpLut);
+  {
+    const int l0 = threadIdx.x;
+    for (int i = l0; i < (kCwClasses + 1) * 20; i += kWave) cwt[i] = kCw.m[i / 20][i % 20];
+    for (int e_ = l0; e_ < 256; e_ += kWave)
+      lut[e_] = make_uint2(__umul24((uint32_t)e_ & 15u, 0x204081u) & 0x01010101u, __umul24((uint32_t)e_ >> 4, 0x204081u) & 0x01010101u);
+  }
+  WAVE_SYNC();
+  const int64_t ngroups = (B + kNB16 - 1) / kNB16;
+  const PairSpan span = pair_span(ngroups, age);
+  for (int64_t grp = span.first; grp < span.end; grp += span.stride) {
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    const int c = lane & 1, h = (lane >> 1) & 1, bl = lane >> 2;
+    const uint32_t hm = h ? ~0u : 0u;
+    const int64_t b_first = grp * kNB16;
+    const bool on = b_first + bl < B;
+    const int64_t b = on ? b_first + bl : B - 1;
+    uint8_t *gi = states + b * (int64_t)S;
+    // ---------------------------------------------------------------- in: flags, the plane of this lane, the move
+    const uint32_t f_turn = gi[2 * P], f_pass = gi[4 * P], f_done = gi[5 * P];
+    int a = actions ? actions[b] : 0;
+    uint64_t x = actions ? 0ull : rng[b];
+    uint32_t m[R];
+    load_plane_rows<R>(gi + (h ? 3 : c) * P, m);          // h = 1: the invalid-move plane (plane 3)
+    const bool frozen = f_done != 0u && !auto_reset;      // go_env.py:53 "assert not self.done"
+    int pl = (int)(f_turn & 1u);
+    uint32_t passed = f_pass != 0u ? 1u : 0u, done = f_done != 0u ? 1u : 0u;
+    if (done && auto_reset) {                             // GoEnv.reset (:40-47) comes before the action
+#pragma unroll
+      for (int r = 0; r < R; ++r) m[r] = 0u;
+      pl = 0; passed = 0u; done = 0u;
+    }
+    if (!actions) {   // GoEnv.uniform_random_action (:78-81) on the h = 1 lanes: the k-th valid point, k == n: the pass
+      uint32_t v[R], p[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        v[r] = full & ~m[r];
+        p[r] = (uint32_t)__popc(v[r]) + (r ? p[r - 1] : 0u);
+      }
+      const uint32_t n = p[R - 1];
+      const uint64_t u = splitmix_next(x);
+      const uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(n + 1)) >> 32);
+      int rr;
+      uint32_t pos;
+      kth_set_bit<R>(v, p, k < n ? k : 0u, rr, pos);
+      a = k < n ? rr * N + (int)pos : P;
+      const int ah = (int)dpp0<QP_HALF>((uint32_t)a);
+      a = h ? a : ah;
+      if (on && !frozen && (lane & 3) == 2) rng[b] = x;
+    }
+    const bool in_range = a >= 0 && a <= P;
+    const bool is_pass = a == P;
+    bool bad = !in_range || frozen;
+    {
+      int tr = 0, tc = 0;
+      if (in_range && !is_pass) split_action(a, N, inv16, tr, tc);
+      const uint32_t oh = (in_range && !is_pass) ? (1u << tr) : 0u;
+      uint32_t hit = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) hit |= (uint32_t)__builtin_amdgcn_sbfe((int)oh, r, 1) & m[r];
+      uint32_t occ = (hit >> tc) & 1u;                    // (meaningful on the h = 1 lanes: plane 3 at the point)
+      const uint32_t occh = dpp0<QP_HALF>(occ);
+      occ = h ? occ : occh;
+      bad = bad || occ != 0u;
+    }
+    // the mask of a board that does not move stays what it was (zero after a reset): parked in the result rows now
+    WAVE_SYNC();
+    if (h == 1 && c == 0) {
+      uint32_t *pi = rows + 2 * PL + bl * RS;
+#pragma unroll
+      for (int r = 0; r < R; ++r) pi[r] = m[r];
+    }
+    // ... and the h = 1 lanes take their colour's stones over from the h = 0 lanes
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t t = dpp0<QP_HALF>(m[r]);
+      m[r] = B3(hm, t, m[r], T_SEL);
+    }
+    const bool moving = !bad && !is_pass;
+    const bool mine = c == pl;
+    int ar = 0, ac = 0;
+    if (moving) split_action(a, N, inv16, ar, ac);
+    const uint32_t bit = moving ? (1u << ac) : 0u;
+    const uint32_t onehot = moving ? (1u << ar) : 0u;
+    bool boxed;
+    {
+      uint32_t Q[R], dq[R], acc = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        Q[r] = (uint32_t)__builtin_amdgcn_sbfe((int)onehot, r, 1) & bit;
+        if (mine) m[r] |= Q[r];
+      }
+      dilate_regs<R>(Q, dq);
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc |= dq[r] & full & ~m[r];
+      asm volatile("" : "+v"(acc));   // (pinned before the passes, see k_next_states16)
+      boxed = acc == 0u;
+    }
+    const int nbrd = (int)((B - b_first) < kNB16 ? (B - b_first) : kNB16);
+    // ---------------------------------------------------------------- six passes: class 2 j + h of all 32 units at once
+    uint32_t alive[R], multi[R];
+    {
+      uint32_t c0[R], c1[R], c2[R], mrev[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        c0[r] = c1[r] = c2[r] = 0u;
+        mrev[r] = __brev(m[r]);
+      }
+#pragma unroll 1
+      for (int j = 0; j < (kCwClasses + 1) / 2; ++j) {
+        uint32_t f[R], g[R];
+        {
+          uint32_t ee[R + 1];
+          const uint4 *pc = reinterpret_cast<const uint4 *>(cwt + (2 * j + h) * 20);
+#pragma unroll
+          for (int i = 0; i < (R + 3) / 4; ++i) {
+            const uint4 d = pc[i];
+            if (4 * i < R) ee[4 * i] = d.x;
+            if (4 * i + 1 < R) ee[4 * i + 1] = d.y;
+            if (4 * i + 2 < R) ee[4 * i + 2] = d.z;
+            if (4 * i + 3 < R) ee[4 * i + 3] = d.w;
+          }
+#pragma unroll
+          for (int r = 0; r < R; ++r) ee[r] = B3(ee[r], m[r], dpp0<QP_COLOUR>(m[r]), TA & ~(TB | TC) & 0xFF) & full;
+          ee[R] = 0;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const uint32_t xx = r > 0 ? B3(shl1(ee[r]), ee[r] >> 1, ee[r - 1], T_OR3) : (shl1(ee[r]) | (ee[r] >> 1));
+            f[r] = B3(m[r], xx, ee[r + 1], T_AND_OR2);
+          }
+        }
+        flood2_serial_regs<R>(m, mrev, f, g);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint32_t k0 = c0[r] & g[r];
+          c0[r] ^= g[r];
+          const uint32_t k1 = c1[r] & k0;
+          c1[r] ^= k0;
+          c2[r] |= k1;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t p0 = dpp0<QP_HALF>(c0[r]), p1 = dpp0<QP_HALF>(c1[r]), p2 = dpp0<QP_HALF>(c2[r]);
+        const uint32_t k0 = c0[r] & p0;
+        const uint32_t s1 = B3(c1[r], p1, k0, TA ^ TB ^ TC);
+        const uint32_t k1 = B3(c1[r], p1, k0, (TA & TB) | (TA & TC) | (TB & TC));
+        const uint32_t s2 = B3(c2[r], p2, k1, TA ^ TB ^ TC);
+        const uint32_t s3 = B3(c2[r], p2, k1, (TA & TB) | (TA & TC) | (TB & TC));
+        alive[r] = B3(c0[r], c1[r], c2[r], T_OR3) | B3(p0, p1, p2, T_OR3);
+        multi[r] = B3(s3, s2, s1, T_OR_AND);
+      }
+    }
+    // ---------------------------------------------------------------- captures, ko, class patch (as k_next_states16)
+    int ko_r = -1;
+    uint32_t ko_bit = 0;
+    uint32_t ndead = 0;
+    {
+      uint32_t dead[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        dead[r] = (!mine && moving) ? (m[r] & ~alive[r]) : 0u;
+        ndead += (uint32_t)__popc(dead[r]);
+      }
+      if (__ballot(ndead != 0u)) {
+        uint32_t krow = 0, kcols = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          krow += dead[r] ? (uint32_t)r : 0u;
+          kcols |= dead[r];
+          m[r] &= ~dead[r];
+        }
+        if (ndead == 1u && boxed) { ko_r = (int)krow; ko_bit = kcols; }
+        uint32_t deadp[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) deadp[r] = dpp0<QP_COLOUR>(dead[r]);
+        {
+          uint32_t G0[R], t[R], n0 = 0;
+#pragma unroll
+          for (int r = 0; r < R; ++r) G0[r] = mine ? (m[r] & ~alive[r]) : 0u;
+          dilate_regs<R>(G0, t);
+#pragma unroll
+          for (int r = 0; r < R; ++r) n0 += (uint32_t)__popc(t[r] & deadp[r]);
+          const uint32_t g0m = n0 >= 2u ? ~0u : 0u;
+#pragma unroll
+          for (int r = 0; r < R; ++r) multi[r] |= G0[r] & g0m;
+        }
+        uint32_t am[R], f[R], anyf = 0;
+        {
+          uint32_t t[R];
+          dilate_regs<R>(deadp, t);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            am[r] = mine ? (m[r] & alive[r] & ~multi[r]) : 0u;
+            f[r] = t[r] & am[r];
+            anyf |= f[r];
+          }
+        }
+        if (__ballot(anyf != 0u)) {
+          uint32_t amrev[R], g[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) amrev[r] = __brev(am[r]);
+          flood2_serial_regs<R>(am, amrev, f, g);
+#pragma unroll
+          for (int r = 0; r < R; ++r) multi[r] |= g[r];
+        }
+      }
+    }
+    // ---------------------------------------------------------------- the new flags (go_env.py:56-64 / gogame.py:77-87)
+    if (!bad) {
+      if (is_pass) { if (passed) done = 1u; passed = 1u; } else passed = 0u;
+      pl ^= 1;
+    }
+    // ---------------------------------------------------------------- out: rows to LDS; the next mover's mask on ITS lanes
+    // (for a board that moved: after the move the lanes of the mover's colour are the opponent's of the next mover)
+    WAVE_SYNC();
+    {
+      uint32_t xs[R], e2[R], nb[R];
+      const uint32_t kohot = ko_r >= 0 ? (1u << ko_r) : 0u;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t pm = dpp0<QP_COLOUR>(m[r]), pmulti = dpp0<QP_COLOUR>(multi[r]);
+        e2[r] = full & ~(m[r] | pm);
+        xs[r] = B3(e2[r], m[r] & multi[r], pm & ~pmulti, T_OR3);
+      }
+      dilate_regs<R>(xs, nb);
+      if (h == 0) {
+        uint32_t *const pr = rows + c * PL + bl * RS;
+#pragma unroll
+        for (int r = 0; r < R; ++r) pr[r] = m[r];
+        if (!bad && !mine) {   // the next mover's lane owns the mask of a board that moved
+          uint32_t *pi = rows + 2 * PL + bl * RS;
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            pi[r] = (full & ~(e2[r] & nb[r])) | ((uint32_t)__builtin_amdgcn_sbfe((int)kohot, r, 1) & ko_bit);
+        }
+        if (c == 0) rows[bl * RS + R] = (uint32_t)pl | (passed << 1) | (done << 2);
+      }
+    }
+    // ---------------------------------------------------------------- GoEnv.reward: Tromp-Taylor areas when they matter
+    int area_own = 0, area_oth = 0;
+    if (__ballot(on && (HEUR || done != 0u))) {
+      uint32_t e[R], erev[R], f[R], g[R], d[R];
+      dilate_regs<R>(m, d);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        e[r] = full & ~(m[r] | dpp0<QP_COLOUR>(m[r]));
+        erev[r] = __brev(e[r]);
+        f[r] = e[r] & d[r];                                // empty points next to this lane's colour
+      }
+      flood2_serial_regs<R>(e, erev, f, g);                // ... and every empty point connected to them
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) cnt += (uint32_t)__popc(m[r]) + (uint32_t)__popc(g[r] & ~dpp0<QP_COLOUR>(g[r]));
+      area_own = (int)cnt;
+      area_oth = (int)dpp0<QP_COLOUR>(cnt);
+    }
+    if (on && (lane & 3) == 0) {   // (c = 0: area_own is black's)
+      const float margin = (float)(area_own - area_oth) - komi;
+      float rwd;
+      if (HEUR) rwd = done ? (margin > 0.f ? 1.f : -1.f) * (float)P : margin;
+      else rwd = done ? (margin > 0.f ? 1.f : margin < 0.f ? -1.f : 0.f) : 0.f;
+      if (rewards) rewards[b] = rwd;
+      if (dones) dones[b] = (uint8_t)done;
+      if (status) status[b] = bad ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
+      if (taken) taken[b] = a;
+    }
+    WAVE_SYNC();
+    emit_rows16<R>(states + b_first * (int64_t)S, nbrd, rows, PL, RS, lds + Lds16<R>::kGrpBits, lut, lane);
+    WAVE_SYNC();
+  }
+}
+
 }  // namespace gg

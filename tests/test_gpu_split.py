@@ -29,7 +29,7 @@ def _chunks(B):
     return [(lo, min(B, lo + CHUNK)) for lo in range(0, B, CHUNK)]
 
 
-@pytest.mark.parametrize('N,B', [(19, 40001), (13, 36865), (9, 33000)])
+@pytest.mark.parametrize('N,B', [(19, 40001), (13, 36865), (9, 33000), (19, 65553), (13, 66001), (9, 70003)])
 def test_whole_batch_equals_chunks(N, B):
     from gymgo_amd import gogame, state_utils
     st, rng = _mixed(B, N, 31 + N)
