@@ -406,6 +406,22 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
     GG_DISPATCH4(N, 0, false, grid, states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
     return (int32_t)hipGetLastError();
   }
+  if (plies == 1) {   // one ply per launch on a big batch of full-size boards: the env step without the GoEnv outputs (gg_ns16.h)
+    const int64_t ngroups = (B + kNB16 - 1) / kNB16;
+    bool big = (N == 9 || N == 13 || N == 19) && ngroups >= (int64_t)cus * 4 * 4 && ngroups <= 0x7FFFFFFF;
+#ifdef GG_AB
+    if (const char *e = getenv("GG_AB_NS16")) big = big && atoi(e) != 0;
+#endif
+    if (big) {
+      AgeSplit as = {cus * 4, {32768u, 49152u, 65536u}};
+      int grid16 = as.cols * 3;
+      if (N != 19) { as.cols = 0; grid16 = (int)ngroups; }
+      GG_DISPATCH(N, (k_env_step16<9, false><<<grid16, kWave, 0, s>>>(states, nullptr, rng, nullptr, nullptr, nullptr, nullptr, B, 0.f, auto_reset, as, last_actions, steps_done)),
+                  (k_env_step16<13, false><<<grid16, kWave, 0, s>>>(states, nullptr, rng, nullptr, nullptr, nullptr, nullptr, B, 0.f, auto_reset, as, last_actions, steps_done)),
+                  (k_env_step16<19, false><<<grid16, kWave, 0, s>>>(states, nullptr, rng, nullptr, nullptr, nullptr, nullptr, B, 0.f, auto_reset, as, last_actions, steps_done)));
+      return (int32_t)hipGetLastError();
+    }
+  }
   const int64_t npairs = (B + 1) / 2;
   if (plies <= 2) {
 #define GG_K(R, F) launch_pairs(k_rollout2<R, true, false, F>, cus, npairs, true, s, states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)

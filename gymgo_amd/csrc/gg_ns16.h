@@ -568,12 +568,15 @@ __global__ __launch_bounds__(kWave, Ns16Waves<R>::value) void k_invalid_mask16(c
 // given one, hand the verdict to their unit, and only then take the stone rows over from the h = 0 lanes.  The
 // Tromp-Taylor areas (gym_go/gogame.py:275-300) are one more flood pass of the empty points, seeded next to the lane's
 // colour - every step for the heuristic reward (HEUR), only in a wave where a game has just ended for the real one.
+// last_actions / steps_done: the outputs of a one-ply gg_batch_rollout, which is this step without the GoEnv outputs.
 template <int R, bool HEUR>
 __global__ __launch_bounds__(kWave, Ns16Waves<R>::value) void k_env_step16(uint8_t *__restrict__ states, const int32_t *__restrict__ actions,
                                                                            uint64_t *__restrict__ rng, float *__restrict__ rewards,
                                                                            uint8_t *__restrict__ dones, int32_t *__restrict__ status,
                                                                            int32_t *__restrict__ taken, int64_t B, float komi,
-                                                                           int auto_reset, AgeSplit age) {
+                                                                           int auto_reset, AgeSplit age,
+                                                                           int32_t *__restrict__ last_actions = nullptr,
+                                                                           int64_t *__restrict__ steps_done = nullptr) {
   constexpr int N = R, P = R * R, S = 6 * P, RS = Lds16<R>::RS, PL = kNB16 * RS;
   constexpr uint32_t full = (1u << R) - 1u;
   constexpr uint32_t inv16 = (65536u + R - 1u) / R;
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(kWave, Ns16Waves<R>::value) void k_env_step16(uint8
     }
     // ---------------------------------------------------------------- GoEnv.reward: Tromp-Taylor areas when they matter
     int area_own = 0, area_oth = 0;
-    if (__ballot(on && (HEUR || done != 0u))) {
+    if (rewards && __ballot(on && (HEUR || done != 0u))) {
       uint32_t e[R], erev[R], f[R], g[R], d[R];
       dilate_regs<R>(m, d);
 #pragma unroll
@@ -847,6 +850,9 @@ __global__ __launch_bounds__(kWave, Ns16Waves<R>::value) void k_env_step16(uint8
       if (dones) dones[b] = (uint8_t)done;
       if (status) status[b] = bad ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
       if (taken) taken[b] = a;
+      // (a one-ply gg_batch_rollout: the last action of a game that did not move is -1, the plies played are counted)
+      if (last_actions) last_actions[b] = bad ? -1 : a;
+      if (steps_done && !bad) atomicAdd(reinterpret_cast<unsigned long long *>(steps_done) + b, 1ull);
     }
     WAVE_SYNC();
     emit_rows16<R>(states + b_first * (int64_t)S, nbrd, rows, PL, RS, lds + Lds16<R>::kGrpBits, lut, lane);
