@@ -56,6 +56,7 @@ def test_goenv_misc_api():
         st, _, _, _ = env.step(fmt)
         assert st[0, 1, 2] == 1
     env.reset()
+    np.random.seed(20260927)       # (uniform_random_action draws with NumPy's global generator, like the reference)
     for _ in range(20):
         env.step(env.uniform_random_action())
         if env.game_ended():
