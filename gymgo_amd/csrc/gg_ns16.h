@@ -1,5 +1,6 @@
-// gg_ns16.h - gogame.batch_next_states for big batches: SIXTEEN BOARDS PER WAVEFRONT, one lane per (board, colour, class
-// half), every liberty class from scratch with (nearly) all 64 lanes flooding.
+// gg_ns16.h - the from-scratch step kernels for big batches of full-size boards (k_next_states16: gogame.batch_next_states;
+// k_env_step16: the batched GoEnv.step and the one-ply rollout on byte planes; k_invalid_mask16): SIXTEEN BOARDS PER
+// WAVEFRONT, one lane per (board, colour, class half), every liberty class from scratch with (nearly) all 64 lanes flooding.
 //
 // The two-boards-per-wave kernel (k_next_states2, gg_v2.h) runs the 22 floods of a board (11 liberty classes x 2 colours,
 // constant-weight code) side by side: 44 of 64 lanes carry a flood, and every point-wise rule runs in the "row per lane"
@@ -20,7 +21,8 @@
 // instructions than the two-board kernel, but 256 VGPRs = two lock-step wave-iterations per SIMD at 65 536 boards, whose
 // loads and stores nothing overlapped).  Three waves per SIMD and the arbiter's oldest-wave-first order change that: the
 // groups of a SIMD are split 2 : 1 : 1 by wave age (pair_span, gg_common.h), so the oldest wave is storing its first
-// group while the younger ones still flood theirs.
+// group while the younger ones still flood theirs.  (13x13 and 9x9 need fewer registers: four waves per SIMD, one
+// workgroup per group.)  Dispatch: gg_kernels.hip, from 65 536 boards of exactly 9x9 / 13x13 / 19x19 on.
 #pragma once
 #include "gg_v4.h"
 
