@@ -69,8 +69,35 @@ def test_snake_groups_vs_oracle(n):
     pass through the ORACLE-consistent route: we only compare functions that are defined on any stone layout."""
     from gymgo_amd import gogame, state_utils
     from oracle import c_oracle
+    st = consistent_boards(n)
+    d = dev(st)
+    # 1. invalid mask for the side to move (the flood-heavy part)
+    got = state_utils.batch_compute_invalid_moves(d, None, None).cpu().numpy()
+    for i in range(len(st)):
+        want = c_oracle.compute_invalid_moves(st[i], 1 - int(st[i, 2, 0, 0]))
+        assert np.array_equal(got[i], want), (n, i)
+    st[:, 3] = got
+    d = dev(st)
+    # 2. areas
+    b, w = gogame.batch_areas(d)
+    ob, ow = c_oracle.batch_areas(st)
+    assert np.array_equal(b.cpu().numpy(), ob) and np.array_equal(w.cpu().numpy(), ow)
+    # 3. every legal move of every board (children, both canonical settings) and a pass
+    for canon in (False, True):
+        kids = gogame.batch_children(d, canonical=canon).cpu().numpy()
+        assert np.array_equal(kids, c_oracle.batch_children(st, canon)), (n, canon)
+    # 4. fused rollout from these positions (v2 atari carry-over across plies, captures of big snakes)
+    rng = gogame.rng_seed(len(st), 5)
+    rng_np = c_oracle.rng_seed(5, len(st))
+    roll = d.clone()
+    gogame.batch_rollout(roll, rng, 40, True)
+    want, _, _ = c_oracle.batch_rollout(st, rng_np, 40, True)
+    assert np.array_equal(roll.cpu().numpy(), want), n
+
+
+def consistent_boards(n):
+    """boards(n) with the stones of liberty-less groups dropped (both colours): layouts every function is defined on"""
     st = boards(n)
-    # make the layouts consistent: drop stones of groups without liberties (both colours), oracle side
     for i in range(len(st)):
         for colour in (0, 1):
             lab_dead = []
@@ -98,29 +125,7 @@ def test_snake_groups_vs_oracle(n):
                     lab_dead += cells
             for r, c in lab_dead:
                 st[i, colour, r, c] = 0
-    d = dev(st)
-    # 1. invalid mask for the side to move (the flood-heavy part)
-    got = state_utils.batch_compute_invalid_moves(d, None, None).cpu().numpy()
-    for i in range(len(st)):
-        want = c_oracle.compute_invalid_moves(st[i], 1 - int(st[i, 2, 0, 0]))
-        assert np.array_equal(got[i], want), (n, i)
-    st[:, 3] = got
-    d = dev(st)
-    # 2. areas
-    b, w = gogame.batch_areas(d)
-    ob, ow = c_oracle.batch_areas(st)
-    assert np.array_equal(b.cpu().numpy(), ob) and np.array_equal(w.cpu().numpy(), ow)
-    # 3. every legal move of every board (children, both canonical settings) and a pass
-    for canon in (False, True):
-        kids = gogame.batch_children(d, canonical=canon).cpu().numpy()
-        assert np.array_equal(kids, c_oracle.batch_children(st, canon)), (n, canon)
-    # 4. fused rollout from these positions (v2 atari carry-over across plies, captures of big snakes)
-    rng = gogame.rng_seed(len(st), 5)
-    rng_np = c_oracle.rng_seed(5, len(st))
-    roll = d.clone()
-    gogame.batch_rollout(roll, rng, 40, True)
-    want, _, _ = c_oracle.batch_rollout(st, rng_np, 40, True)
-    assert np.array_equal(roll.cpu().numpy(), want), n
+    return st
 
 
 def test_full_size_properties_and_shard_invariance():

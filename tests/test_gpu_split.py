@@ -202,3 +202,40 @@ def test_invalid_mask_sixteen_boards_per_wave(N, B):
         assert np.array_equal(got[j], want), (N, int(idx[j]))
     sub = st[5:5 + 65536 + 16]
     assert torch.equal(gogame._invalid_mask_dev(sub, None), gogame._invalid_mask_dev(sub.clone(), None))
+
+
+@pytest.mark.parametrize('N', [19, 13, 9])
+def test_sixteen_board_kernels_on_snakes_spirals_and_combs(N):
+    """The class-major kernels on the shapes that stress the flood (one-stone-wide spirals, serpentines, combs with
+    opponent stones in the corridors: many sweep rounds, big captures): 24 synthetic layouts tiled to 66 000 boards, every
+    board with its own move - gg_batch_next_states, gg_batch_env_step (drawn moves) and gg_batch_invalid_mask on the
+    whole batch equal the same batch in chunks on the two-board kernels (which test_gpu_adversarial.py pins to the
+    oracle), and the first 24 x 8 boards the oracle directly."""
+    from test_gpu_adversarial import consistent_boards
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    base = consistent_boards(N)
+    d0 = torch.from_numpy(base).cuda()
+    base[:, 3] = gogame._invalid_mask_dev(d0, None).cpu().numpy()      # plane 3 of a legal state
+    B = 66000
+    reps = (B + len(base) - 1) // len(base)
+    st = torch.from_numpy(np.tile(base, (reps, 1, 1, 1))[:B].copy()).cuda()
+    rng = gogame.rng_seed(B, 1234 + N)
+    acts = gogame.batch_sample_actions(st, rng)                        # a different legal move per copy
+    acts[::11] = (acts[::11] * 7 + 1) % (N * N + 2) - 1                # ... and some that are not
+    out, status = gogame.batch_next_states(st, acts, check=False)
+    parts = [gogame.batch_next_states(st[lo:hi], acts[lo:hi], check=False) for lo, hi in _chunks(B)]
+    assert torch.equal(out, torch.cat([p[0] for p in parts], 0)) and torch.equal(status, torch.cat([p[1] for p in parts], 0))
+    head = 24 * 8
+    ok = np.flatnonzero(status[:head].cpu().numpy() == 0)
+    want = c_oracle.batch_next_states(st[:head].cpu().numpy()[ok], acts[:head].cpu().numpy()[ok], False)[0]
+    assert np.array_equal(out[:head].cpu().numpy()[ok], want)
+    a, ra, b, rb = st.clone(), rng.clone(), st.clone(), rng.clone()
+    wa = gogame.batch_env_step(a, None, ra, 6.5, 'heuristic', True)
+    wb = [gogame.batch_env_step(b[lo:hi], None, rb[lo:hi], 6.5, 'heuristic', True) for lo, hi in _chunks(B)]
+    for i in range(4):
+        assert torch.equal(wa[i], torch.cat([w[i] for w in wb], 0)), (N, i)
+    assert torch.equal(a, b) and torch.equal(ra, rb)
+    m1 = gogame._invalid_mask_dev(out, None)
+    m2 = torch.cat([gogame._invalid_mask_dev(out[lo:hi], None) for lo, hi in _chunks(B)], 0)
+    assert torch.equal(m1, m2)
