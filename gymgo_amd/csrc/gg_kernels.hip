@@ -2,7 +2,7 @@
 // grid sizing and dispatch on the board-size template.  The kernels live in gg_common.h (shared building blocks),
 // gg_v2.h (per-ply kernels: two boards per wavefront, every liberty class from scratch), gg_v4.h (multi-ply kernels:
 // sixteen boards per wavefront, liberty classes carried from ply to ply), gg_aux.h (stand-alone sampler and capture
-// resolution), gg_ws.h (policy-weighted sampling) and gg_sym.h (batched symmetries).  Which kernel serves an entry point depends on the arguments only (batch size, plies per launch): there
+// resolution), gg_ws.h (policy-weighted sampling), gg_sym.h (batched symmetries) and gg_ns16.h (the per-ply kernels for big batches).  Which kernel serves an entry point depends on the arguments only (batch size, plies per launch): there
 // are no environment switches and no mutable global state besides the per-device CU-count cache below.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
