@@ -2,8 +2,11 @@
 // grid sizing and dispatch on the board-size template.  The kernels live in gg_common.h (shared building blocks),
 // gg_v2.h (per-ply kernels: two boards per wavefront, every liberty class from scratch), gg_v4.h (multi-ply kernels:
 // sixteen boards per wavefront, liberty classes carried from ply to ply), gg_aux.h (stand-alone sampler and capture
-// resolution), gg_ws.h (policy-weighted sampling), gg_sym.h (batched symmetries) and gg_ns16.h (the per-ply kernels for big batches).  Which kernel serves an entry point depends on the arguments only (batch size, plies per launch): there
-// are no environment switches and no mutable global state besides the per-device CU-count cache below.
+// resolution), gg_ws.h (policy-weighted sampling), gg_sym.h (batched symmetries) and gg_ns16.h (the per-ply kernels for
+// big batches).  Which kernel serves an entry point depends on the arguments only (board size, batch size, plies per
+// launch): there are no environment switches in the shipped build, and the only mutable global state is caches of
+// device facts (CU count per device, occupancy per kernel) and the FairShare progress board in device memory
+// (gg_common.h), on which no result depends.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <mutex>
