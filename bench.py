@@ -423,7 +423,7 @@ def extras(dev, back, opts):
     nxt, status = torch.empty_like(states), torch.empty(count, dtype=torch.int32, device=dev)
     r, ms = event_rate(torch, dev, lambda: gogame.batch_next_states(states, acts, check=False, out=nxt, status=status), count, 32)
     # (gg_kernels.hip: full-size boards take the sixteen-boards-per-wave kernel from four groups per SIMD on)
-    big = N in (9, 13, 19) and (count + 15) // 16 >= 16 * int(_lib.lib().gg_device_cus())
+    big = N in (9, 13, 19) and (count + 15) // 16 >= (16 if N == 19 else 8) * int(_lib.lib().gg_device_cus())
     per_ply = {'kernel': ('k_next_states16<%d>' % N) if big else 'k_next_states2<%d>' % (9 if N <= 9 else 13 if N <= 13 else 19),
                'entry': 'gg_batch_next_states',
                'algorithmic_bytes_per_step': algo, 'launch_us': round(ms * 1e3, 2), 'env_steps_per_s': round(r, 1),

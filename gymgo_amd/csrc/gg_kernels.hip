@@ -133,6 +133,25 @@ void launch_pairs(void (*kern)(KArgs...), int cus, int64_t npairs, bool split, h
   kern<<<grid, kWave, 0, s>>>(args..., as);
 }
 
+// The sixteen-boards-per-wave kernels of gg_ns16.h serve batches of exactly 9x9 / 13x13 / 19x19 boards from a number of
+// groups per SIMD on that depends on the entry point and the board size (tools/exp/ns16_min.py, us per call, two-board
+// kernel -> sixteen-board kernel):
+//   gg_batch_next_states    19x19 from 4 (49 152 boards: 48.6 -> 47.3, 32 768: 35.7 -> 38.3), 13x13 and 9x9 from 2
+//                           (32 768: 28.7 -> 27.6 / 23.9 -> 18.7; 16 384: 18.5 -> 19.2 / 14.2 -> 15.1)
+//   gg_batch_env_step       19x19 from 3 (49 152: 57.7 -> 52.3, 32 768: 42.6 -> 41.0, 24 576: 35.3 -> 39.1), 13x13 from 2
+//   (+ one-ply rollout)     (32 768: 32.5 -> 26.7, 24 576: 24.1 -> 25.5), 9x9 from 1 (16 384: 17.1 -> 12.8)
+//   gg_batch_invalid_mask   13x13 from 2 (32 768: 20.8 -> 17.5), 9x9 from 1 (16 384: 10.0 -> 9.0); 19x19 never
+bool use_ns16(int cus, int64_t B, int32_t N, int per19, int per13, int per9) {
+  const int64_t ngroups = (B + 15) / 16;
+  int per_simd = N == 19 ? per19 : N == 13 ? per13 : per9;
+  bool big = (N == 9 || N == 13 || N == 19) && per_simd > 0 && ngroups <= 0x7FFFFFFF;
+#ifdef GG_AB
+  if (const char *e = getenv("GG_AB_NS16")) big = big && atoi(e) != 0;
+  if (const char *e = getenv("GG_AB_NS16_MIN")) per_simd = atoi(e);
+#endif
+  return big && ngroups >= (int64_t)cus * 4 * per_simd;
+}
+
 // multi-ply kernel: boards per wave (even, <= kNB4 = 16).  The flood batch of a ply costs the same for 2 or 16 boards, so
 // the more the better; small batches take fewer per wave so that every SIMD still gets a wave.  65 536 games on 256 CUs:
 // 16 boards x 4 096 waves = exactly the resident set (4 waves per SIMD).
@@ -270,17 +289,15 @@ int32_t gg_batch_next_states(const uint8_t *in, const int32_t *actions, uint8_t 
                              int32_t N, int32_t canonical, void *hip_stream) {
   GG_ENTER(in);
   if (!actions || !out) return GG_E_NULLPTR;
-  // Big batches of full-size boards: sixteen boards per wave, floods class-major (gg_ns16.h), from four groups per SIMD on
-  // (65 536 boards on 256 CUs; at 49 152 - one group per wave of 19x19's three per SIMD, a single lock-step round - the
-  // two-board kernel is still ahead: 46 against 47 us).  19x19 runs the resident set with a SIMD's groups split 2 : 1 : 1
-  // by wave age (58.6 us per 65 536 boards against 60.0 with one workgroup per group; 1 : 1 : 2 70.6), the smaller
-  // boards (four waves per SIMD) one workgroup per group.
+  // Big batches of full-size boards: sixteen boards per wave, floods class-major (gg_ns16.h; use_ns16 above has the
+  // batch sizes).  19x19 runs the resident set with a SIMD's groups split 2 : 1 : 1 by wave age (58.6 us per 65 536 boards
+  // against 60.0 with one workgroup per group; 1 : 1 : 2 70.6), the smaller boards (four waves per SIMD) one workgroup
+  // per group.
   {
     const int64_t ngroups = (B + kNB16 - 1) / kNB16;
-    bool big = (N == 9 || N == 13 || N == 19) && ngroups >= (int64_t)cus * 4 * 4 && ngroups <= 0x7FFFFFFF;
+    const bool big = use_ns16(cus, B, N, 4, 2, 2);
     double c1 = 0.5, c2 = 0.75;
 #ifdef GG_AB
-    if (const char *e = getenv("GG_AB_NS16")) big = big && atoi(e) != 0;
     if (const char *e = getenv("GG_AB_NS16_CUT")) sscanf(e, "%lf,%lf", &c1, &c2);
 #endif
     if (big) {
@@ -340,10 +357,7 @@ int32_t gg_batch_invalid_mask(const uint8_t *states, const int32_t *ko, uint8_t 
       // faster than the two-board kernel at four, 47 us both, and stays out: what it gains gg_batch_next_states is the
       // write-back, which the mask does not have)
     const int64_t ngroups = (B + kNB16 - 1) / kNB16;
-    bool big = (N == 9 || N == 13) && ngroups >= (int64_t)cus * 4 * 4 && ngroups <= 0x7FFFFFFF;
-#ifdef GG_AB
-    if (const char *e = getenv("GG_AB_NS16")) big = big && atoi(e) != 0;
-#endif
+    const bool big = use_ns16(cus, B, N, 0, 2, 1);
     if (big) {
       const AgeSplit as = {0, {0u, 0u, 0u}};   // one workgroup per group
       const int grid16 = (int)ngroups;
@@ -411,10 +425,7 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
   }
   if (plies == 1) {   // one ply per launch on a big batch of full-size boards: the env step without the GoEnv outputs (gg_ns16.h)
     const int64_t ngroups = (B + kNB16 - 1) / kNB16;
-    bool big = (N == 9 || N == 13 || N == 19) && ngroups >= (int64_t)cus * 4 * 4 && ngroups <= 0x7FFFFFFF;
-#ifdef GG_AB
-    if (const char *e = getenv("GG_AB_NS16")) big = big && atoi(e) != 0;
-#endif
+    const bool big = use_ns16(cus, B, N, 3, 2, 1);
     if (big) {
       AgeSplit as = {cus * 4, {32768u, 49152u, 65536u}};
       int grid16 = as.cols * 3;
@@ -446,10 +457,7 @@ int32_t gg_batch_env_step(uint8_t *states, const int32_t *actions, uint64_t *rng
   if (!actions && !rng) return GG_E_NULLPTR;
   {   // big batches of full-size boards: the class-major analysis, sixteen boards per wave (as gg_batch_next_states)
     const int64_t ngroups = (B + kNB16 - 1) / kNB16;
-    bool big = (N == 9 || N == 13 || N == 19) && ngroups >= (int64_t)cus * 4 * 4 && ngroups <= 0x7FFFFFFF;
-#ifdef GG_AB
-    if (const char *e = getenv("GG_AB_NS16")) big = big && atoi(e) != 0;
-#endif
+    const bool big = use_ns16(cus, B, N, 3, 2, 1);
     if (big) {
       AgeSplit as = {cus * 4, {32768u, 49152u, 65536u}};   // 19x19: a SIMD's groups 2 : 1 : 1 by wave age
       int grid16 = as.cols * 3;
