@@ -63,6 +63,11 @@ __device__ unsigned long long gg_prof[8];
 #define GG_PROF(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); \
     const unsigned long long n_ = clock64(); __builtin_amdgcn_sched_barrier(0); tph_[k] += n_ - tc_; tc_ = n_; } while (0)
 #define GG_PROF_FLUSH do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&gg_prof[k_], tph_[k_]); } while (0)
+#elif defined(GG_AB_MARK)
+// A/B builds only: phase markers in the assembly listing (tools/isa_mix.py --phases)
+#define GG_PROF_DECL do {} while (0)
+#define GG_PROF(k) asm volatile("; GGMARK " #k ::: "memory")
+#define GG_PROF_FLUSH do {} while (0)
 #else
 #define GG_PROF_DECL do {} while (0)
 #define GG_PROF(k) do {} while (0)
@@ -74,17 +79,21 @@ struct Lds4 {
   static constexpr int RS = Cfg<R>::kRowStride;
   static constexpr int RPL = (R + 3) / 4;                        // rows per lane in phases 1 and 3
   static_assert(4 * RPL <= RS, "a quad's rows must fit the row stride");
-  static constexpr int kState = 0;                               // [2][kNB4][RS]: black, white
+  static constexpr int kPad = 4;                                 // zero words in front of the planes: "row -1" / "row -2" of the first board
+  static constexpr int kState = kPad;                            // [2][kNB4][RS]: black, white
   static constexpr int kMeta = kState + 2 * kNB4 * RS;           // flags[16], act[16], last[16], played[16], rng[32]
   static constexpr int kFair = kMeta + 6 * kNB4;                 // [16]: the progress words of this SIMD's wave slots (FairShare)
-  static constexpr int kInfo = kFair + 16;                       // per board: what phase 2 learnt about q's neighbours
-  static constexpr int kTmp = kInfo + kNB4;                      // [2][2][RS]: layout change of one pair at load / store
+  static constexpr int kTmp = kFair + 16;                        // [2][2][RS]: layout change of one pair at load / store
   static constexpr int kUnion = kTmp + 4 * RS;
   // ply loop: per flood lane its result word (liberty class, size, role, seed) + the transpose buffer of the group masks
   static constexpr int kCls = kUnion;
   static constexpr int kSc = kCls + kWave;
-  static constexpr int kScPad = 4;                               // words of padding per board between its four flood blocks and the next board's
-  static constexpr int kLoopEnd = kSc + kWave * RS + kNB4 * kScPad;
+  // per board FIVE blocks of RS words: one per flood lane of its quad + the flood of the mover's group G (all the lanes
+  // that flood G write the same rows there).  The board stride in units of four words must be odd: phase 3 reads
+  // twenty-five words per lane at this stride, and a stride of 4 x even words puts the sixteen boards on 2 or 4 banks
+  static constexpr int kScPad = ((5 * RS / 4) % 2 == 0) ? 4 : 0;
+  static constexpr int kScBoard = 5 * RS + kScPad;
+  static constexpr int kLoopEnd = kSc + kNB4 * kScBoard;
   // load / store: the v2 analysis in its compact form (region 0 only: staging / transpose buffer); at store time the
   // emitter's scratch (2 x 128 words) and the spread table (uint2[256]); tracked boards: the parked mask / class rows
   static constexpr int kV2 = kUnion;
@@ -99,7 +108,7 @@ struct Lds4 {
   static constexpr int kTotal = (kLoopEnd > kIoEnd ? kLoopEnd : kIoEnd) > kGrpEnd ? (kLoopEnd > kIoEnd ? kLoopEnd : kIoEnd) : kGrpEnd;
   static_assert(kTotal * 4 <= 10240, "four waves per SIMD: 10 KB of LDS per wave");
   static_assert(kUnion % 4 == 0, "16-byte alignment of the flood blocks");
-  static_assert(3 * kNB4 * RS <= kWave * RS + kWave, "parked tracked rows fit the flood blocks");
+  static_assert(3 * kNB4 * RS <= kNB4 * kScBoard + kWave, "parked tracked rows fit the flood blocks");
 };
 
 // DPP inside a quad (quad_perm: lane i of each quad reads lane perm[i]); bound_ctrl off: every source lane exists
@@ -218,11 +227,12 @@ __device__ __forceinline__ void emit_group(uint8_t *g, int nbrd, int N, const ui
 }
 
 // cls word of a flood lane: bits 0-1 liberties of the group (saturated at 2), 2 the group is one stone, 3 the group
-// exists (the seed was a stone), 4 the lane flooded G (the mover's group), 8-15 / 16-23 row / column of the seed
-constexpr uint32_t CL_LIBS = 3u, CL_ONE = 4u, CL_ANY = 8u, CL_G = 16u;
-// per-board word of phase 2: bits 0-1 empty neighbours of q (saturated at 2), 2 q has a friendly neighbour, 3 every
-// on-board neighbour of q holds an opponent stone (state_utils.adj_data's `surrounded`, gym_go/state_utils.py:214-223)
-constexpr uint32_t BI_EMPTY = 3u, BI_FRIEND = 4u, BI_BOXED = 8u;
+// exists (the seed was a stone), 4 the lane flooded G (the mover's group), 5 an opponent group without a liberty
+// (captured); and what the lane knows about the board (the same in all four words of a quad, or zero): 6-7 liberties
+// of G among the empty points (saturated at 2: G's own count, or the empty neighbours of q when the stone stands alone),
+// 11 q has a friendly neighbour, 19 some on-board neighbour of q does NOT hold an opponent stone (clear: q is boxed in,
+// state_utils.adj_data's `surrounded`, gym_go/state_utils.py:214-223).  (The seed of lane t is q's neighbour in direction t.)
+constexpr uint32_t CL_LIBS = 3u, CL_ONE = 4u, CL_ANY = 8u, CL_G = 16u, CL_CAPT = 32u, CL_FRIEND = 1u << 11, CL_OPEN = 1u << 19;
 
 // MOVES: the moves are given (moves: int32 [B][plies], gg_batch_play_moves) instead of drawn: a game stops at its first
 // move that is out of range, on an invalid point or made after the game has ended; played_out[b] = moves applied.
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
   constexpr int RV = (R + 3) / 4;
   constexpr int RPL = Lds4<R>::RPL;
   constexpr int PL = kNB4 * RS;   // words per plane of all boards
-  constexpr int SCP = Lds4<R>::kScPad;
+  constexpr int SCB = Lds4<R>::kScBoard;   // words per board in the flood blocks
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds4<R>::kTotal];
   if (FULLN) N = R;   // a compile-time constant from here on: row masks, r * N + c and the "row exists" tests fold
   uint32_t *st = lds + Lds4<R>::kState;     // st[colour * PL + board * RS + row]
@@ -281,7 +291,6 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
   int *lastv = reinterpret_cast<int *>(lds + Lds4<R>::kMeta + 2 * kNB4);
   int *playedv = reinterpret_cast<int *>(lds + Lds4<R>::kMeta + 3 * kNB4);
   uint32_t *rngv = lds + Lds4<R>::kMeta + 4 * kNB4;   // [2 * s], [2 * s + 1]
-  uint32_t *binfo = lds + Lds4<R>::kInfo;
   uint32_t *tmp = lds + Lds4<R>::kTmp;      // tmp[(half * 2 + set) * RS + row], set 0 = invalid, 1 = M
   uint32_t *clsv = lds + Lds4<R>::kCls;
   uint32_t *sc = lds + Lds4<R>::kSc;
@@ -321,6 +330,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       const int nw = (int)nbrd * W;
       const uint32_t *gp = reinterpret_cast<const uint32_t *>(states) + b_first * (int64_t)W;
       for (int i = hf.lane; i < 2 * PL; i += kWave) st[i] = 0;      // rows N .. RS-1 and absent boards read as zero
+      if (hf.lane < Lds4<R>::kPad) lds[hf.lane] = 0;
       for (int i = hf.lane; i < 3 * PL; i += kWave) park[i] = 0;
       const uint32_t invW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;   // i / W exactly for i < 16 * 96
       // the generator states of the group: requested before the block, so that they do not cost a round trip of their own
@@ -374,6 +384,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
     } else {
       if (hf.lane < kNB4) flagsv[hf.lane] = 0;                       // boards beyond nb: off
       for (int i = hf.lane; i < 2 * PL; i += kWave) st[i] = 0;
+      if (hf.lane < Lds4<R>::kPad) lds[hf.lane] = 0;
       WAVE_SYNC();
     }
     // Byte planes / packed boards: pairs, first classes by the per-ply-style analysis.  The global loads of pair i + 1 are
@@ -585,7 +596,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       // (volatile asm: neither hoisted nor merged)
       int ln;   // = hf.lane (one wave per workgroup), straight from the hardware
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-      const int s4 = ln >> 2, t5 = ln & 3, r0 = RPL * t5;   // board, lane of the quad, first row of this lane
+      const int s4 = (ln >> 2) & 15, t5 = ln & 3, r0 = RPL * t5;   // board, lane of the quad, first row of this lane
       const bool bl = s4 < nb;
       uint32_t full[RPL];   // the N-bit row mask of the lane's rows that exist
 #pragma unroll
@@ -692,62 +703,96 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       WAVE_SYNC();
       GG_PROF(0);
 
-      // phase 2 - one lane per (board, role).  The six rows around q say which neighbours hold a friendly / an
-      // opponent stone; the opponent neighbours take lanes 0.. in the order up, down, left, right, G takes lane 3 when
-      // q has a friendly neighbour (then at most three neighbours are the opponent's).
+      // phase 2 - one lane per (board, direction): lane t of a quad looks at ONE neighbour of q (0 up, 1 down, 2 left, 3 right).
+      // An opponent stone there: the lane floods that stone's group.  A friendly stone: the lane floods G from q (every such
+      // lane of the board runs the same flood and writes the same rows into the board's G block, a benign duplicate - the
+      // flood batch costs the same whatever its lanes carry - so no lane has to find out which of them is "the" G lane).
+      // Nothing there: the lane idles (an all-zero flood).  What the board-level tests of phase 3 need - empty neighbours
+      // of q, is any of them friendly, is q boxed in - is one packed quad sum, and travels in the lanes' class words.
+      // (round 3 compacted the opponent neighbours onto lanes 0.. and kept G on lane 3: 128 VALU instructions of
+      // compares and selects per wave-ply for the role assignment alone, against 45 here.)
       {
         const int a = bl ? actv[s4] : -1;
-        const int turn = flagsv[s4] & 1u;
-        const bool moving = a >= 0 && a < hf.P;
-        int ar = 0, ac = 0;
-        if (moving) split_action(a, N, hf.inv, ar, ac);
-        const uint32_t bit = moving ? (1u << ac) : 0u;
-        const uint32_t *pm = st + turn * PL + s4 * RS, *po = st + (1 - turn) * PL + s4 * RS;
-        const int aru = ar > 0 ? ar - 1 : 0;
-        const uint32_t upok = ar > 0 ? bit : 0u;
-        const uint32_t mU = pm[aru], mC = pm[ar], mD = pm[ar + 1], oU = po[aru], oC = po[ar], oD = po[ar + 1];
-        // direction bits: 1 up, 2 down, 4 left, 8 right (rows / columns off the board read as empty: no stone there)
-        const uint32_t fm = ((mU & upok) ? 1u : 0u) | ((mD & bit) ? 2u : 0u) | ((mC & (bit >> 1)) ? 4u : 0u) | ((mC & shl1(bit)) ? 8u : 0u);
-        const uint32_t om = ((oU & upok) ? 1u : 0u) | ((oD & bit) ? 2u : 0u) | ((oC & (bit >> 1)) ? 4u : 0u) | ((oC & shl1(bit)) ? 8u : 0u);
-        const bool friendly = fm != 0u;
-        uint32_t mk = om;                      // the t5-th opponent direction
-        if (t5 >= 1) mk &= mk - 1u;
-        if (t5 >= 2) mk &= mk - 1u;
-        if (t5 >= 3) mk &= mk - 1u;
-        const uint32_t d = mk & (0u - mk);
-        const bool isG = friendly && t5 == 3;  // (then om has at most three bits: d == 0 on lane 3)
-        const int sr = ar + (isG ? 0 : ((d & 1u) ? -1 : ((d & 2u) ? 1 : 0)));
-        const int scol = ac + (isG ? 0 : ((d & 4u) ? -1 : ((d & 8u) ? 1 : 0)));
-        const uint32_t sbit = isG ? bit : (d ? (1u << scol) : 0u);
-        const uint32_t *own = isG ? pm : po;   // the colour this lane floods
-        const uint32_t *oth = isG ? po : pm;
-        if (t5 == 0 && bl) {
-          const uint32_t onb = (ar > 0 ? 1u : 0u) | (ar < N - 1 ? 2u : 0u) | (ac > 0 ? 4u : 0u) | (ac < N - 1 ? 8u : 0u);
-          const uint32_t ne = (uint32_t)__popc(onb & ~(om | fm));
-          binfo[s4] = (ne < 2u ? ne : 2u) | (friendly ? BI_FRIEND : 0u) | ((onb & ~om) == 0u ? BI_BOXED : 0u);
+        const uint32_t turn = flagsv[s4] & 1u;
+        // this lane's flood block is cleared first: the flood's seed row set is staged through it (below), and a lane
+        // that floods G or nothing must leave it empty for phase 3
+        uint32_t *blk = sc + s4 * SCB + t5 * RS;
+        {
+          uint4 *pz = reinterpret_cast<uint4 *>(blk);
+#pragma unroll
+          for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
         }
-        uint32_t cnt = 0, sz = 0;
+        const uint32_t mv1 = ((uint32_t)a < (uint32_t)hf.P) ? 1u : 0u;   // a stone was placed (not a pass, not an idle board)
+        int ar, ac;
+        split_action(mv1 ? a : 0, N, hf.inv, ar, ac);
+        const int sg = 2 * (t5 & 1) - 1;
+        const int dr = (t5 & 2) ? 0 : sg, dc = (t5 & 2) ? sg : 0;
+        const int nr = ar + dr, nc = ac + dc;   // this lane's neighbour of q: row -1 .. N, column -1 .. N
+        const uint32_t *pm = st + turn * PL + s4 * RS, *po = st + (1u - turn) * PL + s4 * RS;
+        // (row -1 / -2 of a board is the zero row 19 / 18.. of the board before it or the pad in front of the planes, row N
+        // a zero row, row N + 1 - read for an off-board neighbour only - whatever follows: masked by obit)
+        const uint32_t rowm = pm[nr], rowo = po[nr], oup = po[nr - 1], odn = po[nr + 1];
+        const uint32_t ncs = (uint32_t)nc & 31u;   // column -1 reads bit 31, column N bit N: never set in a row
+        const uint32_t mbit = (rowm >> ncs) & mv1, obit = (rowo >> ncs) & mv1;
+        const uint32_t onb = ((uint32_t)nr < (uint32_t)N && (uint32_t)nc < (uint32_t)N) ? mv1 : 0u;
+        const uint32_t ex = mbit | obit;           // this lane floods
+        // quad totals in one packed word: bits 0-2 empty neighbours of q, 8-10 friendly ones, 16-18 on-board neighbours
+        // that are not the opponent's (none: q is boxed in, state_utils.adj_data's `surrounded`)
+        // (+ 7 in a three-bit field carries into the bit above it iff the field is not zero: bit 11 = q has a friendly
+        // neighbour, bit 19 = q is NOT boxed in)
+        const uint32_t qs = quad_sum((onb & ~ex) | (mbit << 8) | ((onb & ~obit) << 16)) + 0x70700u;
+        const uint32_t ne = qs & 7u, ne2 = ne < 2u ? ne : 2u;
+        const uint32_t lone = ~(uint32_t)__builtin_amdgcn_sbfe((int)qs, 11, 1);   // ~0: no friendly neighbour
+        // the seed: q itself for G, the neighbour stone for an opponent group
+        const uint32_t gm = 0u - mbit;
+        const int sr = nr - (dr & (int)gm), scol = nc - (dc & (int)gm);
+        const uint32_t sbit = ex << ((uint32_t)scol & 31u);
+        // the colour this lane floods (G: the mover's) and the other one, as 16-byte row sets (indexed from the aligned
+        // base of the LDS array: behind the pad the compiler no longer sees the alignment of `st + ...` and would split the
+        // row loads into dwords)
+        const uint32_t ownc = turn ^ mbit ^ 1u;
+        const uint4 *lds4 = reinterpret_cast<const uint4 *>(lds);
+        const uint4 *pmv = lds4 + (Lds4<R>::kState + (int)ownc * PL + s4 * RS) / 4;
+        const uint4 *pov = lds4 + (Lds4<R>::kState + (int)(ownc ^ 1u) * PL + s4 * RS) / 4;
+        uint32_t *out = mbit ? sc + s4 * SCB + 4 * RS : blk;
+        // the opponent's stone is a group of its own iff none of its neighbours holds an opponent stone (ko needs it)
+        const uint32_t onbr = B3(oup, odn, rowo >> 1, T_OR3) | shl1(rowo);
+        const uint32_t single = obit & ~(onbr >> ncs);
+        // the class word (below) but for the liberties of the lane's group, which the flood has yet to find
+        const uint32_t pre = (qs & (CL_FRIEND | CL_OPEN)) | (single << 2) | (ex << 3) | (mbit << 4) | ((ne2 & lone) << 6);
+        uint32_t cnt = 0;
         {
           uint32_t m[R];
           {
             uint32_t mrev[R], f[R];
-            uint32_t mt[RV * 4];
-            const uint4 *pmv = reinterpret_cast<const uint4 *>(own);
+            uint32_t mt[RV * 4], ft[RV * 4];
 #pragma unroll
             for (int i = 0; i < RV; ++i) {
               const uint4 x = pmv[i];
               mt[4 * i] = x.x; mt[4 * i + 1] = x.y; mt[4 * i + 2] = x.z; mt[4 * i + 3] = x.w;
             }
-            // the seed is one bit of row sr: a one-hot row selector turns "r == sr" into a sign-extending bit extract
-            // (the flood keeps its odd rows bit-reversed: their seeds are cut out of mrev with the reversed seed bit)
-            const uint32_t onehot = (sbit != 0u) ? (1u << sr) : 0u;
-            const uint32_t sbit_rev = __brev(sbit);
+            // the seeds are one bit of one row: written into the cleared block at its (dynamic) row and read back as the
+            // flood's row set - two LDS instructions instead of a select per row (the flood keeps its odd rows
+            // bit-reversed; a lane without a seed writes a zero to row 0); the block is cleared again behind the read
+            {
+              const int srw = sr & (int)(0u - ex);
+              asm volatile("" ::: "memory");   // (DS instructions of a wave execute in order; the compiler must keep it too)
+              blk[srw] = (sr & 1) ? __brev(sbit) : sbit;
+              asm volatile("" ::: "memory");
+              const uint4 *pf = reinterpret_cast<const uint4 *>(blk);
+#pragma unroll
+              for (int i = 0; i < RV; ++i) {
+                const uint4 x = pf[i];
+                ft[4 * i] = x.x; ft[4 * i + 1] = x.y; ft[4 * i + 2] = x.z; ft[4 * i + 3] = x.w;
+              }
+              asm volatile("" ::: "memory");
+              blk[srw] = 0u;
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
               m[r] = mt[r];
               mrev[r] = __brev(m[r]);
-              const uint32_t sel = (uint32_t)__builtin_amdgcn_sbfe((int)onehot, r, 1);   // 0 or ~0
-              f[r] = (r & 1) ? B3(mrev[r], sbit_rev, sel, TA & TB & TC) : B3(m[r], sbit, sel, TA & TB & TC);
+              f[r] = ft[r];
             }
             // (measured on this kernel, 65 536 games x 256 plies: the two-chain flood2_dual 2.78 ms against 2.33 ms, a first
             // closure test already after the second sweep 2.43 ms)
@@ -755,14 +800,13 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
             // (the closure test's copy of the fill goes to LDS four rows per ds_write_b128: 32-bit stores of one row
             // from lanes RS = 20 words apart are a 4-way bank conflict - removing it measured 2.327 vs 2.327 ms per
             // 256-ply launch: the LDS is not on this kernel's critical path)
-            flood2_serial<R, true, true>(m, mrev, f, sc + ln * RS + (ln >> 2) * SCP);
+            flood2_serial<R, true, true>(m, mrev, f, out);
             GG_PROF(2);
           }
           // liberties of this lane's group on the position with the new stone (captures not yet removed); m[] still
           // holds the flooded colour's rows
           uint32_t gt[RV * 4], ot[RV * 4];
-          const uint4 *pg = reinterpret_cast<const uint4 *>(sc + ln * RS + (ln >> 2) * SCP);
-          const uint4 *pov = reinterpret_cast<const uint4 *>(oth);
+          const uint4 *pg = reinterpret_cast<const uint4 *>(out);
 #pragma unroll
           for (int i = 0; i < RV; ++i) {
             const uint4 x = pg[i], y = pov[i];
@@ -777,14 +821,18 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
             const uint32_t dd = B3(shl1(gt[r]), gt[r] >> 1, up, T_OR3);
             const uint32_t l = B3(dd, dn, e, (TA | TB) & TC);
             cnt += (uint32_t)__popc(l);   // only min(cnt, 2) is used: one accumulating v_bcnt per row
-            sz += gt[r];   // sum of the row words: equals the seed bit iff the group is the seed stone alone
           }
         }
-        clsv[ln] = (cnt < 2u ? cnt : 2u) | ((sz != 0u && sz == sbit) ? CL_ONE : 0u) | (sz != 0u ? CL_ANY : 0u) |
-                   (isG ? CL_G : 0u) | ((uint32_t)(sr & 0xFF) << 8) | ((uint32_t)(scol & 0xFF) << 16);
+        // liberties of G among the empty points, as phase 3 wants them (bits 6-7; phase 3 ORs the four words of a quad):
+        // G's own count from the lanes that flooded it, the empty neighbours of q (in `pre`) when the stone stands alone
+        const uint32_t lib2 = cnt < 2u ? cnt : 2u;
+        const uint32_t gsel6 = (uint32_t)__builtin_amdgcn_sbfe((int)pre, 4, 1);   // ~0: this lane flooded G
+        const uint32_t pre2 = pre + pre;   // CL_ANY at bit 4, CL_G at bit 5; doubled again: CL_ANY at bit 5
+        const uint32_t dead = ((cnt - 1u) >> 26) & B3(pre2 + pre2, pre2, CL_CAPT, TA & ~TB & TC & 0xFF);   // no liberty, flooded, not G
+        clsv[ln] = B3(lib2 << 6, gsel6, pre, T_ANDOR) | lib2 | dead;
         // an opponent group that keeps >= 2 liberties keeps its class: phase 3 must not see it
-        if (!isG && cnt >= 2u) {
-          uint4 *pz = reinterpret_cast<uint4 *>(sc + ln * RS + (ln >> 2) * SCP);
+        if (!mbit && cnt >= 2u) {
+          uint4 *pz = reinterpret_cast<uint4 *>(blk);
 #pragma unroll
           for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
         }
@@ -803,19 +851,17 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         const uint32_t fl = flagsv[s4];
         const uint4 cq = *reinterpret_cast<const uint4 *>(clsv + 4 * s4);
         const uint32_t c0 = cq.x, c1 = cq.y, c2 = cq.z, c3 = cq.w;
-        const uint32_t bi = binfo[s4];
         const int turn0 = fl & 1u;
         uint32_t *pmine = st + turn0 * PL + s4 * RS + r0;
         uint32_t *popp = st + (1 - turn0) * PL + s4 * RS + r0;
-        // (a board's four flood blocks are 4 RS + 4 words from the next board's: with a stride of exactly 4 RS = 80 words
-        // the 32-bit reads below hit every sixteenth bank only - a 4-way conflict on all twenty of them)
-        const uint32_t *gr = sc + (4 * s4) * RS + s4 * SCP + r0;   // block j: gr[j * RS + r]
-        uint32_t mine1[RPL], opp0[RPL], b0[RPL], b1[RPL], b2[RPL], b3[RPL];
+        const uint32_t *gr = sc + s4 * SCB + r0;   // block j: gr[j * RS + r], j = 4: the board's G block (valid when q has a friendly neighbour)
+        uint32_t mine1[RPL], opp0[RPL], b0[RPL], b1[RPL], b2[RPL], b3[RPL], bg[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
           mine1[r] = pmine[r];   // (rows >= N are zero)
           opp0[r] = popp[r];
           b0[r] = gr[r]; b1[r] = gr[RS + r]; b2[r] = gr[2 * RS + r]; b3[r] = gr[3 * RS + r];
+          bg[r] = gr[4 * RS + r];
         }
         const bool moves_now = a >= 0;
         const bool is_pass = a == hf.P;
@@ -823,46 +869,50 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         int ar, ac;
         split_action(a, N, hf.inv, ar, ac);                       // (garbage for a pass / an idle board: masked below)
         const uint32_t bitc = stone_m & (1u << (ac & 31));
-        const uint32_t gmask = (uint32_t)__builtin_amdgcn_sbfe((int)c3, 4, 1);   // CL_G: lane 3 flooded G
+        const uint32_t gmask = (uint32_t)__builtin_amdgcn_sbfe((int)c0, 11, 1);   // CL_FRIEND: q has a friendly neighbour, G was flooded
         // G is the new stone alone (no friendly neighbour): its row as a one-hot selector of this lane's rows
         const uint32_t dr = (uint32_t)(ar - r0);
-        const uint32_t lone_m = stone_m & ~(uint32_t)__builtin_amdgcn_sbfe((int)bi, 2, 1);   // !BI_FRIEND
+        const uint32_t lone_m = stone_m & ~gmask;
         const uint32_t oh = (dr < (uint32_t)RPL) ? (lone_m & (1u << (dr & 31))) : 0u;
-        // captured = an opponent group (not G) that exists and has no liberty left
-        const uint32_t kmask = CL_LIBS | CL_ANY | CL_G;
-        const uint32_t km0 = stone_m & (((c0 & kmask) == CL_ANY) ? ~0u : 0u), km1 = stone_m & (((c1 & kmask) == CL_ANY) ? ~0u : 0u),
-                       km2 = stone_m & (((c2 & kmask) == CL_ANY) ? ~0u : 0u), km3 = stone_m & (((c3 & kmask) == CL_ANY) ? ~0u : 0u);
+        // captured = an opponent group with no liberty left (CL_CAPT, set by its flood lane; never on a board that does not move)
+        const uint32_t km0 = (uint32_t)__builtin_amdgcn_sbfe((int)c0, 5, 1), km1 = (uint32_t)__builtin_amdgcn_sbfe((int)c1, 5, 1),
+                       km2 = (uint32_t)__builtin_amdgcn_sbfe((int)c2, 5, 1), km3 = (uint32_t)__builtin_amdgcn_sbfe((int)c3, 5, 1);
         const uint32_t capt_m = km0 | km1 | km2 | km3;
         uint32_t g0[RPL], gch[RPL], cap[RPL], Mm_fix[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
           const uint32_t one = (uint32_t)__builtin_amdgcn_sbfe((int)oh, r, 1) & bitc;
-          g0[r] = B3(b3[r], gmask, one, T_ANDOR) & full[r];
-          gch[r] = B3(B3(b0[r], b1[r], b2[r], T_OR3), b3[r], gmask, TA | (TB & ~TC & 0xFF)) & full[r];   // the opponent groups whose class changes
-          cap[r] = B3(b3[r], km3, B3(b2[r], km2, B3(b1[r], km1, b0[r] & km0, T_ANDOR), T_ANDOR), T_ANDOR) & full[r];
+          // (no row mask: a flood block's rows >= N are zero - the flooded colour has no stone there - and so is word R)
+          g0[r] = B3(bg[r], gmask, one, T_ANDOR);
+          gch[r] = B3(b0[r], b1[r], b2[r], T_OR3) | b3[r];   // the opponent groups whose class changes (a lane that flooded G or nothing left its block empty)
+          cap[r] = B3(b3[r], km3, B3(b2[r], km2, B3(b1[r], km1, b0[r] & km0, T_ANDOR), T_ANDOR), T_ANDOR);
           Mm_fix[r] = 0u;
         }
-        uint32_t libsG = gmask ? (c3 & CL_LIBS) : (bi & BI_EMPTY);   // liberties of G among the empty points (saturated at 2)
+        uint32_t libsG = (B3(c0, c1, c2, T_OR3) | c3) >> 6 & 3u;   // liberties of G among the empty points (saturated at 2)
         uint32_t ko_oh = 0u, ko_bit = 0u;
         if (__ballot(capt_m != 0u)) {   // a capture on some board of the wave (85 % of the plies at 16 boards per wave)
-          // captured stones next to G are liberties of G too
-          {
+          // Captured stones next to G are liberties of G too.  Every captured group holds a neighbour of q, and q is part
+          // of G: with ncapn captured neighbours G gains at least ncapn liberties.  Only when that leaves the count below
+          // two (no empty liberty, one captured neighbour) do the captured points next to G have to be counted (rare)
+          const uint32_t ncapn = 0u - (km0 + km1 + km2 + km3);    // masks are 0 / -1
+          if (__ballot(ncapn == 1u && libsG == 0u)) {
             uint32_t dg[RPL];
             dilate_rows<RPL>(g0, dg);
             uint32_t cntc = 0;
 #pragma unroll
             for (int r = 0; r < RPL; ++r) cntc += (uint32_t)__popc(dg[r] & cap[r]);
             const uint32_t tot = quad_sum(cntc < 2u ? cntc : 2u);
-            libsG += tot < 2u ? tot : 2u;
+            libsG += (ncapn == 1u && libsG == 0u) ? (tot < 2u ? tot : 2u) : ncapn;
+          } else {
+            libsG += ncapn;
           }
           // gogame.py:72-75: ko iff exactly one stone died and the new stone is boxed in
-          const uint32_t ncapn = 0u - (km0 + km1 + km2 + km3);    // masks are 0 / -1
           const uint32_t ncap1 = ((c0 >> 2) & km0 & 1u) + ((c1 >> 2) & km1 & 1u) + ((c2 >> 2) & km2 & 1u) + ((c3 >> 2) & km3 & 1u);
-          const uint32_t ck = B3(c3, km3, B3(c2, km2, B3(c1, km1, c0 & km0, T_ANDOR), T_ANDOR), T_ANDOR);   // the one captured group's word
-          const bool ko = (bi & BI_BOXED) && ncapn == 1u && ncap1 == 1u;
-          const uint32_t kr = ((ck >> 8) & 0xFFu) - (uint32_t)r0;
+          const bool ko = !(c0 & CL_OPEN) && ncapn == 1u && ncap1 == 1u;
+          // the one captured stone is q's neighbour in the direction of its flood lane (0 up, 1 down, 2 left, 3 right; masks are 0 / -1)
+          const uint32_t kr = (uint32_t)ar + km0 - km1 - (uint32_t)r0;
           ko_oh = (ko && kr < (uint32_t)RPL) ? (1u << (kr & 31)) : 0u;
-          ko_bit = 1u << ((ck >> 16) & 31u);
+          ko_bit = 1u << (((uint32_t)ac + km2 - km3) & 31u);
           // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties
           uint32_t atari[RPL], f[RPL];
           dilate_rows<RPL>(cap, f);
