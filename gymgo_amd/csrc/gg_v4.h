@@ -602,6 +602,11 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
 #pragma unroll
       for (int r = 0; r < RPL; ++r) full[r] = (r0 + r < N) ? (1u << N) - 1u : 0u;
 
+      // the board's move of this ply and its flag word as the ply finds it (after an auto-reset), the same in the four
+      // lanes of a quad: the three phases run on one lane assignment, so they travel in registers - read back from LDS
+      // they cost phases 2 and 3 a dependent round trip each (action -> addresses of the rows around it -> rows)
+      int a_q;
+      uint32_t fl_q;
       // phase 1 - four lanes per board, RPL rows each: liveness, the generator (drawn redundantly by the four lanes),
       // the k-th valid point of the mask (or the given move)
       {
@@ -674,6 +679,9 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
           if (ENV && on && !live && t5 == 0) flagsv[s4] = fl | 16u;   // a frozen game refuses the step
         }
         if (wr_act) actv[s4] = a;
+        // (one lane of a board announces the move - the one that holds the point, or the first: a quad OR hands it round)
+        a_q = MOVES ? a : (int)quad_or(wr_act ? (uint32_t)(a + 2) : 0u) - 2;
+        fl_q = reset ? 40u : fl;   // a board being reset: on, dirty, black to move
         if (!MOVES && bl && t5 == 0 && live) { rngv[2 * s4] = (uint32_t)x; rngv[2 * s4 + 1] = (uint32_t)(x >> 32); }
         // (a finished game whose move is refused is still reset when auto_reset - GoEnv.reset comes before the action
         // check - also when no board of the wave moves: the resets are applied before the early exit)
@@ -695,9 +703,17 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         }
         WAVE_SYNC();
         // the new stone goes into the mover's plane right away: every later phase sees the position with it
+        // ... and, as the group G it forms on its own, into the board's G block (phase 2 floods over it when q has a
+        // friendly neighbour): phase 3 then reads G from one place whatever the case
         if (place) {
           const int turn = reset ? 0 : (int)(fl & 1u);
           st[turn * PL + s4 * RS + rabs] |= 1u << pos;
+          uint32_t *gb = sc + s4 * SCB + 4 * RS;
+          uint4 *pz = reinterpret_cast<uint4 *>(gb);
+#pragma unroll
+          for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
+          asm volatile("" ::: "memory");
+          gb[rabs] = 1u << pos;
         }
       }
       WAVE_SYNC();
@@ -712,8 +728,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       // (round 3 compacted the opponent neighbours onto lanes 0.. and kept G on lane 3: 128 VALU instructions of
       // compares and selects per wave-ply for the role assignment alone, against 45 here.)
       {
-        const int a = bl ? actv[s4] : -1;
-        const uint32_t turn = flagsv[s4] & 1u;
+        const int a = a_q;
+        const uint32_t turn = fl_q & 1u;
         // this lane's flood block is cleared first: the flood's seed row set is staged through it (below), and a lane
         // that floods G or nothing must leave it empty for phase 3
         uint32_t *blk = sc + s4 * SCB + t5 * RS;
@@ -846,9 +862,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       // is a VALU -> SALU -> VALU round trip on this wave's critical path, and with 16 boards per wave the "rare"
       // capture path runs on 85 % of the plies (some board of the wave captures), so it is straight-line code too.
       {
-        const int av = actv[s4];
-        const int a = bl ? av : -1;
-        const uint32_t fl = flagsv[s4];
+        const int a = a_q;
+        const uint32_t fl = fl_q;
         const uint4 cq = *reinterpret_cast<const uint4 *>(clsv + 4 * s4);
         const uint32_t c0 = cq.x, c1 = cq.y, c2 = cq.z, c3 = cq.w;
         const int turn0 = fl & 1u;
@@ -868,12 +883,6 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         const uint32_t stone_m = (moves_now && !is_pass) ? ~0u : 0u;
         int ar, ac;
         split_action(a, N, hf.inv, ar, ac);                       // (garbage for a pass / an idle board: masked below)
-        const uint32_t bitc = stone_m & (1u << (ac & 31));
-        const uint32_t gmask = (uint32_t)__builtin_amdgcn_sbfe((int)c0, 11, 1);   // CL_FRIEND: q has a friendly neighbour, G was flooded
-        // G is the new stone alone (no friendly neighbour): its row as a one-hot selector of this lane's rows
-        const uint32_t dr = (uint32_t)(ar - r0);
-        const uint32_t lone_m = stone_m & ~gmask;
-        const uint32_t oh = (dr < (uint32_t)RPL) ? (lone_m & (1u << (dr & 31))) : 0u;
         // captured = an opponent group with no liberty left (CL_CAPT, set by its flood lane; never on a board that does not move)
         const uint32_t km0 = (uint32_t)__builtin_amdgcn_sbfe((int)c0, 5, 1), km1 = (uint32_t)__builtin_amdgcn_sbfe((int)c1, 5, 1),
                        km2 = (uint32_t)__builtin_amdgcn_sbfe((int)c2, 5, 1), km3 = (uint32_t)__builtin_amdgcn_sbfe((int)c3, 5, 1);
@@ -881,15 +890,16 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         uint32_t g0[RPL], gch[RPL], cap[RPL], Mm_fix[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-          const uint32_t one = (uint32_t)__builtin_amdgcn_sbfe((int)oh, r, 1) & bitc;
           // (no row mask: a flood block's rows >= N are zero - the flooded colour has no stone there - and so is word R)
-          g0[r] = B3(bg[r], gmask, one, T_ANDOR);
+          g0[r] = bg[r] & stone_m;   // the G block: the flood of G, or the stone alone as phase 1 left it there
           gch[r] = B3(b0[r], b1[r], b2[r], T_OR3) | b3[r];   // the opponent groups whose class changes (a lane that flooded G or nothing left its block empty)
           cap[r] = B3(b3[r], km3, B3(b2[r], km2, B3(b1[r], km1, b0[r] & km0, T_ANDOR), T_ANDOR), T_ANDOR);
           Mm_fix[r] = 0u;
         }
         uint32_t libsG = (B3(c0, c1, c2, T_OR3) | c3) >> 6 & 3u;   // liberties of G among the empty points (saturated at 2)
-        uint32_t ko_oh = 0u, ko_bit = 0u;
+        uint32_t kor[RPL];   // the ko point as rows of this lane (almost always none)
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) kor[r] = 0u;
         if (__ballot(capt_m != 0u)) {   // a capture on some board of the wave (85 % of the plies at 16 boards per wave)
           // Captured stones next to G are liberties of G too.  Every captured group holds a neighbour of q, and q is part
           // of G: with ncapn captured neighbours G gains at least ncapn liberties.  Only when that leaves the count below
@@ -911,8 +921,12 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
           const bool ko = !(c0 & CL_OPEN) && ncapn == 1u && ncap1 == 1u;
           // the one captured stone is q's neighbour in the direction of its flood lane (0 up, 1 down, 2 left, 3 right; masks are 0 / -1)
           const uint32_t kr = (uint32_t)ar + km0 - km1 - (uint32_t)r0;
-          ko_oh = (ko && kr < (uint32_t)RPL) ? (1u << (kr & 31)) : 0u;
-          ko_bit = 1u << (((uint32_t)ac + km2 - km3) & 31u);
+          const uint32_t ko_oh = (ko && kr < (uint32_t)RPL) ? (1u << (kr & 31)) : 0u;
+          if (__ballot(ko_oh != 0u)) {
+            const uint32_t ko_bit = 1u << (((uint32_t)ac + km2 - km3) & 31u);
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) kor[r] = (uint32_t)__builtin_amdgcn_sbfe((int)ko_oh, r, 1) & ko_bit;
+          }
           // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties
           uint32_t atari[RPL], f[RPL];
           dilate_rows<RPL>(cap, f);
@@ -940,21 +954,22 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         uint32_t Mo2[RPL], opp1[RPL], Mm2[RPL], e[RPL], x[RPL], nbr[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-          const uint32_t Mm = M[r] & mine1[r], Mo = M[r] & opp0[r];
-          Mo2[r] = Mo & ~gch[r];
+          Mo2[r] = B3(M[r], opp0[r], gch[r], TA & TB & ~TC & 0xFF);         // (a captured group was in atari: never in M)
           opp1[r] = opp0[r] & ~cap[r];
-          Mm2[r] = B3(Mm, gsel, g0[r], (TA & ~TC & 0xFF) | (TB & TC)) | Mm_fix[r];   // (Mm & ~g0) | (gsel & g0)
+          const uint32_t Mm = B3(M[r], mine1[r], g0[r], TA & TB & ~TC & 0xFF);
+          Mm2[r] = B3(gsel, g0[r], Mm, T_ANDOR) | Mm_fix[r];               // (M & mine & ~g0) | (gsel & g0)
           // state_utils.compute_invalid_moves on the lane's rows (invalid_from2, RPL rows per lane)
-          e[r] = full[r] & ~(opp1[r] | mine1[r]);
-          x[r] = B3(e[r], opp1[r] & Mo2[r], mine1[r] & ~Mm2[r], T_OR3);
+          e[r] = B3(full[r], opp1[r], mine1[r], TA & ~(TB | TC) & 0xFF);
+          x[r] = B3(mine1[r], Mm2[r], e[r], (TA & ~TB & 0xFF) | TC) | Mo2[r];
         }
         dilate_rows<RPL>(x, nbr);
         const uint32_t mv_m = moves_now ? ~0u : 0u;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-          const uint32_t invalid = (full[r] & ~(e[r] & nbr[r])) | ((uint32_t)__builtin_amdgcn_sbfe((int)ko_oh, r, 1) & ko_bit);
+          const uint32_t invalid = B3(e[r], nbr[r], full[r], ~(TA & TB) & TC & 0xFF) | kor[r];
           inv_r[r] = B3(mv_m, invalid, inv_r[r], T_SEL);
-          M[r] = B3(mv_m, Mm2[r] | Mo2[r], M[r], T_SEL);
+          // (a board that does not move, or passes, has no flood, no G and no capture: the classes below are M again)
+          M[r] = Mm2[r] | Mo2[r];
         }
         if (capt_m) {
 #pragma unroll

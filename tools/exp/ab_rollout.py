@@ -4,7 +4,7 @@ sys.path.insert(0, ROOT)
 import torch
 from gymgo_amd import _lib
 if os.environ.get('LIB'):
-    _lib.LIB_PATH = os.path.join(ROOT, 'tools', 'exp', os.environ['LIB'])
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ['LIB'])
 from gymgo_amd import gogame
 import numpy as np
 N, F = 19, 256
