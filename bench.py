@@ -167,6 +167,14 @@ class HipBackend:
         import hashlib
         return hashlib.sha256(self.states.cpu().numpy().tobytes()).hexdigest()
 
+    def device_identity(self):
+        """(device index, 48-bit digest of what identifies the physical device): lets the gathered line show that the
+        ranks really sat on distinct GPUs."""
+        import hashlib
+        props = self.torch.cuda.get_device_properties(self.device)
+        ident = '%s|%s|%s' % (getattr(props, 'uuid', ''), getattr(props, 'pci_bus_id', ''), props.name)
+        return int(self.device.index or 0), int(hashlib.sha256(ident.encode()).hexdigest()[:12], 16)
+
 
 class ClockSampler:
     """Shader clock / board power of the run, sampled from a host thread through amdsmi (torch.cuda.clock_rate /
@@ -274,6 +282,13 @@ def run_rank(rank, world, backend, opts, dist=None):
     red = backend.comm_tensor([wall, float(played)])
     comm = {'backend': None, 'world_size': 1, 'ranks_counted': 1}
     per_rank_ms = [kernel_ms / K]
+    clocks = sampler.record() if sampler is not None else None
+    sclk = ((clocks or {}).get('sclk_mhz') or {}).get('median') or 0.0
+    # what every rank reports about itself: the first global game index of its shard, the steps it played, the device it
+    # ran on (index + a 48-bit digest of its uuid / name: two ranks on ONE device show up as equal pairs) and its clock
+    dev_index, dev_tag = backend.device_identity() if hasattr(backend, 'device_identity') else (-1, 0)
+    mine = [float(first), float(played), float(dev_index), float(dev_tag), float(sclk)]
+    per_rank = [dict(zip(('first_game', 'steps_played', 'device_index', 'device_tag', 'sclk_mhz_median'), mine))]
     if dist is not None:
         tmax = red[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -288,25 +303,103 @@ def run_rank(rank, world, backend, opts, dist=None):
         dist.all_reduce(gathered, op=dist.ReduceOp.SUM)
         per_rank_ms = [float(x) for x in gathered[:world]]
         comm = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'ranks_counted': int(round(float(gathered[world])))}
+        table = [0.0] * (world * len(mine))
+        table[rank * len(mine):(rank + 1) * len(mine)] = mine
+        table = backend.comm_tensor(table)
+        dist.all_reduce(table, op=dist.ReduceOp.SUM)
+        keys = ('first_game', 'steps_played', 'device_index', 'device_tag', 'sclk_mhz_median')
+        per_rank = [dict(zip(keys, (float(x) for x in table[r * len(mine):(r + 1) * len(mine)]))) for r in range(world)]
     else:
         wall_max, played_all = wall, played
-    assert played_all == K * F * total_games
-    assert comm['ranks_counted'] == world
-    if rank != 0:
+    # (dist None at world > 1: ONE rank of a bigger job driven on its own - tests/test_gpu_configs.py runs rank 5 of 8 that way)
+    lone = dist is None and world > 1
+    assert played_all == K * F * (count if lone else total_games)
+    assert comm['ranks_counted'] == (1 if lone else world)
+    for r, rec in enumerate(per_rank):      # every rank played its own shard, no two ranks the same one
+        want_first, want_count = shard(total_games, rank if lone else r, world)
+        assert int(rec['first_game']) == want_first and int(rec['steps_played']) == K * F * want_count, (r, rec)
+        rec['first_game'], rec['steps_played'], rec['device_index'] = int(rec['first_game']), int(rec['steps_played']), int(rec['device_index'])
+        rec['device_tag'] = '%012x' % int(rec['device_tag'])
+    if rank != 0 and not lone:
         return None
+    devs = [(rec['device_index'], rec['device_tag']) for rec in per_rank]
     return {'value': played_all / wall_max, 'wall_s': wall_max, 'kernel_ms': kernel_ms, 'total_games': total_games,
             'games_per_gpu': per_gpu, 'count': count, 'first': first, 'steps_played': played_all,
-            'per_rank_launch_ms': per_rank_ms, 'comm': comm, 'clocks': sampler.record() if sampler is not None else None}
+            'per_rank_launch_ms': per_rank_ms, 'per_rank': per_rank, 'distinct_devices': len(set(devs)) if devs[0][0] >= 0 else None,
+            'comm': comm, 'clocks': clocks}
 
 
 # ------------------------------------------------------------------------------------------------ roofline records
 def rollout_kernel_name(n, games, plies, cus):
-    """Mirror of gg_batch_rollout's dispatch (gymgo_amd/csrc/gg_kernels.hip): which kernel serves this launch."""
+    """Mirror of gg_batch_rollout's dispatch (gymgo_amd/csrc/gg_kernels.hip: use_multi_ply, use_ns16): which kernel
+    serves this launch."""
     rcap = 9 if n <= 9 else 13 if n <= 13 else 19
     full = 'true' if n == rcap else 'false'
     if plies >= 2 and games >= 32 * cus:
         return 'k_rollout4<%d, 0, false, %s, false, false>' % (rcap, full)
+    if plies == 1 and n in (9, 13, 19):
+        # one ply per launch on a big batch of full-size boards: the sixteen-board env-step kernel from 3 / 2 / 1 groups of
+        # sixteen boards per SIMD on (19x19 / 13x13 / 9x9)
+        per_simd = {19: 3, 13: 2, 9: 1}[n]
+        if (games + 15) // 16 >= cus * 4 * per_simd:
+            return 'k_env_step16<%d, false>' % n
     return 'k_rollout2<%d, %s, false, %s>' % (rcap, 'true' if plies <= 2 else 'false', full)
+
+
+def kernel_code_hash(symbol_prefix, lib_path=None):
+    """sha256[:16] of the machine code of the kernel whose mangled name starts with `symbol_prefix`, cut out of the gfx950
+    code object inside the shared library (clang offload bundle -> AMDGPU ELF -> .symtab).  tools/summarize_profiles.py
+    stores it next to the PMC record of a profile pass; bench.py recomputes it from the library it runs, so an edit of
+    the kernel after the PMC pass shows up as `pmc_stale: true` instead of silently keeping the old instruction mix.
+    None when the library or the symbol cannot be found."""
+    import hashlib
+    import struct
+    path = lib_path or os.path.join(ROOT, 'gymgo_amd', 'libgymgo_amd.so')
+    try:
+        d = open(path, 'rb').read()
+        magic = b'__CLANG_OFFLOAD_BUNDLE__'
+        i = d.find(magic)
+        if i < 0:
+            return None
+        n = struct.unpack_from('<Q', d, i + len(magic))[0]
+        p, elf = i + len(magic) + 8, None
+        for _ in range(n):
+            off, size, tl = struct.unpack_from('<QQQ', d, p)
+            p += 24
+            triple = d[p:p + tl]
+            p += tl
+            if b'amdgcn' in triple and size:
+                elf = d[i + off:i + off + size]
+        if elf is None or elf[:4] != b'\x7fELF':
+            return None
+        shoff, = struct.unpack_from('<Q', elf, 0x28)
+        shentsize, shnum, shstrndx = struct.unpack_from('<HHH', elf, 0x3A)
+        secs = [struct.unpack_from('<IIQQQQIIQQ', elf, shoff + k * shentsize) for k in range(shnum)]
+        for sec in secs:
+            if sec[1] != 2:      # SHT_SYMTAB
+                continue
+            stroff = secs[sec[6]][4]
+            for k in range(sec[5] // 24):
+                name_i, info, other, shndx, value, size = struct.unpack_from('<IBBHQQ', elf, sec[4] + 24 * k)
+                end = elf.index(b'\0', stroff + name_i)
+                name = elf[stroff + name_i:end]
+                if (info & 15) == 2 and size and name.startswith(symbol_prefix.encode()) and not name.endswith(b'.kd'):
+                    tsec = secs[shndx]
+                    code = elf[tsec[4] + (value - tsec[3]):tsec[4] + (value - tsec[3]) + size]
+                    return hashlib.sha256(code).hexdigest()[:16]
+    except Exception:
+        return None
+    return None
+
+
+def rollout_symbol_prefix(kernel):
+    """Mangled-name prefix of a k_rollout4<R, IO, MOVES, FULLN, ENV, WTS> instantiation given as rollout_kernel_name writes it."""
+    import re
+    m = re.match(r'k_rollout4<(\d+), (\d+), (\w+), (\w+), (\w+), (\w+)>', kernel)
+    if not m:
+        return None
+    b = lambda x: 'Lb1E' if x == 'true' else 'Lb0E'
+    return '_ZN2gg10k_rollout4ILi%sELi%sE%s%s%s%sEE' % (m.group(1), m.group(2), b(m.group(3)), b(m.group(4)), b(m.group(5)), b(m.group(6)))
 
 
 def load_pmc(kernel, n, plies, games):
@@ -354,19 +447,32 @@ def roofline_record(dev, n, games, plies, launch_ms, per_ply, clocks=None):
     }
     if pmc:
         ipe = pmc['instr_per_step']
-        issued = ipe['valu'] + ipe['salu'] + ipe['lds']
+        # the peak is a VALU-port peak, so only VALU instructions count against it; SALU and LDS instructions issue on
+        # other ports and are reported beside it (round 3 added them into the numerator: 0.65 instead of 0.56)
         rec.update({
-            'achieved': round(issued * steps_per_s / 1e9, 2), 'frac': round(issued * steps_per_s / 1e9 / peak, 4),
-            'frac_valu_only': round(ipe['valu'] * steps_per_s / 1e9 / peak, 4),
+            'achieved': round(ipe['valu'] * steps_per_s / 1e9, 2), 'frac': round(ipe['valu'] * steps_per_s / 1e9 / peak, 4),
+            'other_ports': {'salu_Ginstr_per_s': round(ipe['salu'] * steps_per_s / 1e9, 2), 'lds_Ginstr_per_s': round(ipe['lds'] * steps_per_s / 1e9, 2),
+                            'note': 'not part of achieved / frac'},
             'instr_per_step': ipe, 'traffic': pmc.get('hbm_bytes_per_launch'), 'pmc_source': pmc.get('source'),
         })
+        # is the PMC pass still about the code that runs?  (hash of the kernel's machine code in the loaded library)
+        now = kernel_code_hash(rollout_symbol_prefix(kernel) or '\0')
+        rec['kernel_code_sha16'] = now
+        rec['pmc_kernel_code_sha16'] = pmc.get('kernel_code_sha16')
+        rec['pmc_stale'] = (now is None or pmc.get('kernel_code_sha16') is None or now != pmc.get('kernel_code_sha16'))
+        if rec['pmc_stale']:
+            rec['pmc_stale_note'] = ('the instruction mix / traffic above were counted on ANOTHER build of this kernel (or the '
+                                     'hash is missing): re-run tools/profile_round.sh')
+        busy = pmc.get('valu_busy')
+        if busy:
+            rec['valu_busy_counters'] = busy      # counter-derived (tools/summarize_profiles.py), with its formula
         cpi = pmc.get('valu_issue_cycles_per_instr')
         if cpi:
-            # `frac` prices every instruction at the 2-cycle peak; about a third of this kernel's VALU instructions are
-            # 4-cycle ops (v_bfrev, v_bcnt, v_cndmask, v_cmp ...): the share of cycles the VALU pipe is actually busy
-            rec['valu_pipe_busy_estimate'] = round(ipe['valu'] * steps_per_s / 1e9 / peak * cpi / 2.0, 4)
-            rec['valu_pipe_busy_note'] = ('frac_valu_only x %.2f / 2 issue cycles per VALU instruction: %s'
-                                          % (cpi, pmc.get('valu_issue_cycles_source')))
+            # a STATIC estimate (tools/isa_mix.py: the instruction mix of the ply loop priced with the measured issue
+            # rates - about a third of the VALU instructions are 4-cycle ops), kept next to the counter-derived figure
+            rec['valu_pipe_busy_static_estimate'] = round(ipe['valu'] * steps_per_s / 1e9 / peak * cpi / 2.0, 4)
+            rec['valu_pipe_busy_static_note'] = ('frac x %.2f / 2 issue cycles per VALU instruction: %s'
+                                                 % (cpi, pmc.get('valu_issue_cycles_source')))
     else:
         rec.update({'achieved': None, 'frac': None, 'traffic': None,
                     'pmc_source': 'no PMC pass for this launch shape under profiles/ (tools/profile_round.sh collects one)'})
@@ -675,7 +781,14 @@ def main(argv=None):
 
     import torch
     import torch.distributed as dist
-    local_rank %= max(1, torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit('bench.py: no GPU visible (the HIP path has no CPU fallback)')
+    if world > ndev and args.comm == 'nccl':
+        # RCCL refuses two ranks on one device with an opaque "duplicate GPU" error deep inside init: say it here
+        raise SystemExit('bench.py: %d ranks but %d visible GPU(s): --comm nccl needs one GPU per rank (use --comm gloo to '
+                         'rehearse the N > 1 path with ranks sharing devices round-robin)' % (world, ndev))
+    local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     # under a launcher (WORLD_SIZE set, also with one rank) the process group is real: barrier and reductions run over RCCL
@@ -685,10 +798,13 @@ def main(argv=None):
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('NCCL_DEBUG', 'WARN')       # no version banner on stdout unless asked for
+        # rank 0 joins after its CPU baseline (cores x --cpu-seconds of wall time + worker start-up): the others wait that long
+        import datetime
+        patience = datetime.timedelta(seconds=600 + 4 * int(args.cpu_seconds))
         if args.comm == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
+            dist.init_process_group('nccl', device_id=dev, timeout=patience)
         else:
-            dist.init_process_group('gloo')
+            dist.init_process_group('gloo', timeout=patience)
         dist.barrier()                                    # the communicator exists from here on (banner printed, if any)
         _flush_c_stdio()
 
@@ -720,6 +836,8 @@ def main(argv=None):
             # all-reduce of ones counted; and every rank's own average launch time (HIP events on its stream)
             'comm': res['comm'], 'rccl_world_size': res['comm']['world_size'] if res['comm']['backend'] else None,
             'per_rank_launch_ms': [round(x, 5) for x in res['per_rank_launch_ms']],
+            # every rank about itself: first game of its shard, steps it played, device (index + identity digest), clock
+            'per_rank': res.get('per_rank'), 'distinct_devices': res.get('distinct_devices'),
             'per_gpu_steps_per_s': [round(F * res['games_per_gpu'] / (x * 1e-3), 1) for x in res['per_rank_launch_ms']],
         }
         if cpu is not None:

@@ -4,11 +4,14 @@
 // sixteen boards per wavefront, liberty classes carried from ply to ply), gg_aux.h (stand-alone sampler and capture
 // resolution), gg_ws.h (policy-weighted sampling), gg_sym.h (batched symmetries) and gg_ns16.h (the per-ply kernels for
 // big batches).  Which kernel serves an entry point depends on the arguments only (board size, batch size, plies per
-// launch): there are no environment switches in the shipped build, and the only mutable global state is caches of
-// device facts (CU count per device, occupancy per kernel) and the FairShare progress board in device memory
-// (gg_common.h), on which no result depends.
+// launch): there are no environment switches in the shipped build.  Mutable global state, all of it performance-only
+// (no result depends on any of it): g_cus (CU count per device, relaxed atomics: racing first callers store the same value), the
+// occupancy cache of waves_per_simd_of (per device and kernel, behind a mutex) and the FairShare progress board in device
+// memory (gg_common.h: one word per hardware wave slot, written by every fused launch; foreign or stale entries only shift
+// issue priorities).  Every entry point is re-entrant and may be called from several threads on several streams.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #ifdef GG_AB
@@ -30,14 +33,15 @@ namespace {
 using namespace gg;
 
 constexpr int kMaxDevices = 64;
-int g_cus[kMaxDevices];   // 0 = not queried yet; a benign race: every thread writes the same value
+std::atomic<int> g_cus[kMaxDevices];   // 0 = not queried yet; racing first callers all store the same value (relaxed atomics:
+                                       // round 4's ThreadSanitizer pass flagged the plain ints this used to be)
 
 int cus_of(int dev) {
   if (dev < 0 || dev >= kMaxDevices) return 256;
-  int c = g_cus[dev];
+  int c = g_cus[dev].load(std::memory_order_relaxed);
   if (c <= 0) {
     if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) return 256;
-    g_cus[dev] = c;
+    g_cus[dev].store(c, std::memory_order_relaxed);
   }
   return c;
 }
@@ -84,16 +88,21 @@ int grid_resident(int cus, int64_t work, int waves_per_simd) {
 // waves 0.39 / 0.665 / 0.86 (12 / 9 / 6 / 5: invalid mask 50.9 -> 47, track 50.4 -> 45, packed next states 42.8 -> 41,
 // packed env step 52.3 -> 47.5 us).  Equal shares on the same resident grid gain nothing or lose (tools/exp/grid_cap.py).
 // Anything smaller, or an occupancy the split has no shares for: one wave per pair, at most 32 per CU, as before.
+// (the occupancy is a fact of the CURRENT device - OnDeviceOf has made the buffers' device current by now - so the cache
+// is keyed on (device, kernel): a process that drives devices of different SKUs or partition modes gets each one's own)
 int waves_per_simd_of(const void *kern) {
   static std::mutex mu;
-  static std::unordered_map<const void *, int> known;
+  static std::unordered_map<uint64_t, int> known;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  const uint64_t key = (uint64_t)(uintptr_t)kern * 64u + (uint64_t)(dev & 63);   // (kernel stubs are >= 16 bytes apart)
   std::lock_guard<std::mutex> lock(mu);
-  auto it = known.find(kern);
+  auto it = known.find(key);
   if (it != known.end()) return it->second;
   int blocks = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, kWave, 0) != hipSuccess) { (void)hipGetLastError(); blocks = 0; }
   const int w = blocks / 4;
-  known.emplace(kern, w);
+  known.emplace(key, w);
   return w;
 }
 
@@ -122,6 +131,21 @@ AgeSplit age_split(const void *kern, int cus, int64_t npairs, bool split, int &g
     as.cols = cus * 4;
     for (int i = 0; i < kAgeRanks - 1; ++i) as.cut[i] = (uint32_t)(c[i] * 65536.0);
     grid = as.cols * w;
+  }
+  return as;
+}
+
+// Grid of a sixteen-board kernel (gg_ns16.h).  19x19: the resident set of three waves per SIMD with a SIMD's groups split
+// by wave age (cumulative shares c1, c2) - but only when this kernel really has three resident waves per SIMD on this
+// device; any other occupancy (a compiler that needs more registers, a partitioned device) takes one workgroup per group
+// like the smaller boards, whose results are the same and whose performance degrades gently.
+template <typename... KArgs>
+AgeSplit ns16_grid(void (*kern19)(KArgs...), int cus, int64_t ngroups, int32_t N, uint32_t c1, uint32_t c2, int &grid16) {
+  AgeSplit as = {0, {c1, c2, 65536u}};
+  grid16 = (int)ngroups;
+  if (N == 19 && waves_per_simd_of(reinterpret_cast<const void *>(kern19)) == 3) {
+    as.cols = cus * 4;
+    grid16 = as.cols * 3;
   }
   return as;
 }
@@ -301,9 +325,8 @@ int32_t gg_batch_next_states(const uint8_t *in, const int32_t *actions, uint8_t 
     if (const char *e = getenv("GG_AB_NS16_CUT")) sscanf(e, "%lf,%lf", &c1, &c2);
 #endif
     if (big) {
-      AgeSplit as = {cus * 4, {(uint32_t)(c1 * 65536.0), (uint32_t)(c2 * 65536.0), 65536u}};
-      int grid16 = as.cols * 3;
-      if (N != 19) { as.cols = 0; grid16 = (int)ngroups; }
+      int grid16;
+      AgeSplit as = ns16_grid(k_next_states16<19>, cus, ngroups, N, (uint32_t)(c1 * 65536.0), (uint32_t)(c2 * 65536.0), grid16);
 #ifdef GG_AB
       if (const char *e = getenv("GG_AB_NS16_GRID")) { grid16 = atoi(e); as.cols = 0; }
       {
@@ -427,9 +450,8 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
     const int64_t ngroups = (B + kNB16 - 1) / kNB16;
     const bool big = use_ns16(cus, B, N, 3, 2, 1);
     if (big) {
-      AgeSplit as = {cus * 4, {32768u, 49152u, 65536u}};
-      int grid16 = as.cols * 3;
-      if (N != 19) { as.cols = 0; grid16 = (int)ngroups; }
+      int grid16;
+      const AgeSplit as = ns16_grid(k_env_step16<19, false>, cus, ngroups, N, 32768u, 49152u, grid16);
       GG_DISPATCH(N, (k_env_step16<9, false><<<grid16, kWave, 0, s>>>(states, nullptr, rng, nullptr, nullptr, nullptr, nullptr, B, 0.f, auto_reset, as, last_actions, steps_done)),
                   (k_env_step16<13, false><<<grid16, kWave, 0, s>>>(states, nullptr, rng, nullptr, nullptr, nullptr, nullptr, B, 0.f, auto_reset, as, last_actions, steps_done)),
                   (k_env_step16<19, false><<<grid16, kWave, 0, s>>>(states, nullptr, rng, nullptr, nullptr, nullptr, nullptr, B, 0.f, auto_reset, as, last_actions, steps_done)));
@@ -459,9 +481,9 @@ int32_t gg_batch_env_step(uint8_t *states, const int32_t *actions, uint64_t *rng
     const int64_t ngroups = (B + kNB16 - 1) / kNB16;
     const bool big = use_ns16(cus, B, N, 3, 2, 1);
     if (big) {
-      AgeSplit as = {cus * 4, {32768u, 49152u, 65536u}};   // 19x19: a SIMD's groups 2 : 1 : 1 by wave age
-      int grid16 = as.cols * 3;
-      if (N != 19) { as.cols = 0; grid16 = (int)ngroups; }
+      int grid16;   // 19x19: a SIMD's groups 2 : 1 : 1 by wave age
+      const AgeSplit as = reward_method == GG_REWARD_HEURISTIC ? ns16_grid(k_env_step16<19, true>, cus, ngroups, N, 32768u, 49152u, grid16)
+                                                               : ns16_grid(k_env_step16<19, false>, cus, ngroups, N, 32768u, 49152u, grid16);
       if (reward_method == GG_REWARD_HEURISTIC) {
         GG_DISPATCH(N, (k_env_step16<9, true><<<grid16, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, komi, auto_reset, as)),
                     (k_env_step16<13, true><<<grid16, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, komi, auto_reset, as)),

@@ -4,7 +4,7 @@
 // The reference L1-normalises the move weights in float64 and draws with NumPy's global generator.  Floating-point sums
 // depend on their order, so the build defines an EXACT integer form that the device and the CPU restatement the
 // tests check it against evaluate identically (spelled out in include/gymgo_amd.h, gg_batch_sample_weighted):
-//   1. v[a] = the float32 weight clamped to [+0, FLT_MAX] on its bit pattern (negative -> 0, NaN / +inf -> FLT_MAX), and 0
+//   1. v[a] = the float32 weight clamped to [+0, FLT_MAX] on its bit pattern (sign bit set, -NaN included -> 0; +NaN / +inf -> FLT_MAX), and 0
 //      where plane 3 marks the point invalid (":387 assumes all invalid moves have weight 0" - enforced here); the pass is
 //      never masked, a finished game masks nothing (gogame.invalid_moves, gym_go/gogame.py:155-156);
 //   2. E = max(biased exponent of max v, 24), S = 2^(148 - E), q[a] = trunc(v[a] * S) < 2^22 - an exact power-of-two

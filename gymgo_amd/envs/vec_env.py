@@ -118,11 +118,19 @@ class GoVecEnv:
         if actions is not None:
             actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
         if probs is not None and self.layout != 'tracked':
-            # (a finished game is reset by the step before the move is checked, so it is drawn for on the empty board)
+            # (a finished game is reset by the step before the move is checked, so it is drawn for on the empty board;
+            # without auto_reset it is frozen and draws NOTHING, as in the fused step of layout 'tracked': its generator
+            # is put back and its move is -1 - the layouts walk the same games and the same generator streams)
+            over = self._store_done()
             if self.auto_reset:
-                self.reset(self._store_done())
+                self.reset(over)
+            else:
+                rng_before = self.rng.clone()
             actions = (gogame.batch_sample_weighted(self._states, probs, self.rng) if self.layout == 'bytes' else
                        gogame.batch_sample_weighted_rows(self.packed_states, self.size, probs, self.rng))
+            if not self.auto_reset:
+                torch.where(over, rng_before, self.rng, out=self.rng)
+                actions.masked_fill_(over, -1)
             probs = None
         if self.layout == 'tracked':
             rewards, dones, status, taken = gogame.batch_env_step_tracked(

@@ -12,10 +12,22 @@
  *     5 game over).  Planes 2, 4 and 5 are uniform by construction (the reference only ever writes
  *     them whole: gym_go/gogame.py:49-56, gym_go/state_utils.py:241); the kernels read one byte of each.
  *   - Every pointer is a DEVICE pointer owned by the caller; the library allocates nothing, reads no environment
- *     variable, keeps no mutable global state besides a per-device cache of the CU count, and never synchronises:
- *     work is enqueued on `hip_stream` (a hipStream_t of the device that owns the buffers, NULL = its default
- *     stream) and the call returns immediately.  The kernels run on the device that owns the first buffer argument,
- *     whatever the calling thread's current device is (it is restored before the call returns).
+ *     variable and never synchronises: work is enqueued on `hip_stream` (a hipStream_t of the device that owns the
+ *     buffers, NULL = its default stream) and the call returns immediately.  The kernels run on the device that owns
+ *     the first buffer argument, whatever the calling thread's current device is (it is restored before the call
+ *     returns).
+ *   - Global state.  No result depends on anything but the arguments.  The library keeps three pieces of mutable state,
+ *     all performance-only: a per-device cache of the CU count (relaxed atomics; racing first callers store the same value), a
+ *     per-(device, kernel) cache of kernel occupancy (behind a mutex) and, in device memory, the "FairShare" progress
+ *     board of the fused multi-ply kernels (512 KB per device: every wave of such a launch publishes the ply it has
+ *     reached and reads its SIMD-mates' words to set its own issue priority; stale or foreign words - another
+ *     stream's launch, another process never - only shift priorities).  Every entry point is re-entrant and
+ *     thread-safe: concurrent calls from several threads on several streams are supported
+ *     (tests/test_gpu_threads.py; tools/sanitize.sh: the host side under ASan / UBSan / TSan).
+ *   - CPU twins.  SURVEY 8(b) sketched `_cpu`-suffixed entry points with host pointers next to these.  They are
+ *     deliberately NOT exported: the CPU restatement of the path is test infrastructure (oracle/gg_oracle.c,
+ *     `gg_oracle_*`, linked by tests and the bench's cpu_baseline only), and a product library that could fall back
+ *     to it would void every parity claim.  A missing GPU is an error (hipErrorNoDevice / GymGoNativeError).
  *   - Which kernel serves a call depends on its arguments only (board size, batch size, plies per launch).
  *   - 2 <= N <= 19.  Actions are int32 in [0, N*N]; N*N = pass (gym_go/gogame.py:40-42).
  *   - Return value: 0 on success, a hipError_t (> 0) for launch/runtime errors, or a negative
@@ -263,7 +275,7 @@ int32_t gg_batch_env_step_tracked_weighted(uint32_t *tracked, const void *weight
  * for every game: actions[b] ~ weights[b] / sum(weights[b]) over the playable actions.  The reference normalises in
  * float64 and draws from NumPy's global generator; so that device and oracle agree bit for bit the draw is defined in
  * integers: (1) each weight (float32, or bfloat16 / float16 widened exactly: weight_dtype = GG_W_*) is clamped to
- * [+0, FLT_MAX] on its float32 bit pattern (negative -> 0, NaN / inf -> FLT_MAX)
+ * [+0, FLT_MAX] on its float32 bit pattern (anything with the sign bit set, -NaN included -> 0; +NaN / +inf -> FLT_MAX)
  * and zeroed where plane 3 of states[b] is set (the reference ASSUMES invalid moves have weight 0, :387; the pass is
  * never masked, a finished game masks nothing, gym_go/gogame.py:155-156; states == NULL: no mask); (2) with E = max(the
  * largest weight's biased exponent, 24), q[a] = trunc(w[a] * 2^(148 - E)) < 2^22: the weights as 22-bit fixed point

@@ -18,12 +18,10 @@ def _seeds(c_oracle, base, idx):
     return np.array([c_oracle.lib().gg_oracle_rng_seed(int(base), int(i)) for i in idx], dtype=np.uint64)
 
 
-def test_bench_trajectory_subsample_vs_oracle():
-    """The bench's own driver on the bench's own workload: every launch bench.run_rank issues (15 de-synchronising
-    slice launches of 40 ... 600 plies, 1 burn-in + 5 warm-up + 4 timed launches of 256 plies over all 65 536 games -
-    k_rollout4<19, 0, false, true, false, false>) is followed by an oracle replay of 512 games chosen by global game index
-    (every 128th, offset 5: all 16 slices); states, generator states and the kernel's own step counters must agree
-    after each of the 25 launches, i.e. up to ~3 160 plies into a slot's life (mean game length ~640)."""
+def _checked_backend(sample):
+    """bench.HipBackend whose every launch is followed by an oracle replay of `sample` games chosen by index inside the
+    rank's shard (generators seeded by GLOBAL game index): states, generator states and, at the end, the kernel's own
+    step counters must agree."""
     import bench
     from oracle import c_oracle
 
@@ -33,7 +31,7 @@ def test_bench_trajectory_subsample_vs_oracle():
 
         def setup(self, count, size, first_game):
             super().setup(count, size, first_game)
-            self.idx = np.arange(5, count, count // 512)
+            self.idx = np.arange(5, count, count // sample)
             self.idx_t = torch.as_tensor(self.idx, device=self.device)
             self.want = np.zeros((len(self.idx), 6, size, size), np.uint8)
             self.want_rng = _seeds(c_oracle, bench.SEED, first_game + self.idx)
@@ -57,7 +55,17 @@ def test_bench_trajectory_subsample_vs_oracle():
             self.launches += 1
             self.deepest = int(self.plies.max())
 
-    back = Checked(torch.device('cuda', 0))
+    return Checked(torch.device('cuda', 0))
+
+
+def test_bench_trajectory_subsample_vs_oracle():
+    """The bench's own driver on the bench's own workload: every launch bench.run_rank issues (15 de-synchronising
+    slice launches of 40 ... 600 plies, 1 burn-in + 5 warm-up + 4 timed launches of 256 plies over all 65 536 games -
+    k_rollout4<19, 0, false, true, false, false>) is followed by an oracle replay of 512 games chosen by global game index
+    (every 128th, offset 5: all 16 slices); states, generator states and the kernel's own step counters must agree
+    after each of the 25 launches, i.e. up to ~3 160 plies into a slot's life (mean game length ~640)."""
+    import bench
+    back = _checked_backend(512)
     opts = {'size': 19, 'plies_per_step': 256, 'steps': 4, 'warmup': 5, 'games_per_gpu': 65536, 'desync': 640,
             'burn_in_steps': 1, 'world': 1}
     res = bench.run_rank(0, 1, back, opts, None)
@@ -71,6 +79,24 @@ def test_bench_trajectory_subsample_vs_oracle():
     assert len(np.unique(back.idx // 4096)) == 16
     # and the whole batch agrees with its own sub-sample replay in aggregate (no game was skipped)
     assert int(back.steps_done.min()) == 4 * 256 and int(back.steps_done.max()) == 4 * 256
+
+
+def test_bench_driver_as_rank_5_of_8_at_the_per_gpu_size_vs_oracle():
+    """BASELINE config 4 as the N > 1 bench lines run it: bench.run_rank itself as RANK 5 OF 8 - 131 072 games per GPU,
+    the shard's first global game 655 360, the default de-synchronisation / burn-in / warm-up and 3 timed launches of
+    256 plies (two rounds of waves of k_rollout4 per launch) - with 512 games of the shard replayed by the oracle after
+    every launch.  (No process group: the rank is driven on its own; the two-rank reductions are tests/test_multirank_gloo.py.)"""
+    import bench
+    back = _checked_backend(512)
+    opts = {'size': 19, 'plies_per_step': 256, 'steps': 3, 'warmup': 2, 'games_per_gpu': 131072, 'desync': 640,
+            'burn_in_steps': 1, 'world': 8}
+    res = bench.run_rank(5, 8, back, opts, None)
+    assert (res['first'], res['count'], res['total_games']) == (5 * 131072, 131072, 1048576)
+    assert res['per_rank'] == [dict(res['per_rank'][0], first_game=655360, steps_played=3 * 256 * 131072)]
+    assert back.launches == 15 + 1 + 2 + 3 and back.deepest >= 6 * 256 + 560
+    assert np.array_equal(back.steps_done[back.idx_t].cpu().numpy(), back.counted)
+    assert int(back.steps_done.min()) == 3 * 256 and int(back.steps_done.max()) == 3 * 256
+    assert len(np.unique(back.idx // 8192)) == 16       # every de-synchronisation slice is in the sub-sample
 
 
 @pytest.mark.parametrize('B,launch', [(16384, 256), (8192, 173)])

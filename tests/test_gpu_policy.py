@@ -199,21 +199,30 @@ def test_weighted_env_step_tracked_vs_oracle(N, B, auto_reset):
 
 
 @pytest.mark.parametrize('layout', ['tracked', 'bytes', 'packed'])
-def test_vecenv_step_with_probs_all_layouts_walk_the_same_games(layout):
+@pytest.mark.parametrize('auto_reset', [True, False])
+def test_vecenv_step_with_probs_all_layouts_walk_the_same_games(layout, auto_reset):
     """GoVecEnv.step(probs=...) - fused with layout 'tracked', sample + step otherwise - against the oracle restatement;
-    all three layouts therefore walk the same games."""
+    all three layouts therefore walk the same games.  Without auto_reset the finished games are frozen: they draw
+    nothing (generator untouched, move -1, step refused) in every layout."""
     from gymgo_amd.envs import GoVecEnv
     from oracle import c_oracle
     B, N = 1500, 9
-    env = GoVecEnv(B, N, komi=0.5, reward_method='real', seed=21, layout=layout)
+    env = GoVecEnv(B, N, komi=0.5, reward_method='real', seed=21, layout=layout, auto_reset=auto_reset)
     env.rollout(25)
+    if not auto_reset:       # two passes in a row end the first 300 games: frozen from here on
+        for _ in range(2):
+            a = env.sample_actions()
+            a[:300] = N * N
+            env.step(a)
     host = env.states.cpu().numpy().copy()
     gen = np.random.default_rng(3)
     for step in range(5):
         w = (gen.random((B, N * N + 1)) ** 3).astype(np.float32)
         w[:, -1] *= 8.0
         rng0 = _rng_np(env.rng).copy()
-        want, acts, status, rng1 = _oracle_weighted_step(c_oracle, host, w, rng0, True)
+        want, acts, status, rng1 = _oracle_weighted_step(c_oracle, host, w, rng0, auto_reset)
+        if not auto_reset and step == 0:
+            assert (host[:, 5, 0, 0] == 1).sum() > 10     # the case under test occurs
         obs, rewards, dones, st = env.step(probs=_dev(w))
         assert np.array_equal(obs.cpu().numpy() if layout != 'packed' else env.states.cpu().numpy(), want), (layout, step)
         assert np.array_equal(env.last_actions.cpu().numpy(), acts) and np.array_equal(st.cpu().numpy(), status)

@@ -96,6 +96,11 @@ def test_bench_run_rank_two_ranks_over_gloo(tmp_path):
     # time per rank (each written by its own rank into its slot)
     assert res['comm'] == {'backend': 'gloo', 'world_size': 2, 'ranks_counted': 2}
     assert len(res['per_rank_launch_ms']) == 2 and all(x > 0 for x in res['per_rank_launch_ms'])
+    # every rank about itself, gathered through the communicator: DISTINCT shard offsets, and the steps of ITS shard
+    per = res['per_rank']
+    assert [p['first_game'] for p in per] == [bench.shard(total, r, world)[0] for r in range(world)] == [0, 24]
+    assert [p['steps_played'] for p in per] == [OPTS['steps'] * OPTS['plies_per_step'] * OPTS['games_per_gpu']] * 2
+    assert sum(p['steps_played'] for p in per) == res['steps_played']
     # the union of the shards == bench's own driver at world 1 over the whole batch with the same schedule per game:
     # rank r's games get the schedule of a 24-game shard (de-sync slices are per shard), so rebuild it shard by shard
     got = np.concatenate([np.load(tmp_path / ('states_%d.npy' % r)) for r in range(world)])
@@ -136,4 +141,7 @@ def test_bench_argument_plumbing():
     assert bench.algo_bytes_per_step(19) == 4336 and bench.fused_bytes_per_game(19) == 4348
     assert bench.rollout_kernel_name(19, 65536, 256, 256) == 'k_rollout4<19, 0, false, true, false, false>'
     assert bench.rollout_kernel_name(9, 4096, 256, 256) == 'k_rollout2<9, false, false, true>'
-    assert bench.rollout_kernel_name(19, 65536, 1, 256) == 'k_rollout2<19, true, false, true>'
+    assert bench.rollout_kernel_name(19, 65536, 1, 256) == 'k_env_step16<19, false>'        # (gg_kernels.hip: use_ns16, 3 groups per SIMD)
+    assert bench.rollout_kernel_name(19, 32768, 1, 256) == 'k_rollout2<19, true, false, true>'
+    assert bench.rollout_kernel_name(9, 16384, 1, 256) == 'k_env_step16<9, false>'
+    assert bench.rollout_kernel_name(7, 65536, 1, 256) == 'k_rollout2<9, true, false, false>'

@@ -135,6 +135,44 @@ __global__ void kM(uint8_t *p, int64_t total, unsigned long long *ctr) {
     for (int k = 0; k < 16; ++k) *reinterpret_cast<V16 *>(q + k * 1024 + threadIdx.x * 16) = z;
   }
 }
+// N: the 4 KB tiles of K, one per 256-thread workgroup, but WHICH tile a workgroup writes is remapped:
+//   mode 0  tile = workgroup + shift             (shift 1..7: does it matter which XCD writes which tile? workgroups go
+//                                                 round-robin over the 8 XCDs, memory is interleaved over the HBM stacks)
+//   mode 1  tile = a pseudo-random permutation   (does the dense sliding window of in-flight stores matter?)
+__global__ void kN(uint8_t *p, int64_t ntiles, int mode, int shift) {
+  const V16 z = {{0, 0, 0, 0}};
+  int64_t t = blockIdx.x;
+  if (mode == 0) t = (t + shift) % ntiles;
+  else t = (int64_t)(((unsigned long long)t * 0x9E3779B97F4A7C15ull) % (unsigned long long)ntiles);
+  *reinterpret_cast<V16 *>(p + t * 4096 + threadIdx.x * 16) = z;
+}
+// O: PERSISTENT 256-thread workgroups that write 4 KB tiles grid-strided (tile = workgroup + k * grid): K's window, but
+// the waves live on; P: the same, XCD-affine: a workgroup reads its XCC_ID and writes only tiles = xcc (mod 8)
+__global__ void kO(uint8_t *p, int64_t ntiles) {
+  const V16 z = {{0, 0, 0, 0}};
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) *reinterpret_cast<V16 *>(p + t * 4096 + threadIdx.x * 16) = z;
+}
+__global__ void kP(uint8_t *p, int64_t ntiles, unsigned long long *ctr, int shift) {
+  const V16 z = {{0, 0, 0, 0}};
+  unsigned int xc;
+  asm volatile("s_getreg_b32 %0, hwreg(20)" : "=s"(xc));
+  xc &= 7u;
+  __shared__ unsigned long long slot;
+  for (;;) {
+    if (threadIdx.x == 0) slot = atomicAdd(ctr + xc * 16, 1ull);     // per-XCD tile counter (own cache line)
+    __syncthreads();
+    const int64_t t = (int64_t)slot * 8 + ((xc + shift) & 7);
+    __syncthreads();
+    if (t >= ntiles) break;
+    *reinterpret_cast<V16 *>(p + t * 4096 + threadIdx.x * 16) = z;
+  }
+}
+// Q: single-wave workgroups, one 1 KB tile each, non-persistent, in address order (K at wave granularity)
+__global__ void kQ(uint8_t *p, int64_t total) {
+  const V16 z = {{0, 0, 0, 0}};
+  const int64_t o = (int64_t)blockIdx.x * 1024 + threadIdx.x * 16;
+  if (o + 16 <= total) *reinterpret_cast<V16 *>(p + o) = z;
+}
 template <class F> float timeit(F f) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   f(); hipDeviceSynchronize();
@@ -153,8 +191,19 @@ int main() {
     t = timeit([&] { kK<4><<<(unsigned)((total + 4095) / 4096), 64>>>(p, total); }); printf("L tiles 4 KB, 64 thr       %6.3f ms %6.2f TB/s\n", t, total / t / 1e9);
     t = timeit([&] { kK<16><<<(unsigned)((total + 16383) / 16384), 64>>>(p, total); }); printf("L tiles 16 KB, 64 thr      %6.3f ms %6.2f TB/s\n", t, total / t / 1e9);
     t = timeit([&] { kK<64><<<(unsigned)((total + 65535) / 65536), 64>>>(p, total); }); printf("L tiles 64 KB, 64 thr      %6.3f ms %6.2f TB/s\n", t, total / t / 1e9);
-    for (int G : {3072, 8192, 16384}) {
+    if (false) for (int G : {3072, 8192, 16384}) {   // (measured: 1.3 TB/s - one global counter serialises the waves)
       t = timeit([&] { hipMemsetAsync(ctr, 0, 8, 0); kM<<<G, 64>>>(p, total, ctr); }); printf("M atomic 16 KB tiles G=%5d %6.3f ms %6.2f TB/s\n", G, t, total / t / 1e9);
+    }
+    {
+      const int64_t nt = total / 4096;
+      for (int sh : {0, 1, 2, 3, 4, 7}) { t = timeit([&] { kN<<<(unsigned)nt, 256>>>(p, nt, 0, sh); }); printf("N tiles 4 KB shifted by %d      %6.3f ms %6.2f TB/s\n", sh, t, nt * 4096.0 / t / 1e9); }
+      t = timeit([&] { kN<<<(unsigned)nt, 256>>>(p, nt, 1, 0); }); printf("N tiles 4 KB permuted          %6.3f ms %6.2f TB/s\n", t, nt * 4096.0 / t / 1e9);
+      for (int G : {2048, 4096, 8192}) { t = timeit([&] { kO<<<G, 256>>>(p, nt); }); printf("O persistent 4 KB tiles G=%5d %6.3f ms %6.2f TB/s\n", G, t, nt * 4096.0 / t / 1e9); }
+      unsigned long long *c8; hipMalloc(&c8, 8 * 16 * 8);
+      for (int sh : {0, 1, 3}) for (int G : {2048, 4096}) {
+        t = timeit([&] { hipMemsetAsync(c8, 0, 8 * 16 * 8, 0); kP<<<G, 256>>>(p, nt, c8, sh); }); printf("P persistent XCD-affine sh=%d G=%5d %6.3f ms %6.2f TB/s\n", sh, G, t, nt * 4096.0 / t / 1e9);
+      }
+      t = timeit([&] { kQ<<<(unsigned)(total / 1024), 64>>>(p, total); }); printf("Q tiles 1 KB, 64 thr           %6.3f ms %6.2f TB/s\n", t, total / t / 1e9);
     }
   }
   for (int G : {3072}) {
