@@ -349,7 +349,7 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 
 // ---------------------------------------------------------------- which pairs of boards a wave of a persistent grid takes
 // A persistent per-pair kernel runs the resident set: `cols` SIMDs x W waves, and the dispatcher places workgroups c,
-// c + cols, c + 2 cols ... on the same SIMD in that order (tools/ubench/placement.hip, tools/exp/where_ns.py).  The arbiter
+// c + cols, c + 2 cols ... on the same SIMD in that order (tools/ubench/placement.hip, tools/exp/where_ns.py (round 3, in git history)).  The arbiter
 // of a SIMD serves its oldest wave first, so W waves with equal shares finish one after the other and the SIMD idles
 // towards the end of the launch.  The pairs of a column (c, c + cols, c + 2 cols ...) are therefore split UNEVENLY by
 // age: wave r of the column takes the pairs [cut[r-1], cut[r]) of it (cumulative 16.16 fractions; cut[-1] = 0, unused

@@ -83,10 +83,10 @@ int grid_resident(int cus, int64_t work, int waves_per_simd) {
 
 // Persistent per-pair kernels (pair_span, gg_common.h): from two pairs per resident wave on, the grid is exactly the
 // resident set of THIS kernel (its occupancy, asked of the runtime once per kernel) and the pairs of a SIMD are split by
-// wave age.  Cumulative shares from sweeps on 65 536 boards (tools/exp/age_split.py; 32 pairs per SIMD): three waves
+// wave age.  Cumulative shares from sweeps on 65 536 boards (tools/exp/age_split.py (round 3, in git history); 32 pairs per SIMD): three waves
 // 0.40 / 0.74 (12 / 11 / 9 pairs: gg_batch_env_step 81.0 -> 73 us, the one-ply gg_batch_rollout 77.4 -> 69.5 us), four
 // waves 0.39 / 0.665 / 0.86 (12 / 9 / 6 / 5: invalid mask 50.9 -> 47, track 50.4 -> 45, packed next states 42.8 -> 41,
-// packed env step 52.3 -> 47.5 us).  Equal shares on the same resident grid gain nothing or lose (tools/exp/grid_cap.py).
+// packed env step 52.3 -> 47.5 us).  Equal shares on the same resident grid gain nothing or lose (tools/exp/grid_cap.py (round 3, in git history)).
 // Anything smaller, or an occupancy the split has no shares for: one wave per pair, at most 32 per CU, as before.
 // (the occupancy is a fact of the CURRENT device - OnDeviceOf has made the buffers' device current by now - so the cache
 // is keyed on (device, kernel): a process that drives devices of different SKUs or partition modes gets each one's own)
@@ -158,7 +158,7 @@ void launch_pairs(void (*kern)(KArgs...), int cus, int64_t npairs, bool split, h
 }
 
 // The sixteen-boards-per-wave kernels of gg_ns16.h serve batches of exactly 9x9 / 13x13 / 19x19 boards from a number of
-// groups per SIMD on that depends on the entry point and the board size (tools/exp/ns16_min.py, us per call, two-board
+// groups per SIMD on that depends on the entry point and the board size (tools/exp/ns16_min.py (round 3, in git history), us per call, two-board
 // kernel -> sixteen-board kernel):
 //   gg_batch_next_states    19x19 from 4 (49 152 boards: 48.6 -> 47.3, 32 768: 35.7 -> 38.3), 13x13 and 9x9 from 2
 //                           (32 768: 28.7 -> 27.6 / 23.9 -> 18.7; 16 384: 18.5 -> 19.2 / 14.2 -> 15.1)

@@ -17,7 +17,7 @@
 // Boards come in by one aligned 16-byte vector stream per lane (its own plane, 361 bytes), bit-packed with v_dot4; they
 // leave as one contiguous byte range per group through a bit-string in LDS and aligned 1 KB blocks.
 //
-// This is the 16-board, three-waves-per-SIMD form of the 32-board kernel measured in round 3 (tools/exp/attic/: 45 % fewer
+// This is the 16-board, three-waves-per-SIMD form of the 32-board kernel measured in round 3 (tools/exp/attic/ (round 3, in git history): 45 % fewer
 // instructions than the two-board kernel, but 256 VGPRs = two lock-step wave-iterations per SIMD at 65 536 boards, whose
 // loads and stores nothing overlapped).  Three waves per SIMD and the arbiter's oldest-wave-first order change that: the
 // groups of a SIMD are split 2 : 1 : 1 by wave age (pair_span, gg_common.h), so the oldest wave is storing its first

@@ -598,7 +598,7 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_next_states2(const uint8_t
   const int S = 6 * hf.P;
   const int64_t npairs = (B + 1) >> 1;
   // Which pairs a wave takes.  The grid is the resident set: `cols` SIMDs x 3 waves, and the dispatcher places workgroups
-  // c, c + cols, c + 2 cols on the same SIMD in that order (tools/exp/where_ns.py: on all 1 024 SIMDs).  The arbiter serves
+  // c, c + cols, c + 2 cols on the same SIMD in that order (tools/exp/where_ns.py (round 3, in git history): on all 1 024 SIMDs).  The arbiter serves
   // the oldest wave first, so with equal shares the three finish at 0.69 / 0.86 / 1.00 of the launch and the SIMD idles
   // towards the end.  The pairs of a column (c, c + cols, c + 2 cols ...) are therefore split UNEVENLY among its three
   // waves - the oldest takes the fraction share1, the next share2 - share1, the youngest the rest - so that they finish
