@@ -659,6 +659,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
           const uint32_t T = p[RPL - 1];
           // valid points of the board up to and including this lane (Sx) and on the whole board (n): quad scan
           // (the DPP moves are evaluated by every lane, THEN masked: inside a conditional the source lanes would be off)
+          // (a DPP bank mask cannot do the masking: its banks are the four QUADS of a row, not the lanes of a quad)
           const uint32_t sh1 = dpp0<QP_SHR1>(T);
           const uint32_t x1 = T + (t5 >= 1 ? sh1 : 0u);
           const uint32_t sh2 = dpp0<QP_SHR2>(x1);
@@ -762,7 +763,6 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         // the seed: q itself for G, the neighbour stone for an opponent group
         const uint32_t gm = 0u - mbit;
         const int sr = nr - (dr & (int)gm), scol = nc - (dc & (int)gm);
-        const uint32_t sbit = ex << ((uint32_t)scol & 31u);
         // the colour this lane floods (G: the mover's) and the other one, as 16-byte row sets (indexed from the aligned
         // base of the LDS array: behind the pad the compiler no longer sees the alignment of `st + ...` and would split the
         // row loads into dwords)
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
             {
               const int srw = sr & (int)(0u - ex);
               asm volatile("" ::: "memory");   // (DS instructions of a wave execute in order; the compiler must keep it too)
-              blk[srw] = (sr & 1) ? __brev(sbit) : sbit;
+              blk[srw] = ex << (((uint32_t)scol ^ (0u - ((uint32_t)sr & 1u))) & 31u);   // odd rows: bit 31 - scol
               asm volatile("" ::: "memory");
               const uint4 *pf = reinterpret_cast<const uint4 *>(blk);
 #pragma unroll
@@ -927,12 +927,19 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
 #pragma unroll
             for (int r = 0; r < RPL; ++r) kor[r] = (uint32_t)__builtin_amdgcn_sbfe((int)ko_oh, r, 1) & ko_bit;
           }
-          // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties
+          // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties.  (Most
+          // capturing boards have no such group at all: the neighbourhood of the captured stones is only worked out when
+          // some capturing board of the wave has a mover's stone in atari outside G)
           uint32_t atari[RPL], f[RPL];
-          dilate_rows<RPL>(cap, f);
-          uint32_t anyf = 0;
+          uint32_t anya = 0;
 #pragma unroll
-          for (int r = 0; r < RPL; ++r) { atari[r] = mine1[r] & ~M[r] & ~g0[r]; f[r] &= atari[r]; anyf |= f[r]; }
+          for (int r = 0; r < RPL; ++r) { atari[r] = B3(mine1[r], M[r], g0[r], TA & ~(TB | TC) & 0xFF); f[r] = 0u; anya |= atari[r]; }
+          uint32_t anyf = 0;
+          if (__ballot(anya != 0u && capt_m != 0u)) {
+            dilate_rows<RPL>(cap, f);
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) { f[r] &= atari[r]; anyf |= f[r]; }
+          }
           if (__ballot(anyf != 0)) {
 #pragma unroll 1
             for (int it = 0; it < R * R; ++it) {
