@@ -625,6 +625,26 @@ def extras(dev, back, opts):
         'kernel': rollout_kernel_name(9, 4096, F, torch.cuda.get_device_properties(dev).multi_processor_count),
         'per_ply_rollout_steps_per_s': round(r1, 1), 'per_ply_launch_us': round(ms1 * 1e3, 2),
         'per_ply_hbm_frac': round(algo_bytes_per_step(9) * r1 / 1e9 / HBM_PEAK_GBS, 4)}
+    # the same one-ply launches as a hipGraph of 64 (captured once, replayed): at this batch size a launch through the
+    # Python API is paced by the host (ctypes call + hipLaunchKernel per ply), not by the 4 096 boards - a loop that steps
+    # small batches ply by ply should replay a graph (every entry point is capturable: no allocation, no synchronisation)
+    try:
+        side = torch.cuda.Stream(device=dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            b2.rollout(1, count_steps=False)
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(64):
+                b2.rollout(1, count_steps=False)
+        rg, msg = event_rate(torch, dev, graph.replay, 4096 * 64, 16)
+        configs['config2_9x9_4096_games'].update({
+            'per_ply_graph_steps_per_s': round(rg, 1), 'per_ply_graph_launch_us': round(msg * 1e3 / 64, 2),
+            'per_ply_graph_hbm_frac': round(algo_bytes_per_step(9) * rg / 1e9 / HBM_PEAK_GBS, 4),
+            'per_ply_graph_note': '64 one-ply launches of gg_batch_rollout captured in one hipGraph, replayed 16 times'})
+        del graph
+    except Exception as e:      # no graph support on this stack: the API-loop number above stands alone
+        configs['config2_9x9_4096_games']['per_ply_graph_note'] = 'hipGraph capture failed: %s' % (str(e)[:160],)
     del b2
     # --- config 4's per-GPU batch (131 072 games) on this one GPU: the base for weak-scaling ratios
     if opts['world'] == 1 and N == 19 and count != 131072:

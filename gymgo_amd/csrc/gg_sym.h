@@ -64,6 +64,82 @@ __global__ __launch_bounds__(kWave) void k_symmetry_bytes(const uint8_t *__restr
   }
 }
 
+// All eight views of every game (orient == nullptr), boards of up to MAXB staged bytes: the SCATTER form.  The gather above
+// reads every source byte eight times (once per view) through one-byte LDS instructions: 8 x (C reads + C writes + 1 table
+// read) per point, and the kernel is bound by the LDS instruction rate, not by HBM (2.8 TB/s moved).  Here a lane reads the C
+// bytes of a source point ONCE and writes them to the point's place in each of the eight views - the eight destinations are
+// the combinations of (r | N-1-r, c | N-1-c) and their transposes: four products and eight adds - so the byte reads and the
+// table reads are shared.  Four output boards at a time are assembled in LDS (views 0-3, then 4-7: (1 + C + 4 C) LDS
+// instructions per point and half instead of 4 (1 + 2 C)) and leave as aligned 16-byte vectors.
+template <int MAXB>
+__global__ __launch_bounds__(kWave) void k_symmetry_all8(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int64_t B, int C, int N) {
+  constexpr int VH = 4;                                   // views assembled at a time (two halves: LDS for ~12 waves per CU instead of 7)
+  constexpr int NV = (MAXB + 30 + 15) / 16 / kWave + 1;   // 16-byte vectors per lane of a staged board
+  static_assert(NV <= 3, "vectors per lane of a staged board");
+  __shared__ __attribute__((aligned(16))) uint8_t src[MAXB + 32];
+  __shared__ __attribute__((aligned(16))) uint8_t dst[VH][MAXB + 32];
+  __shared__ uint16_t rc[GG_MAX_BOARD * GG_MAX_BOARD];   // (row << 8) | column of point q
+  const int lane = threadIdx.x;
+  const int P = N * N, S = C * P;
+  for (int q = lane; q < P; q += kWave) {
+    const int r = q / N;
+    rc[q] = (uint16_t)((r << 8) | (q - r * N));
+  }
+  // the source board of the NEXT iteration is fetched (aligned superset, into registers) before this one is worked on:
+  // a wave's load -> scatter -> store chain is a few microseconds long and the occupancy is low, so the load is hidden
+  uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0;
+  uint32_t nmi = 0;
+  int nnv = 0;
+#define GG_SYM_FETCH(BB)                                                                  \
+  do {                                                                                     \
+    const uint8_t *g_ = in + (BB) * (int64_t)S;                                            \
+    nmi = (uint32_t)((uintptr_t)g_ & 15u);                                                 \
+    nnv = (int)(nmi + (uint32_t)S + 15u) >> 4;                                             \
+    const uint4 *gv_ = reinterpret_cast<const uint4 *>(g_ - nmi);                          \
+    n0 = gv_[lane < nnv ? lane : nnv - 1];                                                 \
+    if (NV > 1) n1 = gv_[lane + 64 < nnv ? lane + 64 : nnv - 1];                           \
+    if (NV > 2) n2 = gv_[lane + 128 < nnv ? lane + 128 : nnv - 1];                         \
+  } while (0)
+  if ((int64_t)blockIdx.x < B) GG_SYM_FETCH((int64_t)blockIdx.x);
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    WAVE_SYNC();   // (the previous board's scatter has read src, its stage_out has read dst; rc is written)
+    const uint32_t mi = nmi;
+    {
+      uint4 *sv = reinterpret_cast<uint4 *>(src);
+      if (lane < nnv) sv[lane] = n0;
+      if (NV > 1 && lane + 64 < nnv) sv[lane + 64] = n1;
+      if (NV > 2 && lane + 128 < nnv) sv[lane + 128] = n2;
+    }
+    if (b + gridDim.x < B) GG_SYM_FETCH(b + gridDim.x);
+    uint8_t *g0 = out + b * 8 * (int64_t)S;
+#pragma unroll 1
+    for (int vh = 0; vh < 8; vh += VH) {
+      WAVE_SYNC();
+      for (int q = lane; q < P; q += kWave) {
+        const int w = rc[q];
+        const int r = w >> 8, c = w & 0xFF, rr = N - 1 - r, cc = N - 1 - c;
+        // where the source point (r, c) lands in view o (the inverse of sym_source): o & 4 transposes the flipped point;
+        // views 0-3: (r | rr) N + (c | cc), views 4-7: (cc | c) N + (r | rr)
+        const int a0 = vh ? cc * N : r * N, a1 = vh ? c * N : rr * N, e0 = vh ? r : c, e1 = vh ? rr : cc;
+        const int d[VH] = {a0 + e0, vh ? a1 + e0 : a0 + e1, vh ? a0 + e1 : a1 + e0, a1 + e1};
+        const uint8_t *sp = src + mi + q;
+        uint8_t *dp[VH];
+#pragma unroll
+        for (int v = 0; v < VH; ++v) dp[v] = dst[v] + (uint32_t)((uintptr_t)(g0 + (vh + v) * (int64_t)S) & 15u) + d[v];
+        for (int ch = 0; ch < C; ++ch) {
+          const uint8_t x = sp[ch * P];
+#pragma unroll
+          for (int v = 0; v < VH; ++v) dp[v][ch * P] = x;
+        }
+      }
+      WAVE_SYNC();
+#pragma unroll 1
+      for (int v = 0; v < VH; ++v) stage_out(g0 + (vh + v) * (int64_t)S, S, dst[v], lane);
+    }
+  }
+#undef GG_SYM_FETCH
+}
+
 // row-mask boards: one board per 32-lane half (lane r of the half = row r of every plane).
 // planes = 3 (packed) or 5 (tracked); the last word of a board (flags) is copied.
 __global__ __launch_bounds__(kWave) void k_symmetry_rows(const uint32_t *__restrict__ in, const int32_t *__restrict__ orient,
