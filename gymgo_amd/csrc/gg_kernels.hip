@@ -790,8 +790,8 @@ int32_t gg_batch_symmetry(const uint8_t *in, const int32_t *orient, uint8_t *out
   GG_ENTER(in);
   if (!out) return GG_E_NULLPTR;
   const int grid = grid_for(cus, B);
-  if (!orient && C * N * N <= 2304) {   // all eight views of boards of state size: shared reads, eight scattered writes (gg_sym.h)
-    k_symmetry_all8<2304><<<grid, kWave, 0, s>>>(in, out, B, C, N);
+  if (C * N * N <= 2304 && C * N <= 128) {   // boards of state size: through the bit domain when the planes are 0 / 1 (gg_sym.h)
+    k_symmetry_bits<2304><<<grid, kWave, 0, s>>>(in, orient, out, B, C, N);
     return (int32_t)hipGetLastError();
   }
   if (C * N * N <= 2304) k_symmetry_bytes<2304><<<grid, kWave, 0, s>>>(in, orient, out, B, C, N);

@@ -13,6 +13,7 @@
 // geometric, so a transformed tracked board is a valid tracked board.
 #pragma once
 #include "gg_common.h"
+#include "gg_v2.h"
 #include "gymgo_amd.h"
 
 namespace gg {
@@ -64,29 +65,38 @@ __global__ __launch_bounds__(kWave) void k_symmetry_bytes(const uint8_t *__restr
   }
 }
 
-// All eight views of every game (orient == nullptr), boards of up to MAXB staged bytes: the SCATTER form.  The gather above
-// reads every source byte eight times (once per view) through one-byte LDS instructions: 8 x (C reads + C writes + 1 table
-// read) per point, and the kernel is bound by the LDS instruction rate, not by HBM (2.8 TB/s moved).  Here a lane reads the C
-// bytes of a source point ONCE and writes them to the point's place in each of the eight views - the eight destinations are
-// the combinations of (r | N-1-r, c | N-1-c) and their transposes: four products and eight adds - so the byte reads and the
-// table reads are shared.  Four output boards at a time are assembled in LDS (views 0-3, then 4-7: (1 + C + 4 C) LDS
-// instructions per point and half instead of 4 (1 + 2 C)) and leave as aligned 16-byte vectors.
+// The fast form for what the entry point is used for most - states and observations, i.e. planes of 0 / 1 bytes: one
+// wave per game, the board goes through the BIT domain.  The staged bytes are packed into row masks (v_dot4, four cells
+// per instruction), every plane is transposed once (the five-stage 32 x 32 bit transpose of k_symmetry_rows), a view
+// is then a row selection + optional bit reversal per row - the geometry of k_symmetry_rows - ORed into a bit-string
+// of the OUTPUT range (all the views of a game are one contiguous byte range: bit i = byte i), and the bit-string leaves
+// through the 8 bits -> 8 bytes table as aligned 16-byte vectors, like every board emitter of this library.  ~0.1 LDS
+// instructions per output byte instead of the ~1.2 of a per-byte gather or scatter (which bound those at 2.8 - 3.9 TB/s).
+// A game whose bytes are not all 0 / 1 (per-point targets ...) is detected while it is staged and takes the per-byte
+// gather of k_symmetry_bytes inside this kernel: same results, round-3 speed.  The next game's bytes are fetched
+// (aligned superset, registers) before the current one is worked on.  C * N <= 128 rows, C * N * N <= MAXB.
 template <int MAXB>
-__global__ __launch_bounds__(kWave) void k_symmetry_all8(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int64_t B, int C, int N) {
-  constexpr int VH = 4;                                   // views assembled at a time (two halves: LDS for ~12 waves per CU instead of 7)
+__global__ __launch_bounds__(kWave) void k_symmetry_bits(const uint8_t *__restrict__ in, const int32_t *__restrict__ orient,
+                                                         uint8_t *__restrict__ out, int64_t B, int C, int N) {
   constexpr int NV = (MAXB + 30 + 15) / 16 / kWave + 1;   // 16-byte vectors per lane of a staged board
   static_assert(NV <= 3, "vectors per lane of a staged board");
+  constexpr int BSW = ((15 + 8 * MAXB + 31) / 32 + 4) & ~3;   // words of the output bit-string (eight views)
+  constexpr int DSW = (MAXB + 32 + 3) / 4;                    // words of the fallback's byte buffer (aliases the bit-string)
   __shared__ __attribute__((aligned(16))) uint8_t src[MAXB + 32];
-  __shared__ __attribute__((aligned(16))) uint8_t dst[VH][MAXB + 32];
-  __shared__ uint16_t rc[GG_MAX_BOARD * GG_MAX_BOARD];   // (row << 8) | column of point q
-  const int lane = threadIdx.x;
-  const int P = N * N, S = C * P;
+  __shared__ __attribute__((aligned(16))) uint32_t buf[BSW > DSW ? BSW : DSW];
+  __shared__ uint32_t rowsX[128], rowsT[128];
+  __shared__ uint2 lut[256];
+  __shared__ uint16_t rc[GG_MAX_BOARD * GG_MAX_BOARD];   // fallback: (row << 8) | column of point q
+  const int lane = threadIdx.x, hl = lane & 31, hh = lane >> 5;
+  const int P = N * N, S = C * P, NR = C * N;
+  const int views = orient ? 1 : 8;
+  load_spread_lut(lut, lane);
   for (int q = lane; q < P; q += kWave) {
     const int r = q / N;
     rc[q] = (uint16_t)((r << 8) | (q - r * N));
   }
-  // the source board of the NEXT iteration is fetched (aligned superset, into registers) before this one is worked on:
-  // a wave's load -> scatter -> store chain is a few microseconds long and the occupancy is low, so the load is hidden
+  // this lane's rows lane and lane + 64 of the C * N rows of a board: (plane, row in the plane)
+  const int pA = lane / N, rA = lane - pA * N, pB = (lane + 64) / N, rB = lane + 64 - pB * N;
   uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0;
   uint32_t nmi = 0;
   int nnv = 0;
@@ -102,39 +112,142 @@ __global__ __launch_bounds__(kWave) void k_symmetry_all8(const uint8_t *__restri
   } while (0)
   if ((int64_t)blockIdx.x < B) GG_SYM_FETCH((int64_t)blockIdx.x);
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
-    WAVE_SYNC();   // (the previous board's scatter has read src, its stage_out has read dst; rc is written)
+    WAVE_SYNC();   // (the previous game has read src and buf)
     const uint32_t mi = nmi;
+    const int nv = nnv;
     {
       uint4 *sv = reinterpret_cast<uint4 *>(src);
-      if (lane < nnv) sv[lane] = n0;
-      if (NV > 1 && lane + 64 < nnv) sv[lane + 64] = n1;
-      if (NV > 2 && lane + 128 < nnv) sv[lane + 128] = n2;
+      if (lane < nv) sv[lane] = n0;
+      if (NV > 1 && lane + 64 < nv) sv[lane + 64] = n1;
+      if (NV > 2 && lane + 128 < nv) sv[lane + 128] = n2;
     }
     if (b + gridDim.x < B) GG_SYM_FETCH(b + gridDim.x);
-    uint8_t *g0 = out + b * 8 * (int64_t)S;
-#pragma unroll 1
-    for (int vh = 0; vh < 8; vh += VH) {
+    WAVE_SYNC();
+    // the <= 15 + 15 bytes of the aligned superset that are not the game's are cleared, so that whole vectors can be tested
+    if (lane < 16) { if (lane < (int)mi) src[lane] = 0; }
+    else if (lane < 32) { const int e = (int)mi + S + (lane - 16); if (e < 16 * nv) src[e] = 0; }
+    WAVE_SYNC();
+    uint32_t big = 0;
+    {
+      const uint4 *sv = reinterpret_cast<const uint4 *>(src);
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        if (lane + 64 * k < nv) { const uint4 x = sv[lane + 64 * k]; big |= (x.x | x.y | x.z | x.w) & 0xFEFEFEFEu; }
+      }
+    }
+    const int o1 = orient ? (orient[b] & 7) : 0;
+    uint8_t *g = out + b * views * (int64_t)S;
+    if (__ballot(big != 0u) == 0) {
+      // ---- 0 / 1 planes: rows -> masks
       WAVE_SYNC();
-      for (int q = lane; q < P; q += kWave) {
-        const int w = rc[q];
-        const int r = w >> 8, c = w & 0xFF, rr = N - 1 - r, cc = N - 1 - c;
-        // where the source point (r, c) lands in view o (the inverse of sym_source): o & 4 transposes the flipped point;
-        // views 0-3: (r | rr) N + (c | cc), views 4-7: (cc | c) N + (r | rr)
-        const int a0 = vh ? cc * N : r * N, a1 = vh ? c * N : rr * N, e0 = vh ? r : c, e1 = vh ? rr : cc;
-        const int d[VH] = {a0 + e0, vh ? a1 + e0 : a0 + e1, vh ? a0 + e1 : a1 + e0, a1 + e1};
-        const uint8_t *sp = src + mi + q;
-        uint8_t *dp[VH];
 #pragma unroll
-        for (int v = 0; v < VH; ++v) dp[v] = dst[v] + (uint32_t)((uintptr_t)(g0 + (vh + v) * (int64_t)S) & 15u) + d[v];
-        for (int ch = 0; ch < C; ++ch) {
-          const uint8_t x = sp[ch * P];
+      for (int k = 0; k < 2; ++k) {
+        const int rho = lane + 64 * k;
+        if (rho < NR) {
+          const uint8_t *p = src + mi + rho * N;
+          const uint32_t sft = (uint32_t)((uintptr_t)p & 3u);
+          const uint32_t *d = reinterpret_cast<const uint32_t *>(p - sft);
+          uint32_t acc = 0;
 #pragma unroll
-          for (int v = 0; v < VH; ++v) dp[v][ch * P] = x;
+          for (int j = 0; j < 6; j += 2) {   // six aligned dwords cover 3 + 19 bytes
+            uint32_t t = __builtin_amdgcn_udot4(d[j] & 0x01010101u, 0x08040201u, 0u, false);
+            t = __builtin_amdgcn_udot4(d[j + 1] & 0x01010101u, 0x80402010u, t, false);
+            acc |= t << (4 * j);
+          }
+          rowsX[rho] = (acc >> sft) & ((1u << N) - 1u);
         }
       }
       WAVE_SYNC();
+      // ---- every plane transposed once (two planes per pass, one per 32-lane half)
+      for (int p0 = 0; p0 < C; p0 += 2) {
+        const int pl = p0 + hh;
+        uint32_t xt = (pl < C && hl < N) ? rowsX[pl * N + hl] : 0u;
+#define GG_TSTAGE(J, LOWM)                                                       \
+        {                                                                        \
+          const uint32_t y_ = (uint32_t)__shfl_xor((int)xt, J);                  \
+          const uint32_t up_ = (xt & (LOWM)) | ((y_ & (LOWM)) << (J));           \
+          const uint32_t dn_ = (xt & ~(LOWM)) | ((y_ & ~(LOWM)) >> (J));         \
+          xt = (hl & (J)) ? dn_ : up_;                                           \
+        }
+        GG_TSTAGE(16, 0x0000FFFFu)
+        GG_TSTAGE(8, 0x00FF00FFu)
+        GG_TSTAGE(4, 0x0F0F0F0Fu)
+        GG_TSTAGE(2, 0x33333333u)
+        GG_TSTAGE(1, 0x55555555u)
+#undef GG_TSTAGE
+        if (pl < C && hl < N) rowsT[pl * N + hl] = xt;
+      }
+      // ---- the bit-string of the output range
+      const uint32_t mo = (uint32_t)((uintptr_t)g & 15u);
+      const int nbits = (int)mo + views * S;
+      for (int i = lane; i < (nbits + 31) / 32 + 1; i += kWave) buf[i] = 0;
+      WAVE_SYNC();
 #pragma unroll 1
-      for (int v = 0; v < VH; ++v) stage_out(g0 + (vh + v) * (int64_t)S, S, dst[v], lane);
+      for (int v = 0; v < views; ++v) {
+        const int o = orient ? o1 : v;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int rho = lane + 64 * k, pl = k ? pB : pA, r = k ? rB : rA;
+          if (rho < NR) {
+            // (k_symmetry_rows' geometry: without the rotation out[r] bit c = x[R(r)] bit C(c); with it, on the transposed
+            // plane, out[r] bit c = xt[C(N-1-r)] bit R(c))
+            uint32_t y;
+            if (o & 4) {
+              const uint32_t t = rowsT[pl * N + ((o & 1) ? r : N - 1 - r)];
+              y = (o & 2) ? (__brev(t) >> (32 - N)) : t;
+            } else {
+              const uint32_t t = rowsX[pl * N + ((o & 2) ? N - 1 - r : r)];
+              y = (o & 1) ? (__brev(t) >> (32 - N)) : t;
+            }
+            if (y) {
+              const uint32_t q = mo + (uint32_t)(v * S + rho * N);
+              const uint64_t x = (uint64_t)y << (q & 31u);
+              atomicOr(buf + (q >> 5), (uint32_t)x);
+              if ((uint32_t)(x >> 32)) atomicOr(buf + (q >> 5) + 1, (uint32_t)(x >> 32));
+            }
+          }
+        }
+      }
+      WAVE_SYNC();
+      // ---- bits -> bytes: aligned 16-byte vectors through the table, the ragged ends as single bytes
+      uint8_t *ga = g - mo;
+      const int v0 = mo ? 1 : 0, v1 = nbits >> 4;
+      const uint8_t *bb = reinterpret_cast<const uint8_t *>(buf);
+      typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+      u4v *gv = reinterpret_cast<u4v *>(__builtin_assume_aligned(ga, 16));
+      for (int v = v0 + lane; v < v1; v += kWave) {
+        const uint2 lo = lut[bb[2 * v]], hi = lut[bb[2 * v + 1]];
+        u4v ov;
+        ov.x = lo.x; ov.y = lo.y; ov.z = hi.x; ov.w = hi.y;
+        gv[v] = ov;
+      }
+      const int head = mo ? 16 - (int)mo : 0, tail = nbits & 15, total = views * S;
+      int j = -1;
+      if (lane < 16) { if (lane < head) j = lane; }
+      else if (lane < 32 && lane - 16 < tail) j = total - tail + (lane - 16);
+      if (j >= 0 && j < total) {
+        const uint32_t q = mo + (uint32_t)j;
+        g[j] = (uint8_t)((buf[q >> 5] >> (q & 31u)) & 1u);
+      }
+    } else {
+      // ---- arbitrary bytes: the per-byte gather of k_symmetry_bytes, one view at a time through `buf`
+      uint8_t *dst = reinterpret_cast<uint8_t *>(buf);
+      for (int v = 0; v < views; ++v) {
+        const int o = orient ? o1 : v;
+        uint8_t *gv = g + v * (int64_t)S;
+        const uint32_t mo = (uint32_t)((uintptr_t)gv & 15u);
+        WAVE_SYNC();
+        for (int q = lane; q < P; q += kWave) {
+          const int w = rc[q];
+          int sr, sc;
+          sym_source(o, N, w >> 8, w & 0xFF, sr, sc);
+          const uint8_t *sp = src + mi + sr * N + sc;
+          uint8_t *dp = dst + mo + q;
+          for (int ch = 0; ch < C; ++ch) dp[ch * P] = sp[ch * P];
+        }
+        WAVE_SYNC();
+        stage_out(gv, S, dst, lane);
+      }
     }
   }
 #undef GG_SYM_FETCH

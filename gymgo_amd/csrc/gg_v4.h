@@ -578,13 +578,22 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
     FairShare fair(lds + Lds4<R>::kFair);
     // (a wide band - an eighth of the launch, at most 24 plies: measured 4 / 8 / 16 / 24 / 32 plies at 256 plies per launch:
     // 2.076 / 2.062 / 2.049 / 2.042 / 2.046 ms)
-    const uint32_t fair_lag = plies >= 192 ? 24u : (plies >= 16 ? (uint32_t)plies >> 3 : 2u);
+#ifndef GG_AB_FAIRLAG
+#define GG_AB_FAIRLAG 24u
+#endif
+#ifndef GG_AB_FAIRSTEP
+#define GG_AB_FAIRSTEP 3
+#endif
+#ifndef GG_AB_EARLY4
+#define GG_AB_EARLY4 false
+#endif
+    const uint32_t fair_lag = plies >= 192 ? GG_AB_FAIRLAG : (plies >= 16 ? (uint32_t)plies >> 3 : 2u);
     int mv_next = 0;
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
       // fair share of the SIMD (gg_common.h): every fourth ply the wave publishes the ply it has reached and sets its issue
       // priority by how many of its SIMD-mates are >= fair_lag plies behind it
-      if ((t & 3) == 0 && plies >= 8) {
+      if ((t & GG_AB_FAIRSTEP) == 0 && plies >= 8) {
         // ... and the band never exceeds the plies that are left: towards the end of the launch the stragglers are let
         // through, the four waves of a SIMD reach their write-back together (2.046 -> 2.022 ms per 256-ply launch;
         // half / a quarter / an eighth of the plies left: 2.027 / 2.032 / 2.040; checks every 2 / 8 plies: 2.05 / 2.09)
@@ -816,7 +825,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
             // (the closure test's copy of the fill goes to LDS four rows per ds_write_b128: 32-bit stores of one row
             // from lanes RS = 20 words apart are a 4-way bank conflict - removing it measured 2.327 vs 2.327 ms per
             // 256-ply launch: the LDS is not on this kernel's critical path)
-            flood2_serial<R, true, true>(m, mrev, f, out);
+            flood2_serial<R, true, true, GG_AB_EARLY4>(m, mrev, f, out);
             GG_PROF(2);
           }
           // liberties of this lane's group on the position with the new stone (captures not yet removed); m[] still

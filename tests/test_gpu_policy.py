@@ -268,6 +268,37 @@ def test_batch_symmetry_matches_reference_views(golden):
             assert np.array_equal(one[b], all8[b, orient[b]])
 
 
+@pytest.mark.parametrize('N,C,B', [(19, 6, 301), (19, 1, 70), (9, 6, 515), (13, 3, 129), (7, 18, 65), (2, 6, 9), (19, 7, 40)])
+def test_batch_symmetry_mixed_binary_and_arbitrary_games(N, C, B):
+    """gg_batch_symmetry takes 0 / 1 planes through the bit domain and any other game of the SAME batch through the
+    per-byte gather (decided per game, on the device): a batch that mixes both kinds - every third game carries bytes
+    above 1, one of them only in its very last byte - on an UNALIGNED slice of a bigger buffer, all eight views and one
+    random view per game, against the NumPy restatement of gym_go/gogame.py:373-381.  (19, 7): more rows than the bit
+    path holds - the whole batch takes the generic kernel.)"""
+    from gymgo_amd import gogame
+    gen = np.random.default_rng(N * 100 + C)
+    host = (gen.random((B, C, N, N)) < 0.4).astype(np.uint8)
+    host[::3] = gen.integers(0, 256, size=host[::3].shape, dtype=np.uint8)
+    host[1] = 0
+    host[1, -1, -1, -1] = 200                       # arbitrary only in the last byte of the game
+    host[2] = 1                                     # all ones: binary
+    flat = torch.zeros(B * C * N * N + 64, dtype=torch.uint8, device='cuda')
+    dev = flat[7:7 + B * C * N * N].view(B, C, N, N)          # 7 bytes off any alignment
+    dev.copy_(_dev(host))
+    out8 = torch.full((B * 8 * C * N * N + 64,), 255, dtype=torch.uint8, device='cuda')
+    o8 = out8[3:3 + B * 8 * C * N * N].view(B, 8, C, N, N)
+    all8 = gogame.batch_symmetry(dev, out=o8)
+    got = all8.cpu().numpy()
+    assert bool((out8[:3] == 255).all()) and bool((out8[3 + B * 8 * C * N * N:] == 255).all())   # nothing outside the range is touched
+    for b in range(B):
+        for o in range(8):
+            assert np.array_equal(got[b, o], _np_view(host[b], o)), (b, o)
+    orient = gen.integers(0, 8, size=B).astype(np.int32)
+    one = gogame.batch_symmetry(dev, orient).cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(one[b], got[b, orient[b]]), b
+
+
 @pytest.mark.parametrize('N,B', [(5, 33), (9, 1001), (13, 257), (19, 4096)])
 def test_symmetry_of_packed_and_tracked_boards_is_geometric(N, B):
     """Row-mask symmetries: pack(view(states)) == view_rows(pack(states)) and - because liberty classes and the invalid

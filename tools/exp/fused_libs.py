@@ -1,4 +1,4 @@
-"""fused rollout (65 536 games x 256 plies per launch, stationary mix) for a list of A/B libraries in tools/exp/:
+"""fused rollout (65 536 games x 256 plies per launch, stationary mix) for a list of A/B libraries (paths relative to the repo root):
     python tools/exp/fused_libs.py libgymgo_ab.so libgymgo_T2.so ...      (each measured twice, interleaved)"""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,7 @@ if sys.argv[1] != 'run':
 sys.path.insert(0, ROOT)
 import torch
 from gymgo_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, 'tools', 'exp', sys.argv[2])
+_lib.LIB_PATH = os.path.join(ROOT, sys.argv[2])
 from gymgo_amd import gogame
 N, B, F = 19, 65536, int(os.environ.get('PLIES', '256'))
 st = gogame.batch_init_state(B, N, device='cuda'); rng = gogame.rng_seed(B, 20260927)
