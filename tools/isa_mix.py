@@ -82,7 +82,7 @@ def main(path):
     valu = tot['valu fast (2 cycles)'] + tot['valu slow (4 cycles)']
     print('  VALU issue cycles per wave-ply: %.0f  (%.2f cycles per VALU instruction on average)' % (cyc, cyc / valu))
     print('  slow ops: ' + ', '.join('%s %.0f' % (k, v) for k, v in slow.most_common(12)))
-    print('  => VALU pipe busy = frac_valu_only x %.2f / 2 (bench.py prices every VALU instruction at the 2-cycle peak)' % (cyc / valu))
+    print('  => VALU pipe busy (static estimate) = roofline.frac x %.2f / 2 (bench.py prices every VALU instruction at the 2-cycle peak)' % (cyc / valu))
 
 
 if __name__ == '__main__':

@@ -14,6 +14,7 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- $SHORT > $O/pmc_write.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_inst -o p -- $SHORT > $O/pmc_inst.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_act -o p -- $SHORT > $O/pmc_act.log 2>&1
+timeout 600 rocprofv3 --pmc VALUBusy SQ_BUSY_CU_CYCLES SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU2 --kernel-trace --output-format csv -d $O/pmc_busy -o p -- $SHORT > $O/pmc_busy.log 2>&1
 # calibration of FETCH_SIZE / WRITE_SIZE on launches whose byte counts are known (the guide: WRITE_SIZE is uncalibrated)
 CAL="python $R/tools/calib_traffic.py"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cal_fetch -o p -- $CAL > $O/cal_fetch.log 2>&1

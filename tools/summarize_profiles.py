@@ -108,15 +108,40 @@ md.append('FETCH_SIZE = %.0f KiB -> %.1f MB read; WRITE_SIZE = %.0f KiB -> %.1f 
 
 md.append('\n## instruction mix per env step (PMC / (games x plies))\n')
 mix = {}
-for sub in ('pmc_inst', 'pmc_act'):
-    c = counters(sub, kshort)
+for sub in ('pmc_inst', 'pmc_act', 'pmc_busy'):
+    try:
+        c = counters(sub, kshort)
+    except Exception as e:      # (pmc_busy: derived / newer counters that a stack may not offer)
+        md.append('- (%s not collected: %s)' % (sub, str(e)[:80]))
+        continue
     keys = [k for k in c[0] if not k.startswith('_')]
     avg = {k: mean(d[k] for d in c) / steps for k in keys}
     mix.update(avg)
     md.append('- ' + ', '.join('%s %.2f' % (k, v) for k, v in sorted(avg.items())))
     md.append('  (VGPRs %s, LDS %s B per 64-thread workgroup)' % (c[0]['_vgpr'], c[0]['_lds']))
-md.append('\nSQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles.  bench.py prints achieved = (VALU + SALU + LDS instructions '
-          'per step) x env steps/s against a peak of one wave64 instruction per SIMD every 2 cycles.')
+md.append('\nSQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are documented as quad-cycles.  bench.py prints achieved = VALU instructions '
+          'per step x env steps/s against a peak of one wave64 VALU instruction per SIMD every 2 cycles (SALU / LDS beside it).')
+# ---- how busy is the VALU pipe, from counters (SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE x SIMDs))
+valu_busy = None
+try:
+    xcds, simds = 8, 256 * 4
+    act, gui = mix['SQ_ACTIVE_INST_VALU'], mix['GRBM_GUI_ACTIVE']
+    per_xcd = gui / xcds            # the collected value is the sum over the 8 XCDs (= 8 x launch cycles)
+    quad = act * 4.0 / (per_xcd * simds)
+    valu_busy = {'formula': 'SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)',
+                 'sq_active_inst_valu_per_step': round(act, 3), 'grbm_gui_active_per_step_sum_of_8_xcds': round(gui, 4),
+                 'value': round(quad, 4)}
+    note = ('SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU on this kernel (%.2f vs %.2f per step): the counter advances once per VALU '
+            'instruction, so the formula prices every instruction at a full quad-cycle' % (act, mix['SQ_INSTS_VALU']))
+    if quad > 1.0:
+        note += ' and comes out above 1 - the simple ops of this kernel issue in 2 cycles (profiles/r01_ubench_valu_rates.txt)'
+    valu_busy['note'] = note
+    if 'VALUBusy' in mix:
+        valu_busy['rocprof_VALUBusy_percent'] = round(mix['VALUBusy'] * steps, 2)    # a per-launch percentage, not per step
+    md.append('\n## VALU busy from counters\n')
+    md.append('%s = **%.3f**.  %s.' % (valu_busy['formula'], quad, note))
+except Exception as e:
+    md.append('\n(VALU-busy counters not available: %s)' % e)
 
 # ---- the record bench.py reads
 pmc_path = os.path.join(dst, 'pmc_rollout.json')
@@ -130,6 +155,13 @@ rec = {'kernel': kernel, 'size': N, 'plies_per_launch': F, 'games': games,
        'hbm_bytes_per_launch': round(fetch_b + write_b), 'fetch_bytes': round(fetch_b), 'write_bytes': round(write_b),
        'fetch_scale': round(fetch_scale, 4), 'write_scale': round(write_scale, 4),
        'source': 'profiles/%s_summary.md (rocprofv3 --pmc passes of `bench.py --plies-per-step %d`, tools/profile_round.sh)' % (tag, F)}
+# the machine code these counters were collected on (the in-tree library travelled to the GPU box as it is here): bench.py
+# recomputes the hash from the library it runs and says `pmc_stale` when the kernel has been rebuilt differently since
+sys.path.insert(0, ROOT)
+import bench as _bench   # noqa: E402
+rec['kernel_code_sha16'] = _bench.kernel_code_hash(_bench.rollout_symbol_prefix(kernel) or '\0')
+if valu_busy:
+    rec['valu_busy'] = valu_busy
 # static issue-cycle estimate of the ply loop (tools/isa_mix.py), when this round recorded one
 try:
     mixtxt = open(os.path.join(dst, '%s_isa_mix.txt' % tag)).read()
