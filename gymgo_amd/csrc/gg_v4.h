@@ -329,44 +329,47 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
       const int64_t nbrd = (B - b_first) < nb ? (B - b_first) : nb;
       const int nw = (int)nbrd * W;
       const uint32_t *gp = reinterpret_cast<const uint32_t *>(states) + b_first * (int64_t)W;
-      for (int i = hf.lane; i < 2 * PL; i += kWave) st[i] = 0;      // rows N .. RS-1 and absent boards read as zero
-      if (hf.lane < Lds4<R>::kPad) lds[hf.lane] = 0;
-      for (int i = hf.lane; i < 3 * PL; i += kWave) park[i] = 0;
-      const uint32_t invW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;   // i / W exactly for i < 16 * 96
-      // the generator states of the group: requested before the block, so that they do not cost a round trip of their own
+      // Round 4: the block travels global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per instruction, no register
+      // is held while it flies), ALL of it in flight at once, into the flood blocks (free until the first ply), and is
+      // sorted from there: the stone rows into their planes, the flag words into the meta words, the mask / class rows
+      // straight into the registers of their owner lanes.  (Round 3 fetched it through registers, eight loads per lane
+      // at a time - all twenty-four at once cost 47 spilled registers - i.e. three dependent memory round trips on the
+      // head of a launch that, for the one-ply entry points, is one iteration long.)
+      constexpr int KD = ((kNB4 * (5 * R + 1) * 4 + 12 + 15) / 16 + kWave - 1) / kWave;   // DMA instructions per lane
+      static_assert(((kNB4 * (5 * R + 1) * 4 + 12 + 15) / 16) * 4 <= kNB4 * Lds4<R>::kScBoard, "a group's tracked block fits the flood blocks");
+      const uint8_t *gb = reinterpret_cast<const uint8_t *>(gp);
+      const uint32_t mis = (uint32_t)((uintptr_t)gb & 15u);   // (a multiple of 4: the aligned superset of the block is fetched)
+      const int nvec = (int)((mis + (uint32_t)nw * 4u + 15u) >> 4);
+      WAVE_SYNC();
+      lds_drain();   // (whatever read the flood blocks before - the previous group's write-back - has its data: the DMA's LDS writes are not ordered with the DS queue)
+      {
+        const uint32_t stage_lds = lds_addr(sc);
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+          const int v = hf.lane + kWave * k;
+          if (v < nvec) dma16(gb - mis + 16 * v, stage_lds + 1024u * (uint32_t)k);   // lane L's 16 bytes land at m0 + 16 L
+        }
+      }
+      // the generator states of the group: requested with the block, so that they do not cost a round trip of their own
       uint64_t xg = 0;
       if ((!MOVES || WTS) && hf.lane < kNB4) xg = rng[(hf.lane < nb && b_first + hf.lane < B) ? b_first + hf.lane : B - 1];
-      // eight loads of the block are in flight at a time (a plain copy loop waits for each load in turn: 24 dependent
-      // round trips on the head of a launch; all 24 at once cost 47 spilled registers)
+      for (int i = hf.lane; i < 2 * PL; i += kWave) st[i] = 0;      // rows N .. RS-1 and absent boards read as zero
+      if (hf.lane < Lds4<R>::kPad) lds[hf.lane] = 0;
+      dma_wait();
       WAVE_SYNC();
-#pragma unroll 1
-      for (int i0 = 0; i0 < nw; i0 += GG_KLD * kWave) {
-        uint32_t buf[GG_KLD];
-#pragma unroll
-        for (int k = 0; k < GG_KLD; ++k) {
-          const int i = i0 + hf.lane + kWave * k;
-          buf[k] = gp[i < nw ? i : nw - 1];
-        }
-#pragma unroll
-        for (int k = 0; k < GG_KLD; ++k) {
-          const int i = i0 + hf.lane + kWave * k;
-          if (i < nw) {
-            const uint32_t v = buf[k];
-            const int sb = (int)(((uint32_t)i * invW) >> 20), w = i - sb * W;
-            if (w == 5 * N) {
-              flagsv[sb] = (v & 7u) | 8u;
-            } else {
-              const int pl = (int)(((uint32_t)w * hf.inv) >> 16), rw = w - pl * N;
-              if (pl < 2) st[pl * PL + sb * RS + rw] = v;
-              else park[(pl - 2) * PL + sb * RS + rw] = v;
-            }
-          }
+      const uint32_t *stg = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(sc) + mis);   // word i of the block
+      {
+        const uint32_t N2 = 2u * (uint32_t)N, inv2 = (65536u + N2 - 1u) / N2;   // i / (2 N) exactly for i < 16 * 2 N
+        for (int i = hf.lane; i < (int)nbrd * (int)N2; i += kWave) {
+          const int sb = (int)(((uint32_t)i * inv2) >> 16), w = i - sb * (int)N2;
+          const int pl = w >= N ? 1 : 0;
+          st[pl * PL + sb * RS + (w - pl * N)] = stg[sb * W + w];
         }
       }
       if (hf.lane < kNB4) {
         const int sb = hf.lane;
         const bool on = sb < nb && b_first + sb < B;
-        if (!on) flagsv[sb] = 0;
+        flagsv[sb] = on ? ((stg[sb * W + 5 * N] & 7u) | 8u) : 0u;
         lastv[sb] = -1;
         playedv[sb] = 0;
         if (!MOVES || WTS) {
@@ -374,11 +377,18 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
           rngv[2 * sb + 1] = (uint32_t)(xg >> 32);
         }
       }
-      WAVE_SYNC();
+      {
+        const bool have = q4 < (int)nbrd;
+        const uint32_t *bq = stg + (have ? q4 : 0) * W;
 #pragma unroll
-      for (int r = 0; r < RPL; ++r) {
-        inv_r[r] = park[0 * PL + q4 * RS + r04 + r];
-        M[r] = park[1 * PL + q4 * RS + r04 + r] | park[2 * PL + q4 * RS + r04 + r];
+        for (int r = 0; r < RPL; ++r) {
+          const int rw = r04 + r;
+          const bool ok = have && rw < N;
+          const int rc = ok ? rw : 0;
+          const uint32_t iv = bq[2 * N + rc], mb = bq[3 * N + rc], mw = bq[4 * N + rc];
+          inv_r[r] = ok ? iv : 0u;
+          M[r] = ok ? (mb | mw) : 0u;
+        }
       }
       WAVE_SYNC();
     } else {
