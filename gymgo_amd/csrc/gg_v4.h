@@ -14,8 +14,10 @@ namespace gg {
 //   * the mover's group G that the new stone joins - only when q has a friendly neighbour (otherwise G = {q}, whose
 //     liberties are q's empty neighbours: no flood);
 //   * the opponent's group at each neighbour of q that holds an opponent stone.
-// A friendly neighbour leaves at most three opponent neighbours, so four lanes always suffice: the roles are
-// assigned per ply (opponent neighbours in direction order on lanes 0.., G on lane 3).  Round 1's kernel gave every
+// Four lanes always suffice: lane t of a board's quad takes the neighbour of q in direction t (up, down, left, right) -
+// an opponent stone: the lane floods its group; a friendly stone: the lane floods G from q into the board's G block
+// (every friendly lane the same flood, a benign duplicate); nothing: an empty flood.  (Round 3 compacted the opponent
+// neighbours onto lanes 0.. and kept G on lane 3, which cost more instructions than two floods.)  Round 1's kernel gave every
 // board five fixed roles (12 boards x 5 lanes); with four lanes a board is exactly one DPP QUAD - every
 // board-level reduction is two quad_perm moves - 16 boards share a flood batch instead of 12, and 65 536 games are
 // exactly 4 096 waves = ONE resident set of an MI355X (256 CUs x 4 SIMDs x 4 waves): no second, part-filled round.
@@ -24,21 +26,21 @@ namespace gg {
 //   1. sampling: liveness, the generator (drawn redundantly by the four lanes), the k-th valid point of the mask (a
 //      lane counts its own rows, the board's prefix / total come from a two-step quad scan, the lane that holds the
 //      point selects row and bit), the stone ORed into the mover's plane; auto-reset on a rare path;
-//   2. one lane per (board, role): role assignment from the six rows around q, the flood, then the liberties (dilate
-//      & empty, saturated at 2) and the size of the lane's own group, all rows in registers; an opponent group that
-//      keeps >= 2 liberties zeroes its result, so phase 3 never sees it;
+//   2. one lane per (board, direction): what its neighbour of q holds (two row reads), the flood (seed staged through
+//      the lane's cleared flood block), then the liberties (dilate & empty, saturated at 2) of the lane's group, all
+//      rows in registers; the class word carries them together with what the quad learnt about q (one packed quad sum:
+//      empty neighbours, any friendly one, boxed in); an opponent group that keeps >= 2 liberties zeroes its result,
+//      so phase 3 never sees it;
 //   3. class patch, all sixteen boards in one pass: an opponent group next to q with no liberty left is captured, with
 //      one left it leaves M; G takes the class of its own count (+ the captured points next to it); a mover's group in
 //      atari next to a captured stone gains a liberty (rare; a flood through the atari set in this layout); every
 //      other group keeps its class.  The invalid-move mask follows from the classes exactly as in the per-ply kernels.
 // M and the mask are produced and consumed by the same lanes (phases 3 -> 1 -> 3), so they live in REGISTERS for the
 // whole launch (2 x RPL VGPRs); LDS holds the two stone planes (which the flood lanes read in the other layout), the
-// flood results and a few words per board: 8 704 B per wave at 19x19 in the ply loop, 9 728 B with the write-back's group
-// bit-string and table (the limit for four waves per SIMD is 10 240 B).
+// flood results (five blocks per board: one per lane + G) and a few words per board: 10 000 B per wave at 19x19 (the limit
+// for four waves per SIMD is 10 240 B).  The action and the flag word of a ply travel from phase 1 to phases 2 and 3 in
+// registers; tracked boards enter a launch by LDS-DMA.
 constexpr int kNB4 = 16;
-#ifndef GG_KLD
-#define GG_KLD 8   // loads of a tracked block in flight per lane
-#endif
 
 // gg_ws.h (policy-weighted sampling, one DPP row of 16 lanes per board); used by the weighted env step below
 template <int NJ> __device__ __forceinline__ int wsample_row(const uint32_t (&bits)[NJ], const uint32_t (&vm)[NJ], uint32_t uhi, int lane);
