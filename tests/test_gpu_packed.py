@@ -208,6 +208,37 @@ def test_tracked_boards_step_like_the_oracle(N, B):
     assert torch.equal(tr, gogame.batch_track(gogame.batch_untrack(tr)))
 
 
+@pytest.mark.parametrize('N,B', [(18, 700), (6, 300), (2, 50), (19, 333), (9, 1000)])
+def test_tracked_entry_points_on_unaligned_slices(N, B):
+    """A group's tracked block enters a launch by LDS-DMA as the ALIGNED superset of its bytes (round 4).  Tracked boards
+    are 5 N + 1 words, so a slice of a bigger buffer starts 0 / 4 / 8 / 12 bytes off a 16-byte boundary (odd word counts:
+    even N): fused rollouts, the env step (with the observation) and replays on such slices must equal the same calls
+    on an aligned copy, and must not touch the boards on either side of the slice."""
+    from gymgo_amd import gogame
+    st, rng = _mid(B + 8, N, 5, auto_reset=True)
+    big = gogame.batch_track(st)
+    W = 5 * N + 1
+    seen = set()
+    for k in (1, 2, 3, 5):
+        lo, hi = k, k + B
+        seen.add((big[lo:hi].data_ptr() & 15))
+        ref = big[lo:hi].clone()                     # (a fresh allocation: aligned)
+        rng_a, rng_b = rng[lo:hi].clone(), rng[lo:hi].clone()
+        guard = big.clone()
+        sl = big[lo:hi]
+        for plies in (1, 7):
+            gogame.batch_rollout_tracked(sl, rng_a, plies, True)
+            gogame.batch_rollout_tracked(ref, rng_b, plies, True)
+            assert torch.equal(sl, ref) and torch.equal(rng_a, rng_b), (N, k, plies)
+        obs_a, obs_b = torch.empty((B, 6, N, N), dtype=torch.uint8, device='cuda'), torch.empty((B, 6, N, N), dtype=torch.uint8, device='cuda')
+        out_a = gogame.batch_env_step_tracked(sl, None, rng_a, 0.5, 'real', True, states_out=obs_a)
+        out_b = gogame.batch_env_step_tracked(ref, None, rng_b, 0.5, 'real', True, states_out=obs_b)
+        assert torch.equal(sl, ref) and torch.equal(obs_a, obs_b) and all(torch.equal(x, y) for x, y in zip(out_a, out_b)), (N, k)
+        assert torch.equal(gogame.batch_untrack(sl), obs_a)
+        assert torch.equal(big[:lo], guard[:lo]) and torch.equal(big[hi:], guard[hi:]), (N, k)
+    assert seen == {(big.data_ptr() + k * W * 4) & 15 for k in (1, 2, 3, 5)} and (len(seen) >= 3 or N % 2), seen   # (even N: 4 / 8 / 12 bytes off)
+
+
 @pytest.mark.parametrize('N,B,plies', [(19, 16384, 420), (13, 8200, 200), (9, 12300, 260)])
 def test_multi_ply_kernel_soak_all_layouts(N, B, plies):
     """The multi-ply kernel at its own dispatch sizes over whole games: byte-plane, packed and tracked boards walk the same
