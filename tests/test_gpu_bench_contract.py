@@ -89,3 +89,24 @@ def test_bench_two_ranks(launcher):
     assert len(line['per_rank_launch_ms']) == 2 and all(x > 0 for x in line['per_rank_launch_ms'])
     assert len(line['per_gpu_steps_per_s']) == 2
     assert line['value'] <= sum(line['per_gpu_steps_per_s']) * 1.001    # the whole job cannot beat the sum of its ranks
+
+
+def test_bench_per_rank_records_and_nccl_device_check():
+    """The N > 1 line says what every rank did - first game of its shard, steps played, device (two ranks rehearsed on ONE
+    GPU over gloo show up as equal device identities: `distinct_devices` 1) - and `--comm nccl` with more ranks than
+    visible GPUs is refused with a clear message instead of RCCL's duplicate-GPU failure."""
+    import torch
+    line = _run([sys.executable, 'bench.py', '--gpus', '2', '--comm', 'gloo', '--games-per-gpu', '16384', '--steps', '2', '--warmup', '1',
+                 '--no-also', '--no-cpu-baseline'])
+    per = line['per_rank']
+    assert [p['first_game'] for p in per] == [0, 16384] and [p['steps_played'] for p in per] == [2 * 256 * 16384] * 2
+    ndev = torch.cuda.device_count()
+    assert line['distinct_devices'] == min(2, ndev)
+    assert line['roofline']['pmc_stale'] in (True, False) and 'kernel_code_sha16' in line['roofline']
+    if ndev < 2:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+            env.pop(k, None)
+        res = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--comm', 'nccl', '--steps', '1', '--warmup', '0', '--no-also',
+                              '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert res.returncode != 0 and 'one GPU per rank' in (res.stderr + res.stdout)
