@@ -584,6 +584,11 @@ def extras(dev, back, opts):
     out['fused_rollout_tracked_boards_steps_per_s'] = round(r, 1)
     out['fused_rollout_tracked_boards_launch_ms'] = round(ms, 4)
     del tr2, rng2
+    # what the launch boundary (first analysis of the byte planes, write-back, the spread between SIMDs at the end of a launch)
+    # costs the headline: the same batch with four times the plies per launch (NOT the headline: `value` stays at --plies-per-step)
+    r_long, ms_long = event_rate(torch, dev, lambda: back.rollout(4 * plies, count_steps=False), count * 4 * plies, 3)
+    out['fused_rollout_4x_plies_per_launch_steps_per_s'] = round(r_long, 1)
+    out['fused_rollout_4x_plies_per_launch_ms'] = round(ms_long, 4)
     # the same step with the move of every game drawn from policy weights (float32 [B, N^2+1]: 1 448 B more to read per
     # game) by the launch itself - what a self-play loop with a policy network runs per ply
     probs = torch.rand((count, N * N + 1), dtype=torch.float32, device=dev)
