@@ -358,35 +358,34 @@ def kernel_code_hash(symbol_prefix, lib_path=None):
     try:
         d = open(path, 'rb').read()
         magic = b'__CLANG_OFFLOAD_BUNDLE__'
-        i = d.find(magic)
-        if i < 0:
-            return None
-        n = struct.unpack_from('<Q', d, i + len(magic))[0]
-        p, elf = i + len(magic) + 8, None
-        for _ in range(n):
-            off, size, tl = struct.unpack_from('<QQQ', d, p)
-            p += 24
-            triple = d[p:p + tl]
-            p += tl
-            if b'amdgcn' in triple and size:
-                elf = d[i + off:i + off + size]
-        if elf is None or elf[:4] != b'\x7fELF':
-            return None
-        shoff, = struct.unpack_from('<Q', elf, 0x28)
-        shentsize, shnum, shstrndx = struct.unpack_from('<HHH', elf, 0x3A)
-        secs = [struct.unpack_from('<IIQQQQIIQQ', elf, shoff + k * shentsize) for k in range(shnum)]
-        for sec in secs:
-            if sec[1] != 2:      # SHT_SYMTAB
-                continue
-            stroff = secs[sec[6]][4]
-            for k in range(sec[5] // 24):
-                name_i, info, other, shndx, value, size = struct.unpack_from('<IBBHQQ', elf, sec[4] + 24 * k)
-                end = elf.index(b'\0', stroff + name_i)
-                name = elf[stroff + name_i:end]
-                if (info & 15) == 2 and size and name.startswith(symbol_prefix.encode()) and not name.endswith(b'.kd'):
-                    tsec = secs[shndx]
-                    code = elf[tsec[4] + (value - tsec[3]):tsec[4] + (value - tsec[3]) + size]
-                    return hashlib.sha256(code).hexdigest()[:16]
+        elfs, i = [], d.find(magic)
+        while i >= 0:       # one bundle per translation unit (gg_kernels.hip, gg_rollout.hip)
+            n = struct.unpack_from('<Q', d, i + len(magic))[0]
+            p = i + len(magic) + 8
+            for _ in range(n):
+                off, size, tl = struct.unpack_from('<QQQ', d, p)
+                p += 24
+                triple = d[p:p + tl]
+                p += tl
+                if b'amdgcn' in triple and size and d[i + off:i + off + 4] == b'\x7fELF':
+                    elfs.append(d[i + off:i + off + size])
+            i = d.find(magic, i + 1)
+        for elf in elfs:
+            shoff, = struct.unpack_from('<Q', elf, 0x28)
+            shentsize, shnum, shstrndx = struct.unpack_from('<HHH', elf, 0x3A)
+            secs = [struct.unpack_from('<IIQQQQIIQQ', elf, shoff + k * shentsize) for k in range(shnum)]
+            for sec in secs:
+                if sec[1] != 2:      # SHT_SYMTAB
+                    continue
+                stroff = secs[sec[6]][4]
+                for k in range(sec[5] // 24):
+                    name_i, info, other, shndx, value, size = struct.unpack_from('<IBBHQQ', elf, sec[4] + 24 * k)
+                    end = elf.index(b'\0', stroff + name_i)
+                    name = elf[stroff + name_i:end]
+                    if (info & 15) == 2 and size and name.startswith(symbol_prefix.encode()) and not name.endswith(b'.kd'):
+                        tsec = secs[shndx]
+                        code = elf[tsec[4] + (value - tsec[3]):tsec[4] + (value - tsec[3]) + size]
+                        return hashlib.sha256(code).hexdigest()[:16]
     except Exception:
         return None
     return None

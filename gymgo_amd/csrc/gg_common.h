@@ -396,7 +396,9 @@ __device__ __forceinline__ PairSpan pair_span(int64_t npairs, const AgeSplit &as
 // The mates' words travel global -> LDS by LDS-DMA and are read at the NEXT check: no register is held and nothing
 // waits for the load.  The board carries no result: stale or foreign entries (another stream's kernel) only shift
 // priorities.  It is the one piece of mutable device-global state of the library (512 KB per device).
-__device__ unsigned int gg_fair_board[8 * 8 * 2 * 16 * 4 * 16];   // [XCC][SE][SH][CU][SIMD][wave slot]: progress + 1, 0 / ~0 = free
+// (internal linkage: the library is two translation units - gg_kernels.hip and gg_rollout.hip - and each has its own board;
+// waves of kernels from the other unit are "foreign entries" to it, like another process's)
+static __device__ unsigned int gg_fair_board[8 * 8 * 2 * 16 * 4 * 16];   // [XCC][SE][SH][CU][SIMD][wave slot]: progress + 1, 0 / ~0 = free
 
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
@@ -457,7 +459,7 @@ __device__ __forceinline__ uint64_t splitmix_next(uint64_t &x) {
 
 // GoVecEnv auto-reset: games whose game-over plane is set are zeroed IN PLACE (build-side policy);
 // one wave per finished board does the stores, everyone else only reads one byte.
-__global__ void k_reset_finished(uint8_t *__restrict__ states, int64_t B, int N) {
+static __global__ void k_reset_finished(uint8_t *__restrict__ states, int64_t B, int N) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / kWave;
   const int64_t nwaves = (gridDim.x * (int64_t)blockDim.x) / kWave;
@@ -484,7 +486,7 @@ __global__ void k_reset_finished(uint8_t *__restrict__ states, int64_t B, int N)
   }
 }
 
-__global__ void k_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B) {
+static __global__ void k_rng_seed(uint64_t *rng, uint64_t base_seed, int64_t first_game, int64_t B) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= B) return;
   uint64_t x = base_seed ^ ((uint64_t)(first_game + i) * 0xD1342543DE82EF95ull);

@@ -28,6 +28,12 @@
 #include "gg_ns16.h"
 #include "gymgo_amd.h"
 
+namespace gg {
+// gg_rollout.hip: the fused multi-ply launches with drawn moves, a translation unit of their own (one code-generation switch differs)
+void launch_rollout4(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N,
+                     uint32_t inv, int plies, int auto_reset, int nb, int grid, hipStream_t s);
+}
+
 namespace {
 
 using namespace gg;
@@ -443,7 +449,7 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
   if (use_multi_ply(cus, B, plies)) {   // liberty classes carried across the plies, 16 boards per wave
     int grid;
     const int nb = boards_per_wave(cus, B, grid);
-    GG_DISPATCH4(N, 0, false, grid, states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
+    launch_rollout4(0, states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb, grid, s);
     return (int32_t)hipGetLastError();
   }
   if (plies == 1) {   // one ply per launch on a big batch of full-size boards: the env step without the GoEnv outputs (gg_ns16.h)
@@ -587,7 +593,7 @@ int32_t gg_batch_rollout_packed(uint32_t *packed, uint64_t *rng, int32_t *last_a
   if (use_multi_ply(cus, B, plies)) {
     int grid3;
     const int nb = boards_per_wave(cus, B, grid3);
-    GG_DISPATCH4(N, 1, false, grid3, st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
+    launch_rollout4(1, st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb, grid3, s);
     return (int32_t)hipGetLastError();
   }
   const int64_t npairs = (B + 1) / 2;
@@ -700,7 +706,7 @@ int32_t gg_batch_rollout_tracked(uint32_t *tracked, uint64_t *rng, int32_t *last
   uint8_t *st = reinterpret_cast<uint8_t *>(tracked);
   int grid3;
   const int nb = boards_per_wave(cus, B, grid3);
-  GG_DISPATCH4(N, 2, false, grid3, st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb);
+  launch_rollout4(2, st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb, grid3, s);
   return (int32_t)hipGetLastError();
 }
 

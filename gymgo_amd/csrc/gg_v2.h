@@ -21,7 +21,7 @@ constexpr int kCwClasses = 11, kCwWeight = 5, kCwLanes = 2 * kCwClasses;
 
 #ifdef GG_AB_WHERE
 // A/B builds only: per workgroup (XCC, HW_ID, duration in 100 MHz ticks) - how evenly do the waves of a launch finish?
-__device__ unsigned int gg_where[3 * 16384];
+static __device__ unsigned int gg_where[3 * 16384];
 #endif
 
 struct CwTable { uint32_t m[kCwClasses + 1][20]; };  // [class][row] -> columns of the class; last row = zeros
@@ -40,7 +40,7 @@ constexpr CwTable make_cw_table() {
   }
   return t;
 }
-__constant__ CwTable kCw = make_cw_table();
+static __constant__ CwTable kCw = make_cw_table();   // (internal linkage: one copy per translation unit)
 
 #ifndef GG_LB_CH3
 #define GG_LB_CH3 4   // waves per SIMD k_children3 is compiled for (128 VGPRs, no spills; 3 waves / 140 VGPRs measures the same +-3 %)

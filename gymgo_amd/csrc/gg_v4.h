@@ -60,7 +60,7 @@ template <int NJ> __device__ __forceinline__ void wmask_from_bits(const uint32_t
 
 #ifdef GG_AB_PROF
 // A/B builds only: shader-clock time of the phases of a ply as one wave experiences them (incl. waiting for the SIMD)
-__device__ unsigned long long gg_prof[8];
+static __device__ unsigned long long gg_prof[8];
 #define GG_PROF_DECL unsigned long long tph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc_ = clock64()
 #define GG_PROF(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); \
     const unsigned long long n_ = clock64(); __builtin_amdgcn_sched_barrier(0); tph_[k] += n_ - tc_; tc_ = n_; } while (0)

@@ -11,6 +11,9 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
+from gymgo_amd import _lib  # noqa: E402
+if os.environ.get('LIB'):      # A/B: another build of the library (path relative to the repo root), e.g. LIB=ab_libs/libgg_x.so
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.environ['LIB'])
 from gymgo_amd import gogame, state_utils  # noqa: E402
 
 PEAK = 8.0e12

@@ -2,7 +2,7 @@
 profiles/r01_ubench_valu_rates*.txt (2 cycles per wave64 instruction for v_and/or/xor/add/sub/lshrrev/bitop3/mov, 4 for the
 rest: v_bfrev, v_bcnt, v_cndmask, v_cmp, v_lshlrev, three-operand ops, DPP moves ...).
 
-    hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -S --cuda-device-only -o /tmp/gg.s gymgo_amd/csrc/gg_kernels.hip
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -mllvm -enable-post-misched=false -S --cuda-device-only -o /tmp/gg.s gymgo_amd/csrc/gg_rollout.hip
     python tools/isa_mix.py /tmp/gg.s > profiles/rNN_isa_mix.txt
 
 The ply loop is the longest stretch between two consecutive `v_mbcnt_lo` markers of k_rollout4<19, 0, false, true, false, false> (the kernel reads
