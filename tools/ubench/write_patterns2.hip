@@ -1,0 +1,68 @@
+// Microbenchmark (round 4): from the per-wave stream of write_patterns.hip (pattern B) towards what k_children3 does, one
+// step at a time - which step costs the bandwidth?  8 192 regions x 784 092 B, one single-wave workgroup per region.
+//   hipcc -O3 --offload-arch=gfx950 write_patterns2.hip -o write_patterns2 && ./write_patterns2
+//   R  regions of 783 360 B (1 KB multiples), LDS sized for W waves per CU, 4 stores (4 KB) per round
+//   S  the true regions: 784 092 B apart, written as 1 KB blocks aligned in absolute address (ragged ends skipped)
+//   T  S + a pause of `sleep` x 64 cycles after every 4 KB (a wave that derives children between its bursts)
+//   U  T with the pause filled by LDS traffic instead (8 table reads + 12 atomic ORs per 4 KB)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+struct __attribute__((aligned(16))) V16 { uint32_t w[4]; };
+constexpr int64_t REGION = 2166 * 362;
+template <int LDSB, bool TRUE_REGIONS, bool LDSWORK>
+__global__ __launch_bounds__(64) void kR(uint8_t *p, int64_t nregions, int sleep) {
+  __shared__ uint32_t pad[LDSB / 4];
+  if (LDSWORK) for (int i = threadIdx.x; i < LDSB / 4; i += 64) pad[i] = i * 0x9E3779B9u;
+  const V16 z = {{0, 0, 0, 0}};
+  uint32_t acc = 0;
+  for (int64_t r = blockIdx.x; r < nregions; r += gridDim.x) {
+    uint8_t *q; int64_t per;
+    if (TRUE_REGIONS) {
+      uint8_t *s = p + r * REGION, *e = s + REGION;
+      q = (uint8_t *)(((uintptr_t)s + 1023) & ~(uintptr_t)1023);
+      per = (((uintptr_t)e & ~(uintptr_t)1023) - (uintptr_t)q);
+    } else { per = (REGION / 1024) * 1024; q = p + r * per; }
+    for (int64_t o = 0; o + 4096 <= per; o += 4096) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *reinterpret_cast<V16 *>(q + o + k * 1024 + threadIdx.x * 16) = z;
+      if (LDSWORK) {
+        uint32_t x = (uint32_t)o + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const uint2 v = reinterpret_cast<const uint2 *>(pad)[(x * 2654435761u >> 24) & 255u]; x += v.x; acc ^= v.y; }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) atomicOr(&pad[512 + ((threadIdx.x * 19 + k * 361 + (uint32_t)o) >> 5 & 255u)], 1u << (threadIdx.x & 31));
+      }
+      for (int i = 0; i < sleep; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  if (LDSWORK && acc == 0x12345u) pad[0] = acc;
+  if (LDSB && pad[threadIdx.x] == 0xdeadbeefu) p[0] = 1;   // keep the array
+}
+template <class F> float timeit(F f) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  f(); hipDeviceSynchronize();
+  hipEventRecord(a); for (int i = 0; i < 5; ++i) f(); hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b); return ms / 5;
+}
+int main() {
+  const int64_t P = 8192, total = P * REGION;
+  uint8_t *p; hipMalloc(&p, total + 8192);
+  float t;
+#define RUN(name, ...) t = timeit([&] { __VA_ARGS__; }); printf("%-44s %6.3f ms %6.2f TB/s\n", name, t, total / t / 1e9);
+  for (int G : {3072, 4096, 8192}) {
+    char nm[96];
+    snprintf(nm, 96, "R 12 waves/CU G=%d", G); RUN(nm, kR<13312, false, false><<<G, 64>>>(p, P, 0));
+    snprintf(nm, 96, "R 16 waves/CU G=%d", G); RUN(nm, kR<10240, false, false><<<G, 64>>>(p, P, 0));
+    snprintf(nm, 96, "S 16 waves/CU true regions G=%d", G); RUN(nm, kR<10240, true, false><<<G, 64>>>(p, P, 0));
+  }
+  for (int sl : {8, 16, 32, 48, 64, 80}) {
+    char nm[96];
+    snprintf(nm, 96, "T 16 waves/CU G=8192 pause %d x 64 cycles", sl); RUN(nm, kR<10240, true, false><<<8192, 64>>>(p, P, sl));
+  }
+  for (int sl : {0, 16, 32}) {
+    char nm[96];
+    snprintf(nm, 96, "U 16 waves/CU G=8192 LDS work + pause %d", sl); RUN(nm, kR<10240, true, true><<<8192, 64>>>(p, P, sl));
+  }
+  return 0;
+}
