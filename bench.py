@@ -580,27 +580,26 @@ def extras(dev, back, opts):
     # the write-back of the other's.  What a self-play loop gets that ping-pongs two half-batches between inference and
     # stepping (a single launch that returns the observation of its own step cannot beat 37 - 39 us per 65 536 games)
     try:
-        half = count // 2
-        parts = []
-        for h in range(2):
-            sl = slice(h * half, (h + 1) * half)
-            parts.append((torch.cuda.Stream(device=dev), tracked[sl], rng[sl], obs[sl], tuple(t[sl] for t in env_out)))
+        from gymgo_amd.envs import GoVecEnvParts
+        halves = GoVecEnvParts(count, N, parts=2, komi=7.5, reward_method='real', device=dev)   # the product's form of it
+        for e, (lo, hi) in zip(halves.envs, halves.bounds):
+            e.tracked.copy_(tracked[lo:hi]); e.rng.copy_(rng[lo:hi])
         torch.cuda.synchronize(dev)
 
         def both(n):
             for _ in range(n):
-                for st_, tr_, rg_, ob_, eo_ in parts:
-                    with torch.cuda.stream(st_):
-                        gogame.batch_env_step_tracked(tr_, None, rg_, 7.5, 'real', True, out=eo_, states_out=ob_)
+                for h in range(2):
+                    halves.step_part(h)
         both(4)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         both(48)
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
-        out['gg_batch_env_step_two_half_batches_two_streams_steps_per_s'] = round(48 * 2 * half / dt, 1)
+        out['gg_batch_env_step_two_half_batches_two_streams_steps_per_s'] = round(48 * count / dt, 1)
         out['gg_batch_env_step_two_half_batches_us_per_full_step'] = round(dt / 48 * 1e6, 2)
-        del parts
+        out['gg_batch_env_step_two_half_batches_note'] = 'GoVecEnvParts(parts=2).step_part: each half on its own stream, free-running'
+        del halves
     except Exception as e:
         out['gg_batch_env_step_two_half_batches_note'] = 'failed: %s' % (str(e)[:160],)
     # the headline's launch on boards that STAY in the tracked format (GoVecEnv.rollout, gg_batch_rollout_tracked): no first

@@ -23,7 +23,7 @@ def _register_if_gym_present():
 
 _register_if_gym_present()
 
-__all__ = ['govars', 'gogame', 'state_utils', 'envs', 'GoEnv', 'GoVecEnv', 'make', 'register_gym']
+__all__ = ['govars', 'gogame', 'state_utils', 'envs', 'GoEnv', 'GoVecEnv', 'GoVecEnvParts', 'make', 'register_gym']
 
 
 def __getattr__(name):
@@ -31,6 +31,6 @@ def __getattr__(name):
     import importlib
     if name in ('gogame', 'state_utils', 'envs', '_lib'):
         return importlib.import_module('gymgo_amd.' + name)
-    if name in ('GoEnv', 'GoVecEnv', 'make', 'register_gym'):
+    if name in ('GoEnv', 'GoVecEnv', 'GoVecEnvParts', 'make', 'register_gym'):
         return getattr(importlib.import_module('gymgo_amd.envs'), name)
     raise AttributeError(name)

@@ -6,7 +6,7 @@ one of them is importable, so `gym.make('gymgo_amd:go-v0', size=19)` works; `mak
 """
 from gymgo_amd.envs import spaces  # noqa: F401
 from gymgo_amd.envs.go_env import GoEnv, RewardMethod  # noqa: F401
-from gymgo_amd.envs.vec_env import GoVecEnv  # noqa: F401
+from gymgo_amd.envs.vec_env import GoVecEnv, GoVecEnvParts  # noqa: F401
 
 ENV_IDS = {'go-v0': GoEnv}
 

@@ -194,3 +194,96 @@ class GoVecEnv:
 
     def turns(self):
         return self.states[:, govars.TURN_CHNL, 0, 0]
+
+
+class GoVecEnvParts:
+    """The games of a GoVecEnv as `parts` (default 2) sub-batches, each stepping on a HIP stream of its own.
+
+    A step launch has a head (launch, board load, the ply: little memory traffic) and a tail (the observation
+    write-back: nothing but memory traffic); one launch over the whole batch runs them one after the other on every CU at
+    the same time.  Two half-batches that step independently put the head of one under the tail of the other
+    (bench.py `gg_batch_env_step_two_half_batches_*`: 65 536 games of 19x19 step in ~34 us instead of ~39).  That is also
+    the shape of a self-play loop: while the policy network evaluates one half's observation, the other half steps.
+
+        env = GoVecEnvParts(65536, 19)
+        env.step_part(0); env.step_part(1)                 # both halves in flight
+        while True:
+            for h in range(env.parts):
+                obs, rewards, dones, status = env.wait(h)       # the caller's stream now sees part h's step
+                probs = policy(obs)                             # caller's stream
+                env.step_part(h, probs=probs)                   # queued behind `policy` on part h's stream
+
+    The games are the games of ONE GoVecEnv(batch_size, ...): part h holds the games [first(h), first(h) + count(h)) of
+    the contiguous split `shard` makes, seeded by their global index - stepping the parts in any interleaving walks the
+    same games as the single env (tests/test_gpu_env.py).  Ordering: step_part(h) starts after everything queued so far on
+    the caller's current stream (its inputs are ready, readers of part h's previous outputs are done) and after part h's
+    own previous step; the tensors it returns are part h's fixed buffers, valid on the caller's stream after wait(h).
+    Inside a hipGraph capture the parts' streams fork from and join the capturing stream (wait every part stepped
+    before the capture ends)."""
+
+    def __init__(self, batch_size, size, parts=2, first_game=0, device=None, **kwargs):
+        if parts < 1 or parts > max(1, batch_size):
+            raise ValueError('parts must be in [1, batch_size]')
+        self.batch_size, self.size, self.parts = batch_size, size, parts
+        self.device = torch.device(device) if device is not None else gogame._device()
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(parts)]
+        self.envs, self.bounds = [], []
+        for h in range(parts):
+            first, count = shard(batch_size, h, parts)
+            self.bounds.append((first, first + count))
+            # (the part's buffers are allocated on the part's stream: the caching allocator ties them to it)
+            with torch.cuda.stream(self.streams[h]):
+                self.envs.append(GoVecEnv(count, size, device=self.device, first_game=first_game + first, **kwargs))
+        self._done = [torch.cuda.Event() for _ in range(parts)]
+        self._last = [None] * parts
+        torch.cuda.current_stream(self.device).wait_stream(self.streams[-1])
+        for s in self.streams[:-1]:
+            torch.cuda.current_stream(self.device).wait_stream(s)
+
+    def step_part(self, h, actions=None, probs=None, check=False):
+        """Queue GoVecEnv.step of part h on its stream, behind the caller's current stream.  Returns part h's
+        (states, rewards, dones, status) buffers - read them after wait(h)."""
+        cur, s = torch.cuda.current_stream(self.device), self.streams[h]
+        s.wait_stream(cur)
+        for t in (actions, probs):
+            if t is not None and t.is_cuda:
+                t.record_stream(s)
+        with torch.cuda.stream(s):
+            self._last[h] = self.envs[h].step(actions, check=check, probs=probs)
+            self._done[h].record(s)
+        return self._last[h]
+
+    def wait(self, h):
+        """The caller's current stream waits for part h's last step; returns that step's buffers (None before the first)."""
+        torch.cuda.current_stream(self.device).wait_event(self._done[h])
+        return self._last[h]
+
+    def step(self, actions=None, probs=None, check=False):
+        """Every part steps (actions / probs are split along the game axis), the caller's stream waits for all of them:
+        the lock-step form, for code that wants one call - the overlap between parts is then limited to this one step."""
+        outs = []
+        for h, (lo, hi) in enumerate(self.bounds):
+            self.step_part(h, None if actions is None else actions[lo:hi], None if probs is None else probs[lo:hi], check)
+        for h in range(self.parts):
+            outs.append(self.wait(h))
+        return outs
+
+    def rollout_part(self, h, plies):
+        cur, s = torch.cuda.current_stream(self.device), self.streams[h]
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            out = self.envs[h].rollout(plies)
+            self._done[h].record(s)
+        return out
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def gather(self, name):
+        """torch.cat of an attribute of the parts (`states`, `rng`, `steps_done`, `last_actions`, `tracked` ...), on the
+        caller's stream after waiting for every part."""
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            cur.wait_stream(s)
+        return torch.cat([getattr(e, name) for e in self.envs])

@@ -285,3 +285,81 @@ def test_symmetries_and_helpers_on_device_tensors():
     assert int(libs_b.sum()) == int(nb) and int(libs_w.sum()) == int(nw)
     empties = (host[0] + host[1]) == 0
     assert not (libs_b & ~empties).any() and not (libs_w & ~empties).any()
+
+
+def _cat_step(outs):
+    return [torch.cat([o[i] for o in outs]) for i in range(4)]
+
+
+@pytest.mark.parametrize('layout,B,parts', [('tracked', 4096, 2), ('tracked', 1001, 3), ('bytes', 515, 2), ('packed', 700, 4)])
+def test_vecenv_parts_walk_the_same_games_as_one_env(layout, B, parts):
+    """GoVecEnvParts: the sub-batches step on streams of their own, in lock-step (step) or each at its own pace
+    (step_part / wait), and are the games of ONE GoVecEnv - same boards, generators, rewards, move counts - with
+    device-drawn moves, given moves and policy weights."""
+    from gymgo_amd.envs import GoVecEnv, GoVecEnvParts
+    N = 9
+    kw = dict(komi=0.5, reward_method='heuristic', seed=11, layout=layout)
+    one, many = GoVecEnv(B, N, **kw), GoVecEnvParts(B, N, parts=parts, **kw)
+    assert [hi - lo for lo, hi in many.bounds] == [e.batch_size for e in many.envs] and many.bounds[-1][1] == B
+    one.rollout(30)
+    for h in range(parts):
+        many.rollout_part(h, 30)
+    assert torch.equal(many.gather('states'), one.states) and torch.equal(many.gather('rng'), one.rng)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    for k in range(6):
+        if k % 3 == 0:
+            kwargs = {}
+        elif k % 3 == 1:
+            kwargs = {'probs': torch.rand((B, N * N + 1), device='cuda', generator=g) ** 4}
+        else:
+            kwargs = {'actions': one.sample_actions().clone()}   # (drawn from a COPY of the generators below)
+            one.rng.copy_(many.gather('rng'))
+        want = [t.clone() for t in one.step(**kwargs)]
+        got = _cat_step(many.step(**kwargs))
+        for w, t in zip(want, got):
+            assert torch.equal(w, t)
+        assert torch.equal(many.gather('rng'), one.rng) and torch.equal(many.gather('last_actions'), one.last_actions)
+    assert torch.equal(many.gather('steps_done'), one.steps_done)
+    # each part at its own pace: three steps of part 0 before part 1 has made any
+    order = [h for h in range(parts) for _ in range(3)]
+    for h in order:
+        many.step_part(h)
+    for _ in range(3):
+        one.step()
+    assert torch.equal(many.gather('states'), one.states) and torch.equal(many.gather('rng'), one.rng)
+    assert torch.equal(many.gather('steps_done'), one.steps_done)
+    last = [many.wait(h) for h in range(parts)]
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([o[1] for o in last]), one._step_out[0])
+
+
+def test_vecenv_parts_step_captured_in_hipgraph():
+    """The parts' streams fork from and join the capturing stream: K lock-step rounds of a two-part env replay as one
+    hipGraph and land where the fused rollout lands."""
+    from gymgo_amd import gogame
+    from gymgo_amd.envs import GoVecEnvParts
+    B, N, K = 4096, 9, 8
+    env = GoVecEnvParts(B, N, parts=2, komi=0.5, seed=3)
+    for h in range(2):
+        env.rollout_part(h, 25)
+    s0, r0 = env.gather('states').clone(), env.gather('rng').clone()
+    env.step()                                 # warm-up outside the capture
+    torch.cuda.synchronize()
+
+    def restore():
+        for e, (lo, hi) in zip(env.envs, env.bounds):
+            e.states = s0[lo:hi].clone(); e.rng.copy_(r0[lo:hi])
+    restore()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(K):
+            outs = env.step()
+    restore()
+    torch.cuda.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
+    want, wr = s0.clone(), r0.clone()
+    gogame.batch_rollout(want, wr, K, True)
+    assert torch.equal(env.gather('states'), want) and torch.equal(env.gather('rng'), wr)
+    assert int(torch.cat([o[3] for o in outs]).sum()) == 0
