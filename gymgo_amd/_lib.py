@@ -6,6 +6,7 @@ current HIP stream; every entry point of include/gymgo_amd.h is bound here with 
 """
 import ctypes
 import os
+import threading
 
 import torch  # must be imported before the library so both share ONE HIP runtime (libamdhip64.so.7)
 
@@ -103,9 +104,74 @@ def check(code, what):
             what, code, 'bad argument' if code < 0 else 'hipError_t'))
 
 
+_stream_override = threading.local()   # .raw: a hipStream_t that replaces torch's current stream (GoVecEnvParts)
+
+
 def stream_ptr(device=None):
-    """torch's current stream on `device` as a hipStream_t: launches go where the caller's torch work goes."""
-    return torch.cuda.current_stream(device).cuda_stream
+    """torch's current stream on `device` as a hipStream_t: launches go where the caller's torch work goes.  (A
+    GoVecEnvParts sub-batch steps on its own stream: it names that stream here for the duration of its call instead of
+    switching torch's current stream, which costs more host time than the launch.)"""
+    raw = getattr(_stream_override, 'raw', None)
+    if raw is not None:
+        return raw
+    return current_raw_stream(device)
+
+
+def current_raw_stream(device=None):
+    """hipStream_t of torch's current stream on `device` (an int; 0 = the null stream)."""
+    try:
+        idx = device.index if isinstance(device, torch.device) else device
+        return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
+    except (AttributeError, TypeError):   # an older / newer torch without the raw getter
+        return torch.cuda.current_stream(device).cuda_stream
+
+
+class stream_override:
+    """with stream_override(raw): every launch of this thread goes to the hipStream_t `raw`."""
+
+    def __init__(self, raw):
+        self.raw = raw
+
+    def __enter__(self):
+        self.prev = getattr(_stream_override, 'raw', None)
+        _stream_override.raw = self.raw
+
+    def __exit__(self, *exc):
+        _stream_override.raw = self.prev
+
+
+_hip = None
+
+
+def hip_runtime():
+    """The HIP runtime torch and the library already share, bound for the three stream-ordering calls GoVecEnvParts
+    makes per step (torch's Stream.wait_stream creates and destroys an event per call: 8 us of host time against 2)."""
+    global _hip
+    if _hip is None:
+        H = None
+        for name in ('libamdhip64.so.7', 'libamdhip64.so'):
+            try:
+                H = ctypes.CDLL(name)
+                break
+            except OSError:
+                continue
+        if H is None:
+            raise GymGoNativeError('libamdhip64.so not found (it is loaded with torch)')
+        H.hipEventCreateWithFlags.argtypes, H.hipEventCreateWithFlags.restype = [ctypes.POINTER(_vp), ctypes.c_uint], _i32
+        H.hipEventRecord.argtypes, H.hipEventRecord.restype = [_vp, _vp], _i32
+        H.hipStreamWaitEvent.argtypes, H.hipStreamWaitEvent.restype = [_vp, _vp, ctypes.c_uint], _i32
+        H.hipEventDestroy.argtypes, H.hipEventDestroy.restype = [_vp], _i32
+        H.hipStreamQuery.argtypes, H.hipStreamQuery.restype = [_vp], _i32
+        H.hipStreamIsCapturing.argtypes, H.hipStreamIsCapturing.restype = [_vp, ctypes.POINTER(ctypes.c_int)], _i32
+        _hip = H
+    return _hip
+
+
+def hip_event():
+    """A HIP event without timing (usable inside a stream capture)."""
+    ev = _vp()
+    check(hip_runtime().hipEventCreateWithFlags(ctypes.byref(ev), 2), 'hipEventCreateWithFlags')   # hipEventDisableTiming
+    return ev
 
 
 def dev_ptr(t, dtype, name):

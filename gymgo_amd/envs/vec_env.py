@@ -202,7 +202,7 @@ class GoVecEnvParts:
     A step launch has a head (launch, board load, the ply: little memory traffic) and a tail (the observation
     write-back: nothing but memory traffic); one launch over the whole batch runs them one after the other on every CU at
     the same time.  Two half-batches that step independently put the head of one under the tail of the other
-    (bench.py `gg_batch_env_step_two_half_batches_*`: 65 536 games of 19x19 step in ~34 us instead of ~39).  That is also
+    (bench.py `gg_batch_env_step_two_half_batches_*`: 65 536 games of 19x19 step in 32 - 34 us instead of 38 - 39).  That is also
     the shape of a self-play loop: while the policy network evaluates one half's observation, the other half steps.
 
         env = GoVecEnvParts(65536, 19)
@@ -226,7 +226,17 @@ class GoVecEnvParts:
             raise ValueError('parts must be in [1, batch_size]')
         self.batch_size, self.size, self.parts = batch_size, size, parts
         self.device = torch.device(device) if device is not None else gogame._device()
+        from gymgo_amd import _lib
+        self._lib = _lib
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(parts)]
+        self._raw = [s.cuda_stream for s in self.streams]
+        self._hip = _lib.hip_runtime()
+        # per part: "the caller's stream up to here" (fork) and "the part's last step" (done), re-recorded every step
+        self._fork = [_lib.hip_event() for _ in range(parts)]
+        self._done = [_lib.hip_event() for _ in range(parts)]
+        import ctypes
+        self._cap = ctypes.c_int(0)
+        self._cap_ref = ctypes.byref(self._cap)
         self.envs, self.bounds = [], []
         for h in range(parts):
             first, count = shard(batch_size, h, parts)
@@ -234,29 +244,59 @@ class GoVecEnvParts:
             # (the part's buffers are allocated on the part's stream: the caching allocator ties them to it)
             with torch.cuda.stream(self.streams[h]):
                 self.envs.append(GoVecEnv(count, size, device=self.device, first_game=first_game + first, **kwargs))
-        self._done = [torch.cuda.Event() for _ in range(parts)]
         self._last = [None] * parts
         torch.cuda.current_stream(self.device).wait_stream(self.streams[-1])
         for s in self.streams[:-1]:
             torch.cuda.current_stream(self.device).wait_stream(s)
 
+    def _fork_part(self, h):
+        """Part h's stream waits for everything queued so far on the caller's current stream - unless that stream is
+        idle (then everything on it HAS happened): an event pair per step is a marker in one hardware queue and a
+        barrier in the other, microseconds of GPU time that would eat what the parts gain.  (Inside a stream capture
+        the stream must not be queried: the fork is always recorded, it becomes an edge of the graph.)"""
+        H, cur = self._hip, self._lib.current_raw_stream(self.device)
+        H.hipStreamIsCapturing(cur, self._cap_ref)
+        if self._cap.value == 0 and H.hipStreamQuery(cur) == 0:
+            return
+        H.hipEventRecord(self._fork[h], cur)
+        H.hipStreamWaitEvent(self._raw[h], self._fork[h], 0)
+
     def step_part(self, h, actions=None, probs=None, check=False):
         """Queue GoVecEnv.step of part h on its stream, behind the caller's current stream.  Returns part h's
         (states, rewards, dones, status) buffers - read them after wait(h)."""
-        cur, s = torch.cuda.current_stream(self.device), self.streams[h]
-        s.wait_stream(cur)
-        for t in (actions, probs):
-            if t is not None and t.is_cuda:
-                t.record_stream(s)
-        with torch.cuda.stream(s):
-            self._last[h] = self.envs[h].step(actions, check=check, probs=probs)
-            self._done[h].record(s)
+        env = self.envs[h]
+        # conversions of the inputs (if any) are torch work on the CALLER's stream: done before the fork
+        if actions is not None:
+            actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        if probs is not None:
+            probs = gogame._weights_tensor(probs, env.batch_size, self.size, self.device)[0]
+        self._fork_part(h)
+        if env.layout == 'tracked' and not check:
+            # no torch work inside this step (fixed buffers only): the launch is simply sent to the part's stream
+            for t in (actions, probs):
+                if t is not None and t.is_cuda:
+                    t.record_stream(self.streams[h])
+            with self._lib.stream_override(self._raw[h]):
+                self._last[h] = env.step(actions, probs=probs)
+        else:
+            for t in (actions, probs):
+                if t is not None and t.is_cuda:
+                    t.record_stream(self.streams[h])
+            with torch.cuda.stream(self.streams[h]):
+                self._last[h] = env.step(actions, check=check, probs=probs)
         return self._last[h]
 
     def wait(self, h):
-        """The caller's current stream waits for part h's last step; returns that step's buffers (None before the first)."""
-        torch.cuda.current_stream(self.device).wait_event(self._done[h])
+        """The caller's current stream waits for everything queued on part h's stream - its last step; returns that
+        step's buffers (None before the first).  (The event is recorded here, not by the step: a loop that never waits
+        puts no markers between its launches.)"""
+        self._hip.hipEventRecord(self._done[h], self._raw[h])
+        self._hip.hipStreamWaitEvent(self._lib.current_raw_stream(self.device), self._done[h], 0)
         return self._last[h]
+
+    def ready(self, h):
+        """True when everything queued on part h's stream has finished (a host-side poll, no synchronisation)."""
+        return self._hip.hipStreamQuery(self._raw[h]) == 0
 
     def step(self, actions=None, probs=None, check=False):
         """Every part steps (actions / probs are split along the game axis), the caller's stream waits for all of them:
@@ -269,12 +309,17 @@ class GoVecEnvParts:
         return outs
 
     def rollout_part(self, h, plies):
-        cur, s = torch.cuda.current_stream(self.device), self.streams[h]
-        s.wait_stream(cur)
-        with torch.cuda.stream(s):
+        self._fork_part(h)
+        with torch.cuda.stream(self.streams[h]):
             out = self.envs[h].rollout(plies)
-            self._done[h].record(s)
         return out
+
+    def __del__(self):
+        try:
+            for ev in self._fork + self._done:
+                self._hip.hipEventDestroy(ev)
+        except Exception:
+            pass
 
     def synchronize(self):
         for s in self.streams:

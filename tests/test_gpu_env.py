@@ -330,6 +330,7 @@ def test_vecenv_parts_walk_the_same_games_as_one_env(layout, B, parts):
     assert torch.equal(many.gather('steps_done'), one.steps_done)
     last = [many.wait(h) for h in range(parts)]
     torch.cuda.synchronize()
+    assert all(many.ready(h) for h in range(parts))
     assert torch.equal(torch.cat([o[1] for o in last]), one._step_out[0])
 
 
