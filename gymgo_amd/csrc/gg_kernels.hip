@@ -14,9 +14,9 @@
 #include <atomic>
 #include <mutex>
 #include <unordered_map>
+#include <stdlib.h>   // getenv: GYMGO_AMD_CUS (below); the GG_AB_* tuning overrides exist in A/B builds (make ab) only
 #ifdef GG_AB
 #include <stdio.h>
-#include <stdlib.h>   // A/B builds only (make ab): tuning overrides read from the environment; never in the shipped library
 #endif
 
 #include "gg_common.h"
@@ -42,7 +42,21 @@ constexpr int kMaxDevices = 64;
 std::atomic<int> g_cus[kMaxDevices];   // 0 = not queried yet; racing first callers all store the same value (relaxed atomics:
                                        // round 4's ThreadSanitizer pass flagged the plain ints this used to be)
 
+// GYMGO_AMD_CUS=<n> (read once per process): size every grid, batch split and kernel choice for n compute units instead of
+// the device's own count - a partition of the GPU (CPX / TPX), a GPU shared with other work, and tests/test_gpu_cus.py, which
+// runs the entry points for 8 ... 1 024 units and expects bit-identical results (no kernel waits for a co-resident workgroup,
+// so a grid larger than the device is merely queued).
+int forced_cus() {
+  static const int forced = [] {
+    const char *e = getenv("GYMGO_AMD_CUS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 && v <= 4096 ? v : 0;
+  }();
+  return forced;
+}
+
 int cus_of(int dev) {
+  if (const int f = forced_cus()) return f;
   if (dev < 0 || dev >= kMaxDevices) return 256;
   int c = g_cus[dev].load(std::memory_order_relaxed);
   if (c <= 0) {
@@ -296,6 +310,7 @@ int32_t gg_ab_where_read(unsigned int *out, int n) {
 int32_t gg_version(void) { return GG_ABI_VERSION; }
 
 int32_t gg_device_cus(void) {
+  if (const int f = forced_cus()) return f;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
   int c = 0;

@@ -62,7 +62,9 @@ extern "C" {
 
 int32_t gg_version(void);
 
-/* Number of compute units of the calling thread's current device (0 if no device) - lets the host mirror size grids. */
+/* Number of compute units the library sizes its grids for: those of the calling thread's current device (0 if no device),
+   or the value of the environment variable GYMGO_AMD_CUS (1 ... 4096, read once per process) - for a partition of the GPU
+   or a GPU shared with other work.  Results never depend on it (tests/test_gpu_cus.py). */
 int32_t gg_device_cus(void);
 
 /*
