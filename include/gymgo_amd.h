@@ -11,8 +11,8 @@
  *     (0 black, 1 white, 2 turn, 3 invalid moves for the side to move, 4 previous move was a pass,
  *     5 game over).  Planes 2, 4 and 5 are uniform by construction (the reference only ever writes
  *     them whole: gym_go/gogame.py:49-56, gym_go/state_utils.py:241); the kernels read one byte of each.
- *   - Every pointer is a DEVICE pointer owned by the caller; the library allocates nothing, reads no environment
- *     variable and never synchronises: work is enqueued on `hip_stream` (a hipStream_t of the device that owns the
+ *   - Every pointer is a DEVICE pointer owned by the caller; the library allocates nothing, reads one environment
+ *     variable (GYMGO_AMD_CUS, see gg_device_cus: performance only) and never synchronises: work is enqueued on `hip_stream` (a hipStream_t of the device that owns the
  *     buffers, NULL = its default stream) and the call returns immediately.  The kernels run on the device that owns
  *     the first buffer argument, whatever the calling thread's current device is (it is restored before the call
  *     returns).
