@@ -39,6 +39,32 @@ __global__ __launch_bounds__(64) void kR(uint8_t *p, int64_t nregions, int sleep
   if (LDSWORK && acc == 0x12345u) pad[0] = acc;
   if (LDSB && pad[threadIdx.x] == 0xdeadbeefu) p[0] = 1;   // keep the array
 }
+// V / W: the split VERDICT r3 proposed for the children kernel - the all-zero slots of the illegal moves as a tile-ordered
+// fill (V: K's 4 KB tiles, a vector is written iff the slot of its first byte is "illegal"), the legal children as per-wave
+// streams that skip the zero blocks (W: S, a 1 KB block is written iff it overlaps a legal slot).  `pz` = percent of illegal
+// slots (hash of the slot index); V + W against S writing everything.
+__device__ __forceinline__ bool slot_illegal(int64_t slot, int pz) {
+  return (int)(((unsigned long long)slot * 0x9E3779B97F4A7C15ull >> 40) % 100ull) < pz;
+}
+__global__ __launch_bounds__(256) void kV(uint8_t *p, int64_t total, int pz) {
+  const V16 z = {{0, 0, 0, 0}};
+  const int64_t o = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  if (o + 16 <= total && slot_illegal(o / 2166, pz)) *reinterpret_cast<V16 *>(p + o) = z;
+}
+__global__ __launch_bounds__(64) void kW(uint8_t *p, int64_t nregions, int pz) {
+  __shared__ uint32_t pad[10240 / 4];
+  const V16 z = {{0, 0, 0, 0}};
+  for (int64_t r = blockIdx.x; r < nregions; r += gridDim.x) {
+    uint8_t *s = p + r * REGION, *e = s + REGION;
+    uint8_t *q = (uint8_t *)(((uintptr_t)s + 1023) & ~(uintptr_t)1023);
+    const int64_t per = (((uintptr_t)e & ~(uintptr_t)1023) - (uintptr_t)q);
+    for (int64_t o = 0; o + 1024 <= per; o += 1024) {
+      const int64_t b0 = (q + o) - p, s0 = b0 / 2166, s1 = (b0 + 1023) / 2166;
+      if (!slot_illegal(s0, pz) || !slot_illegal(s1, pz)) *reinterpret_cast<V16 *>(q + o + threadIdx.x * 16) = z;
+    }
+  }
+  if (pad[threadIdx.x] == 0xdeadbeefu) p[0] = 1;
+}
 template <class F> float timeit(F f) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   f(); hipDeviceSynchronize();
@@ -63,6 +89,17 @@ int main() {
   for (int sl : {0, 16, 32}) {
     char nm[96];
     snprintf(nm, 96, "U 16 waves/CU G=8192 LDS work + pause %d", sl); RUN(nm, kR<10240, true, true><<<8192, 64>>>(p, P, sl));
+  }
+  for (int pz : {6, 45, 72}) {
+    char nm[96];
+    const unsigned nt = (unsigned)((total + 4095) / 4096);
+    float tv, tw, tb;
+    tv = timeit([&] { kV<<<nt, 256>>>(p, total, pz); });
+    tw = timeit([&] { kW<<<8192, 64>>>(p, P, pz); });
+    tb = timeit([&] { kV<<<nt, 256>>>(p, total, pz); kW<<<8192, 64>>>(p, P, pz); });
+    snprintf(nm, 96, "V fill of %d %% illegal slots", pz); printf("%-44s %6.3f ms\n", nm, tv);
+    snprintf(nm, 96, "W streams of the other %d %%", 100 - pz); printf("%-44s %6.3f ms\n", nm, tw);
+    snprintf(nm, 96, "V then W, one stream"); printf("%-44s %6.3f ms %6.2f TB/s\n", nm, tb, total / tb / 1e9);
   }
   return 0;
 }
