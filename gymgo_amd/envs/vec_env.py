@@ -232,8 +232,9 @@ class GoVecEnvParts:
         self._raw = [s.cuda_stream for s in self.streams]
         self._hip = _lib.hip_runtime()
         # per part: "the caller's stream up to here" (fork) and "the part's last step" (done), re-recorded every step
-        self._fork = [_lib.hip_event() for _ in range(parts)]
-        self._done = [_lib.hip_event() for _ in range(parts)]
+        with torch.cuda.device(self.device):       # (an event belongs to the device that is current when it is created)
+            self._fork = [_lib.hip_event() for _ in range(parts)]
+            self._done = [_lib.hip_event() for _ in range(parts)]
         import ctypes
         self._cap = ctypes.c_int(0)
         self._cap_ref = ctypes.byref(self._cap)
@@ -258,8 +259,8 @@ class GoVecEnvParts:
         H.hipStreamIsCapturing(cur, self._cap_ref)
         if self._cap.value == 0 and H.hipStreamQuery(cur) == 0:
             return
-        H.hipEventRecord(self._fork[h], cur)
-        H.hipStreamWaitEvent(self._raw[h], self._fork[h], 0)
+        self._lib.check(H.hipEventRecord(self._fork[h], cur) or H.hipStreamWaitEvent(self._raw[h], self._fork[h], 0),
+                        'GoVecEnvParts fork (hipEventRecord / hipStreamWaitEvent)')
 
     def step_part(self, h, actions=None, probs=None, check=False):
         """Queue GoVecEnv.step of part h on its stream, behind the caller's current stream.  Returns part h's
@@ -290,8 +291,12 @@ class GoVecEnvParts:
         """The caller's current stream waits for everything queued on part h's stream - its last step; returns that
         step's buffers (None before the first).  (The event is recorded here, not by the step: a loop that never waits
         puts no markers between its launches.)"""
-        self._hip.hipEventRecord(self._done[h], self._raw[h])
-        self._hip.hipStreamWaitEvent(self._lib.current_raw_stream(self.device), self._done[h], 0)
+        H, cur = self._hip, self._lib.current_raw_stream(self.device)
+        H.hipStreamIsCapturing(cur, self._cap_ref)
+        if self._cap.value == 0 and H.hipStreamQuery(self._raw[h]) == 0:
+            return self._last[h]            # the part has finished: there is nothing left to order
+        self._lib.check(H.hipEventRecord(self._done[h], self._raw[h]) or H.hipStreamWaitEvent(cur, self._done[h], 0),
+                        'GoVecEnvParts wait (hipEventRecord / hipStreamWaitEvent)')
         return self._last[h]
 
     def ready(self, h):
