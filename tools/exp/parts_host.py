@@ -60,3 +60,21 @@ for parts in (2, 3, 4):
     for name, f in (('free-running', free), ('wait(h) before every step_part(h)', pingpong)):
         h_us, g_us = rate(f, 200)
         print('%d parts, %-34s host %.1f us per full step, with GPU %.1f us -> %.3e steps/s' % (parts, name, h_us, g_us, 65536 / g_us * 1e6))
+# policy-weighted steps (bfloat16 / float32 weights): one env against two free-running parts
+for dt in (torch.bfloat16, torch.float32):
+    B = 65536
+    w = (torch.rand((B, 362), device='cuda') ** 4).to(dt)
+    e1 = GoVecEnv(B, 19); e1.rollout(100)
+    h_us, g1 = rate(lambda: e1.step(probs=w), 200)
+    h_us, g0 = rate(lambda: e1.step(), 200)
+    p = GoVecEnvParts(B, 19, parts=2)
+    for h in range(2):
+        p.rollout_part(h, 100)
+    ws = [w[lo:hi] for lo, hi in p.bounds]
+    def both_w():
+        p.step_part(0, probs=ws[0]); p.step_part(1, probs=ws[1])
+    def both_u():
+        p.step_part(0); p.step_part(1)
+    h_us, g2 = rate(both_w, 200)
+    h_us, g3 = rate(both_u, 200)
+    print('%s weights: one env %.1f us (uniform %.1f: x%.2f); two parts %.1f us (uniform %.1f: x%.2f)' % (dt, g1, g0, g0 / g1, g2, g3, g3 / g2))
