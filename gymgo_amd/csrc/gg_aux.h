@@ -190,11 +190,16 @@ struct LdsAreas {
   static constexpr int kVec = (2 * R * R + 15 + 15) / 16 + 1;                     // 16-byte vectors covering planes 0 / 1 at any alignment
   static constexpr int kStageBoard = kVec * 16;
   static constexpr int kPerLane = (kHalf * kVec + kWave - 1) / kWave;             // vectors per lane and half
+  // The staging area is free once the boards are packed: the converged floods (32 lanes x kRS words) and the rows the idle
+  // upper half of the wave writes (another 32 x kRS) take its place.  (Round 4: they had 2 560 B of their own at 19x19 -
+  // 11 264 B per workgroup, 14 waves per CU, so 512 of the 4 096 workgroups of a 65 536-board call ran as a second round.)
+  static constexpr int kBlocks = 2 * kBoards * kRS;                               // words of one set of 32 flood outputs
   static constexpr int kStage = 0;                                                // bytes: kHalf * kStageBoard
-  static constexpr int kSt = (kHalf * kStageBoard + 3) / 4;                       // words: [2][kBoards][kRS] stone rows
-  static constexpr int kSc = kSt + 2 * kBoards * kRS;                             // words: [32][kRS] converged floods
-  static constexpr int kTotal = kSc + 2 * kBoards * kRS;
-  static_assert(kHalf * kStageBoard >= 4 * 2 * kBoards * kRS, "the staging area doubles as the idle lanes' flood output");
+  static constexpr int kFront = (kHalf * kStageBoard + 3) / 4 > 2 * kBlocks ? (kHalf * kStageBoard + 3) / 4 : 2 * kBlocks;
+  static constexpr int kSc = 0;                                                   // words: [32][kRS] converged floods
+  static constexpr int kIdle = kBlocks;                                           // words: the idle lanes' rows
+  static constexpr int kSt = (kFront + 3) & ~3;                                   // words: [2][kBoards][kRS] stone rows
+  static constexpr int kTotal = kSt + kBlocks;
 };
 
 template <int R, bool FULLN>
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(kWave) void k_areas4(const uint8_t *__restrict__ st
   WAVE_SYNC();
   // ---- lane 2 s + c floods the empty points of board s from the neighbours of colour c (the idle upper half's rows go
   // to the staging area, which is free by now)
-  const uint32_t cnt = areas16<R, FULLN>(st, sc, lds, N, lane);
+  const uint32_t cnt = areas16<R, FULLN>(st, sc, lds + L::kIdle, N, lane);
   const int s = lane >> 1, c = lane & 1;
   if (lane < 2 * L::kBoards && b_first + s < B) (c ? white_area : black_area)[b_first + s] = (int32_t)cnt;
 }
