@@ -705,6 +705,18 @@ def extras(dev, back, opts):
             'roofline': {'bound': 'hbm', 'kernel': 'k_children3<19, false>', 'algorithmic_bytes_per_parent': bytes_per_parent,
                          'achieved': round(bytes_per_parent * r / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(bytes_per_parent * r / 1e9 / HBM_PEAK_GBS, 4)}}
+        # HBM bytes of this launch from the committed counter passes (tools/calib_traffic.py under rocprofv3 --pmc), tied to
+        # the kernel's machine code like the fused kernel's record
+        try:
+            crec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_rollout.json'))).get('children') or {}
+            chash = kernel_code_hash('_ZN2gg11k_children3ILi19ELb0EEE')
+            stale = crec.get('kernel_code_sha16') != chash
+            configs['config5_children_8192_parents']['roofline'].update({
+                'traffic': None if stale else crec.get('hbm_bytes_per_launch'),
+                'algorithmic_bytes_per_launch': bytes_per_parent * 8192, 'kernel_code_sha16': chash,
+                'pmc_kernel_code_sha16': crec.get('kernel_code_sha16'), 'pmc_stale': stale, 'pmc_source': crec.get('source')})
+        except Exception:
+            configs['config5_children_8192_parents']['roofline']['traffic'] = None
         # the same expansion for parents of ONE game phase each (the floods run over the empty points next to a stone,
         # the 362 slots are written whatever the position: the rate barely depends on the phase)
         by_phase = {}

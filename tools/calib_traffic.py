@@ -24,4 +24,10 @@ for _ in range(8):
     pk2 = gogame.batch_pack(st2)
 torch.cuda.synchronize()
 assert torch.equal(st2, st) and torch.equal(pk2, pk)
+# config 5's launch under the same counters: 8 192 parents (the stationary mix) x 362 slots, 786 258 B per parent by the
+# algorithm (1 444 B read, 362 x 2 166 B written) - tools/summarize_profiles.py sets the counters against that
+kids = torch.empty((8192, N * N + 1, 6, N, N), dtype=torch.uint8, device='cuda')
+for _ in range(4):
+    gogame.batch_children(st[:8192], out=kids)
+torch.cuda.synchronize()
 print('calib ok')
