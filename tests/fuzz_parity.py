@@ -4,8 +4,8 @@
     python tests/fuzz_parity.py [seconds=120] [seed=1]
 
 Every round draws a board size (2 .. 19), a batch, a layout, a launch length and a mix of game phases, then walks the same
-games on the device (fused rollouts in one to three launches, one env step with rewards, next_states with drawn - partly
-illegal - moves, children of a few parents, areas, the invalid-move mask) and through oracle/gg_oracle.c, and compares
+games on the device (fused rollouts in one to three launches, one env step with rewards, one policy-weighted step with
+float32 / bfloat16 / float16 weights, next_states with drawn - partly illegal - moves, children of a few parents, areas, the invalid-move mask) and through oracle/gg_oracle.c, and compares
 boards, generators, moves, rewards and masks bit for bit.  The seeded tests of the suite pin known cases; this looks for
 the cases nobody wrote down (rare capture / ko / suicide sub-paths of the multi-ply kernel take thousands of plies to hit).
 Exit code 1 on the first mismatch, with the round's parameters."""
@@ -74,6 +74,36 @@ def main():
             want = np.where(over, np.where(margin > 0, 1.0, -1.0) * N * N, margin)
         if not np.array_equal(rewards.cpu().numpy().astype(np.float64)[~frozen], want[~frozen]):
             fail('rewards of GoVecEnv.step', params)
+        # one policy-weighted step (float32 / bfloat16 / float16 weights, some rows all zero): reset, draw, refuse, step
+        wdt = [torch.float32, torch.bfloat16, torch.float16][int(rs.integers(0, 3))]
+        w = (rs.random((B, N * N + 1)) ** 3).astype(np.float32)
+        w[rs.random(B) < 0.02] = 0.0
+        wd = torch.from_numpy(w).cuda().to(wdt)
+        params['weights'] = str(wdt)
+        start = st2.copy()
+        over0 = start[:, 5, 0, 0] == 1
+        frozen2 = over0 & (not auto)
+        if auto:
+            start[over0] = 0
+        acts_w = np.full(B, -1, np.int32)
+        rng3 = rng2.copy()
+        if (~frozen2).any():
+            a, r = c_oracle.batch_sample_weighted(start[~frozen2], wd.float().cpu().numpy()[~frozen2], rng2[~frozen2])
+            acts_w[~frozen2], rng3[~frozen2] = a, r
+        okw = np.flatnonzero(acts_w >= 0)
+        want_w = start.copy()
+        if len(okw):
+            want_w[okw] = c_oracle.batch_next_states(start[okw], acts_w[okw])[0]
+        o3, r3, d3, s3 = env.step(probs=wd)
+        if not np.array_equal(env.last_actions.cpu().numpy(), acts_w):
+            fail('moves drawn from policy weights', params)
+        if not (np.array_equal(env.states.cpu().numpy(), want_w) and np.array_equal(env.rng.cpu().numpy().view(np.uint64), rng3)):
+            fail('boards / generators after the policy-weighted step', params)
+        if not np.array_equal(s3.cpu().numpy(), (acts_w < 0).astype(np.int32)):
+            fail('status of the policy-weighted step', params)
+        st2 = want_w
+        b, w_area = c_oracle.batch_areas_mt(st2)
+        w = w_area
         # next_states with moves drawn uniformly from ALL actions (many illegal), children, areas, mask on these positions
         dev = torch.from_numpy(st2).cuda()
         acts = rs.integers(0, N * N + 1, size=B).astype(np.int32)
