@@ -606,7 +606,12 @@ def extras(dev, back, opts):
     # analysis and no byte-plane write-back per launch - what the byte-plane boundary costs the headline
     tr2, rng2 = tracked.clone(), rng.clone()
     plies = opts['plies_per_step']
-    r, ms = event_rate(torch, dev, lambda: gogame.batch_rollout_tracked(tr2, rng2, plies, True), count * plies, 6)
+    # (VALU-bound, hence clock-bound: the memory-bound extras above leave the shader clock low for the first few launches -
+    # measured right behind them this number read 4 % under what the same boards do in tools/exp/ab_layouts.py - so the
+    # clock is brought back up with untimed launches first, as the headline's warm-up steps do)
+    for _ in range(8):
+        gogame.batch_rollout_tracked(tr2, rng2, plies, True)
+    r, ms = event_rate(torch, dev, lambda: gogame.batch_rollout_tracked(tr2, rng2, plies, True), count * plies, 8)
     out['fused_rollout_tracked_boards_steps_per_s'] = round(r, 1)
     out['fused_rollout_tracked_boards_launch_ms'] = round(ms, 4)
     del tr2, rng2
