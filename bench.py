@@ -631,9 +631,10 @@ def extras(dev, back, opts):
     moved_w = moved + 4 * (N * N + 1)          # + the float32 weights of the game
     out['gg_batch_env_step_policy_weighted_bytes_moved_per_step'] = moved_w
     out['gg_batch_env_step_policy_weighted_hbm_frac'] = round(moved_w * r_w / 1e9 / HBM_PEAK_GBS, 4)
-    out['gg_batch_env_step_policy_weighted_note'] = ('reads 1.49x the bytes of the uniform-draw step (%d vs %d B per game): at the '
-                                                     'same achieved bandwidth it cannot be faster than %.2fx the uniform rate'
-                                                     % (moved_w, moved, moved / float(moved_w)))
+    out['gg_batch_env_step_policy_weighted_note'] = ('reads 1.49x the bytes of the uniform-draw step (%d vs %d B per game), but the '
+                                                     'extra time is the same for float32 and bfloat16 weights (the tensor handed over '
+                                                     'here stays in the 256 MB Infinity Cache): it is the draw itself, ~1 600 VALU '
+                                                     'instructions per wave of 16 boards = 1.35 plies (DESIGN 3c)' % (moved_w, moved))
     probs16 = probs.to(torch.bfloat16)      # what a bf16 policy head hands over: widened exactly, half the bytes
     r_h, ms_h = event_rate(torch, dev, lambda: gogame.batch_env_step_tracked(tracked, None, rng, 7.5, 'real', True, out=env_out,
                                                                              states_out=obs, weights=probs16), count, 32)
