@@ -4,7 +4,8 @@
 // sixteen boards per wavefront, liberty classes carried from ply to ply), gg_aux.h (stand-alone sampler and capture
 // resolution), gg_ws.h (policy-weighted sampling), gg_sym.h (batched symmetries) and gg_ns16.h (the per-ply kernels for
 // big batches).  Which kernel serves an entry point depends on the arguments only (board size, batch size, plies per
-// launch): there are no environment switches in the shipped build.  Mutable global state, all of it performance-only
+// launch) and on the CU count the grids are sized for - the device's own, or GYMGO_AMD_CUS (forced_cus below), the one
+// environment variable the shipped build reads; results depend on neither.  Mutable global state, all of it performance-only
 // (no result depends on any of it): g_cus (CU count per device, relaxed atomics: racing first callers store the same value), the
 // occupancy cache of waves_per_simd_of (per device and kernel, behind a mutex) and the FairShare progress board in device
 // memory (gg_common.h: one word per hardware wave slot, written by every fused launch; foreign or stale entries only shift
