@@ -185,7 +185,8 @@ void launch_pairs(void (*kern)(KArgs...), int cus, int64_t npairs, bool split, h
 //                           (32 768: 28.7 -> 27.6 / 23.9 -> 18.7; 16 384: 18.5 -> 19.2 / 14.2 -> 15.1)
 //   gg_batch_env_step       19x19 from 3 (49 152: 57.7 -> 52.3, 32 768: 42.6 -> 41.0, 24 576: 35.3 -> 39.1), 13x13 from 2
 //   (+ one-ply rollout)     (32 768: 32.5 -> 26.7, 24 576: 24.1 -> 25.5), 9x9 from 1 (16 384: 17.1 -> 12.8)
-//   gg_batch_invalid_mask   13x13 from 2 (32 768: 20.8 -> 17.5), 9x9 from 1 (16 384: 10.0 -> 9.0); 19x19 never
+//   gg_batch_invalid_mask   19x19 from 4 (65 536: 49.0 -> 47.0, 49 152: 37.0 -> 38.5), 13x13 from 2 (32 768: 20.8 -> 17.5),
+//                           9x9 from 1 (16 384: 10.0 -> 9.0)
 bool use_ns16(int cus, int64_t B, int32_t N, int per19, int per13, int per9) {
   const int64_t ngroups = (B + 15) / 16;
   int per_simd = N == 19 ? per19 : N == 13 ? per13 : per9;
@@ -397,17 +398,20 @@ int32_t gg_batch_invalid_mask(const uint8_t *states, const int32_t *ko, uint8_t 
                               void *hip_stream) {
   GG_ENTER(states);
   if (!mask) return GG_E_NULLPTR;
-  {   // big batches of 9x9 / 13x13 boards: the class-major analysis, sixteen boards per wave (as gg_batch_next_states;
-      // per 65 536 boards 33.3 -> 28.6 us at 13x13, 29.1 -> 18.8 us at 9x9.  At 19x19 - three waves per SIMD - it is no
-      // faster than the two-board kernel at four, 47 us both, and stays out: what it gains gg_batch_next_states is the
-      // write-back, which the mask does not have)
+  {   // big batches of full-size boards: the class-major analysis, sixteen boards per wave (as gg_batch_next_states;
+      // per 65 536 boards 33.3 -> 28.6 us at 13x13, 29.1 -> 18.8 us at 9x9.  At 19x19 - three waves per SIMD, one
+      // workgroup per group - it was no faster than the two-board kernel at four (round 3: 47 us both: 4 096 groups on
+      // 3 072 resident waves are one round and a third); with the groups of a SIMD split 2 : 1 : 1 over its three waves by
+      // age it is, from four groups per SIMD on (round 4: 65 536 boards 49.0 -> 47.0 us, 131 072: 87.3 -> 81.3; 49 152:
+      // 37.0 -> 38.5, so not below))
     const int64_t ngroups = (B + kNB16 - 1) / kNB16;
-    const bool big = use_ns16(cus, B, N, 0, 2, 1);
+    const bool big = use_ns16(cus, B, N, 4, 2, 1);
     if (big) {
-      const AgeSplit as = {0, {0u, 0u, 0u}};   // one workgroup per group
-      const int grid16 = (int)ngroups;
+      int grid16;   // (19x19: three waves per SIMD share a SIMD's groups 2 : 1 : 1 by age, like gg_batch_next_states)
+      const AgeSplit as = ns16_grid(k_invalid_mask16<19>, cus, ngroups, N, 32768u, 49152u, grid16);
       if (N == 9) k_invalid_mask16<9><<<grid16, kWave, 0, s>>>(states, ko, mask, B, as);
-      else k_invalid_mask16<13><<<grid16, kWave, 0, s>>>(states, ko, mask, B, as);
+      else if (N == 13) k_invalid_mask16<13><<<grid16, kWave, 0, s>>>(states, ko, mask, B, as);
+      else k_invalid_mask16<19><<<grid16, kWave, 0, s>>>(states, ko, mask, B, as);
       return (int32_t)hipGetLastError();
     }
   }
