@@ -187,6 +187,7 @@ void launch_pairs(void (*kern)(KArgs...), int cus, int64_t npairs, bool split, h
 //   (+ one-ply rollout)     (32 768: 32.5 -> 26.7, 24 576: 24.1 -> 25.5), 9x9 from 1 (16 384: 17.1 -> 12.8)
 //   gg_batch_invalid_mask   19x19 from 4 (65 536: 49.0 -> 47.0, 49 152: 37.0 -> 38.5), 13x13 from 2 (32 768: 20.8 -> 17.5),
 //                           9x9 from 1 (16 384: 10.0 -> 9.0)
+//   gg_batch_track_states   like the mask (round 4: k_track16)
 bool use_ns16(int cus, int64_t B, int32_t N, int per19, int per13, int per9) {
   const int64_t ngroups = (B + 15) / 16;
   int per_simd = N == 19 ? per19 : N == 13 ? per13 : per9;
@@ -700,6 +701,19 @@ int32_t gg_tracked_words(int32_t N) { return (N < 2 || N > GG_MAX_BOARD) ? GG_E_
 int32_t gg_batch_track_states(const uint8_t *states, uint32_t *tracked, int64_t B, int32_t N, void *hip_stream) {
   GG_ENTER(states);
   if (!tracked) return GG_E_NULLPTR;
+  {   // big batches of full-size boards: the class-major analysis, sixteen boards per wave (as gg_batch_invalid_mask)
+    const int64_t ngroups = (B + kNB16 - 1) / kNB16;
+    // (us per 65 536 / 131 072 boards, two-board kernel -> sixteen-board kernel: 19x19 48.3 -> 47.3 / 110.5 -> 102.1,
+    // 13x13 39.0 -> 30.7 / 80.4 -> 62.7, 9x9 30.3 -> 22.0 / 52.6 -> 35.4; the take-over sizes are the mask's)
+    if (use_ns16(cus, B, N, 4, 2, 1)) {
+      int grid16;
+      const AgeSplit as = ns16_grid(k_track16<19>, cus, ngroups, N, 32768u, 49152u, grid16);
+      if (N == 9) k_track16<9><<<grid16, kWave, 0, s>>>(states, tracked, B, as);
+      else if (N == 13) k_track16<13><<<grid16, kWave, 0, s>>>(states, tracked, B, as);
+      else k_track16<19><<<grid16, kWave, 0, s>>>(states, tracked, B, as);
+      return (int32_t)hipGetLastError();
+    }
+  }
   const int64_t npairs = (B + 1) / 2;
   GG_DISPATCH(N, (launch_pairs(k_track<9>, cus, npairs, true, s, states, tracked, B, N, inv)),
               (launch_pairs(k_track<13>, cus, npairs, true, s, states, tracked, B, N, inv)),

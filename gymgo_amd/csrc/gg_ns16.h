@@ -565,6 +565,106 @@ __global__ __launch_bounds__(kWave, Ns16Waves<R>::value) void k_invalid_mask16(c
   }
 }
 
+// byte planes -> tracked boards (gg_batch_track_states; k_track of gg_v4.h for big batches of full-size boards): the same
+// class-major analysis; lane (h = 0, c) writes its colour's stone rows and their ">= 2 liberties" rows, lane (1, 0) plane 3
+// as it stands (it carries the ko point of the last move: not recomputed), lane (1, 1) the flag word.
+template <int R>
+__global__ __launch_bounds__(kWave, Ns16Waves<R>::value) void k_track16(const uint8_t *__restrict__ states,
+                                                                        uint32_t *__restrict__ tracked, int64_t B, AgeSplit age) {
+  constexpr int N = R, P = R * R, S = 6 * P, W = 5 * N + 1;
+  constexpr uint32_t full = (1u << R) - 1u;
+  __shared__ __attribute__((aligned(16))) uint32_t cwt[(kCwClasses + 1) * 20];
+  {
+    const int l0 = threadIdx.x;
+    for (int i = l0; i < (kCwClasses + 1) * 20; i += kWave) cwt[i] = kCw.m[i / 20][i % 20];
+  }
+  WAVE_SYNC();
+  const int64_t ngroups = (B + kNB16 - 1) / kNB16;
+  const PairSpan span = pair_span(ngroups, age);
+  for (int64_t grp = span.first; grp < span.end; grp += span.stride) {
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    const int c = lane & 1, h = (lane >> 1) & 1, bl = lane >> 2;
+    const int64_t b_first = grp * kNB16;
+    const bool on = b_first + bl < B;
+    const int64_t b = on ? b_first + bl : B - 1;
+    const uint8_t *gi = states + b * (int64_t)S;
+    uint32_t m[R];
+    load_plane_rows<R>(gi + c * P, m);
+    uint32_t multi[R];
+    {
+      uint32_t c0[R], c1[R], c2[R], mrev[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        c0[r] = c1[r] = c2[r] = 0u;
+        mrev[r] = __brev(m[r]);
+      }
+#pragma unroll 1
+      for (int j = 0; j < (kCwClasses + 1) / 2; ++j) {
+        uint32_t f[R], g[R];
+        {
+          uint32_t ee[R + 1];
+          const uint4 *pc = reinterpret_cast<const uint4 *>(cwt + (2 * j + h) * 20);
+#pragma unroll
+          for (int i = 0; i < (R + 3) / 4; ++i) {
+            const uint4 d = pc[i];
+            if (4 * i < R) ee[4 * i] = d.x;
+            if (4 * i + 1 < R) ee[4 * i + 1] = d.y;
+            if (4 * i + 2 < R) ee[4 * i + 2] = d.z;
+            if (4 * i + 3 < R) ee[4 * i + 3] = d.w;
+          }
+#pragma unroll
+          for (int r = 0; r < R; ++r) ee[r] = B3(ee[r], m[r], dpp0<QP_COLOUR>(m[r]), TA & ~(TB | TC) & 0xFF) & full;
+          ee[R] = 0;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const uint32_t x = r > 0 ? B3(shl1(ee[r]), ee[r] >> 1, ee[r - 1], T_OR3) : (shl1(ee[r]) | (ee[r] >> 1));
+            f[r] = B3(m[r], x, ee[r + 1], T_AND_OR2);
+          }
+        }
+        flood2_serial_regs<R>(m, mrev, f, g);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint32_t k0 = c0[r] & g[r];
+          c0[r] ^= g[r];
+          const uint32_t k1 = c1[r] & k0;
+          c1[r] ^= k0;
+          c2[r] |= k1;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t p0 = dpp0<QP_HALF>(c0[r]), p1 = dpp0<QP_HALF>(c1[r]), p2 = dpp0<QP_HALF>(c2[r]);
+        const uint32_t k0 = c0[r] & p0;
+        const uint32_t s1 = B3(c1[r], p1, k0, TA ^ TB ^ TC);
+        const uint32_t k1 = B3(c1[r], p1, k0, (TA & TB) | (TA & TC) | (TB & TC));
+        const uint32_t s2 = B3(c2[r], p2, k1, TA ^ TB ^ TC);
+        const uint32_t s3 = B3(c2[r], p2, k1, (TA & TB) | (TA & TC) | (TB & TC));
+        multi[r] = B3(s3, s2, s1, T_OR_AND);          // >= 6 floods: two or more liberties
+      }
+    }
+    uint32_t *gp = tracked + b * (int64_t)W;
+    if (h == 0) {
+      if (on) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          gp[c * N + r] = m[r];
+          gp[(3 + c) * N + r] = m[r] & multi[r];
+        }
+      }
+    } else if (c == 0) {
+      uint32_t iv[R];
+      load_plane_rows<R>(gi + 3 * P, iv);
+      if (on) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) gp[2 * N + r] = iv[r];
+      }
+    } else if (on) {
+      gp[5 * N] = (gi[2 * P] & 1u) | ((gi[4 * P] & 1u) << 1) | ((gi[5 * P] & 1u) << 2);
+    }
+  }
+}
+
 // One GoEnv.step for every game of a batched env on byte planes, in place (gym_go/envs/go_env.py:49-76; the contract of
 // k_env_step2, gg_v2.h: auto-reset or refusal of finished games, the action given or drawn uniformly among the valid
 // moves, legality, next_state, game_ended, GoEnv.reward :128-149), for big batches: the class-major analysis of

@@ -7,12 +7,12 @@ from gymgo_amd import _lib
 if os.environ.get('LIB'):
     _lib.LIB_PATH = os.path.join(ROOT, os.environ['LIB'])
 from gymgo_amd import gogame
-N = 19
+N = int(os.environ.get('GGN', 19))
 for B in (65536, 131072, 49152):
     st = gogame.batch_init_state(B, N, device='cuda'); rng = gogame.rng_seed(B, 3)
     ch = B // 16
     for g in range(16):
-        gogame.batch_rollout(st[g * ch:(g + 1) * ch], rng[g * ch:(g + 1) * ch], 5 + g * 38, True)
+        gogame.batch_rollout(st[g * ch:(g + 1) * ch], rng[g * ch:(g + 1) * ch], 5 + g * (2 * N), True)
     res = []
     for name, f in (('mask', lambda: gogame._invalid_mask_dev(st)), ('track', lambda: gogame.batch_track(st))):
         out = f(); torch.cuda.synchronize()
