@@ -5,7 +5,8 @@
 
 Every round draws a board size (2 .. 19), a batch, a layout, a launch length and a mix of game phases, then walks the same
 games on the device (fused rollouts in one to three launches, one env step with rewards, one policy-weighted step with
-float32 / bfloat16 / float16 weights, next_states with drawn - partly illegal - moves, children of a few parents, areas, the invalid-move mask) and through oracle/gg_oracle.c, and compares
+float32 / bfloat16 / float16 weights, next_states with drawn - partly illegal - moves, children of a few parents, areas, the invalid-move mask, track_states followed by a fused rollout on the tracked boards)
+and through oracle/gg_oracle.c, and compares
 boards, generators, moves, rewards and masks bit for bit.  The seeded tests of the suite pin known cases; this looks for
 the cases nobody wrote down (rare capture / ko / suicide sub-paths of the multi-ply kernel take thousands of plies to hit).
 Exit code 1 on the first mismatch, with the round's parameters."""
@@ -125,6 +126,17 @@ def main():
         missing = (mask[playable] == 0) & (st2[playable, 3] == 1)
         if extra.any() or (missing.sum(axis=(1, 2)) > 1).any():
             fail('invalid-move mask recomputed from planes 0-2', params)
+        # byte planes -> tracked boards (from-scratch liberty classes) -> a fused rollout that lives on those classes
+        tr = gogame.batch_track(dev)
+        if not torch.equal(gogame.batch_untrack(tr), dev):
+            fail('untrack(track(states))', params)
+        F2 = int(rs.integers(1, 2 * N + 2))
+        r_dev = torch.from_numpy(rng3.view(np.int64)).cuda()
+        gogame.batch_rollout_tracked(tr, r_dev, F2, auto)
+        st4, rng4, _ = c_oracle.batch_rollout_mt(st2, rng3, F2, auto)
+        if not (np.array_equal(gogame.batch_untrack(tr).cpu().numpy(), st4) and np.array_equal(r_dev.cpu().numpy().view(np.uint64), rng4)):
+            fail('fused rollout on freshly tracked boards (%d plies)' % F2, params)
+        steps += B * F2
         rounds += 1
     print('fuzz ok: %d rounds, %.2e oracle-checked plies in %.0f s (seed %d)' % (rounds, steps, budget, seed), flush=True)
 
