@@ -210,3 +210,25 @@ def test_gym_registration_is_checked_not_assumed(tmp_path):
     for code in (clean, taken):
         res = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stderr[-1500:]
+
+
+def test_cu_count_override_is_read_from_the_environment(built):
+    """GYMGO_AMD_CUS=<n> (read once per process) sizes the grids for n compute units: gg_device_cus reports it without
+    touching a device; values out of range are ignored (the device's own count - 0 without a GPU - is reported)."""
+    import subprocess
+    import sys
+    code = ('import ctypes, sys; L = ctypes.CDLL(%r); L.gg_device_cus.restype = ctypes.c_int32; print(L.gg_device_cus())'
+            % os.path.join(ROOT, 'gymgo_amd', 'libgymgo_amd.so'))
+
+    def run(value):
+        env = dict(os.environ)
+        env.pop('GYMGO_AMD_CUS', None)
+        if value is not None:
+            env['GYMGO_AMD_CUS'] = value
+        p = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr[-500:]
+        return int(p.stdout.strip().splitlines()[-1])
+
+    assert run('77') == 77 and run('4096') == 4096
+    base = run(None)
+    assert run('0') == base and run('-3') == base and run('5000') == base and run('many') == base
