@@ -120,6 +120,8 @@ def stream_ptr(device=None):
 def current_raw_stream(device=None):
     """hipStream_t of torch's current stream on `device` (an int; 0 = the null stream)."""
     try:
+        if isinstance(device, str):           # 'cuda' / 'cuda:1', as torch's own factory functions accept
+            device = torch.device(device)
         idx = device.index if isinstance(device, torch.device) else device
         return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
     except (AttributeError, TypeError):   # an older / newer torch without the raw getter

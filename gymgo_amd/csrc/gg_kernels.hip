@@ -27,6 +27,7 @@
 #include "gg_ws.h"
 #include "gg_sym.h"
 #include "gg_ns16.h"
+#include "gg_lat.h"
 #include "gymgo_amd.h"
 
 namespace gg {
@@ -225,6 +226,17 @@ bool use_multi_ply(int cus, int64_t B, int plies) {
   if (const char *e = getenv("GG_AB_MULTI_MIN")) min_games = atoll(e);
 #endif
   return plies >= 2 && B >= min_games;
+}
+
+// The latency-shaped multi-ply kernel (gg_lat.h: one row per lane, four 9x9 / 13x13 boards or two 19x19 boards per wave, the
+// ply in registers) serves the fused launches of batches that leave the SIMDs under-filled: below `per_cu` games per
+// compute unit (GG_AB_LAT_MAX in A/B builds).
+bool use_lat(int cus, int64_t B, int32_t N, int plies) {
+  int64_t per_cu = N <= 9 ? 64 : N <= 13 ? 32 : 16;
+#ifdef GG_AB
+  if (const char *e = getenv("GG_AB_LAT_MAX")) per_cu = atoll(e);
+#endif
+  return plies >= 2 && B < (int64_t)cus * per_cu;
 }
 
 int32_t check(int64_t B, int32_t N) { return (N < 2 || N > GG_MAX_BOARD || B < 0) ? GG_E_BADSIZE : 0; }
@@ -467,6 +479,12 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
   GG_ENTER(states);
   if (plies == 0) return 0;
   if (!rng) return GG_E_NULLPTR;
+  if (use_lat(cus, B, N, plies)) {   // an under-filled machine: one row per lane, the ply in registers (gg_lat.h)
+#define GG_K(R, F) k_rollout_lat<R, F><<<(unsigned)((B + Lat<R>::NBW - 1) / Lat<R>::NBW), kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, plies, auto_reset)
+    GG_DISPATCH_N(N);
+#undef GG_K
+    return (int32_t)hipGetLastError();
+  }
   if (use_multi_ply(cus, B, plies)) {   // liberty classes carried across the plies, 16 boards per wave
     int grid;
     const int nb = boards_per_wave(cus, B, grid);

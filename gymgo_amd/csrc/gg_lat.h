@@ -1,0 +1,428 @@
+// gg_lat.h - the LATENCY-SHAPED multi-ply kernel for batches that leave the machine under-filled (config 2: 4 096 games of
+// 9x9 are four boards per SIMD): ONE ROW PER LANE, one board per DPP row of 16 lanes (R <= 13) or per 32 lanes (R = 19),
+// the whole ply in registers - no LDS between the phases, no layout change, no transposes.
+//
+// The other two families pay per ply for work that only amortises over many boards: gg_v2.h re-derives every liberty class
+// (22 floods per board, flood-per-lane layout reached through LDS), gg_v4.h keeps the classes but hands the board from the
+// quad layout to the flood lanes and back through LDS three times per ply.  With four boards per SIMD neither has the
+// boards to hide those round trips behind: the ply is a serial dependency chain (1.46 us per ply for two boards in
+// k_rollout2, 2.2 us for a lone 9x9 wave of k_rollout4).  Here the chain itself is short:
+//   * lane (b, r) holds row r of board b: the mover's and the opponent's stones, M = the stones of either colour whose group
+//     has >= 2 liberties (every other stone is in atari), the mover's invalid-move mask, the flag word and the generator;
+//   * the draw: popcount of the lane's valid points, prefix / total inside the board by DPP row shifts / rotations, every
+//     lane draws the same number, the lane that holds the k-th valid point finds the bit (binary search on popcounts);
+//   * a move at q changes the classes of the groups ADJACENT to q only (gg_v4.h): the opponent's group at each of q's four
+//     neighbours and the mover's group G that the stone joins - FIVE floods, run AT THE SAME TIME in bit fields of the same
+//     registers: a 9x9 row is 9 bits, so three floods share a VGPR (10-bit fields, one guard bit; 13x13: two 16-bit fields;
+//     19x19: one).  A flood step is "one row up / down (two DPP moves) + a complete horizontal run fill (carry chain, once per
+//     direction - gg_common.h)", the closure test is the first two instructions of the next step;
+//   * liberties = dilate & empty per field, counted per lane, summed per board by four DPP rotations (all five counts, the
+//     number of captured stones and "q is boxed in" travel in two words); the class patch and the next mover's mask follow
+//     point-wise exactly as in gg_v4.h (phase 3) - here on one row per lane with the rows above / below one DPP move away.
+// ~300 wave-instructions per ply for FOUR boards, none of them an LDS or memory instruction, so one wave per SIMD already
+// runs at the speed of its dependency chain and a second / third wave fills the issue slots it leaves.
+// Byte planes enter through LDS once per launch (aligned staging as everywhere, gg_common.h); the first classes come from
+// the constant-weight analysis of gg_v2.h restated in this layout (eleven floods in lock-step, black and white in two fields
+// of one register).  Reference: the loop gym_go/envs/go_env.py:49-81 (uniform_random_action + step) over
+// gym_go/gogame.py:34-87, gym_go/state_utils.py:24-83,159-180.
+#pragma once
+#include "gg_v2.h"
+
+namespace gg {
+
+template <int R>
+struct Lat {
+  static constexpr int LPB = R <= 15 ? 16 : 32;                   // lanes per board
+  static constexpr int NBW = kWave / LPB;                         // boards per wave: 4 / 2
+  static constexpr int FW = R <= 9 ? 10 : (R <= 15 ? 16 : 32);    // bits per flood field (one guard bit above the row unless the field is the register)
+  static constexpr int NF = 32 / FW;                              // fields per register: 3 / 2 / 1
+  static constexpr int NFL = 5;                                   // floods per ply: up, down, left, right (opponent), G (mover)
+  static constexpr int NREG = (NFL + NF - 1) / NF;                // 2 / 3 / 5
+  static constexpr uint32_t FM = FW >= 32 ? 0xFFFFFFFFu : ((1u << (FW & 31)) - 1u);
+  static constexpr int kBits = R <= 16 ? 16 : 32;                 // width of the k-th-set-bit search
+  static constexpr bool kSat = R > 9;                             // per-lane liberty counts saturated at 2 (the board sums are 8-bit fields)
+  static constexpr int kIoBytes = Cfg<R>::kIoBytes;
+  static constexpr int kBsWords = ((((15 + 6 * R * R + 31) / 32 + 1) + LPB - 1) / LPB) * LPB;   // bit-string of one board, a multiple of LPB
+  static_assert(R < LPB, "rows >= N of a board are zero: nothing leaks between the boards of a wave");
+  static_assert(NF == 1 || R < FW, "guard bit between the fields");
+};
+
+// rows above / below: one DPP move.  16 lanes per board: row shifts (zero fill at the row's ends); 32: wave shifts (rows
+// >= N of every board are zero, so nothing crosses a board boundary)
+template <int LPB> __device__ __forceinline__ uint32_t lat_above(uint32_t x) { return LPB == 16 ? dpp0<0x111>(x) : dpp0<0x138>(x); }   // lane i reads lane i - 1
+template <int LPB> __device__ __forceinline__ uint32_t lat_below(uint32_t x) { return LPB == 16 ? dpp0<0x101>(x) : dpp0<0x130>(x); }   // lane i reads lane i + 1
+
+// 4-neighbourhood dilation of a (possibly field-packed) row set; the centre is not part of the result.  Bits that cross a
+// field's edge land on a guard bit / beyond N: every caller masks with a set that is zero there.
+template <int LPB> __device__ __forceinline__ uint32_t lat_dilate(uint32_t x) {
+  return B3(shl1(x), x >> 1, lat_above<LPB>(x), T_OR3) | lat_below<LPB>(x);
+}
+
+// sum over the lanes of a board, result in every lane: four row rotations (+ one swap of the two rows of a 32-lane board)
+template <int LPB> __device__ __forceinline__ uint32_t lat_board_sum(uint32_t x) {
+  x += dpp0<0x128>(x);   // row_ror:8
+  x += dpp0<0x124>(x);
+  x += dpp0<0x122>(x);
+  x += dpp0<0x121>(x);
+  if (LPB == 32) x += (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x401F);   // lane ^ 16 (and 0x1F, or 0, xor 0x10)
+  return x;
+}
+template <int LPB> __device__ __forceinline__ int lat_board_max(int x) {
+  int y;
+  y = (int)dpp0<0x128>((uint32_t)x); x = x > y ? x : y;
+  y = (int)dpp0<0x124>((uint32_t)x); x = x > y ? x : y;
+  y = (int)dpp0<0x122>((uint32_t)x); x = x > y ? x : y;
+  y = (int)dpp0<0x121>((uint32_t)x); x = x > y ? x : y;
+  if (LPB == 32) { y = __builtin_amdgcn_ds_swizzle(x, 0x401F); x = x > y ? x : y; }
+  return x;
+}
+// inclusive prefix sum over the lanes of a board (half_scan of gg_v2.h without / with the row broadcast)
+template <int LPB> __device__ __forceinline__ uint32_t lat_board_scan(uint32_t v) {
+  v += dpp0<0x111>(v);
+  v += dpp0<0x112>(v);
+  v += dpp0<0x114>(v);
+  v += dpp0<0x118>(v);
+  if (LPB == 32) v += dpp0<0x142, 0xA>(v);   // lane 15 of rows 0 / 2 added to every lane of rows 1 / 3
+  return v;
+}
+
+// position of the tt-th (0-based) set bit of v (tt < popc(v); anything otherwise): binary search on popcounts, branch-free
+// on 0 / ~0 masks (kth_set_bit of gg_v4.h for one row)
+template <int BITS> __device__ __forceinline__ uint32_t lat_kth_bit(uint32_t v, uint32_t tt) {
+  uint32_t ps = 0;
+#pragma unroll
+  for (int sh = BITS / 2; sh >= 1; sh >>= 1) {
+    const uint32_t c = (uint32_t)__popc((v >> ps) & ((1u << sh) - 1u));
+    const uint32_t d = tt - c;
+    const uint32_t lt = (uint32_t)((int32_t)d >> 31);                   // tt < c: the bit is in the lower half
+    tt = B3(lt, tt, d, T_SEL);
+    ps = B3(ps, (uint32_t)sh, lt, TA | (TB & ~TC & 0xFF));              // ps | (sh & ~lt)
+  }
+  return ps;
+}
+
+// one visit of a row: the seeds s (a subset of ma) fill their runs towards the MSB, the row is flipped and fills towards
+// the MSB again; the result is in the OTHER bit order (ma / mb = the mask in the current / the other order): FLOOD_VISIT
+// of gg_common.h without the vertical term.  Works on field-packed rows as long as a zero bit separates the fields.
+__device__ __forceinline__ uint32_t lat_visit(uint32_t ma, uint32_t mb, uint32_t s) {
+  const uint32_t t = ma + s;
+  const uint32_t u = B3(t, s, ma, T_SEL);
+  const uint32_t v = __brev(u);
+  const uint32_t t2 = mb + v;
+  return B3(t2, v, mb, T_SEL);
+}
+
+// K row sets flooded in lock-step to their fixed points (Jacobi over the rows: one row up / down per step, complete
+// horizontal fill per step), F = seeds (subsets of Mk) in, filled sets out, Mkr = Mk bit-reversed.  The bit order alternates
+// from step to step (one v_bfrev per visit); the closure test of a step - "a fillable point above / below a filled one" - is
+// the head of the next step, so a flood that is already closed costs 3 instructions + the branch.
+template <int LPB, int K>
+__device__ __forceinline__ void lat_flood(uint32_t (&F)[K], const uint32_t (&Mk)[K], const uint32_t (&Mkr)[K]) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) F[k] = lat_visit(Mk[k], Mkr[k], F[k]);   // the seeds' own runs; now bit-reversed
+#pragma unroll 1
+  for (int it = 0; it < 512; ++it) {
+    uint32_t open = 0, s[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t v = lat_above<LPB>(F[k]) | lat_below<LPB>(F[k]);
+      const uint32_t o = B3(v, Mkr[k], F[k], T_AND_ANDN);
+      s[k] = o | F[k];
+      open |= o;
+    }
+    if (__ballot(open != 0) == 0) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) F[k] = __brev(F[k]);
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) F[k] = lat_visit(Mkr[k], Mk[k], s[k]);   // back in normal order
+    open = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t v = lat_above<LPB>(F[k]) | lat_below<LPB>(F[k]);
+      const uint32_t o = B3(v, Mk[k], F[k], T_AND_ANDN);
+      s[k] = o | F[k];
+      open |= o;
+    }
+    if (__ballot(open != 0) == 0) return;
+#pragma unroll
+    for (int k = 0; k < K; ++k) F[k] = lat_visit(Mk[k], Mkr[k], s[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) F[k] = __brev(F[k]);   // (iteration bound: cannot be reached for R <= 19)
+}
+
+// The stones (of either colour) whose group has >= 2 liberties, from the stones alone: the constant-weight code of gg_v2.h
+// (point q gets the q-th 11-bit word of weight 5; flood i is seeded next to the empty points whose word has bit i; a group
+// with one liberty is reached by exactly 5 floods, with two or more by >= 6) in the row-per-lane layout - eleven floods in
+// lock-step, black and white in two fields of a register (19x19: two passes).  r = the lane's row.
+template <int R>
+__device__ __forceinline__ uint32_t lat_classes(uint32_t bl, uint32_t wh, uint32_t full, int r) {
+  using L = Lat<R>;
+  constexpr int NC = L::NF >= 2 ? 1 : 2;
+  const uint32_t E = full & ~(bl | wh);
+  uint32_t d[kCwClasses];
+#pragma unroll
+  for (int i = 0; i < kCwClasses; ++i) d[i] = lat_dilate<L::LPB>(E & kCw.m[i][r < 19 ? r : 19]);
+  uint32_t multi_all = 0;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const uint32_t P = NC == 1 ? (bl | (wh << (L::FW & 31))) : (c ? wh : bl);
+    const uint32_t Pr = __brev(P);
+    uint32_t F[kCwClasses], Mk[kCwClasses], Mkr[kCwClasses];
+#pragma unroll
+    for (int i = 0; i < kCwClasses; ++i) {
+      F[i] = (NC == 1 ? (d[i] | (d[i] << (L::FW & 31))) : d[i]) & P;
+      Mk[i] = P;
+      Mkr[i] = Pr;
+    }
+    lat_flood<L::LPB, kCwClasses>(F, Mk, Mkr);
+    uint32_t alive, multi;
+    classify11(F, alive, multi);
+    multi_all |= NC == 1 ? ((multi & L::FM) | (multi >> (L::FW & 31))) : multi;
+  }
+  return multi_all & full;
+}
+
+// Board emission, L1 rows -> HBM, by the lanes of ONE board (emit_store_h of gg_v2.h for a board of LPB lanes): the six
+// planes are ORed row by row into a bit-string (bit (g & 15) + i = board byte i), every aligned 16-byte vector of HBM is one
+// halfword of it, expanded through the 8 bits -> 8 bytes table; the ragged head / tail leave as single bytes.
+template <int R>
+__device__ __forceinline__ void lat_emit(uint8_t *g, uint32_t black, uint32_t white, uint32_t invalid, uint32_t turn,
+                                         uint32_t passed, uint32_t done, uint32_t full, int N, int r, uint32_t *bs,
+                                         const uint2 *lut, bool wr) {
+  using L = Lat<R>;
+  const int P = N * N, S = 6 * P;
+  const uint32_t mo = (uint32_t)((uintptr_t)g & 15u);
+  WAVE_SYNC();
+#pragma unroll
+  for (int k = 0; k < L::kBsWords / L::LPB; ++k) bs[r + L::LPB * k] = 0;
+  WAVE_SYNC();
+  if (wr && r < N) {
+    const uint32_t rows[6] = {black, white, turn ? full : 0u, invalid, passed ? full : 0u, done ? full : 0u};
+    const uint32_t q0 = mo + (uint32_t)(r * N);
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      if (rows[p]) {
+        const uint32_t q = q0 + (uint32_t)(p * P);
+        const uint64_t x = (uint64_t)rows[p] << (q & 31u);
+        uint32_t *w = bs + (q >> 5);
+        atomicOr(w, (uint32_t)x);
+        if ((uint32_t)(x >> 32)) atomicOr(w + 1, (uint32_t)(x >> 32));
+      }
+    }
+  }
+  WAVE_SYNC();
+  if (wr) {
+    uint8_t *ga = g - mo;
+    const int end = (int)mo + S;
+    const int v0 = mo ? 1 : 0, v1 = end >> 4;
+    const uint8_t *bb = reinterpret_cast<const uint8_t *>(bs);
+    for (int v = v0 + r; v < v1; v += L::LPB) {
+      const uint2 lo = lut[bb[2 * v]], hi = lut[bb[2 * v + 1]];
+      V16a o;
+      o.w[0] = lo.x; o.w[1] = lo.y; o.w[2] = hi.x; o.w[3] = hi.y;
+      *reinterpret_cast<V16a *>(ga + 16 * v) = o;
+    }
+    if (v1 >= v0) {
+      const int head = mo ? 16 - (int)mo : 0, tail = end & 15;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {   // (a board of 16 lanes takes the two ragged edges one after the other)
+        int j = -1;
+        if (e == 0) { if (r < head) j = r; }
+        else if (r < tail) j = S - tail + r;
+        if (j >= 0) {
+          const uint32_t q = mo + (uint32_t)j;
+          g[j] = (uint8_t)((bs[q >> 5] >> (q & 31u)) & 1u);
+        }
+      }
+    } else {   // the board lies inside one 16-byte chunk (N = 2 only: 24 bytes never do, kept for symmetry)
+      for (int i = r; i < S; i += L::LPB) {
+        const uint32_t q = mo + (uint32_t)i;
+        g[i] = (uint8_t)((bs[q >> 5] >> (q & 31u)) & 1u);
+      }
+    }
+  }
+}
+
+template <int R>
+struct LdsLat {
+  using L = Lat<R>;
+  static constexpr int kIo = 0;                                        // [NBW][kIoBytes] bytes: staged boards
+  static constexpr int kBs = kIo + L::NBW * L::kIoBytes / 4;           // [NBW][kBsWords]: the emitters' bit-strings
+  static constexpr int kTotal = kBs + L::NBW * L::kBsWords;
+};
+
+// gg_batch_rollout on byte planes (uint8 [B][6][N][N], in place): `plies` uniform-random plies per game, boards on-chip in
+// between.  One single-wave workgroup per NBW boards.
+template <int R, bool FULLN>
+__global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+                                                          int32_t *__restrict__ last_actions,
+                                                          int64_t *__restrict__ steps_done, int64_t B, int N, int plies,
+                                                          int auto_reset) {
+  using L = Lat<R>;
+  constexpr int LPB = L::LPB, NBW = L::NBW, FW = L::FW, NF = L::NF, NREG = L::NREG;
+  if (FULLN) N = R;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[LdsLat<R>::kTotal];
+  __shared__ uint2 lut[256];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int r = lane & (LPB - 1), j = lane / LPB;      // row, board of the wave
+  const int P = N * N, S = 6 * P;
+  const uint32_t full = r < N ? (1u << N) - 1u : 0u;
+  load_spread_lut(lut, lane);
+  const int64_t ngroups = (B + NBW - 1) / NBW;
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t b_first = g * NBW;
+    const bool on = b_first + j < B;
+    const int64_t b = on ? b_first + j : B - 1;
+    uint8_t *gs = states + b * (int64_t)S;
+    // ---------------------------------------------------------------- load: all boards of the wave staged, then one row per lane
+    WAVE_SYNC();
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+      const int64_t bi = b_first + i < B ? b_first + i : B - 1;
+      stage_in(states + bi * (int64_t)S, S, reinterpret_cast<uint8_t *>(lds + LdsLat<R>::kIo) + i * L::kIoBytes, lane);
+    }
+    uint64_t x = rng[b];
+    WAVE_SYNC();
+    uint32_t me, op, M, inv, fl;
+    {
+      const uint8_t *io = reinterpret_cast<const uint8_t *>(lds + LdsLat<R>::kIo) + j * L::kIoBytes + ((uintptr_t)gs & 15u);
+      uint32_t bl = plane_to_row<R>(io, N, r), wh = plane_to_row<R>(io + P, N, r);
+      inv = plane_to_row<R>(io + 3 * P, N, r);
+      fl = (io[2 * P] ? 1u : 0u) | (io[4 * P] ? 2u : 0u) | (io[5 * P] ? 4u : 0u);   // turn, passed, done
+      if (!on) { bl = wh = inv = 0; fl = 0; }
+      M = lat_classes<R>(bl, wh, full, r);
+      me = (fl & 1u) ? wh : bl;
+      op = (fl & 1u) ? bl : wh;
+    }
+    int lastv = -1, played = 0;
+    // ---------------------------------------------------------------- plies
+#pragma unroll 1
+    for (int t = 0; t < plies; ++t) {
+      const bool live = on && !((fl & 4u) && !auto_reset);
+      if (__ballot(live) == 0) break;
+      if (__ballot(live && (fl & 4u))) {     // auto-reset of a finished game (rare)
+        const uint32_t keep = (live && (fl & 4u)) ? 0u : ~0u;
+        me &= keep; op &= keep; M &= keep; inv &= keep; fl &= keep;
+      }
+      const uint32_t lv = live ? ~0u : 0u;
+      // 1. the draw: uniform over the valid points + the pass (GoEnv.uniform_random_action; oracle/gg_oracle.c rollout_ply)
+      const uint32_t valid = full & ~inv;
+      const uint32_t cnt = (uint32_t)__popc(valid);
+      const uint32_t incl = lat_board_scan<LPB>(cnt);
+      const uint32_t total = lat_board_sum<LPB>(cnt);
+      uint64_t xn = x;
+      const uint64_t u = splitmix_next(xn);
+      if (live) x = xn;
+      const uint32_t k = __umulhi((uint32_t)(u >> 32), total + 1u);
+      const uint32_t tt = k - (incl - cnt);
+      const bool hit = live && tt < cnt;                 // this lane's row holds the k-th valid point
+      const uint32_t pos = lat_kth_bit<L::kBits>(valid, tt);
+      const uint32_t Q = hit ? (1u << pos) : 0u;
+      const bool pass = k == total;                      // (the same in every lane of the board)
+      if (live) lastv = hit ? r * N + (int)pos : (pass ? P : -1);
+      played += live ? 1 : 0;
+      // 2. the stone, its four neighbours, the five floods
+      const uint32_t me1 = me | Q;
+      const uint32_t su = lat_below<LPB>(Q), sd = lat_above<LPB>(Q);   // the point above q lies one row up: that lane takes Q from the lane below it
+      const uint32_t sl = Q >> 1, sr = shl1(Q);
+      const uint32_t open = B3(B3(su, sd, sl, T_OR3) | sr, full, op, T_AND_ANDN);   // on-board neighbours of q that do not hold an opponent stone
+      uint32_t F[NREG], Mk[NREG], Mkr[NREG];
+      {
+        const uint32_t seeds[L::NFL] = {su & op, sd & op, sl & op, sr & op, Q};
+#pragma unroll
+        for (int k2 = 0; k2 < NREG; ++k2) { F[k2] = 0; Mk[k2] = 0; }
+#pragma unroll
+        for (int f = 0; f < L::NFL; ++f) {
+          F[f / NF] |= seeds[f] << ((FW * (f % NF)) & 31);
+          Mk[f / NF] |= (f < 4 ? op : me1) << ((FW * (f % NF)) & 31);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < NREG; ++k2) Mkr[k2] = __brev(Mk[k2]);
+      }
+      lat_flood<LPB, NREG>(F, Mk, Mkr);
+      uint32_t fr[L::NFL];
+#pragma unroll
+      for (int f = 0; f < L::NFL; ++f) fr[f] = NF == 1 ? F[f] : ((F[f / NF] >> ((FW * (f % NF)) & 31)) & L::FM);
+      const uint32_t U = B3(fr[0], fr[1], fr[2], T_OR3) | fr[3], G = fr[4];
+      const uint32_t C = U & ~M;                          // an opponent group next to q that was in atari: captured
+      // 3. liberties of the five groups: dilate & empty (G's include the captured points), counted per lane, summed per board
+      const uint32_t E1 = full & ~(me1 | op), EG = E1 | C;
+      uint32_t W1 = 0, W2 = 0;
+      {
+        uint32_t Ee[NREG];
+#pragma unroll
+        for (int k2 = 0; k2 < NREG; ++k2) Ee[k2] = 0;
+#pragma unroll
+        for (int f = 0; f < L::NFL; ++f) Ee[f / NF] |= (f < 4 ? E1 : EG) << ((FW * (f % NF)) & 31);
+        uint32_t Lb[NREG];
+#pragma unroll
+        for (int k2 = 0; k2 < NREG; ++k2) Lb[k2] = lat_dilate<LPB>(F[k2]) & Ee[k2];
+#pragma unroll
+        for (int f = 0; f < L::NFL; ++f) {
+          uint32_t c = (uint32_t)__popc(NF == 1 ? Lb[f] : (Lb[f / NF] & (L::FM << ((FW * (f % NF)) & 31))));
+          if (L::kSat) c = c < 2u ? c : 2u;
+          if (f < 4) W1 |= c << (8 * f);
+          else W2 = c;
+        }
+        uint32_t pc = (uint32_t)__popc(C);
+        pc = pc < 2u ? pc : 2u;
+        W2 |= (pc << 8) | (open ? 0x10000u : 0u);
+      }
+      const uint32_t S1 = lat_board_sum<LPB>(W1), S2 = lat_board_sum<LPB>(W2);
+      // 4. class patch: every flooded group leaves M and comes back with >= 2 liberties (count + 126 carries into bit 7)
+      const uint32_t g1 = S1 + 0x7E7E7E7Eu;
+      uint32_t M1 = B3(M, U, G, TA & ~(TB | TC) & 0xFF);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) M1 = B3((uint32_t)((int32_t)(g1 << (24 - 8 * f)) >> 31), fr[f], M1, T_ANDOR);
+      M1 = B3((uint32_t)((int32_t)(1u - (S2 & 0xFFu)) >> 31), G, M1, T_ANDOR);
+      uint32_t K = 0;
+      if (__ballot(C != 0)) {   // some board of the wave captures
+        // ko: exactly one stone died and q is boxed in (gym_go/gogame.py:72-75, state_utils.adj_data)
+        if (((S2 >> 8) & 0xFFu) == 1u && ((S2 >> 16) & 0xFFu) == 0u) K = C;
+        // a mover's group in atari next to a captured stone (not G: its count above includes them) gains a liberty
+        uint32_t X[1], Xm[1], Xr[1];
+        Xm[0] = B3(me1, M, G, TA & ~(TB | TC) & 0xFF);
+        X[0] = lat_dilate<LPB>(C) & Xm[0];
+        if (__ballot(X[0] != 0)) {
+          Xr[0] = __brev(Xm[0]);
+          lat_flood<LPB, 1>(X, Xm, Xr);
+          M1 |= X[0];
+        }
+      }
+      // 5. the next mover's invalid-move mask (state_utils.compute_invalid_moves restated point-wise): an empty
+      // point is playable iff some neighbour is empty, a next-mover stone with >= 2 liberties or a mover's stone in atari
+      const uint32_t op2 = op & ~C;
+      const uint32_t E2 = full & ~(me1 | op2);
+      const uint32_t xs = E2 | B3(M1, op2, me1, T_SEL);
+      const uint32_t nbs = lat_dilate<LPB>(xs);
+      const uint32_t inv2 = B3(full, E2, nbs, TA & ~(TB & TC) & 0xFF) | K;
+      // 6. roles swap for the boards that moved; flags: turn flips, passed = pass, done = two passes in a row
+      me = B3(lv, op2, me1, T_SEL);
+      op = B3(lv, me1, op2, T_SEL);
+      inv = B3(lv, inv2, inv, T_SEL);
+      M = M1;
+      const uint32_t pm = pass ? ~0u : 0u;
+      const uint32_t fl2 = ((fl ^ 1u) & 1u) | (pm & 2u) | (pm & (fl << 1) & 4u);
+      fl = B3(lv, fl2, fl, T_SEL);
+    }
+    // ---------------------------------------------------------------- store
+    {
+      const uint32_t turn = fl & 1u;
+      const uint32_t bl = turn ? op : me, wh = turn ? me : op;
+      const int lastb = lat_board_max<LPB>(lastv);
+      if (__ballot(played != 0))
+        lat_emit<R>(gs, bl, wh, inv, turn, (fl >> 1) & 1u, (fl >> 2) & 1u, full, N, r,
+                    lds + LdsLat<R>::kBs + j * L::kBsWords, lut, on && played != 0);
+      if (on && r == 0) {
+        rng[b] = x;
+        if (last_actions) last_actions[b] = lastb;
+        if (steps_done && played) atomicAdd(reinterpret_cast<unsigned long long *>(steps_done) + b, (unsigned long long)played);
+      }
+    }
+  }
+}
+
+}  // namespace gg

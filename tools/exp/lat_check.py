@@ -1,0 +1,95 @@
+"""The latency-shaped multi-ply kernel (gg_lat.h) on the GPU box: parity against the C oracle over board sizes, batch sizes
+and launch lengths that gg_batch_rollout sends to it, then its rate against the kernels it replaces.
+  LIB=<path>   library under test (default: the shipped one)
+  MODE=parity|time|sweep (default: all)
+With an A/B build GG_AB_LAT_MAX=<games per CU> moves the take-over point (0: never).
+"""
+import os, sys, time, hashlib
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from gymgo_amd import _lib
+if os.environ.get('LIB'):
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ['LIB'])
+from gymgo_amd import gogame
+from oracle import c_oracle
+
+dev = 'cuda'
+MODE = os.environ.get('MODE', 'all')
+
+
+def parity():
+    bad = 0
+    total_plies = 0
+    for N, B, launches in ((9, 4096, (2, 30, 64, 104, 256)), (9, 1, (3, 50)), (9, 3, (64, 64)), (9, 5, (64, 200)), (9, 1001, (7, 120, 256)),
+                           (13, 1023, (2, 100, 300)), (13, 6, (200,)), (19, 511, (2, 150, 400)), (19, 2, (300, 300)), (19, 3, (600,)),
+                           (5, 77, (40, 100)), (7, 130, (64, 64, 64)), (2, 9, (20,)), (3, 10, (30,)), (11, 100, (250,)), (16, 33, (300,)),
+                           (8, 64, (128,)), (12, 64, (200,)), (14, 40, (300,)), (19, 4095, (64,)), (13, 4000, (64,)), (9, 8191, (32,))):
+        for auto_reset in (True, False):
+            st = gogame.batch_init_state(B, N, device=dev)
+            rng = gogame.rng_seed(B, 4242 + N, 0, dev)
+            ref, ref_rng = st.cpu().numpy(), rng.cpu().numpy().view(np.uint64)
+            steps = torch.zeros(B, dtype=torch.int64, device=dev)
+            for F in launches:
+                last = torch.full((B,), -7, dtype=torch.int32, device=dev)
+                lib = _lib.lib()
+                _lib.check(lib.gg_batch_rollout(_lib.dev_ptr(st, torch.uint8, 's'), rng.data_ptr(), last.data_ptr(), steps.data_ptr(),
+                                                B, N, F, 1 if auto_reset else 0, _lib.stream_ptr(st.device)), 'rollout')
+                torch.cuda.synchronize()
+                ref, ref_rng, ref_last = c_oracle.batch_rollout_mt(ref, ref_rng, F, auto_reset)
+                got, grng, glast = st.cpu().numpy(), rng.cpu().numpy().view(np.uint64), last.cpu().numpy()
+                total_plies += B * F
+                if not (np.array_equal(got, ref) and np.array_equal(grng, ref_rng) and np.array_equal(glast, ref_last)):
+                    bad += 1
+                    wrong = np.flatnonzero((got != ref).reshape(B, -1).any(axis=1))
+                    print('MISMATCH N %d B %d F %d auto_reset %s: %d boards differ (first %s), rng %d, last %d' %
+                          (N, B, F, auto_reset, len(wrong), wrong[:6].tolist(), int((grng != ref_rng).sum()), int((glast != ref_last).sum())), flush=True)
+                    if len(wrong):
+                        b = int(wrong[0])
+                        d = np.argwhere(got[b] != ref[b])
+                        print('  board %d: planes %s cells %s' % (b, sorted(set(d[:, 0].tolist())), d[:6].tolist()), flush=True)
+                    st.copy_(torch.from_numpy(ref)); rng.copy_(torch.from_numpy(ref_rng.view(np.int64)).view(rng.dtype))
+    print('parity: %d mismatching launches, %.2e oracle-checked plies' % (bad, total_plies), flush=True)
+    return bad
+
+
+def rate(N, B, F, reps=8):
+    st = gogame.batch_init_state(B, N, device=dev); rng = gogame.rng_seed(B, 20260927, 0, dev)
+    ch = max(1, B // 16)
+    for g in range(1, 16):
+        gogame.batch_rollout(st[g * ch:(g + 1) * ch], rng[g * ch:(g + 1) * ch], g * (8 if N <= 9 else 20 if N <= 13 else 40), True)
+    for _ in range(3):
+        gogame.batch_rollout(st, rng, F, True)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        gogame.batch_rollout(st, rng, F, True)
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    return ms, B * F / ms * 1e3, hashlib.sha1(st.cpu().numpy().tobytes()).hexdigest()[:10]
+
+
+def timing():
+    for N, B, F in ((9, 4096, 256), (9, 4096, 64), (9, 4096, 8), (9, 4096, 2)):
+        ms, r, dg = rate(N, B, F)
+        print('%s LAT_MAX %s: N %d B %d F %d: %.4f ms/launch %.3e steps/s digest %s' % (os.environ.get('LIB', 'shipped'), os.environ.get('GG_AB_LAT_MAX'), N, B, F, ms, r, dg), flush=True)
+
+
+def sweep():
+    for N, sizes in ((9, (1024, 2048, 4096, 8192, 16384, 32768, 65536)), (13, (1024, 2048, 4096, 8192, 16384, 32768)), (19, (1024, 2048, 4096, 8192, 16384, 32768))):
+        for B in sizes:
+            ms, r, dg = rate(N, B, 256, reps=4)
+            print('%s LAT_MAX %s: N %d B %d F 256: %.4f ms/launch %.3e steps/s digest %s' % (os.environ.get('LIB', 'shipped'), os.environ.get('GG_AB_LAT_MAX'), N, B, ms, r, dg), flush=True)
+
+
+if __name__ == '__main__':
+    rc = 0
+    if MODE in ('all', 'parity'):
+        rc = parity()
+    if MODE in ('all', 'time'):
+        timing()
+    if MODE in ('sweep',):
+        sweep()
+    sys.exit(1 if rc else 0)
