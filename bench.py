@@ -45,10 +45,27 @@ def fused_bytes_per_game(n):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-# oracle/ref_harness/pin_oracle.py, run where /root/reference exists (the build container, 8 vCPU Xeon @ 2.1 GHz), times the
-# real reference and the port on the same positions: the reference cannot travel to the GPU box, its ratio to the port can
-REFERENCE_STEPS_PER_S_PER_CORE_BUILD_BOX = 1217.0
-PORT_STEPS_PER_S_PER_CORE_BUILD_BOX = 1618.0
+def speed_calibration():
+    """oracle/ref_harness/speed_calibration.json: the NumPy/SciPy port timed against the REAL reference on the same positions
+    (written by `oracle/ref_harness/pin_oracle.py --speed` where /root/reference exists: >= 3 repetitions x >= 2 000
+    positions, with its range).  The reference cannot travel to the GPU box, its ratio to the port can.  None if absent."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'oracle', 'ref_harness', 'speed_calibration.json')))
+        r = rec['port_vs_reference_speed']
+        if not (0.0 < float(r['min']) <= float(r['mean']) <= float(r['max'])):
+            return None
+        return rec
+    except Exception:
+        return None
+
+
+def _two_digits(x):
+    """x rounded to two significant digits (the estimate of the reference on this box is no better than that)."""
+    if not x:
+        return x
+    import math
+    q = 10 ** (int(math.floor(math.log10(abs(x)))) - 1)
+    return float(round(x / q) * q)
 
 
 def _cpu_worker(args):
@@ -104,17 +121,23 @@ def cpu_baseline(size, seconds_per_worker=6.0, max_workers=None):
     except Exception:
         c_rate = None
     total = float(sum(steps))
-    ratio = PORT_STEPS_PER_S_PER_CORE_BUILD_BOX / REFERENCE_STEPS_PER_S_PER_CORE_BUILD_BOX
+    cal = speed_calibration()
+    if cal:
+        r = cal['port_vs_reference_speed']
+        ratio_rec = {'mean': r['mean'], 'min': r['min'], 'max': r['max'], 'positions': cal.get('positions'),
+                     'repetitions': cal.get('repetitions'), 'date': cal.get('date'), 'host': cal.get('host'),
+                     'source': 'oracle/ref_harness/speed_calibration.json (pin_oracle.py --speed against the real reference)'}
+        # the port is FASTER than the reference it restates: divide by the ratio to estimate the reference on this box
+        ref_est = {'mean': _two_digits(total / seconds_per_worker / r['mean']),
+                   'range': [_two_digits(total / seconds_per_worker / r['max']), _two_digits(total / seconds_per_worker / r['min'])]}
+    else:
+        ratio_rec, ref_est = 'unknown (oracle/ref_harness/speed_calibration.json missing or malformed)', None
     return {
         'value': round(total / seconds_per_worker, 1), 'unit': 'env steps/s', 'cores': cores, 'kind': 'port',
         'host_cpu_count': host, 'usable_cpus': usable, 'cgroup_cpu_quota_cores': None if cgroup is None else round(cgroup, 2), 'per_core': round(total / seconds_per_worker / cores, 1),
         'c_restatement_steps_per_s_one_core': c_rate,
-        # the port is FASTER than the reference it restates: divide by this to estimate the reference on this box
-        'port_vs_reference_speed': round(ratio, 3),
-        'reference_estimate_steps_per_s': round(total / seconds_per_worker / ratio, 1),
-        'port_vs_reference_note': 'oracle/ref_harness/pin_oracle.py in the build container (where /root/reference exists): '
-                                  'reference %.0f, port %.0f steps/s/core on the same positions'
-                                  % (REFERENCE_STEPS_PER_S_PER_CORE_BUILD_BOX, PORT_STEPS_PER_S_PER_CORE_BUILD_BOX),
+        'port_vs_reference_speed': ratio_rec,
+        'reference_estimate_steps_per_s': ref_est,
         'sample': '%d worker processes (os.cpu_count() = %d, usable %d, cgroup quota %s cores) x %.1f s of %dx%d uniform-random self-play with '
                   'auto-reset (oracle/np_oracle.py, same scipy.ndimage calls per step as the reference); %d steps total, '
                   'pool wall %.1f s' % (cores, host, usable, 'none' if cgroup is None else '%.1f' % cgroup, seconds_per_worker,
@@ -215,7 +238,7 @@ class ClockSampler:
             return {'sclk_mhz': None, 'note': 'amdsmi clock query unavailable (%s)' % (self.error or 'no samples')}
         m = sorted(self.mhz)
         rec = {'sclk_mhz': {'min': m[0], 'median': m[len(m) // 2], 'max': m[-1], 'samples': len(m)},
-               'note': 'torch.cuda.clock_rate (amdsmi current gfx clock) polled from a host thread during warm-up + timed launches'}
+               'note': 'torch.cuda.clock_rate (amdsmi current gfx clock) polled from a host thread'}
         if self.watts:
             w = sorted(self.watts)
             # torch documents milliwatts, amdsmi's socket power comes back in watts on this stack: raw values, unit unresolved
@@ -252,6 +275,27 @@ def run_rank(rank, world, backend, opts, dist=None):
                 backend.rollout(g * opts['desync'] // 16, lo, hi)
     for _ in range(opts['burn_in_steps']):      # same launch shape as the timed ones (rocprof averages then agree)
         backend.rollout(F, count_steps=False)
+    # THE clock of the line: >= 0.3 s of back-to-back untimed launches of the timed shape BEFORE warm-up + timed region, sampled
+    # through amdsmi; the mean of the second half of the samples (the SMU's read-out is smoothed over tens of ms: it has
+    # settled by then) is the one figure `clocks.sclk_mhz` and `roofline.measured_clock` both carry.  The samples taken
+    # INSIDE the ~50 ms timed region lag (they still show the ramp) and are kept apart, labelled.
+    settle = None
+    if hasattr(backend, 'clock_sampler') and opts.get('clock_settle_s', 0.35) > 0:
+        with backend.clock_sampler() as probe:
+            t_s, n_s = time.perf_counter(), 0
+            while time.perf_counter() - t_s < opts.get('clock_settle_s', 0.35):
+                for _ in range(4):
+                    backend.rollout(F, count_steps=False)
+                backend.sync()
+                n_s += 4
+        settle = probe.record()
+        if probe.mhz:
+            tail = probe.mhz[len(probe.mhz) // 2:]
+            settle = {'sclk_mhz': round(sum(tail) / len(tail), 1), 'samples': len(probe.mhz), 'launches': n_s,
+                      'seconds': round(time.perf_counter() - t_s, 3), 'min': min(probe.mhz), 'max': max(probe.mhz),
+                      'power_raw': settle.get('power_raw'),
+                      'how': 'mean of the second half of the amdsmi samples over %d back-to-back untimed launches of the timed shape, '
+                             'right before warm-up and the timed region' % n_s}
     sampler = backend.clock_sampler() if hasattr(backend, 'clock_sampler') else None
     if sampler is not None:
         sampler.__enter__()
@@ -282,13 +326,23 @@ def run_rank(rank, world, backend, opts, dist=None):
     red = backend.comm_tensor([wall, float(played)])
     comm = {'backend': None, 'world_size': 1, 'ranks_counted': 1}
     per_rank_ms = [kernel_ms / K]
-    clocks = sampler.record() if sampler is not None else None
-    sclk = ((clocks or {}).get('sclk_mhz') or {}).get('median') or 0.0
+    clocks = None
+    if sampler is not None:
+        inreg = sampler.record()
+        if settle and settle.get('sclk_mhz') and not isinstance(settle['sclk_mhz'], dict):
+            clocks = dict(settle)
+            clocks['in_region_samples_smu_smoothed'] = {'sclk_mhz': inreg.get('sclk_mhz'),
+                                                        'note': 'polled during warm-up + the ~50 ms timed region: the SMU read-out '
+                                                                'lags, NOT the clock of the timed region - use sclk_mhz above'}
+        else:       # no settle phase / no amdsmi: say so instead of passing the lagging samples off as the clock
+            clocks = {'sclk_mhz': None, 'note': (settle or inreg).get('note', 'no settled clock sample'),
+                      'in_region_samples_smu_smoothed': {'sclk_mhz': inreg.get('sclk_mhz')}}
+    sclk = (clocks or {}).get('sclk_mhz') or 0.0
     # what every rank reports about itself: the first global game index of its shard, the steps it played, the device it
     # ran on (index + a 48-bit digest of its uuid / name: two ranks on ONE device show up as equal pairs) and its clock
     dev_index, dev_tag = backend.device_identity() if hasattr(backend, 'device_identity') else (-1, 0)
     mine = [float(first), float(played), float(dev_index), float(dev_tag), float(sclk)]
-    per_rank = [dict(zip(('first_game', 'steps_played', 'device_index', 'device_tag', 'sclk_mhz_median'), mine))]
+    per_rank = [dict(zip(('first_game', 'steps_played', 'device_index', 'device_tag', 'sclk_mhz'), mine))]
     if dist is not None:
         tmax = red[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -307,7 +361,7 @@ def run_rank(rank, world, backend, opts, dist=None):
         table[rank * len(mine):(rank + 1) * len(mine)] = mine
         table = backend.comm_tensor(table)
         dist.all_reduce(table, op=dist.ReduceOp.SUM)
-        keys = ('first_game', 'steps_played', 'device_index', 'device_tag', 'sclk_mhz_median')
+        keys = ('first_game', 'steps_played', 'device_index', 'device_tag', 'sclk_mhz')
         per_rank = [dict(zip(keys, (float(x) for x in table[r * len(mine):(r + 1) * len(mine)]))) for r in range(world)]
     else:
         wall_max, played_all = wall, played
@@ -330,11 +384,20 @@ def run_rank(rank, world, backend, opts, dist=None):
 
 
 # ------------------------------------------------------------------------------------------------ roofline records
-def rollout_kernel_name(n, games, plies, cus):
-    """Mirror of gg_batch_rollout's dispatch (gymgo_amd/csrc/gg_kernels.hip: use_multi_ply, use_ns16): which kernel
+def device_cus():
+    """The CU count the LIBRARY sizes its grids and picks its kernels for (the device's own, or GYMGO_AMD_CUS)."""
+    from gymgo_amd import _lib
+    return int(_lib.lib().gg_device_cus())
+
+
+def rollout_kernel_name(n, games, plies, cus, auto_reset=True):
+    """Mirror of gg_batch_rollout's dispatch (gymgo_amd/csrc/gg_kernels.hip: use_lat, use_multi_ply, use_ns16): which kernel
     serves this launch."""
     rcap = 9 if n <= 9 else 13 if n <= 13 else 19
     full = 'true' if n == rcap else 'false'
+    lat_per_cu, lat_plies = {9: (64, 3), 13: (32, 4), 19: (8, 64)}[rcap]
+    if plies >= lat_plies and games <= lat_per_cu * cus:
+        return 'k_rollout_lat<%d, %s, %s>' % (rcap, full, 'true' if auto_reset else 'false')
     if plies >= 2 and games >= 32 * cus:
         return 'k_rollout4<%d, 0, false, %s, false, false>' % (rcap, full)
     if plies == 1 and n in (9, 13, 19):
@@ -392,13 +455,20 @@ def kernel_code_hash(symbol_prefix, lib_path=None):
 
 
 def rollout_symbol_prefix(kernel):
-    """Mangled-name prefix of a k_rollout4<R, IO, MOVES, FULLN, ENV, WTS> instantiation given as rollout_kernel_name writes it."""
+    """Mangled-name prefix of a rollout kernel instantiation given as rollout_kernel_name writes it (k_rollout4<R, IO, MOVES,
+    FULLN, ENV, WTS>, k_rollout_lat<R, FULLN, AUTO>, k_rollout2<R, PERPLY, PACKED, FULLN>)."""
     import re
-    m = re.match(r'k_rollout4<(\d+), (\d+), (\w+), (\w+), (\w+), (\w+)>', kernel)
-    if not m:
-        return None
     b = lambda x: 'Lb1E' if x == 'true' else 'Lb0E'
-    return '_ZN2gg10k_rollout4ILi%sELi%sE%s%s%s%sEE' % (m.group(1), m.group(2), b(m.group(3)), b(m.group(4)), b(m.group(5)), b(m.group(6)))
+    m = re.match(r'k_rollout4<(\d+), (\d+), (\w+), (\w+), (\w+), (\w+)>', kernel)
+    if m:
+        return '_ZN2gg10k_rollout4ILi%sELi%sE%s%s%s%sEE' % (m.group(1), m.group(2), b(m.group(3)), b(m.group(4)), b(m.group(5)), b(m.group(6)))
+    m = re.match(r'k_rollout_lat<(\d+), (\w+), (\w+)>', kernel)
+    if m:
+        return '_ZN2gg13k_rollout_latILi%sE%s%sEE' % (m.group(1), b(m.group(2)), b(m.group(3)))
+    m = re.match(r'k_rollout2<(\d+), (\w+), (\w+), (\w+)>', kernel)
+    if m:
+        return '_ZN2gg10k_rollout2ILi%sE%s%s%sEE' % (m.group(1), b(m.group(2)), b(m.group(3)), b(m.group(4)))
+    return None
 
 
 def load_pmc(kernel, n, plies, games):
@@ -430,7 +500,7 @@ def load_pmc(kernel, n, plies, games):
 def roofline_record(dev, n, games, plies, launch_ms, per_ply, clocks=None):
     import torch
     props = torch.cuda.get_device_properties(dev)
-    cus = props.multi_processor_count
+    cus = device_cus() or props.multi_processor_count      # what the library dispatches for (GYMGO_AMD_CUS included)
     clock_hz = float(getattr(props, 'clock_rate', 2400000)) * 1e3      # kHz -> Hz
     kernel = rollout_kernel_name(n, games, plies, cus)
     steps_per_launch = games * plies
@@ -477,15 +547,14 @@ def roofline_record(dev, n, games, plies, launch_ms, per_ply, clocks=None):
                     'pmc_source': 'no PMC pass for this launch shape under profiles/ (tools/profile_round.sh collects one)'})
     # the same fraction against the clock the run actually held (median of the amdsmi samples), next to the nominal one
     mhz = None
-    if clocks:
-        mhz = clocks.get('sclk_mhz_second_half_mean') or ((clocks.get('sclk_mhz') or {}).get('median'))
+    if clocks and not isinstance(clocks.get('sclk_mhz'), dict):
+        mhz = clocks.get('sclk_mhz')
     if mhz:
         peak_m = cus * 4 * mhz * 1e6 / 2.0 / 1e9
         rec['measured_clock'] = {'sclk_mhz': mhz, 'peak': round(peak_m, 2),
                                  'frac': round(rec['achieved'] / peak_m, 4) if rec.get('achieved') else None,
-                                 'note': 'peak and frac recomputed with the shader clock sampled over ~0.3 s of back-to-back '
-                                         'launches of the timed shape (also.clock_probe; the SMU read-out is smoothed over '
-                                         'tens of ms, so the samples inside the ~50 ms timed region lag - see `clocks`)'}
+                                 'note': 'peak and frac recomputed with THE clock of the line (`clocks.sclk_mhz`: >= 0.3 s of '
+                                         'back-to-back launches of the timed shape right before the timed region)'}
     else:
         rec['measured_clock'] = None
     rec['hbm'] = {
@@ -657,11 +726,20 @@ def extras(dev, back, opts):
     b2.rollout(F)
     r, ms = event_rate(torch, dev, lambda: b2.rollout(F), 4096 * F, 8)
     r1, ms1 = event_rate(torch, dev, lambda: b2.rollout(1), 4096, 64)
+    cus_lib = device_cus()
     configs['config2_9x9_4096_games'] = {
         'fused_rollout_steps_per_s': round(r, 1), 'plies_per_launch': F, 'launch_ms': round(ms, 4),
-        'kernel': rollout_kernel_name(9, 4096, F, torch.cuda.get_device_properties(dev).multi_processor_count),
+        'kernel': rollout_kernel_name(9, 4096, F, cus_lib),
         'per_ply_rollout_steps_per_s': round(r1, 1), 'per_ply_launch_us': round(ms1 * 1e3, 2),
+        'per_ply_kernel': rollout_kernel_name(9, 4096, 1, cus_lib),
         'per_ply_hbm_frac': round(algo_bytes_per_step(9) * r1 / 1e9 / HBM_PEAK_GBS, 4)}
+    # the config's own roofline record, like the headline's: instruction mix and HBM traffic from the committed PMC passes of
+    # THIS launch shape (profiles/pmc_rollout.json, tied to the kernel's machine code), rate measured live above
+    rl2 = roofline_record(dev, 9, 4096, F, ms, None, opts.get('clocks'))
+    rl2['note'] = ('4 096 games of 9x9 are FOUR boards per SIMD: one wave of k_rollout_lat per SIMD (four boards, one row per '
+                   'lane), i.e. a latency chain, not an issue-bound kernel - frac is low by construction; what bounds the '
+                   'launch is instructions per wave-ply x the ~5 - 7 cycles a lone wave needs per instruction (profiles/r05*)')
+    configs['config2_9x9_4096_games']['roofline'] = rl2
     # the same one-ply launches as a hipGraph of 64 (captured once, replayed): at this batch size a launch through the
     # Python API is paced by the host (ctypes call + hipLaunchKernel per ply), not by the 4 096 boards - a loop that steps
     # small batches ply by ply should replay a graph (every entry point is capturable: no allocation, no synchronisation)
@@ -765,17 +843,29 @@ def extras(dev, back, opts):
                             'gg_batch_env_step_bytes_moved_per_step': 8 * (5 * N + 1) + 6 * N * N + 25,
                             'gg_batch_env_step_frac_of_fill': round((8 * (5 * N + 1) + 6 * N * N + 25)
                                                                     * out['gg_batch_env_step_steps_per_s'] / r_fill, 4)}
-    # --- the shader clock over a LONGER busy stretch than the timed region (K launches are ~50 ms: shorter than the
-    # smoothing of the SMU's clock read-out): ~0.3 s of back-to-back launches of the timed shape, sampled the same way
-    with ClockSampler(torch, dev, 0.01) as probe:
-        r_probe, ms_probe = event_rate(torch, dev, lambda: back.rollout(F, count_steps=False), count * F, max(8, int(300.0 / max(0.05, opts.get('launch_ms_hint', 2.5)))))
-    rec = probe.record()
-    rec['steps_per_s_during_probe'] = round(r_probe, 1)
-    rec['launch_ms_during_probe'] = round(ms_probe, 5)
-    if probe.mhz:
-        tail = probe.mhz[len(probe.mhz) // 2:]
-        rec['sclk_mhz_second_half_mean'] = round(sum(tail) / len(tail), 1)
-    out['clock_probe'] = rec
+    # --- throughput against batch size (the dispatch thresholds are one box's tuning - show what they
+    # give): 19x19 and 9x9, fused (F plies per launch) and one ply per launch, with the kernel that served each shape
+    sweep = {}
+    for n_s, sizes in ((19, (1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072)), (9, (1024, 4096, 16384, 65536))):
+        rows = []
+        for games in sizes:
+            bs = HipBackend(dev)
+            bs.setup(games, n_s, 0)
+            chunk = max(1, games // 16)
+            for g in range(1, 16):
+                bs.rollout(g * (40 if n_s == 19 else 8), g * chunk, min(games, (g + 1) * chunk))
+            bs.rollout(F, count_steps=False)
+            rf_, msf = event_rate(torch, dev, lambda: bs.rollout(F, count_steps=False), games * F, 3 if games >= 32768 else 6)
+            r1_, ms1_ = event_rate(torch, dev, lambda: bs.rollout(1, count_steps=False), games, 24)
+            rows.append({'games': games, 'fused_steps_per_s': round(rf_, 1), 'fused_launch_ms': round(msf, 4),
+                         'fused_kernel': rollout_kernel_name(n_s, games, F, cus_lib),
+                         'one_ply_steps_per_s': round(r1_, 1), 'one_ply_launch_us': round(ms1_ * 1e3, 2),
+                         'one_ply_kernel': rollout_kernel_name(n_s, games, 1, cus_lib)})
+            del bs
+        sweep['%dx%d' % (n_s, n_s)] = rows
+    out['batch_sweep'] = {'plies_per_fused_launch': F, 'sizes': sweep,
+                          'note': 'gg_batch_rollout on byte planes through the Python API, HIP events over back-to-back launches; '
+                                  'stationary mix (slices de-synchronised); the kernel column mirrors gg_kernels.hip for %d CUs' % cus_lib}
     out['note'] = ('per-ply rates: HIP events over back-to-back calls through the Python API on the resident config-3 batch; '
                    'configs: one driver-timed number per BASELINE config that is not the headline')
     return out, per_ply
@@ -885,6 +975,7 @@ def main(argv=None):
 
     if rank == 0:
         N, F, K, W = opts['size'], opts['plies_per_step'], opts['steps'], opts['warmup']
+        opts['clocks'] = res.get('clocks')
         also, per_ply = ({}, None) if args.no_also else extras(dev, back, opts)
         launch_ms = res['kernel_ms'] / K
         line = {
@@ -899,7 +990,7 @@ def main(argv=None):
                 'env_steps_per_bench_step': F * res['total_games'], 'burn_in_steps': opts['burn_in_steps'],
                 'desync_plies': opts['desync'], 'sharding': 'batch split across ranks by global game index, no collective',
             },
-            'roofline': roofline_record(dev, N, res['count'], F, launch_ms, per_ply, (also or {}).get('clock_probe') or res.get('clocks')),
+            'roofline': roofline_record(dev, N, res['count'], F, launch_ms, per_ply, res.get('clocks')),
             'clocks': res.get('clocks'),
             # what the communicator saw (None at a plain one-process run): backend, its world size, the ranks an
             # all-reduce of ones counted; and every rank's own average launch time (HIP events on its stream)

@@ -113,8 +113,17 @@ def stream_ptr(device=None):
     switching torch's current stream, which costs more host time than the launch.)"""
     raw = getattr(_stream_override, 'raw', None)
     if raw is not None:
-        return raw
+        dev = getattr(_stream_override, 'device', None)     # the override names a stream of ONE device
+        if dev is None or _device_index(device) == dev:
+            return raw
     return current_raw_stream(device)
+
+
+def _device_index(device):
+    if isinstance(device, str):
+        device = torch.device(device)
+    idx = device.index if isinstance(device, torch.device) else device
+    return torch.cuda.current_device() if idx is None else idx
 
 
 def current_raw_stream(device=None):
@@ -129,17 +138,19 @@ def current_raw_stream(device=None):
 
 
 class stream_override:
-    """with stream_override(raw): every launch of this thread goes to the hipStream_t `raw`."""
+    """with stream_override(raw, device): every launch of this thread ON `device` goes to the hipStream_t `raw` (launches on
+    another device keep torch's current stream there; device None = whatever device the launch is on)."""
 
-    def __init__(self, raw):
+    def __init__(self, raw, device=None):
         self.raw = raw
+        self.device = None if device is None else _device_index(device)
 
     def __enter__(self):
-        self.prev = getattr(_stream_override, 'raw', None)
-        _stream_override.raw = self.raw
+        self.prev = (getattr(_stream_override, 'raw', None), getattr(_stream_override, 'device', None))
+        _stream_override.raw, _stream_override.device = self.raw, self.device
 
     def __exit__(self, *exc):
-        _stream_override.raw = self.prev
+        _stream_override.raw, _stream_override.device = self.prev
 
 
 _hip = None
@@ -150,8 +161,19 @@ def hip_runtime():
     makes per step (torch's Stream.wait_stream creates and destroys an event per call: 8 us of host time against 2)."""
     global _hip
     if _hip is None:
-        H = None
-        for name in ('libamdhip64.so.7', 'libamdhip64.so'):
+        # The runtime ALREADY in the process (torch's and the library's): its path is read from /proc/self/maps and that exact
+        # file is opened - dlopen by soname could bring in a second runtime when a torch wheel bundles its own copy under
+        # another name, and events created in one runtime mean nothing to streams of the other.
+        H, paths = None, []
+        try:
+            with open('/proc/self/maps') as f:
+                for line in f:
+                    path = line.rsplit(None, 1)[-1] if '/' in line else ''
+                    if 'libamdhip64' in os.path.basename(path) and path not in paths:
+                        paths.append(path)
+        except OSError:
+            pass
+        for name in paths + ['libamdhip64.so']:
             try:
                 H = ctypes.CDLL(name)
                 break
@@ -165,6 +187,12 @@ def hip_runtime():
         H.hipEventDestroy.argtypes, H.hipEventDestroy.restype = [_vp], _i32
         H.hipStreamQuery.argtypes, H.hipStreamQuery.restype = [_vp], _i32
         H.hipStreamIsCapturing.argtypes, H.hipStreamIsCapturing.restype = [_vp, ctypes.POINTER(ctypes.c_int)], _i32
+        if torch.cuda.is_available():
+            # the same runtime as torch's: a torch stream must be a stream it knows (0 = idle, 600 = hipErrorNotReady)
+            rc = H.hipStreamQuery(current_raw_stream(None))
+            if rc not in (0, 600):
+                raise GymGoNativeError('the HIP runtime opened for stream ordering (%s) does not know torch\'s stream '
+                                       '(hipStreamQuery -> %d): two runtimes in one process?' % (getattr(H, '_name', '?'), rc))
         _hip = H
     return _hip
 

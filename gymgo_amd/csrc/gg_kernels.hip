@@ -51,8 +51,10 @@ std::atomic<int> g_cus[kMaxDevices];   // 0 = not queried yet; racing first call
 int forced_cus() {
   static const int forced = [] {
     const char *e = getenv("GYMGO_AMD_CUS");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 && v <= 4096 ? v : 0;
+    if (!e || !*e) return 0;
+    char *end = nullptr;
+    const long v = strtol(e, &end, 10);   // the WHOLE string must be a number: "12abc" or "8 " is a typo, not 12 or 8 - ignored
+    return (end && *end == '\0' && v > 0 && v <= 4096) ? (int)v : 0;
   }();
   return forced;
 }
@@ -229,14 +231,22 @@ bool use_multi_ply(int cus, int64_t B, int plies) {
 }
 
 // The latency-shaped multi-ply kernel (gg_lat.h: one row per lane, four 9x9 / 13x13 boards or two 19x19 boards per wave, the
-// ply in registers) serves the fused launches of batches that leave the SIMDs under-filled: below `per_cu` games per
-// compute unit (GG_AB_LAT_MAX in A/B builds).
+// ply in registers) serves the fused launches of batches that leave the SIMDs under-filled.  Take-over points measured per
+// board size (profiles/r05a_lat_sweep.txt, A/B build, 256 plies per launch, new / old kernel):
+//   9x9 (and smaller)  4 096 games x1.77, 8 192 x1.69, 16 384 x1.10, 32 768 x0.73     -> up to 64 games per CU
+//   13x13 (10 .. 13)   4 096 x1.50, 8 192 x1.39, 16 384 x0.87                          -> up to 32 games per CU
+//   19x19 (14 .. 19)   1 024 x1.07, 2 048 x1.05, 4 096 x0.89                           -> up to 8 games per CU
+// and per launch length at 4 096 games: 9x9 1 / 2 / 4 / 16 plies x0.87 / 0.97 / 1.13 / 1.49, 13x13 x0.78 / 0.87 / 1.03 / 1.32,
+// 19x19 x0.50 / 0.59 / 0.73 / 0.82 (the launch pays the first classes of every board: eleven lock-step floods), so from
+// 3 / 4 / 64 plies per launch on.  (A/B builds: GG_AB_LAT_MAX = games per CU, GG_AB_LAT_PLIES = plies.)
 bool use_lat(int cus, int64_t B, int32_t N, int plies) {
-  int64_t per_cu = N <= 9 ? 64 : N <= 13 ? 32 : 16;
+  int64_t per_cu = N <= 9 ? 64 : N <= 13 ? 32 : 8;
+  int min_plies = N <= 9 ? 3 : N <= 13 ? 4 : 64;
 #ifdef GG_AB
   if (const char *e = getenv("GG_AB_LAT_MAX")) per_cu = atoll(e);
+  if (const char *e = getenv("GG_AB_LAT_PLIES")) min_plies = atoi(e);
 #endif
-  return plies >= 2 && B < (int64_t)cus * per_cu;
+  return plies >= min_plies && B <= (int64_t)cus * per_cu;
 }
 
 int32_t check(int64_t B, int32_t N) { return (N < 2 || N > GG_MAX_BOARD || B < 0) ? GG_E_BADSIZE : 0; }
@@ -480,7 +490,12 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
   if (plies == 0) return 0;
   if (!rng) return GG_E_NULLPTR;
   if (use_lat(cus, B, N, plies)) {   // an under-filled machine: one row per lane, the ply in registers (gg_lat.h)
-#define GG_K(R, F) k_rollout_lat<R, F><<<(unsigned)((B + Lat<R>::NBW - 1) / Lat<R>::NBW), kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, plies, auto_reset)
+#define GG_K(R, F)                                                                                                                \
+  do {                                                                                                                            \
+    const unsigned grid = (unsigned)((B + Lat<R>::NBW - 1) / Lat<R>::NBW);                                                       \
+    if (auto_reset) k_rollout_lat<R, F, true><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, plies, 1);     \
+    else k_rollout_lat<R, F, false><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, plies, 0);               \
+  } while (0)
     GG_DISPATCH_N(N);
 #undef GG_K
     return (int32_t)hipGetLastError();

@@ -27,6 +27,7 @@
 // gym_go/gogame.py:34-87, gym_go/state_utils.py:24-83,159-180.
 #pragma once
 #include "gg_v2.h"
+#include "gg_v4.h"   // GG_PROF phase clocks (A/B builds only)
 
 namespace gg {
 
@@ -112,10 +113,13 @@ __device__ __forceinline__ uint32_t lat_visit(uint32_t ma, uint32_t mb, uint32_t
   return B3(t2, v, mb, T_SEL);
 }
 
-// K row sets flooded in lock-step to their fixed points (Jacobi over the rows: one row up / down per step, complete
-// horizontal fill per step), F = seeds (subsets of Mk) in, filled sets out, Mkr = Mk bit-reversed.  The bit order alternates
-// from step to step (one v_bfrev per visit); the closure test of a step - "a fillable point above / below a filled one" - is
-// the head of the next step, so a flood that is already closed costs 3 instructions + the branch.
+// K row sets flooded in lock-step to their fixed points (Jacobi over the rows; complete horizontal fill per step), F = seeds
+// (subsets of Mk) in, filled sets out, Mkr = Mk bit-reversed.  A step moves the fill TWO rows up / down before it fills the
+// runs: the second move costs three instructions per register and takes the mean number of steps from 4.4 to 2.7 on 9x9
+// (6.3 -> 3.7 on 13x13, 5.9 -> 3.4 on 19x19; a third move buys 0.4 - 0.7 more for as many instructions as it saves:
+// tests/devtools/lat_model.py) - random-play groups are blobs, and a blob only needs the vertical moves.  The bit order
+// alternates from step to step (one v_bfrev per visit); the closure test of a step - "a fillable point above / below a filled
+// one" - is the head of the next step, so a flood that is already closed costs 3 instructions + the branch.
 template <int LPB, int K>
 __device__ __forceinline__ void lat_flood(uint32_t (&F)[K], const uint32_t (&Mk)[K], const uint32_t (&Mkr)[K]) {
 #pragma unroll
@@ -136,7 +140,10 @@ __device__ __forceinline__ void lat_flood(uint32_t (&F)[K], const uint32_t (&Mk)
       return;
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) F[k] = lat_visit(Mkr[k], Mk[k], s[k]);   // back in normal order
+    for (int k = 0; k < K; ++k) {
+      s[k] = B3(lat_above<LPB>(s[k]) | lat_below<LPB>(s[k]), Mkr[k], s[k], T_ANDOR);   // the second row up / down
+      F[k] = lat_visit(Mkr[k], Mk[k], s[k]);                                          // back in normal order
+    }
     open = 0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -147,7 +154,10 @@ __device__ __forceinline__ void lat_flood(uint32_t (&F)[K], const uint32_t (&Mk)
     }
     if (__ballot(open != 0) == 0) return;
 #pragma unroll
-    for (int k = 0; k < K; ++k) F[k] = lat_visit(Mk[k], Mkr[k], s[k]);
+    for (int k = 0; k < K; ++k) {
+      s[k] = B3(lat_above<LPB>(s[k]) | lat_below<LPB>(s[k]), Mk[k], s[k], T_ANDOR);
+      F[k] = lat_visit(Mk[k], Mkr[k], s[k]);
+    }
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) F[k] = __brev(F[k]);   // (iteration bound: cannot be reached for R <= 19)
@@ -256,7 +266,8 @@ struct LdsLat {
 
 // gg_batch_rollout on byte planes (uint8 [B][6][N][N], in place): `plies` uniform-random plies per game, boards on-chip in
 // between.  One single-wave workgroup per NBW boards.
-template <int R, bool FULLN>
+// AUTO: auto_reset != 0 (every board of the batch is live for every ply of the launch: no liveness test, no early exit)
+template <int R, bool FULLN, bool AUTO>
 __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                           int32_t *__restrict__ last_actions,
                                                           int64_t *__restrict__ steps_done, int64_t B, int N, int plies,
@@ -264,6 +275,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
   using L = Lat<R>;
   constexpr int LPB = L::LPB, NBW = L::NBW, FW = L::FW, NF = L::NF, NREG = L::NREG;
   if (FULLN) N = R;
+  if (AUTO) auto_reset = 1;
   __shared__ __attribute__((aligned(16))) uint32_t lds[LdsLat<R>::kTotal];
   __shared__ uint2 lut[256];
   const int lane = threadIdx.x & (kWave - 1);
@@ -278,6 +290,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
     const int64_t b = on ? b_first + j : B - 1;
     uint8_t *gs = states + b * (int64_t)S;
     // ---------------------------------------------------------------- load: all boards of the wave staged, then one row per lane
+    GG_PROF_DECL;
     WAVE_SYNC();
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
@@ -298,12 +311,14 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
       op = (fl & 1u) ? bl : wh;
     }
     int lastv = -1, played = 0;
+    const int rN = r * N;
+    GG_PROF(6);   // load + first classes
     // ---------------------------------------------------------------- plies
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
-      const bool live = on && !((fl & 4u) && !auto_reset);
-      if (__ballot(live) == 0) break;
-      if (__ballot(live && (fl & 4u))) {     // auto-reset of a finished game (rare)
+      const bool live = AUTO ? on : (on && !((fl & 4u) && !auto_reset));
+      if (!AUTO && __ballot(live) == 0) break;
+      if (auto_reset && __ballot(live && (fl & 4u))) {     // auto-reset of a finished game (rare)
         const uint32_t keep = (live && (fl & 4u)) ? 0u : ~0u;
         me &= keep; op &= keep; M &= keep; inv &= keep; fl &= keep;
       }
@@ -322,8 +337,12 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
       const uint32_t pos = lat_kth_bit<L::kBits>(valid, tt);
       const uint32_t Q = hit ? (1u << pos) : 0u;
       const bool pass = k == total;                      // (the same in every lane of the board)
-      if (live) lastv = hit ? r * N + (int)pos : (pass ? P : -1);
-      played += live ? 1 : 0;
+      {   // the action of the board's last live ply: the hit lane holds it, every lane holds a pass, the others -1
+        const int cand = hit ? rN + (int)pos : (pass ? P : -1);
+        lastv = (int)B3(lv, (uint32_t)cand, (uint32_t)lastv, T_SEL);
+      }
+      played -= (int)lv;
+      GG_PROF(0);
       // 2. the stone, its four neighbours, the five floods
       const uint32_t me1 = me | Q;
       const uint32_t su = lat_below<LPB>(Q), sd = lat_above<LPB>(Q);   // the point above q lies one row up: that lane takes Q from the lane below it
@@ -342,7 +361,9 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
 #pragma unroll
         for (int k2 = 0; k2 < NREG; ++k2) Mkr[k2] = __brev(Mk[k2]);
       }
+      GG_PROF(1);
       lat_flood<LPB, NREG>(F, Mk, Mkr);
+      GG_PROF(2);
       uint32_t fr[L::NFL];
 #pragma unroll
       for (int f = 0; f < L::NFL; ++f) fr[f] = NF == 1 ? F[f] : ((F[f / NF] >> ((FW * (f % NF)) & 31)) & L::FM);
@@ -372,6 +393,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
         W2 |= (pc << 8) | (open ? 0x10000u : 0u);
       }
       const uint32_t S1 = lat_board_sum<LPB>(W1), S2 = lat_board_sum<LPB>(W2);
+      GG_PROF(3);
       // 4. class patch: every flooded group leaves M and comes back with >= 2 liberties (count + 126 carries into bit 7)
       const uint32_t g1 = S1 + 0x7E7E7E7Eu;
       uint32_t M1 = B3(M, U, G, TA & ~(TB | TC) & 0xFF);
@@ -407,7 +429,9 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
       const uint32_t pm = pass ? ~0u : 0u;
       const uint32_t fl2 = ((fl ^ 1u) & 1u) | (pm & 2u) | (pm & (fl << 1) & 4u);
       fl = B3(lv, fl2, fl, T_SEL);
+      GG_PROF(4);
     }
+    GG_PROF(5);
     // ---------------------------------------------------------------- store
     {
       const uint32_t turn = fl & 1u;
@@ -422,6 +446,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
         if (steps_done && played) atomicAdd(reinterpret_cast<unsigned long long *>(steps_done) + b, (unsigned long long)played);
       }
     }
+    GG_PROF(7);   // write-back
+    GG_PROF_FLUSH;
   }
 }
 

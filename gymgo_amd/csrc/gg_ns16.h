@@ -25,7 +25,8 @@
 // workgroup per group; so does 19x19 on a device where the kernel does not get its three waves.)  Dispatch: gg_kernels.hip,
 // `use_ns16` - batches of exactly 9x9 / 13x13 / 19x19 boards from a number of groups per SIMD on that was measured per
 // entry point and board size (gg_batch_next_states: 65 536 boards of 19x19, 32 768 of 13x13 / 9x9; gg_batch_env_step and the
-// one-ply rollout: 49 152 / 32 768 / 16 384; gg_batch_invalid_mask: 13x13 from 32 768, 9x9 from 16 384, 19x19 never).
+// one-ply rollout: 49 152 / 32 768 / 16 384; gg_batch_invalid_mask and gg_batch_track_states (k_invalid_mask16, k_track16): 19x19
+// from 65 536 - four groups per SIMD, split 2 : 1 : 1 by wave age - 13x13 from 32 768, 9x9 from 16 384).
 #pragma once
 #include "gg_v4.h"
 

@@ -250,14 +250,22 @@ class GoVecEnvParts:
         for s in self.streams[:-1]:
             torch.cuda.current_stream(self.device).wait_stream(s)
 
+    def _capturing(self, raw):
+        """Is `raw` being captured into a graph?  A failed query counts as "capturing": the event is then always recorded
+        and the stream never queried - correct either way (hipStreamQuery on a capturing stream would invalidate the capture,
+        and a stale answer of an earlier call must not be reused)."""
+        self._cap.value = 1
+        if self._hip.hipStreamIsCapturing(raw, self._cap_ref) != 0:
+            return True
+        return self._cap.value != 0
+
     def _fork_part(self, h):
         """Part h's stream waits for everything queued so far on the caller's current stream - unless that stream is
         idle (then everything on it HAS happened): an event pair per step is a marker in one hardware queue and a
         barrier in the other, microseconds of GPU time that would eat what the parts gain.  (Inside a stream capture
         the stream must not be queried: the fork is always recorded, it becomes an edge of the graph.)"""
         H, cur = self._hip, self._lib.current_raw_stream(self.device)
-        H.hipStreamIsCapturing(cur, self._cap_ref)
-        if self._cap.value == 0 and H.hipStreamQuery(cur) == 0:
+        if not self._capturing(cur) and H.hipStreamQuery(cur) == 0:
             return
         self._lib.check(H.hipEventRecord(self._fork[h], cur) or H.hipStreamWaitEvent(self._raw[h], self._fork[h], 0),
                         'GoVecEnvParts fork (hipEventRecord / hipStreamWaitEvent)')
@@ -277,7 +285,7 @@ class GoVecEnvParts:
             for t in (actions, probs):
                 if t is not None and t.is_cuda:
                     t.record_stream(self.streams[h])
-            with self._lib.stream_override(self._raw[h]):
+            with self._lib.stream_override(self._raw[h], self.device):
                 self._last[h] = env.step(actions, probs=probs)
         else:
             for t in (actions, probs):
@@ -292,15 +300,17 @@ class GoVecEnvParts:
         step's buffers (None before the first).  (The event is recorded here, not by the step: a loop that never waits
         puts no markers between its launches.)"""
         H, cur = self._hip, self._lib.current_raw_stream(self.device)
-        H.hipStreamIsCapturing(cur, self._cap_ref)
-        if self._cap.value == 0 and H.hipStreamQuery(self._raw[h]) == 0:
+        if not self._capturing(cur) and H.hipStreamQuery(self._raw[h]) == 0:
             return self._last[h]            # the part has finished: there is nothing left to order
         self._lib.check(H.hipEventRecord(self._done[h], self._raw[h]) or H.hipStreamWaitEvent(cur, self._done[h], 0),
                         'GoVecEnvParts wait (hipEventRecord / hipStreamWaitEvent)')
         return self._last[h]
 
     def ready(self, h):
-        """True when everything queued on part h's stream has finished (a host-side poll, no synchronisation)."""
+        """True when everything queued on part h's stream has finished (a host-side poll, no synchronisation).  Inside a
+        stream capture nothing has run yet and a query would invalidate the capture: False without asking."""
+        if self._capturing(self._lib.current_raw_stream(self.device)) or self._capturing(self._raw[h]):
+            return False
         return self._hip.hipStreamQuery(self._raw[h]) == 0
 
     def step(self, actions=None, probs=None, check=False):

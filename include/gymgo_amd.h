@@ -19,9 +19,10 @@
  *   - Global state.  No result depends on anything but the arguments.  The library keeps three pieces of mutable state,
  *     all performance-only: a per-device cache of the CU count (relaxed atomics; racing first callers store the same value), a
  *     per-(device, kernel) cache of kernel occupancy (behind a mutex) and, in device memory, the "FairShare" progress
- *     board of the fused multi-ply kernels (512 KB per device: every wave of such a launch publishes the ply it has
- *     reached and reads its SIMD-mates' words to set its own issue priority; stale or foreign words - another
- *     stream's launch, another process never - only shift priorities).  Every entry point is re-entrant and
+ *     boards of the fused multi-ply kernels (two of 512 KB per device - one per translation unit of the library: the
+ *     fused rollouts with drawn moves, and the replay / env-step launches; waves of the other unit's kernels are
+ *     "foreign" to a board, like another stream's - every wave of such a launch publishes the ply it has reached and
+ *     reads its SIMD-mates' words to set its own issue priority; stale or foreign words only shift priorities).  Every entry point is re-entrant and
  *     thread-safe: concurrent calls from several threads on several streams are supported
  *     (tests/test_gpu_threads.py; tools/sanitize.sh: the host side under ASan / UBSan / TSan).
  *   - CPU twins.  SURVEY 8(b) sketched `_cpu`-suffixed entry points with host pointers next to these.  They are

@@ -32,6 +32,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--games-scale', type=float, default=1.0)
     ap.add_argument('--speed', action='store_true')
+    ap.add_argument('--speed-reps', type=int, default=3)
+    ap.add_argument('--speed-positions', type=int, default=2000)
     args = ap.parse_args()
     gym, gogame, govars, state_utils = refimport.load()
     rng = np.random.default_rng(20260927)
@@ -100,10 +102,13 @@ def main():
           % (n_steps, n_inv, n_children + 1))
 
     if args.speed:
-        # speed calibration of the NumPy/SciPy port against the real reference (19x19, same actions)
+        # Speed calibration of the NumPy/SciPy port against the real reference (19x19, same positions and actions):
+        # `--speed-reps` interleaved repetitions (reference, port, reference, port ...) over `--speed-positions` positions
+        # of uniform-random self-play.  Written to oracle/ref_harness/speed_calibration.json, which bench.py reads for
+        # `cpu_baseline.port_vs_reference_speed` (the reference cannot travel to the GPU box, its ratio to the port can).
         acts, states = [], []
         s = gogame.init_state(19)
-        for _ in range(600):
+        for _ in range(max(2000, args.speed_positions)):
             if gogame.game_ended(s):
                 s = gogame.init_state(19)
             valid = np.flatnonzero(np.append(s[govars.INVD_CHNL].ravel(), 0) == 0)
@@ -111,20 +116,45 @@ def main():
             states.append(s)
             acts.append(a)
             s = gogame.next_state(s, a)
-        t0 = time.perf_counter()
-        for s, a in zip(states, acts):
-            gogame.next_state(s, a)
-        t_ref = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        for s, a in zip(states, acts):
-            np_oracle.next_state(s, a)
-        t_np = time.perf_counter() - t0
+        ref_rates, port_rates, c_rates = [], [], []
         su = np.stack([u8(s) for s in states])
-        t0 = time.perf_counter()
-        c_oracle.batch_next_states(su, acts)
-        t_c = time.perf_counter() - t0
-        print('speed 19x19 next_state, 1 core: reference %.0f steps/s, np port %.0f steps/s (%.2fx), C oracle %.0f steps/s'
-              % (len(acts) / t_ref, len(acts) / t_np, t_ref / t_np, len(acts) / t_c))
+        for _ in range(max(3, args.speed_reps)):
+            t0 = time.perf_counter()
+            for s, a in zip(states, acts):
+                gogame.next_state(s, a)
+            ref_rates.append(len(acts) / (time.perf_counter() - t0))
+            t0 = time.perf_counter()
+            for s, a in zip(states, acts):
+                np_oracle.next_state(s, a)
+            port_rates.append(len(acts) / (time.perf_counter() - t0))
+            t0 = time.perf_counter()
+            c_oracle.batch_next_states(su, acts)
+            c_rates.append(len(acts) / (time.perf_counter() - t0))
+        ratios = [p / r for p, r in zip(port_rates, ref_rates)]
+        import json
+        import platform
+        import scipy
+        rec = {
+            'what': 'gogame.next_state, 19x19, one core: the real reference vs oracle/np_oracle.py vs oracle/gg_oracle.c on the same '
+                    'positions and actions (uniform-random self-play with restarts)',
+            'positions': len(acts), 'repetitions': len(ratios),
+            'reference_steps_per_s': {'mean': round(float(np.mean(ref_rates)), 1), 'min': round(min(ref_rates), 1), 'max': round(max(ref_rates), 1)},
+            'port_steps_per_s': {'mean': round(float(np.mean(port_rates)), 1), 'min': round(min(port_rates), 1), 'max': round(max(port_rates), 1)},
+            'c_oracle_steps_per_s': {'mean': round(float(np.mean(c_rates)), 1), 'min': round(min(c_rates), 1), 'max': round(max(c_rates), 1)},
+            'port_vs_reference_speed': {'mean': round(float(np.mean(ratios)), 3), 'min': round(min(ratios), 3), 'max': round(max(ratios), 3)},
+            'host': '%s, %d CPUs visible' % (platform.processor() or platform.machine(), os.cpu_count() or 0),
+            'versions': {'python': platform.python_version(), 'numpy': np.__version__, 'scipy': scipy.__version__},
+            'date': time.strftime('%Y-%m-%d'),
+            'generated_by': 'python oracle/ref_harness/pin_oracle.py --speed --speed-reps %d --speed-positions %d' % (len(ratios), len(acts)),
+        }
+        out = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'speed_calibration.json')
+        with open(out, 'w') as f:
+            json.dump(rec, f, indent=1)
+            f.write('\n')
+        print('speed 19x19 next_state, 1 core, %d positions x %d repetitions: reference %.0f steps/s (%.0f - %.0f), np port %.0f '
+              '(%.2fx, %.2f - %.2f), C oracle %.0f  ->  %s'
+              % (len(acts), len(ratios), np.mean(ref_rates), min(ref_rates), max(ref_rates), np.mean(port_rates),
+                 np.mean(ratios), min(ratios), max(ratios), np.mean(c_rates), out))
 
 
 if __name__ == '__main__':

@@ -153,11 +153,15 @@ class Model:
             o = [B3(self.above(F[k]) | self.below(F[k]), Mkr[k], F[k], T_AND_ANDN) for k in range(K)]
             if not any(x.any() for x in o):
                 return [brev(F[k]) for k in range(K)]
-            F = [self.visit(Mkr[k], Mk[k], o[k] | F[k]) for k in range(K)]
+            s = [o[k] | F[k] for k in range(K)]
+            s = [B3(self.above(s[k]) | self.below(s[k]), Mkr[k], s[k], T_ANDOR) for k in range(K)]   # the second row up / down
+            F = [self.visit(Mkr[k], Mk[k], s[k]) for k in range(K)]
             o = [B3(self.above(F[k]) | self.below(F[k]), Mk[k], F[k], T_AND_ANDN) for k in range(K)]
             if not any(x.any() for x in o):
                 return F
-            F = [self.visit(Mk[k], Mkr[k], o[k] | F[k]) for k in range(K)]
+            s = [o[k] | F[k] for k in range(K)]
+            s = [B3(self.above(s[k]) | self.below(s[k]), Mk[k], s[k], T_ANDOR) for k in range(K)]
+            F = [self.visit(Mk[k], Mkr[k], s[k]) for k in range(K)]
         raise RuntimeError('flood bound')
 
     # ---- the constant-weight code table (gg_v2.h make_cw_table)

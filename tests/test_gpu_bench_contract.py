@@ -58,16 +58,29 @@ def test_bench_one_gpu_plain_invocation():
     assert line['comm']['backend'] is None and line['rccl_world_size'] is None and len(line['per_rank_launch_ms']) == 1
     assert line['weak_scaling_base']['games'] == 131072 and line['weak_scaling_base']['steps_per_s_one_gpu'] > 1e8
     assert 'clocks' in line and 'measured_clock' in line['roofline']
+    mc, ck = line['roofline']['measured_clock'], line['clocks']
+    if ck and ck.get('sclk_mhz'):      # ONE clock: the settled figure sampled before the timed region prices the fraction
+        assert mc and abs(mc['sclk_mhz'] - ck['sclk_mhz']) <= 0.02 * ck['sclk_mhz'] and ck['seconds'] >= 0.3
+        assert 'in_region_samples_smu_smoothed' in ck
     assert line['config']['games'] == 65536 and line['config']['board'] == 19 and line['config']['plies_per_step'] == 256
     assert line['roofline']['frac'] is not None                       # the committed PMC record matches the default shape
     assert 0 < line['roofline']['per_ply']['frac'] <= 1
     cpu = line['cpu_baseline']
     assert cpu['kind'] == 'port' and cpu['cores'] == 8 and cpu['value'] > 0 and cpu['unit'] == line['unit']
-    assert cpu['port_vs_reference_speed'] > 1 and cpu['reference_estimate_steps_per_s'] < cpu['value']
+    ratio = cpu['port_vs_reference_speed']    # from oracle/ref_harness/speed_calibration.json, with its range
+    assert 1 < ratio['min'] <= ratio['mean'] <= ratio['max'] and ratio['repetitions'] >= 3 and ratio['positions'] >= 2000
+    est = cpu['reference_estimate_steps_per_s']
+    assert est['range'][0] <= est['mean'] <= est['range'][1] < cpu['value']
     also = line['also']
     assert also['gg_batch_env_step_hbm_frac'] < also['gg_batch_env_step_x_byte_plane_step_roofline'] <= 1.2
     assert also['gg_batch_env_step_steps_per_s'] > 0 and set(also['configs']) >= {
         'config2_9x9_4096_games', 'config5_children_8192_parents', 'config1_7x7_single_game_GoEnv_step'}
+    c2 = also['configs']['config2_9x9_4096_games']
+    assert c2['kernel'].startswith('k_rollout_lat<9') and c2['roofline']['kernel'] == c2['kernel']
+    assert c2['roofline']['frac'] is not None and c2['roofline']['pmc_stale'] is False     # the committed PMC pass is of this code
+    sweep = also['batch_sweep']['sizes']
+    assert [r['games'] for r in sweep['19x19']] == [1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072]
+    assert all(r['fused_steps_per_s'] > 0 and r['one_ply_steps_per_s'] > 0 for rows in sweep.values() for r in rows)
 
 
 @pytest.mark.parametrize('launcher', ['torch.distributed.run', 'self-spawn'])

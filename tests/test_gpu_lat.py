@@ -1,0 +1,112 @@
+"""The latency-shaped multi-ply kernel (gymgo_amd/csrc/gg_lat.h, k_rollout_lat) where gg_batch_rollout dispatches it - and on
+both sides of every take-over point - against the pinned C oracle: states, generator states, last actions and step counters.
+
+gg_batch_rollout serves a launch from one of three kernel families by (board size, games, plies per launch)
+(gg_kernels.hip: use_lat, use_multi_ply, the per-ply kernels); the result must not depend on which.  Reference loop:
+gym_go/envs/go_env.py:49-81 over gym_go/gogame.py:34-87.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cus():
+    from gymgo_amd import _lib
+    return int(_lib.lib().gg_device_cus())
+
+
+def _run(N, B, launches, auto_reset, seed=77, first_game=0):
+    """`launches` plies-per-launch in a row on one batch; every launch compared with the oracle."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, seed, first_game, 'cuda')
+    want = np.zeros((B, 6, N, N), np.uint8)
+    want_rng = rng.cpu().numpy().view(np.uint64).copy()
+    sd = torch.zeros(B, dtype=torch.int64, device='cuda')
+    played = np.zeros(B, np.int64)
+    for F in launches:
+        la = torch.full((B,), -9, dtype=torch.int32, device='cuda')
+        gogame.batch_rollout(st, rng, F, auto_reset, la, sd)
+        want, want_rng, want_last = c_oracle.batch_rollout_mt(want, want_rng, F, auto_reset)
+        got = st.cpu().numpy()
+        bad = np.flatnonzero((got != want).reshape(B, -1).any(axis=1))
+        assert len(bad) == 0, (N, B, F, auto_reset, bad[:6].tolist())
+        assert np.array_equal(rng.cpu().numpy().view(np.uint64), want_rng), (N, B, F)
+        assert np.array_equal(la.cpu().numpy(), want_last), (N, B, F)
+        played += F
+    if auto_reset:      # every game plays every ply; a frozen game (auto_reset off) plays none after its second pass
+        assert np.array_equal(sd.cpu().numpy(), played)
+    else:
+        assert bool((sd.cpu() <= torch.from_numpy(played)).all()) and int(sd.min()) > 0
+    return st
+
+
+# (board size, games): every row capacity (9 / 13 / 19 and sizes below them), whole and ragged waves (4 boards per wave up to
+# 13x13, 2 at 19x19), one board, and the config-2 batch
+@pytest.mark.parametrize('N,B', [(9, 4096), (9, 1), (9, 2), (9, 3), (9, 5), (9, 1001), (7, 130), (5, 77), (2, 9), (3, 10), (8, 64),
+                                 (13, 1023), (13, 6), (11, 100), (12, 67), (10, 33),
+                                 (19, 511), (19, 2), (19, 3), (19, 1), (16, 33), (14, 40), (15, 17)])
+def test_lat_rollout_vs_oracle(N, B):
+    """Launch lengths from the shortest the kernel takes (3 / 4 / 64 plies) to whole games with auto-reset, and frozen
+    games (auto_reset off: a finished game neither moves nor draws)."""
+    launches = (3, 4, 64, 65, 3 * N * N + 9) if N <= 13 else (64, 70, 3 * N * N + 9)
+    if B > 1000:
+        launches = launches[:-1] + (200,)
+    _run(N, B, launches, True)
+    _run(N, B, launches[-2:] + launches[:1], False, seed=5)
+
+
+@pytest.mark.parametrize('N', [9, 13, 19, 7])
+def test_rollout_same_result_on_both_sides_of_every_take_over(N):
+    """The games-per-launch and plies-per-launch thresholds of use_lat (and of use_multi_ply above them): the batch sizes /
+    launch lengths right at, below and above each take-over point, every launch against the oracle."""
+    cus = _cus()
+    per_cu, min_plies = (64, 3) if N <= 9 else (32, 4) if N <= 13 else (8, 64)
+    edge = cus * per_cu
+    for B in (edge - 3, edge, edge + 1, edge + 5):
+        _run(N, B, (min_plies - 1, min_plies, min_plies + 1, 40 if N <= 13 else 90), True, seed=B)
+    # below / above the multi-ply kernel's own take-over (32 games per CU), launches the new kernel does not take
+    for B in (cus * 32 - 2, cus * 32 + 2):
+        _run(N, B, (1, 2), True, seed=B + 1)
+
+
+def test_lat_unaligned_views_and_neighbours_untouched():
+    """Boards at odd byte offsets (views into a larger buffer): results equal the aligned run, bytes outside the batch keep
+    their value (the emitter writes ragged edges as single bytes)."""
+    from gymgo_amd import gogame
+    for N, B in ((9, 37), (13, 21), (19, 9)):
+        S = 6 * N * N
+        for off in (1, 7, 16, 33):
+            buf = torch.full((off + B * S + 64,), 0xAB, dtype=torch.uint8, device='cuda')
+            view = buf[off:off + B * S].view(B, 6, N, N)
+            view.zero_()
+            ref = gogame.batch_init_state(B, N, device='cuda')
+            r1, r2 = gogame.rng_seed(B, 9, 0, 'cuda'), gogame.rng_seed(B, 9, 0, 'cuda')
+            for F in (70, 120):
+                gogame.batch_rollout(view, r1, F, True)
+                gogame.batch_rollout(ref, r2, F, True)
+            assert torch.equal(view, ref) and torch.equal(r1, r2), (N, off)
+            assert bool((buf[:off] == 0xAB).all()) and bool((buf[off + B * S:] == 0xAB).all()), (N, off)
+
+
+def test_lat_starts_from_arbitrary_midgame_positions():
+    """The first classes of a launch come from the stones alone (eleven lock-step floods): start launches from positions
+    produced by OTHER kernels (per-ply path, big-batch path) at many depths."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    for N, B in ((9, 512), (13, 256), (19, 128)):
+        st = gogame.batch_init_state(B, N, device='cuda')
+        rng = gogame.rng_seed(B, 31, 0, 'cuda')
+        want = np.zeros((B, 6, N, N), np.uint8)
+        want_rng = rng.cpu().numpy().view(np.uint64).copy()
+        for depth in (1, 2, 1, 2, 1):          # one- and two-ply launches: the per-ply kernels
+            gogame.batch_rollout(st, rng, depth, True)
+            want, want_rng, _ = c_oracle.batch_rollout_mt(want, want_rng, depth, True)
+        for F in (64, 1, 80, 2, 150, 1, 64):   # alternate the new kernel with per-ply launches
+            gogame.batch_rollout(st, rng, F, True)
+            want, want_rng, _ = c_oracle.batch_rollout_mt(want, want_rng, F, True)
+            assert np.array_equal(st.cpu().numpy(), want), (N, F)
+            assert np.array_equal(rng.cpu().numpy().view(np.uint64), want_rng)

@@ -232,3 +232,4 @@ def test_cu_count_override_is_read_from_the_environment(built):
     assert run('77') == 77 and run('4096') == 4096
     base = run(None)
     assert run('0') == base and run('-3') == base and run('5000') == base and run('many') == base
+    assert run('12abc') == base and run('8 ') == base and run('') == base      # a typo is ignored, not read as 12 / 8

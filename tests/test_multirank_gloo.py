@@ -145,3 +145,18 @@ def test_bench_argument_plumbing():
     assert bench.rollout_kernel_name(19, 32768, 1, 256) == 'k_rollout2<19, true, false, true>'
     assert bench.rollout_kernel_name(9, 16384, 1, 256) == 'k_env_step16<9, false>'
     assert bench.rollout_kernel_name(7, 65536, 1, 256) == 'k_rollout2<9, true, false, false>'
+
+
+def test_speed_calibration_file():
+    """The CPU baseline's port-vs-reference ratio comes from a committed calibration (oracle/ref_harness/pin_oracle.py --speed
+    against the real reference: >= 3 repetitions x >= 2 000 positions), not from constants in bench.py."""
+    import json
+    import bench
+    rec = json.load(open(os.path.join(ROOT, 'oracle', 'ref_harness', 'speed_calibration.json')))
+    assert rec['repetitions'] >= 3 and rec['positions'] >= 2000
+    for key in ('reference_steps_per_s', 'port_steps_per_s', 'port_vs_reference_speed'):
+        assert 0 < rec[key]['min'] <= rec[key]['mean'] <= rec[key]['max'], key
+    assert rec['host'] and rec['date'] and 'pin_oracle.py' in rec['generated_by']
+    assert bench.speed_calibration() == rec
+    assert bench._two_digits(40871.3) == 41000.0 and bench._two_digits(0) == 0
+    assert not hasattr(bench, 'PORT_STEPS_PER_S_PER_CORE_BUILD_BOX')

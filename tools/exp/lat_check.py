@@ -78,10 +78,23 @@ def timing():
 
 
 def sweep():
-    for N, sizes in ((9, (1024, 2048, 4096, 8192, 16384, 32768, 65536)), (13, (1024, 2048, 4096, 8192, 16384, 32768)), (19, (1024, 2048, 4096, 8192, 16384, 32768))):
+    """A/B build only (GG_AB_LAT_MAX / GG_AB_LAT_PLIES are read at every call): the new kernel forced on / off per shape."""
+    def both(N, B, F, reps):
+        out = []
+        for lat in ('1000000', '0'):
+            os.environ['GG_AB_LAT_MAX'] = lat
+            os.environ['GG_AB_LAT_PLIES'] = '1'
+            ms, r, dg = rate(N, B, F, reps=reps)
+            out.append((ms, r, dg))
+        print('N %2d B %6d F %3d: lat %.4f ms %.3e steps/s | old %.4f ms %.3e steps/s | x%.2f %s' %
+              (N, B, F, out[0][0], out[0][1], out[1][0], out[1][1], out[0][1] / out[1][1], 'same digest' if out[0][2] == out[1][2] else 'DIGESTS DIFFER'), flush=True)
+    for N, sizes in ((9, (256, 1024, 2048, 4096, 8192, 16384, 32768, 65536)), (13, (256, 1024, 2048, 4096, 8192, 16384, 32768)), (19, (256, 1024, 2048, 4096, 8192, 16384, 32768)),
+                     (7, (4096, 16384)), (5, (4096,))):
         for B in sizes:
-            ms, r, dg = rate(N, B, 256, reps=4)
-            print('%s LAT_MAX %s: N %d B %d F 256: %.4f ms/launch %.3e steps/s digest %s' % (os.environ.get('LIB', 'shipped'), os.environ.get('GG_AB_LAT_MAX'), N, B, ms, r, dg), flush=True)
+            both(N, B, 256, 4)
+    for N, B in ((9, 4096), (9, 1024), (13, 4096), (19, 4096), (19, 1024)):
+        for F in (1, 2, 4, 16):
+            both(N, B, F, 32)
 
 
 if __name__ == '__main__':

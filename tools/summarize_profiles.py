@@ -87,9 +87,15 @@ try:
     write_scale = known['k_unpack']['write'] / cal['k_unpack']['WRITE_SIZE']  # the rollout kernel's own store pattern
     md.append('\ncorrection factors used below: FETCH_SIZE x %.3f (the guide prescribes x2 for wide coalesced reads on gfx950), '
               'WRITE_SIZE x %.3f (calibrated on `k_unpack`, the same emitter as the write-back of `%s`)' % (fetch_scale, write_scale, kshort))
-except Exception as e:   # calibration pass missing: fall back to the guide's prescription
+except Exception as e:   # calibration pass missing (a LIGHT pass): the factors of the round's calibrated record, else the guide's
     fetch_scale, write_scale = 2.0, 1.0
-    md.append('\n(calibration pass not available: %s; using FETCH_SIZE x2, WRITE_SIZE x1)' % e)
+    try:
+        prev = [r for r in json.load(open(os.path.join(dst, 'pmc_rollout.json')))['records'] if r.get('fetch_scale')]
+        fetch_scale, write_scale = prev[-1]['fetch_scale'], prev[-1]['write_scale']
+        md.append('\n(no calibration pass in this run: the correction factors of %s are used - FETCH_SIZE x %.3f, WRITE_SIZE x %.3f)'
+                  % (prev[-1]['source'].split(' ')[0], fetch_scale, write_scale))
+    except Exception:
+        md.append('\n(calibration pass not available: %s; using FETCH_SIZE x2, WRITE_SIZE x1)' % e)
 
 # ---- config 5 under the same counters (the calibration script also expands 8 192 parents)
 children_rec = None
