@@ -247,6 +247,37 @@ class ClockSampler:
         return rec
 
 
+def pin_to_gpu_numa_node(torch, dev):
+    """Pin this rank's host thread(s) to the CPUs of the NUMA node its GPU hangs off (the launches of one rank must not queue
+    behind another socket's memory): the node from /sys/bus/pci/devices/<bdf>/numa_node, its CPUs from
+    /sys/devices/system/node/node<k>/cpulist, intersected with what the process may use.  Returns a record for the line;
+    never fails the run (a container may hide sysfs or refuse the affinity call)."""
+    rec = {'numa_node': None, 'cpus_pinned': None}
+    try:
+        props = torch.cuda.get_device_properties(dev)
+        bdf = getattr(props, 'pci_bus_id', None)
+        if isinstance(bdf, int) or bdf is None:      # torch exposes domain / bus / device ids separately
+            bdf = '%04x:%02x:%02x.0' % (getattr(props, 'pci_domain_id', 0), getattr(props, 'pci_bus_id', 0), getattr(props, 'pci_device_id', 0))
+        node = int(open('/sys/bus/pci/devices/%s/numa_node' % str(bdf).lower()).read().strip())
+        rec['numa_node'] = node
+        if node < 0:
+            rec['note'] = 'the platform reports no NUMA affinity for this GPU (numa_node = -1)'
+            return rec
+        cpus = set()
+        for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
+            lo, _, hi = part.partition('-')
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = cpus & set(os.sched_getaffinity(0))
+        if allowed:
+            os.sched_setaffinity(0, allowed)
+            rec['cpus_pinned'] = len(allowed)
+        else:
+            rec['note'] = 'no usable CPU on node %d: affinity left as it was' % node
+    except Exception as e:
+        rec['note'] = 'not pinned (%s: %s)' % (type(e).__name__, str(e)[:100])
+    return rec
+
+
 def shard(total_games, rank, world_size):
     """Contiguous equal split of the game index range [0, total_games) -> (first_game, count); the same function as
     gymgo_amd.envs.vec_env.shard (kept importable without torch for the CPU tests)."""
@@ -279,7 +310,7 @@ def run_rank(rank, world, backend, opts, dist=None):
     # through amdsmi; the mean of the second half of the samples (the SMU's read-out is smoothed over tens of ms: it has
     # settled by then) is the one figure `clocks.sclk_mhz` and `roofline.measured_clock` both carry.  The samples taken
     # INSIDE the ~50 ms timed region lag (they still show the ramp) and are kept apart, labelled.
-    settle = None
+    settle, n_s = None, 0
     if hasattr(backend, 'clock_sampler') and opts.get('clock_settle_s', 0.35) > 0:
         with backend.clock_sampler() as probe:
             t_s, n_s = time.perf_counter(), 0
@@ -380,7 +411,7 @@ def run_rank(rank, world, backend, opts, dist=None):
     return {'value': played_all / wall_max, 'wall_s': wall_max, 'kernel_ms': kernel_ms, 'total_games': total_games,
             'games_per_gpu': per_gpu, 'count': count, 'first': first, 'steps_played': played_all,
             'per_rank_launch_ms': per_rank_ms, 'per_rank': per_rank, 'distinct_devices': len(set(devs)) if devs[0][0] >= 0 else None,
-            'comm': comm, 'clocks': clocks}
+            'comm': comm, 'clocks': clocks, 'settle_launches': n_s}
 
 
 # ------------------------------------------------------------------------------------------------ roofline records
@@ -448,10 +479,35 @@ def kernel_code_hash(symbol_prefix, lib_path=None):
                     if (info & 15) == 2 and size and name.startswith(symbol_prefix.encode()) and not name.endswith(b'.kd'):
                         tsec = secs[shndx]
                         code = elf[tsec[4] + (value - tsec[3]):tsec[4] + (value - tsec[3]) + size]
-                        return hashlib.sha256(code).hexdigest()[:16]
+                        return hashlib.sha256(_mask_pc_relative(code)).hexdigest()[:16]
     except Exception:
         return None
     return None
+
+
+def _mask_pc_relative(code):
+    """The kernel's machine code with the PC-relative offsets of the translation unit's globals zeroed: after an s_getpc_b64
+    the 32-bit literals of the s_add_u32 / s_addc_u32 that follow hold `symbol - pc` (the class-code table, the FairShare
+    board), which move whenever ANY kernel of the unit changes size.  With them masked the hash says "this kernel's
+    instructions", which is what a PMC record is about."""
+    import struct
+    n = len(code) // 4
+    w = list(struct.unpack_from('<%dI' % n, code))
+    i = 0
+    while i < n:
+        if (w[i] & 0xFF80FF00) == 0xBE801C00:                       # SOP1 s_getpc_b64
+            j = i + 1
+            while j < min(n - 1, i + 8):
+                d = w[j]
+                if (d & 0xFF800000) in (0x80000000, 0x82000000) and (((d >> 8) & 0xFF) == 0xFF or (d & 0xFF) == 0xFF):
+                    w[j + 1] = 0                                     # s_add_u32 / s_addc_u32 with a 32-bit literal
+                    j += 2
+                else:
+                    j += 1
+            i = j
+        else:
+            i += 1
+    return struct.pack('<%dI' % n, *w) + code[4 * n:]
 
 
 def rollout_symbol_prefix(kernel):
@@ -566,6 +622,84 @@ def roofline_record(dev, n, games, plies, launch_ms, per_ply, clocks=None):
     if per_ply:
         rec['per_ply'] = per_ply
     return rec
+
+
+def children_record(torch, dev, parents, parents_note, by_phase=False, reps=8):
+    """Config 5 - gg_batch_children on `parents` (uint8 [B,6,N,N]) into ONE preallocated buffer - and the un-padded form
+    (gg_batch_children_offsets + gg_batch_children_compact) of the same parents into the same buffer: HIP events over
+    back-to-back calls through the C-ABI.  THE harness for this number: bench.py's line and tools/bench_ops.py both call it
+    (round 4 had two harnesses - another buffer, other parents, an allocation per call - that read 13 % apart on one lease)."""
+    from gymgo_amd import _lib, gogame
+    B, _, N, _ = parents.shape
+    A, S = N * N + 1, 6 * N * N
+    kids = torch.empty((B, A, 6, N, N), dtype=torch.uint8, device=dev)
+    offs = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    lib = _lib.lib()
+    cur = {'p': parents}
+
+    def expand():   # (reads cur['p'] at call time)
+        _lib.check(lib.gg_batch_children(_lib.dev_ptr(cur['p'], torch.uint8, 'states'), _lib.dev_ptr(kids, torch.uint8, 'children'),
+                                         B, N, 0, _lib.stream_ptr(dev)), 'gg_batch_children')
+
+    def expand_compact():
+        _lib.check(lib.gg_batch_children_offsets(_lib.dev_ptr(cur['p'], torch.uint8, 'states'), _lib.dev_ptr(offs, torch.int32, 'offsets'),
+                                                 B, N, _lib.stream_ptr(dev)), 'gg_batch_children_offsets')
+        _lib.check(lib.gg_batch_children_compact(_lib.dev_ptr(cur['p'], torch.uint8, 'states'), _lib.dev_ptr(offs, torch.int32, 'offsets'),
+                                                 _lib.dev_ptr(kids, torch.uint8, 'children'), B, N, 0, _lib.stream_ptr(dev)),
+                   'gg_batch_children_compact')
+    r, ms = event_rate(torch, dev, expand, B, reps)
+    bytes_per_parent = S + A * S
+    rec = {
+        'parents': parents_note, 'harness': 'bench.children_record (one preallocated output buffer, HIP events over %d calls)' % reps,
+        'parents_per_s': round(r, 1), 'child_states_per_s': round(r * A, 1), 'launch_ms': round(ms, 4),
+        'roofline': {'bound': 'hbm', 'kernel': 'k_children3<%d, false, false>' % N, 'algorithmic_bytes_per_parent': bytes_per_parent,
+                     'achieved': round(bytes_per_parent * r / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(bytes_per_parent * r / 1e9 / HBM_PEAK_GBS, 4)}}
+    # HBM bytes of this launch from the committed counter passes (tools/calib_traffic.py under rocprofv3 --pmc), tied to
+    # the kernel's machine code like the fused kernel's record
+    try:
+        crec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_rollout.json'))).get('children') or {}
+        chash = kernel_code_hash(CHILDREN_SYMBOL_PREFIX)
+        stale = crec.get('kernel_code_sha16') != chash
+        rec['roofline'].update({
+            'traffic': None if stale else crec.get('hbm_bytes_per_launch'),
+            'algorithmic_bytes_per_launch': bytes_per_parent * B, 'kernel_code_sha16': chash,
+            'pmc_kernel_code_sha16': crec.get('kernel_code_sha16'), 'pmc_stale': stale, 'pmc_source': crec.get('source')})
+    except Exception:
+        rec['roofline']['traffic'] = None
+    # the un-padded form (gogame.children(padded=False), gym_go/gogame.py:179) of the same parents: only the children
+    # valid_moves() keeps, at their rank - both launches (offsets + children) inside the timed call
+    rc, msc = event_rate(torch, dev, expand_compact, B, reps)
+    total = int(offs[B].item())
+    moved = total * S + B * (4 * N * N + 4) + 8 * B         # children written + planes 0-3 and flags read + offsets
+    rec['compact'] = {
+        'entry': 'gg_batch_children_offsets + gg_batch_children_compact', 'kernel': 'k_children3<%d, false, true>' % N,
+        'parents_per_s': round(rc, 1), 'child_states_per_s': round(rc * total / B, 1), 'launch_ms': round(msc, 4),
+        'mean_children_per_parent': round(total / B, 2), 'of_slots': A,
+        'bytes_moved_per_launch': moved, 'bytes_vs_padded': round(moved / (bytes_per_parent * B), 4),
+        'achieved': round(moved / (msc * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(moved / (msc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'speedup_vs_padded': round(ms / msc, 3)}
+    if by_phase:
+        # the same expansion for parents of ONE game phase each (the floods run over the empty points next to a stone,
+        # the 362 slots are written whatever the position: the padded rate barely depends on the phase, the un-padded one does)
+        phases = {}
+        for phase, plies in (('early_20_plies', 20), ('mid_150_plies', 150), ('late_400_plies', 400)):
+            ph = gogame.batch_init_state(B, N, device=dev)
+            gogame.batch_rollout(ph, gogame.rng_seed(B, 77, 0, dev), plies, False)
+            cur['p'] = ph
+            rp, msp = event_rate(torch, dev, expand, B, 6)
+            rcp, mscp = event_rate(torch, dev, expand_compact, B, 6)
+            phases[phase] = {'parents_per_s': round(rp, 1), 'launch_ms': round(msp, 4),
+                             'mean_stones': round(float((ph[:, 0] | ph[:, 1]).sum()) / B, 1),
+                             'hbm_frac': round(bytes_per_parent * rp / 1e9 / HBM_PEAK_GBS, 4),
+                             'compact_parents_per_s': round(rcp, 1), 'compact_launch_ms': round(mscp, 4),
+                             'compact_mean_children': round(int(offs[B].item()) / B, 1)}
+        rec['by_game_phase'] = phases
+    del kids
+    return rec
+
+
+CHILDREN_SYMBOL_PREFIX = '_ZN2gg11k_children3ILi19ELb0ELb0EEE'      # k_children3<19, false, false>
 
 
 def event_rate(torch, dev, fn, units, reps):
@@ -772,48 +906,10 @@ def extras(dev, back, opts):
         configs['config4_per_gpu_batch_131072_games_on_one_gpu'] = {'fused_rollout_steps_per_s': round(r, 1),
                                                                    'plies_per_launch': F, 'launch_ms': round(ms, 4)}
         del b4
-    # --- config 5: 8 192 mid-game parents, padded 362-slot expansion
+    # --- config 5: 8 192 mid-game parents, padded 362-slot expansion (+ the un-padded form of the same parents)
     if N == 19 and count >= 8192:
-        parents = states[:8192]
-        kids = torch.empty((8192, N * N + 1, 6, N, N), dtype=torch.uint8, device=dev)
-        lib = _lib.lib()
-
-        def expand():   # (reads `parents` at call time)
-            _lib.check(lib.gg_batch_children(_lib.dev_ptr(parents, torch.uint8, 'states'), _lib.dev_ptr(kids, torch.uint8, 'children'),
-                                             8192, N, 0, _lib.stream_ptr(dev)), 'gg_batch_children')
-        r, ms = event_rate(torch, dev, expand, 8192, 8)
-        bytes_per_parent = 6 * N * N + (N * N + 1) * 6 * N * N
-        configs['config5_children_8192_parents'] = {
-            'parents': 'the first 8 192 games of the resident batch (stationary mix: every game phase)',
-            'parents_per_s': round(r, 1), 'child_states_per_s': round(r * (N * N + 1), 1), 'launch_ms': round(ms, 4),
-            'roofline': {'bound': 'hbm', 'kernel': 'k_children3<19, false>', 'algorithmic_bytes_per_parent': bytes_per_parent,
-                         'achieved': round(bytes_per_parent * r / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(bytes_per_parent * r / 1e9 / HBM_PEAK_GBS, 4)}}
-        # HBM bytes of this launch from the committed counter passes (tools/calib_traffic.py under rocprofv3 --pmc), tied to
-        # the kernel's machine code like the fused kernel's record
-        try:
-            crec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_rollout.json'))).get('children') or {}
-            chash = kernel_code_hash('_ZN2gg11k_children3ILi19ELb0EEE')
-            stale = crec.get('kernel_code_sha16') != chash
-            configs['config5_children_8192_parents']['roofline'].update({
-                'traffic': None if stale else crec.get('hbm_bytes_per_launch'),
-                'algorithmic_bytes_per_launch': bytes_per_parent * 8192, 'kernel_code_sha16': chash,
-                'pmc_kernel_code_sha16': crec.get('kernel_code_sha16'), 'pmc_stale': stale, 'pmc_source': crec.get('source')})
-        except Exception:
-            configs['config5_children_8192_parents']['roofline']['traffic'] = None
-        # the same expansion for parents of ONE game phase each (the floods run over the empty points next to a stone,
-        # the 362 slots are written whatever the position: the rate barely depends on the phase)
-        by_phase = {}
-        for phase, plies in (('early_20_plies', 20), ('mid_150_plies', 150), ('late_400_plies', 400)):
-            ph = gogame.batch_init_state(8192, N, device=dev)
-            gogame.batch_rollout(ph, gogame.rng_seed(8192, 77, 0, dev), plies, False)
-            parents = ph
-            rp, msp = event_rate(torch, dev, expand, 8192, 6)
-            by_phase[phase] = {'parents_per_s': round(rp, 1), 'launch_ms': round(msp, 4),
-                               'mean_stones': round(float((ph[:, 0] | ph[:, 1]).sum()) / 8192, 1),
-                               'hbm_frac': round(bytes_per_parent * rp / 1e9 / HBM_PEAK_GBS, 4)}
-        configs['config5_children_8192_parents']['by_game_phase'] = by_phase
-        del kids, parents
+        configs['config5_children_8192_parents'] = children_record(
+            torch, dev, states[:8192], 'the first 8 192 games of the resident batch (stationary mix: every game phase)', by_phase=True)
     # --- config 1: one 7x7 game through GoEnv.step (device round trip per step: plumbing, not a throughput path)
     import numpy as np
     env = make('gym_go:go-v0', size=7)
@@ -950,6 +1046,7 @@ def main(argv=None):
     local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    numa = pin_to_gpu_numa_node(torch, dev) if world > 1 else None      # one rank per GPU: each on its GPU's NUMA node
     # under a launcher (WORLD_SIZE set, also with one rank) the process group is real: barrier and reductions run over RCCL
     use_dist = 'WORLD_SIZE' in os.environ
     if use_dist:
@@ -973,6 +1070,23 @@ def main(argv=None):
     back = HipBackend(dev)
     res = run_rank(rank, world, back, opts, dist if use_dist else None)
 
+    # N > 1: the weak-scaling base of THIS run - rank 0 repeats the timed launches alone (every other rank idle at the barrier:
+    # its shard is the per-GPU batch, the launch shape is the timed one) - so that the line carries its own efficiency =
+    # value(N) / (N x base) instead of leaving the division to a second run
+    solo = None
+    if world > 1:
+        if use_dist:
+            dist.barrier()
+        if rank == 0:
+            import time as _t
+            back.sync()
+            t0 = _t.perf_counter()
+            for _ in range(opts['steps']):
+                back.rollout(opts['plies_per_step'], count_steps=False)
+            back.sync()
+            solo = opts['steps'] * opts['plies_per_step'] * back.count / (_t.perf_counter() - t0)
+        if use_dist:
+            dist.barrier()
     if rank == 0:
         N, F, K, W = opts['size'], opts['plies_per_step'], opts['steps'], opts['warmup']
         opts['clocks'] = res.get('clocks')
@@ -1000,6 +1114,12 @@ def main(argv=None):
             'per_rank': res.get('per_rank'), 'distinct_devices': res.get('distinct_devices'),
             'per_gpu_steps_per_s': [round(F * res['games_per_gpu'] / (x * 1e-3), 1) for x in res['per_rank_launch_ms']],
         }
+        if numa is not None:
+            line['rank0_numa'] = numa
+        if solo:
+            line['weak_scaling_base'] = {'games': res['games_per_gpu'], 'steps_per_s_one_gpu': round(solo, 1),
+                                         'how': 'rank 0 alone, the other ranks idle at a barrier: the same %d launches of the same shape, right after the timed region' % K}
+            line['efficiency'] = round(res['value'] / (world * solo), 4)
         if cpu is not None:
             line['cpu_baseline'] = cpu
         base = (also.get('configs') or {}).get('config4_per_gpu_batch_131072_games_on_one_gpu') if also else None

@@ -12,11 +12,11 @@ import torch  # must be imported before the library so both share ONE HIP runtim
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgymgo_amd.so')   # always the in-tree build: no override, no search path
-ABI_VERSION = 3                                      # GG_ABI_VERSION of include/gymgo_amd.h
+ABI_VERSION = 4                                      # GG_ABI_VERSION of include/gymgo_amd.h
 
 EXPORTS = (
     'gg_version', 'gg_device_cus', 'gg_batch_next_states', 'gg_batch_next_states_ws', 'gg_batch_invalid_mask', 'gg_batch_areas',
-    'gg_batch_children', 'gg_batch_rollout', 'gg_batch_env_step', 'gg_batch_sample_actions', 'gg_batch_update_pieces', 'gg_batch_reset_finished', 'gg_packed_words', 'gg_batch_pack_states',
+    'gg_batch_children', 'gg_batch_children_offsets', 'gg_batch_children_compact', 'gg_batch_rollout', 'gg_batch_env_step', 'gg_batch_sample_actions', 'gg_batch_update_pieces', 'gg_batch_reset_finished', 'gg_packed_words', 'gg_batch_pack_states',
     'gg_batch_unpack_states', 'gg_batch_next_states_packed', 'gg_batch_rollout_packed', 'gg_batch_env_step_packed',
     'gg_batch_children_packed', 'gg_batch_play_moves', 'gg_batch_play_moves_packed', 'gg_tracked_words', 'gg_batch_track_states',
     'gg_batch_untrack_states', 'gg_batch_rollout_tracked', 'gg_batch_play_moves_tracked', 'gg_batch_env_step_tracked',
@@ -33,6 +33,8 @@ _SIGNATURES = {
     'gg_batch_invalid_mask': ([_vp, _vp, _vp, _i64, _i32, _vp], _i32),
     'gg_batch_areas': ([_vp, _vp, _vp, _i64, _i32, _vp], _i32),
     'gg_batch_children': ([_vp, _vp, _i64, _i32, _i32, _vp], _i32),
+    'gg_batch_children_offsets': ([_vp, _vp, _i64, _i32, _vp], _i32),
+    'gg_batch_children_compact': ([_vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
     'gg_batch_rollout': ([_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
     'gg_batch_env_step': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_float, _i32, _i32, _vp], _i32),
     'gg_batch_sample_actions': ([_vp, _vp, _vp, _i64, _i32, _vp], _i32),

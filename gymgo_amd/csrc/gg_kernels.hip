@@ -27,13 +27,14 @@
 #include "gg_ws.h"
 #include "gg_sym.h"
 #include "gg_ns16.h"
-#include "gg_lat.h"
 #include "gymgo_amd.h"
 
 namespace gg {
 // gg_rollout.hip: the fused multi-ply launches with drawn moves, a translation unit of their own (one code-generation switch differs)
 void launch_rollout4(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N,
                      uint32_t inv, int plies, int auto_reset, int nb, int grid, hipStream_t s);
+void launch_rollout_lat(uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N, int plies,
+                        int auto_reset, hipStream_t s);
 }
 
 namespace {
@@ -483,21 +484,42 @@ int32_t gg_batch_children(const uint8_t *states, uint8_t *children, int64_t B, i
   return (int32_t)hipGetLastError();
 }
 
+// un-padded children (gogame.children(padded=False)): per-parent counts -> exclusive offsets, then the same kernel with every
+// child at the rank of its action among the kept ones
+int32_t gg_batch_children_offsets(const uint8_t *states, int32_t *offsets, int64_t B, int32_t N, void *hip_stream) {
+  if (N >= 2 && N <= GG_MAX_BOARD && B > 0 && B > (int64_t)0x7FFFFFFF / (N * N + 1)) return GG_E_BADSIZE;
+  if (B == 0 && offsets && !check(B, N)) {   // an empty batch has offsets[0] = 0
+    OnDeviceOf on_dev(offsets);
+    return (int32_t)hipMemsetAsync(offsets, 0, sizeof(int32_t), (hipStream_t)hip_stream);
+  }
+  GG_ENTER(states);
+  if (!offsets) return GG_E_NULLPTR;
+  k_children_counts<<<grid_for(cus, (B + 3) / 4), 4 * kWave, 0, s>>>(states, offsets, B, N);
+  k_scan_counts<<<1, 1024, 0, s>>>(offsets, B);
+  return (int32_t)hipGetLastError();
+}
+
+int32_t gg_batch_children_compact(const uint8_t *states, const int32_t *offsets, uint8_t *children, int64_t B, int32_t N,
+                                  int32_t canonical, void *hip_stream) {
+  GG_ENTER(states);
+  if (!children || !offsets) return GG_E_NULLPTR;
+  if (B > (int64_t)0x7FFFFFFF / (N * N + 1)) return GG_E_BADSIZE;
+  const int chunks = children_chunks(cus, B, N * N + 1);
+  const int grid = grid_for(cus, B * chunks);
+  GG_DISPATCH(N, (k_children3<9, false, true><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks, offsets)),
+              (k_children3<13, false, true><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks, offsets)),
+              (k_children3<19, false, true><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks, offsets)));
+  return (int32_t)hipGetLastError();
+}
+
 int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B,
                          int32_t N, int32_t plies, int32_t auto_reset, void *hip_stream) {
   if (plies < 0) return GG_E_BADARG;
   GG_ENTER(states);
   if (plies == 0) return 0;
   if (!rng) return GG_E_NULLPTR;
-  if (use_lat(cus, B, N, plies)) {   // an under-filled machine: one row per lane, the ply in registers (gg_lat.h)
-#define GG_K(R, F)                                                                                                                \
-  do {                                                                                                                            \
-    const unsigned grid = (unsigned)((B + Lat<R>::NBW - 1) / Lat<R>::NBW);                                                       \
-    if (auto_reset) k_rollout_lat<R, F, true><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, plies, 1);     \
-    else k_rollout_lat<R, F, false><<<grid, kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, plies, 0);               \
-  } while (0)
-    GG_DISPATCH_N(N);
-#undef GG_K
+  if (use_lat(cus, B, N, plies)) {   // an under-filled machine: one row per lane, the ply in registers (gg_lat.h, launched from gg_rollout.hip)
+    launch_rollout_lat(states, rng, last_actions, steps_done, B, N, plies, auto_reset, s);
     return (int32_t)hipGetLastError();
   }
   if (use_multi_ply(cus, B, plies)) {   // liberty classes carried across the plies, 16 boards per wave

@@ -1043,10 +1043,18 @@ __global__ __launch_bounds__(kWave, PACKED ? 4 : GG_LB_PLY) void k_env_step2(uin
 // points of this work item's chunk (the 5 KB transpose buffer holds one batch; when the board has <= 32 empty points
 // pass 1's batch is reused) and derives two children per L1 pass, one per half, with ~70 VALU ops + the emitter.
 // PACKED: parents and children are packed boards (uint32 [3 N + 1] each): 84 KB instead of 786 KB per 19x19 parent.
-template <int R, bool PACKED = false>
+// COMPACT (byte planes): gogame.children(..., padded=False) - gym_go/gogame.py:179, the un-padded result the reference
+// computes first - for a whole batch: only the slots of the actions valid_moves() keeps (plane 3 clear, + the pass; every
+// action once the game has ended, :155-156), in ascending action order, parent b's first child at offsets[b] (exclusive
+// scan of the per-parent counts, k_children_counts + k_scan_counts below).  The same analysis and the same streaming
+// emitter: a child's place in the stream is the RANK of its action among the kept ones instead of the action itself, so the
+// zero slots of the illegal actions - two thirds of the padded bytes on mid-game 19x19 parents - are never written.
+template <int R, bool PACKED = false, bool COMPACT = false>
 __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *__restrict__ states,
                                                         uint8_t *__restrict__ children, int64_t B, int N,
-                                                        uint32_t inv, int canonical, int chunks) {
+                                                        uint32_t inv, int canonical, int chunks,
+                                                        const int32_t *__restrict__ offsets = nullptr) {
+  static_assert(!(PACKED && COMPACT), "compact children are byte planes");
   constexpr int RS = Cfg<R>::kRowStride;
   constexpr int RV = (R + 3) / 4;
     // (an 8 KB window: with the 16 KB one of rounds 2 - 3 the workgroup's LDS was 11 200 B, 14 waves per CU instead of 16)
@@ -1069,7 +1077,7 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
     const int64_t b = w / chunks;
     const int ch = (int)(w - b * chunks);
     const uint8_t *gi = states + b * (int64_t)S;
-    uint8_t *gc = children + b * A * (int64_t)S;
+    uint8_t *gc = COMPACT ? children + (int64_t)offsets[b] * S : children + b * A * (int64_t)S;
     const int W = 3 * N + 1;
     uint32_t *gcp = reinterpret_cast<uint32_t *>(children) + b * A * (int64_t)W;   // PACKED: this parent's child slots
     uint32_t flags, black, white, invd;   // flags: bit 0 turn, bit 2 passed, bit 3 done
@@ -1111,6 +1119,13 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
     const int EA = __builtin_amdgcn_readlane((int)aincl, 31);
     const int u0 = __builtin_amdgcn_readlane((int)half_scan((uint32_t)__popc(ea & below_lo)), 31);   // ... inside the chunk: [u0, u1)
     const int u1 = __builtin_amdgcn_readlane((int)half_scan((uint32_t)__popc(ea & below_hi)), 31);
+    // COMPACT: the actions valid_moves() keeps, their per-row prefix, and the ranks [k0, k1) of the chunk's first / last slot
+    const uint32_t keep = !COMPACT ? 0u : ((flags & 8u) ? hf.full_l1 : hf.full_l1 & ~invd);
+    const uint32_t kcnt = (uint32_t)__popc(keep);
+    const uint32_t kincl = COMPACT ? half_scan(kcnt) : 0u;
+    const int kall = COMPACT ? __builtin_amdgcn_readlane((int)kincl, 31) : 0;          // the pass's rank
+    const int k0 = COMPACT ? __builtin_amdgcn_readlane((int)half_scan((uint32_t)__popc(keep & below_lo)), 31) : a0;
+    const int k1 = COMPACT ? __builtin_amdgcn_readlane((int)half_scan((uint32_t)__popc(keep & below_hi)), 31) + (a1 == A ? 1 : 0) : a1;
     WAVE_SYNC();  // staging buffer read out
     if (hf.h == 0) {
       planes[hf.hl] = mine;
@@ -1168,7 +1183,7 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
     uint32_t ge1 = 0, ge2 = 0, ge3 = 0;
     const int nbatch = (EA + 31) >> 5;
 #pragma unroll 1
-    for (int i = 0; i < nbatch; ++i) {
+    for (int i = nbatch - 1; i >= 0; --i) {   // last batch first: batch 0 is the one still in sc when pass 2 starts
       flood_batch(32 * i);
       const int cnt = min(32, EA - 32 * i);
       if (hf.hl < R) {
@@ -1192,10 +1207,10 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
     // tools/ubench/write_patterns.hip).  `ring` is a sliding window of the output as a bit-string (bit i = byte
     // origin[i]); a child ORs its 6 N^2 bits into it, a block leaves through the spread table once every child
     // overlapping it has been emitted, and the all-zero slots of the illegal actions cost nothing but zero stores.
-    uint8_t *const cstart = gc + (int64_t)a0 * S;
+    uint8_t *const cstart = gc + (int64_t)k0 * S;
     const uint32_t start_bit = (uint32_t)((uintptr_t)cstart & (kBlk - 1u));
     uint8_t *const origin = cstart - start_bit;
-    const uint32_t end_bit = start_bit + (uint32_t)(a1 - a0) * (uint32_t)S;
+    const uint32_t end_bit = start_bit + (uint32_t)(k1 - k0) * (uint32_t)S;
     uint32_t sbase = 0, dirty_end = 0;   // wave-uniform: window start (multiple of kBlk); no bit set at or above dirty_end
     auto flush_until = [&](uint32_t target) {
       // four whole blocks per round (two adjacent slots are 4.2 blocks): the four ring reads, then the eight table reads,
@@ -1278,7 +1293,7 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
     }
     // one child per half: `a` = its action, `tj` = flood lane of its point inside the current batch (-1: pass, -2: an
     // empty point with no stone next to it - no group is touched, nothing to look up)
-    auto child = [&](int a, int tj, bool on) {
+    auto child = [&](int a, int tj, bool on, int slot) {   // slot: the child's place among the parent's slots (a, or a's rank)
       const bool is_pass = tj == -1;
       uint32_t nmine = mine, nopp = opp, invalid;
       if (__ballot(on && !is_pass) == 0) {
@@ -1353,7 +1368,7 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
         return;
       }
       // both children are emitted in slot order; the window is advanced up to the block the next child starts in
-      const uint32_t pbit = start_bit + (uint32_t)(a - a0) * (uint32_t)S;
+      const uint32_t pbit = start_bit + (uint32_t)(slot - k0) * (uint32_t)S;
       const uint32_t pA = (uint32_t)__builtin_amdgcn_readlane((int)pbit, 0), pB = (uint32_t)__builtin_amdgcn_readlane((int)pbit, 32);
       const bool onB = (__ballot(on) >> 32) != 0;
       WAVE_SYNC();
@@ -1381,7 +1396,7 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
 #pragma unroll 1
       for (int wi = 0; wi < nwin; ++wi) {
         const int ub = u0 + 32 * wi;
-        if (ub < u1 && !(nbatch == 1 && ub == 0)) flood_batch(ub);   // (pass 1's only batch is still in sc)
+        if (ub < u1 && ub != 0) flood_batch(ub);   // (pass 1 ended with batch 0: it is still in sc)
         const int tlo = wi == 0 ? t0 : (int)alist[ub];
         const int thi = (wi + 1 < nwin) ? (int)alist[ub + 32] : t1;
 #pragma unroll 1
@@ -1393,6 +1408,8 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
           const uint32_t irow = __shfl(invd, xr);   // every lane executes the exchanges (a masked-off source lane reads as 0)
           const uint32_t arow = __shfl(ea, xr);
           const uint32_t apre = __shfl(aincl - acnt, xr);
+          const uint32_t krow = __shfl(keep, xr), kpre = __shfl(kincl - kcnt, xr);
+          const int rk = COMPACT ? (int)(kpre + (uint32_t)__popc(krow & ((1u << xc) - 1u))) : x;
           const bool legal = x >= 0 && ((irow >> xc) & 1u) == 0;
           // flood lane of the point inside the window's batch, or -2 for a free point
           const int fl = ((arow >> xc) & 1u) ? (int)(apre + (uint32_t)__popc(arow & ((1u << xc) - 1u))) - ub : -2;
@@ -1408,18 +1425,62 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
             const int src = on ? js : j0;
             const int a = __shfl(x, src);
             const int tj = __shfl(fl, src);
-            child(a, tj, on);
+            child(a, tj, on, __shfl(rk, src));
           }
         }
       }
     }
-    if (a1 == A) child(hf.P, -1, hf.h == 0);
+    if (a1 == A) child(hf.P, -1, hf.h == 0, COMPACT ? kall : hf.P);
     if (!PACKED) {
       WAVE_SYNC();
       flush_until((end_bit + kBlk - 1u) & ~(kBlk - 1u));
       WAVE_SYNC();
     }
   }
+}
+
+// gogame.children(padded=False): how many children valid_moves() keeps per parent (gym_go/gogame.py:153-161, 176-179) - the
+// points whose plane-3 byte is clear + the pass; every action once the game has ended.  One wave per parent at a time.
+static __global__ void k_children_counts(const uint8_t *__restrict__ states, int32_t *__restrict__ counts, int64_t B, int N) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / kWave;
+  const int64_t nwaves = (gridDim.x * (int64_t)blockDim.x) / kWave;
+  const int P = N * N;
+  for (int64_t b = wave; b < B; b += nwaves) {
+    const uint8_t *g = states + b * (int64_t)(6 * P);
+    int c = 0;
+    for (int i = lane; i < P; i += kWave) c += g[3 * P + i] == 0 ? 1 : 0;
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if (lane == 0) counts[b] = g[5 * P] ? P + 1 : c + 1;
+  }
+}
+
+// counts[0 .. B) -> their exclusive prefix sums in place, counts[B] = the total: ONE workgroup of 1 024 threads walks the
+// array in tiles (the per-parent counts of a children batch: microseconds even for a million parents)
+static __global__ __launch_bounds__(1024) void k_scan_counts(int32_t *__restrict__ v, int64_t B) {
+  __shared__ int32_t wsum[16];
+  __shared__ int32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < B; base += 1024) {
+    const int64_t i = base + tid;
+    const int32_t x = i < B ? v[i] : 0;
+    int32_t incl = x;
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int32_t y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    if (lane == kWave - 1) wsum[wv] = incl;
+    __syncthreads();
+    int32_t before = carry_s;
+    for (int k = 0; k < wv; ++k) before += wsum[k];
+    if (i < B) v[i] = before + incl - x;
+    __syncthreads();
+    if (tid == 1023) carry_s = before + incl;
+    __syncthreads();
+  }
+  if (tid == 0) v[B] = carry_s;
 }
 
 // state_utils.batch_compute_invalid_moves (gym_go/state_utils.py:86-156), two boards per wave: plane 3 recomputed from

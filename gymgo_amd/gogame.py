@@ -96,6 +96,35 @@ def _children_dev(states, canonical, out=None):
     return out
 
 
+def _children_offsets_dev(states, offsets=None):
+    """int32 [B+1]: exclusive prefix sums of the number of children valid_moves() keeps per state (gg_batch_children_offsets)."""
+    B, C, N, _ = states.shape
+    if offsets is None:
+        offsets = torch.empty(B + 1, dtype=_I32, device=states.device)
+    code = _lib.lib().gg_batch_children_offsets(_lib.dev_ptr(states, _U8, 'states'), _lib.dev_ptr(offsets, _I32, 'offsets'),
+                                                B, N, _lib.stream_ptr(states.device))
+    _lib.check(code, 'gg_batch_children_offsets')
+    return offsets
+
+
+def _children_compact_dev(states, canonical, offsets=None, out=None):
+    """The un-padded children of every state, concatenated (gg_batch_children_compact) -> (children uint8 [total, 6, N, N],
+    offsets int32 [B+1]).  `out`: a caller-owned buffer of at least offsets[B] boards (e.g. the upper bound
+    B * (N*N+1)): no device -> host read of the total is then needed and the two launches can be captured in a graph."""
+    B, C, N, _ = states.shape
+    offsets = _children_offsets_dev(states, offsets)
+    if out is None:
+        total = int(offsets[B].item())            # (the one host read of the un-padded form: the size of its result)
+        out = torch.empty((total, C, N, N), dtype=_U8, device=states.device)
+    elif out.dim() != 4 or tuple(out.shape[1:]) != (C, N, N):
+        raise ValueError('out must be [n >= total children, 6, N, N]')
+    code = _lib.lib().gg_batch_children_compact(_lib.dev_ptr(states, _U8, 'states'), _lib.dev_ptr(offsets, _I32, 'offsets'),
+                                                _lib.dev_ptr(out, _U8, 'children'), B, N, int(bool(canonical)),
+                                                _lib.stream_ptr(states.device))
+    _lib.check(code, 'gg_batch_children_compact')
+    return out, offsets
+
+
 def _areas_dev(states, out=None):
     B, C, N, _ = states.shape
     if out is None:
@@ -206,19 +235,26 @@ def children(state, canonical=False, padded=True):
     """gym_go/gogame.py:175-186.  padded=True -> [N*N+1, 6, N, N] with all-zero slots for invalid
     actions; padded=False -> only the valid actions' successors, ascending action order."""
     box = _Box(state)
-    kids = _children_dev(box.t[None], canonical)[0]
-    if not padded:
-        keep = torch.nonzero(torch.as_tensor(valid_moves(box.t)).to(kids.device)).flatten()
-        kids = kids[keep]
-    return box.back(kids)
+    if not padded:      # gym_go/gogame.py:179: only the successors of the valid actions - written by the device as such
+        return box.back(_children_compact_dev(box.t[None], canonical)[0])
+    return box.back(_children_dev(box.t[None], canonical)[0])
 
 
-def batch_children(batch_states, canonical=False, padded=True, out=None):
+def batch_children(batch_states, canonical=False, padded=True, out=None, offsets=None):
     """BASELINE.json config 5 (no reference counterpart: == stack(children(s) for s in states)).
-    out (optional): a caller-owned uint8 [B, N*N+1, 6, N, N] device tensor to expand into (6.4 GB at config 5)."""
-    if not padded:
-        raise ValueError('batch_children returns a rectangular tensor; use padded=True')
+    padded=True -> [B, N*N+1, 6, N, N]; out (optional): a caller-owned uint8 device tensor of that shape to expand into
+    (6.4 GB at config 5).
+    padded=False -> (children [total, 6, N, N], offsets int32 [B+1]): the un-padded children of every state concatenated
+    (== cat(children(s, padded=False) for s in states)); state b's are children[offsets[b]:offsets[b+1]].  On mid-game
+    19x19 positions a third of the padded bytes.  out / offsets (optional): caller-owned buffers (out: at least `total`
+    boards, e.g. B * (N*N+1); then nothing is read back to the host)."""
     box = _Box(batch_states)
+    if not padded:
+        kids, offs = _children_compact_dev(box.t, canonical, offsets, out)
+        if box.numpy:
+            offs = offs.cpu().numpy()
+            return box.back(kids[:int(offs[-1])]), offs
+        return kids, offs
     return box.back(_children_dev(box.t, canonical, out))
 
 

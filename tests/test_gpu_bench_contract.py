@@ -102,6 +102,23 @@ def test_bench_two_ranks(launcher):
     assert len(line['per_rank_launch_ms']) == 2 and all(x > 0 for x in line['per_rank_launch_ms'])
     assert len(line['per_gpu_steps_per_s']) == 2
     assert line['value'] <= sum(line['per_gpu_steps_per_s']) * 1.001    # the whole job cannot beat the sum of its ranks
+    # the N > 1 line carries its own weak-scaling base (rank 0 alone, same shape) and the efficiency against it; the ranks are
+    # pinned to their GPU's NUMA node where the platform says which that is
+    assert line['weak_scaling_base']['games'] == 16384 and line['weak_scaling_base']['steps_per_s_one_gpu'] > 0
+    assert line['efficiency'] == pytest.approx(line['value'] / (2 * line['weak_scaling_base']['steps_per_s_one_gpu']), rel=1e-3)
+    assert 0 < line['efficiency'] <= 1.05 and 'numa_node' in line['rank0_numa']          # (two ranks share ONE GPU here: ~0.5)
+
+
+def test_bench_one_rank_over_rccl():
+    """RCCL itself on this box: bench.py under torch.distributed.run with ONE rank and --comm nccl - init_process_group('nccl'),
+    the barriers and the all-reduces of the N > 1 path run over RCCL (world size 1), so the first contact with 8 ranks is not
+    the first contact with the communicator."""
+    line = _run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                 '--master-port', str(_free_port()), 'bench.py', '--gpus', '1', '--comm', 'nccl', '--steps', '2', '--warmup', '1',
+                 '--no-also', '--no-cpu-baseline'])
+    _check(line, 1, 2, 1)
+    assert line['comm'] == {'backend': 'nccl', 'world_size': 1, 'ranks_counted': 1} and line['rccl_world_size'] == 1
+    assert len(line['per_rank']) == 1 and line['per_rank'][0]['first_game'] == 0
 
 
 def test_bench_per_rank_records_and_nccl_device_check():

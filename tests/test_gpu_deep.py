@@ -63,15 +63,15 @@ def test_bench_trajectory_subsample_vs_oracle():
     slice launches of 40 ... 600 plies, 1 burn-in + 5 warm-up + 4 timed launches of 256 plies over all 65 536 games -
     k_rollout4<19, 0, false, true, false, false>) is followed by an oracle replay of 512 games chosen by global game index
     (every 128th, offset 5: all 16 slices); states, generator states and the kernel's own step counters must agree
-    after each of the 25 launches, i.e. up to ~3 160 plies into a slot's life (mean game length ~640)."""
+    after each of the 25 launches (+ the untimed clock-settle launches of the same shape), i.e. up to ~3 160 plies into a slot's life (mean game length ~640)."""
     import bench
     back = _checked_backend(512)
     opts = {'size': 19, 'plies_per_step': 256, 'steps': 4, 'warmup': 5, 'games_per_gpu': 65536, 'desync': 640,
             'burn_in_steps': 1, 'world': 1}
     res = bench.run_rank(0, 1, back, opts, None)
     assert res['steps_played'] == 4 * 256 * 65536
-    assert back.launches == 15 + 1 + 5 + 4
-    assert back.deepest >= 2560 + 560
+    assert back.launches == 15 + 1 + res['settle_launches'] + 5 + 4 and res['settle_launches'] >= 4     # (+ the clock-settle launches, untimed)
+    assert back.deepest >= 2560 + 560 + 256 * res['settle_launches']
     assert np.array_equal(back.steps_done[back.idx_t].cpu().numpy(), back.counted)
     # the sub-sample really is the stationary mix: dense boards, finished-and-restarted games, every slice
     stones = back.want[:, 0].sum(axis=(1, 2)) + back.want[:, 1].sum(axis=(1, 2))
@@ -93,7 +93,7 @@ def test_bench_driver_as_rank_5_of_8_at_the_per_gpu_size_vs_oracle():
     res = bench.run_rank(5, 8, back, opts, None)
     assert (res['first'], res['count'], res['total_games']) == (5 * 131072, 131072, 1048576)
     assert res['per_rank'] == [dict(res['per_rank'][0], first_game=655360, steps_played=3 * 256 * 131072)]
-    assert back.launches == 15 + 1 + 2 + 3 and back.deepest >= 6 * 256 + 560
+    assert back.launches == 15 + 1 + res['settle_launches'] + 2 + 3 and back.deepest >= 6 * 256 + 560
     assert np.array_equal(back.steps_done[back.idx_t].cpu().numpy(), back.counted)
     assert int(back.steps_done.min()) == 3 * 256 and int(back.steps_done.max()) == 3 * 256
     assert len(np.unique(back.idx // 8192)) == 16       # every de-synchronisation slice is in the sub-sample

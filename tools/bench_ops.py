@@ -88,19 +88,13 @@ def main():
     N, B = 19, 8192
     st, _ = midgame(B, N, 250, 7)
     S = 6 * N * N
-    for canon in (False, True):
-        t = timed(lambda: gogame.batch_children(st, canonical=canon), 5)
-        nbytes = B * (S + (N * N + 1) * S)
-        valid = float(gogame.batch_valid_moves(st).float().sum() / B)
-        out['gg_batch_children_19x19_B8192%s' % ('_canonical' if canon else '')] = {
-            'parents_per_s': B / t, 'child_states_per_s': B * (N * N + 1) / t, 'ms_per_batch': t * 1e3,
-            'algorithmic_GBps': nbytes / t / 1e9, 'roofline_frac': nbytes / t / PEAK, 'mean_valid_children': valid}
-    for phase, plies in (('early', 20), ('mid', 150), ('late', 400)):
-        ph = gogame.batch_init_state(B, N, device='cuda')
-        gogame.batch_rollout(ph, gogame.rng_seed(B, 77), plies, False)
-        t = timed(lambda: gogame.batch_children(ph), 5)
-        out['gg_batch_children_19x19_B8192_%s_parents_%d_plies' % (phase, plies)] = {
-            'parents_per_s': B / t, 'ms_per_batch': t * 1e3, 'roofline_frac': B * (S + (N * N + 1) * S) / t / PEAK}
+    # config 5 through THE harness of the bench line (bench.children_record: one preallocated buffer, HIP events) - padded and
+    # un-padded - on this script's parents (250 plies, one phase) next to the bench line's stationary mix
+    import bench
+    out['gg_batch_children_19x19_B8192'] = bench.children_record(torch, torch.device('cuda', 0), st, 'midgame(8192, 19, 250 plies, seed 7)', by_phase=True)
+    out['gg_batch_children_19x19_B8192']['mean_valid_children'] = float(gogame.batch_valid_moves(st).float().sum() / B)
+    t = timed(lambda: gogame.batch_children(st, canonical=True), 5)
+    out['gg_batch_children_19x19_B8192_canonical_with_allocation_per_call'] = {'parents_per_s': B / t, 'ms_per_batch': t * 1e3}
     # the same parents as packed boards: 362 x 232 B per parent
     pk = gogame.batch_pack(st)
     t = timed(lambda: gogame.batch_children_packed(pk), 10)

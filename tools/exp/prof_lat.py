@@ -8,6 +8,7 @@ from gymgo_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, os.environ.get('LIB', 'ab_libs/libgg_prof.so'))
 from gymgo_amd import gogame
 L = ctypes.CDLL(_lib.LIB_PATH)
+L.gg_ab_prof_read = L.gg_ab_prof_read_lat     # (gg_lat.hip's own phase clocks)
 L.gg_ab_prof_read.argtypes = [ctypes.c_void_p]; L.gg_ab_prof_read.restype = ctypes.c_int32
 N, B, F = int(os.environ.get('GGN', 9)), int(os.environ.get('GGB', 4096)), int(os.environ.get('PLIES', 256))
 st = gogame.batch_init_state(B, N, device='cuda'); rng = gogame.rng_seed(B, 20260927)

@@ -103,11 +103,11 @@ try:
     cf = mean(d['FETCH_SIZE'] for d in counters('cal_fetch', 'k_children3', skip=1)) * 1024 * fetch_scale
     cw = mean(d['WRITE_SIZE'] for d in counters('cal_write', 'k_children3', skip=1)) * 1024 * write_scale
     algo = 8192 * (6 * 361 + 362 * 6 * 361)
-    md.append('\n## config 5 (`k_children3<19, false>`, 8 192 parents): HBM traffic per launch\n')
+    md.append('\n## config 5 (`k_children3<19, false, false>`, 8 192 parents): HBM traffic per launch\n')
     md.append('FETCH_SIZE -> %.1f MB read, WRITE_SIZE -> %.1f MB written (same correction factors); the algorithm moves %.1f MB '
               '(1 444 B in, 362 x 2 166 B out per parent): traffic / algorithmic = %.3f - every byte is written once, nothing is re-read.'
               % (cf / 1e6, cw / 1e6, algo / 1e6, (cf + cw) / algo))
-    children_rec = {'kernel': 'k_children3<19, false>', 'parents': 8192, 'fetch_bytes': round(cf), 'write_bytes': round(cw),
+    children_rec = {'kernel': 'k_children3<19, false, false>', 'parents': 8192, 'fetch_bytes': round(cf), 'write_bytes': round(cw),
                     'hbm_bytes_per_launch': round(cf + cw), 'algorithmic_bytes_per_launch': algo,
                     'source': 'profiles/%s_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/calib_traffic.py)' % tag}
 except Exception as e:
@@ -200,7 +200,7 @@ try:
 except Exception:
     pass
 if children_rec:
-    children_rec['kernel_code_sha16'] = _bench.kernel_code_hash('_ZN2gg11k_children3ILi19ELb0EEE')
+    children_rec['kernel_code_sha16'] = _bench.kernel_code_hash(_bench.CHILDREN_SYMBOL_PREFIX)
     blob['children'] = children_rec
 json.dump(blob, open(pmc_path, 'w'), indent=1)
 
