@@ -33,7 +33,7 @@ namespace gg {
 // gg_rollout.hip: the fused multi-ply launches with drawn moves, a translation unit of their own (one code-generation switch differs)
 void launch_rollout4(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N,
                      uint32_t inv, int plies, int auto_reset, int nb, int grid, hipStream_t s);
-void launch_rollout_lat(uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N, int plies,
+void launch_rollout_lat(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N, int plies,
                         int auto_reset, hipStream_t s);
 }
 
@@ -240,12 +240,21 @@ bool use_multi_ply(int cus, int64_t B, int plies) {
 // and per launch length at 4 096 games: 9x9 1 / 2 / 4 / 16 plies x0.87 / 0.97 / 1.13 / 1.49, 13x13 x0.78 / 0.87 / 1.03 / 1.32,
 // 19x19 x0.50 / 0.59 / 0.73 / 0.82 (the launch pays the first classes of every board: eleven lock-step floods), so from
 // 3 / 4 / 64 plies per launch on.  (A/B builds: GG_AB_LAT_MAX = games per CU, GG_AB_LAT_PLIES = plies.)
-bool use_lat(int cus, int64_t B, int32_t N, int plies) {
+// Tracked boards carry their classes - no first analysis on either kernel, a lane loads and stores its own five row words - so
+// the kernel pays from ONE ply per launch on and up to larger batches (profiles/r05e_lat_tracked_sweep.txt, new / k_rollout4
+// at 1 / 4 / 64 / 256 plies per launch): 9x9 4 096 games x1.06 / 2.06 / 2.33 / 2.54, 16 384 x1.61 / 1.41 / 1.16 / 1.14, 32 768
+// x1.35 / 1.04 / 0.76 / 0.76; 13x13 8 192 x1.77 / 1.74 / 1.55 / 1.61, 16 384 x1.86 / 1.37 / 1.00 / 1.01; 19x19 4 096 x1.65 / 1.27 /
+// 1.11 / 1.14, 8 192 x1.52 / 1.03 / 0.76 / 0.72 -> up to 64 / 64 / 16 games per CU.  (A/B builds: GG_AB_LATT_MAX, GG_AB_LATT_PLIES.)
+bool use_lat(int cus, int64_t B, int32_t N, int plies, bool tracked = false) {
   int64_t per_cu = N <= 9 ? 64 : N <= 13 ? 32 : 8;
   int min_plies = N <= 9 ? 3 : N <= 13 ? 4 : 64;
+  if (tracked) {
+    per_cu = N <= 13 ? 64 : 16;
+    min_plies = 1;
+  }
 #ifdef GG_AB
-  if (const char *e = getenv("GG_AB_LAT_MAX")) per_cu = atoll(e);
-  if (const char *e = getenv("GG_AB_LAT_PLIES")) min_plies = atoi(e);
+  if (const char *e = getenv(tracked ? "GG_AB_LATT_MAX" : "GG_AB_LAT_MAX")) per_cu = atoll(e);
+  if (const char *e = getenv(tracked ? "GG_AB_LATT_PLIES" : "GG_AB_LAT_PLIES")) min_plies = atoi(e);
 #endif
   return plies >= min_plies && B <= (int64_t)cus * per_cu;
 }
@@ -519,7 +528,7 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
   if (plies == 0) return 0;
   if (!rng) return GG_E_NULLPTR;
   if (use_lat(cus, B, N, plies)) {   // an under-filled machine: one row per lane, the ply in registers (gg_lat.h, launched from gg_rollout.hip)
-    launch_rollout_lat(states, rng, last_actions, steps_done, B, N, plies, auto_reset, s);
+    launch_rollout_lat(0, states, rng, last_actions, steps_done, B, N, plies, auto_reset, s);
     return (int32_t)hipGetLastError();
   }
   if (use_multi_ply(cus, B, plies)) {   // liberty classes carried across the plies, 16 boards per wave
@@ -793,6 +802,10 @@ int32_t gg_batch_rollout_tracked(uint32_t *tracked, uint64_t *rng, int32_t *last
   if (plies == 0) return 0;
   if (!rng) return GG_E_NULLPTR;
   uint8_t *st = reinterpret_cast<uint8_t *>(tracked);
+  if (use_lat(cus, B, N, plies, true)) {   // an under-filled machine: one row per lane, the ply in registers (gg_lat.h)
+    launch_rollout_lat(2, st, rng, last_actions, steps_done, B, N, plies, auto_reset, s);
+    return (int32_t)hipGetLastError();
+  }
   int grid3;
   const int nb = boards_per_wave(cus, B, grid3);
   launch_rollout4(2, st, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, nb, grid3, s);

@@ -267,7 +267,10 @@ struct LdsLat {
 // gg_batch_rollout on byte planes (uint8 [B][6][N][N], in place): `plies` uniform-random plies per game, boards on-chip in
 // between.  One single-wave workgroup per NBW boards.
 // AUTO: auto_reset != 0 (every board of the batch is live for every ply of the launch: no liveness test, no early exit)
-template <int R, bool FULLN, bool AUTO>
+// IO: 0 = byte planes (uint8 [B][6][N][N]); 2 = TRACKED boards (uint32 [B][5N+1]: the rows of black, white, invalid,
+// multi_black, multi_white + the flag word, gg_v4.h) - a lane reads and writes its own five row words, the classes travel with
+// the board: no LDS, no first analysis, so even a one-ply launch is just the ply
+template <int R, bool FULLN, bool AUTO, int IO = 0>
 __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                           int32_t *__restrict__ last_actions,
                                                           int64_t *__restrict__ steps_done, int64_t B, int N, int plies,
@@ -282,7 +285,10 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
   const int r = lane & (LPB - 1), j = lane / LPB;      // row, board of the wave
   const int P = N * N, S = 6 * P;
   const uint32_t full = r < N ? (1u << N) - 1u : 0u;
-  load_spread_lut(lut, lane);
+  static_assert(IO == 0 || IO == 2, "byte planes or tracked boards");
+  constexpr bool TRACKED = IO == 2;
+  const int W = 5 * N + 1;
+  if (!TRACKED) load_spread_lut(lut, lane);
   const int64_t ngroups = (B + NBW - 1) / NBW;
   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const int64_t b_first = g * NBW;
@@ -291,16 +297,29 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
     uint8_t *gs = states + b * (int64_t)S;
     // ---------------------------------------------------------------- load: all boards of the wave staged, then one row per lane
     GG_PROF_DECL;
-    WAVE_SYNC();
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) {
-      const int64_t bi = b_first + i < B ? b_first + i : B - 1;
-      stage_in(states + bi * (int64_t)S, S, reinterpret_cast<uint8_t *>(lds + LdsLat<R>::kIo) + i * L::kIoBytes, lane);
-    }
-    uint64_t x = rng[b];
-    WAVE_SYNC();
+    uint32_t *gp = reinterpret_cast<uint32_t *>(states) + b * (int64_t)W;   // TRACKED: this lane's board
+    uint64_t x;
     uint32_t me, op, M, inv, fl;
-    {
+    if (TRACKED) {
+      const int rc = r < N ? r : 0;
+      uint32_t bl = gp[rc], wh = gp[N + rc];
+      inv = gp[2 * N + rc];
+      M = gp[3 * N + rc] | gp[4 * N + rc];
+      fl = gp[5 * N] & 7u;
+      x = rng[b];
+      if (!on || r >= N) { bl = wh = inv = M = 0; }
+      if (!on) fl = 0;
+      me = (fl & 1u) ? wh : bl;
+      op = (fl & 1u) ? bl : wh;
+    } else {
+      WAVE_SYNC();
+#pragma unroll
+      for (int i = 0; i < NBW; ++i) {
+        const int64_t bi = b_first + i < B ? b_first + i : B - 1;
+        stage_in(states + bi * (int64_t)S, S, reinterpret_cast<uint8_t *>(lds + LdsLat<R>::kIo) + i * L::kIoBytes, lane);
+      }
+      x = rng[b];
+      WAVE_SYNC();
       const uint8_t *io = reinterpret_cast<const uint8_t *>(lds + LdsLat<R>::kIo) + j * L::kIoBytes + ((uintptr_t)gs & 15u);
       uint32_t bl = plane_to_row<R>(io, N, r), wh = plane_to_row<R>(io + P, N, r);
       inv = plane_to_row<R>(io + 3 * P, N, r);
@@ -437,9 +456,16 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
       const uint32_t turn = fl & 1u;
       const uint32_t bl = turn ? op : me, wh = turn ? me : op;
       const int lastb = lat_board_max<LPB>(lastv);
-      if (__ballot(played != 0))
+      if (TRACKED) {
+        if (on && played != 0 && r < N) {
+          gp[r] = bl; gp[N + r] = wh; gp[2 * N + r] = inv;
+          gp[3 * N + r] = M & bl; gp[4 * N + r] = M & wh;
+        }
+        if (on && played != 0 && r == 0) gp[5 * N] = fl;
+      } else if (__ballot(played != 0)) {
         lat_emit<R>(gs, bl, wh, inv, turn, (fl >> 1) & 1u, (fl >> 2) & 1u, full, N, r,
                     lds + LdsLat<R>::kBs + j * L::kBsWords, lut, on && played != 0);
+      }
       if (on && r == 0) {
         rng[b] = x;
         if (last_actions) last_actions[b] = lastb;

@@ -15,13 +15,19 @@ namespace gg {
 
 // gg_batch_rollout on a batch that leaves the SIMDs under-filled (gg_kernels.hip: use_lat): one single-wave workgroup per
 // four 9x9 / 13x13 boards or two 19x19 boards.
-#define GG_LAT(R, F)                                                                                                   \
-  do {                                                                                                                 \
-    const unsigned grid_ = (unsigned)((B + Lat<R>::NBW - 1) / Lat<R>::NBW);                                            \
-    if (auto_reset) k_rollout_lat<R, F, true><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 1); \
-    else k_rollout_lat<R, F, false><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 0);         \
+// io: 0 byte planes, 2 tracked boards (`st` is the batch in that format)
+#define GG_LAT(R, F)                                                                                                            \
+  do {                                                                                                                          \
+    const unsigned grid_ = (unsigned)((B + Lat<R>::NBW - 1) / Lat<R>::NBW);                                                     \
+    if (io == 0) {                                                                                                              \
+      if (auto_reset) k_rollout_lat<R, F, true, 0><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 1);  \
+      else k_rollout_lat<R, F, false, 0><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 0);            \
+    } else {                                                                                                                    \
+      if (auto_reset) k_rollout_lat<R, F, true, 2><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 1);  \
+      else k_rollout_lat<R, F, false, 2><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 0);            \
+    }                                                                                                                           \
   } while (0)
-void launch_rollout_lat(uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N, int plies,
+void launch_rollout_lat(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N, int plies,
                         int auto_reset, hipStream_t s) {
   if (N == 9) GG_LAT(9, true);
   else if (N < 9) GG_LAT(9, false);

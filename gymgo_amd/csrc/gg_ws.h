@@ -72,9 +72,12 @@ __device__ __forceinline__ int wsample_row(const uint32_t (&bits)[NJ], const uin
   const uint32_t incl = row_scan16(own), T = row_sum16(own), excl = incl - own;
   const uint32_t k = (uint32_t)(((uint64_t)uhi * (uint64_t)T) >> 32);
   const bool hit = T != 0u && k >= excl && k < incl;
+  // position inside the lane's run: how many of its running sums the draw has passed.  (k - excl once instead of excl + p[j]
+  // per weight; in a lane that is not `hit` the difference wraps and the count is not used)
+  const uint32_t kk = k - excl;
   uint32_t cnt = 0;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) cnt += (excl + p[j] <= k) ? 1u : 0u;
+  for (int j = 0; j < NJ; ++j) cnt += (p[j] <= kk) ? 1u : 0u;
   if (hit) return i + 16 * (int)cnt;
   return (T == 0u && i == 0) ? -1 : -2;
 }

@@ -110,3 +110,45 @@ def test_lat_starts_from_arbitrary_midgame_positions():
             want, want_rng, _ = c_oracle.batch_rollout_mt(want, want_rng, F, True)
             assert np.array_equal(st.cpu().numpy(), want), (N, F)
             assert np.array_equal(rng.cpu().numpy().view(np.uint64), want_rng)
+
+
+@pytest.mark.parametrize('N,B', [(9, 4096), (9, 5), (9, 1001), (7, 130), (5, 77), (2, 9), (13, 1023), (11, 100), (19, 511), (19, 3), (16, 33)])
+def test_lat_tracked_rollout_vs_oracle(N, B):
+    """gg_batch_rollout_tracked on batches the latency-shaped kernel takes (tracked boards: from ONE ply per launch on): the
+    untracked boards == the oracle, the tracked words == gg_batch_track_states of the oracle's boards bit for bit (liberty
+    classes are a function of the position), generator states and last actions as well; auto-reset on and off."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    for auto_reset in (True, False):
+        st = gogame.batch_init_state(B, N, device='cuda')
+        tr = gogame.batch_track(st)
+        rng = gogame.rng_seed(B, 11 + N, 0, 'cuda')
+        want, want_rng = st.cpu().numpy(), rng.cpu().numpy().view(np.uint64).copy()
+        sd = torch.zeros(B, dtype=torch.int64, device='cuda')
+        for F in (1, 1, 2, 7, 64, 3 * N * N + 5):
+            la = torch.full((B,), -9, dtype=torch.int32, device='cuda')
+            gogame.batch_rollout_tracked(tr, rng, F, auto_reset, la, sd)
+            want, want_rng, want_last = c_oracle.batch_rollout_mt(want, want_rng, F, auto_reset)
+            assert np.array_equal(gogame.batch_untrack(tr).cpu().numpy(), want), (N, B, F, auto_reset)
+            assert torch.equal(gogame.batch_track(torch.from_numpy(want).cuda()), tr), (N, B, F, auto_reset)
+            assert np.array_equal(rng.cpu().numpy().view(np.uint64), want_rng) and np.array_equal(la.cpu().numpy(), want_last)
+        if auto_reset:
+            assert int(sd.min()) == int(sd.max()) == 1 + 1 + 2 + 7 + 64 + 3 * N * N + 5
+
+
+@pytest.mark.parametrize('N', [9, 13, 19])
+def test_tracked_rollout_same_result_on_both_sides_of_the_take_over(N):
+    """64 / 64 / 16 games per CU: the batch sizes right at and above the point where k_rollout4 takes tracked launches back."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    edge = _cus() * (64 if N <= 13 else 16)
+    for B in (edge, edge + 1):
+        st = gogame.batch_init_state(B, N, device='cuda')
+        tr = gogame.batch_track(st)
+        rng = gogame.rng_seed(B, B, 0, 'cuda')
+        want, want_rng = st.cpu().numpy(), rng.cpu().numpy().view(np.uint64).copy()
+        for F in (1, 3, 40):
+            gogame.batch_rollout_tracked(tr, rng, F, True)
+            want, want_rng, _ = c_oracle.batch_rollout_mt(want, want_rng, F, True)
+            assert np.array_equal(gogame.batch_untrack(tr).cpu().numpy(), want), (N, B, F)
+            assert np.array_equal(rng.cpu().numpy().view(np.uint64), want_rng)

@@ -97,6 +97,65 @@ def sweep():
             both(N, B, F, 32)
 
 
+def tracked_parity():
+    """Tracked boards through gg_batch_rollout_tracked (lat below its take-over point, k_rollout4 above): untracked == oracle,
+    and the tracked words == track(states) bit for bit (the classes are canonical)."""
+    bad = 0
+    for N, B, launches in ((9, 4096, (1, 2, 30, 64, 256)), (9, 5, (1, 64, 200)), (9, 1001, (1, 7, 120)), (13, 1023, (1, 2, 100, 300)),
+                           (19, 511, (1, 2, 150, 400)), (19, 3, (1, 600)), (5, 77, (1, 40, 100)), (7, 130, (1, 64, 64)), (2, 9, (1, 20)),
+                           (11, 100, (250,)), (16, 33, (300,)), (9, 20000, (3, 40)), (13, 9000, (3, 40)), (19, 2500, (70,))):
+        for auto_reset in (True, False):
+            st = gogame.batch_init_state(B, N, device=dev)
+            tr = gogame.batch_track(st)
+            rng = gogame.rng_seed(B, 4242 + N, 0, dev)
+            ref, ref_rng = st.cpu().numpy(), rng.cpu().numpy().view(np.uint64)
+            for F in launches:
+                last = torch.full((B,), -7, dtype=torch.int32, device=dev)
+                gogame.batch_rollout_tracked(tr, rng, F, auto_reset, last)
+                ref, ref_rng, ref_last = c_oracle.batch_rollout_mt(ref, ref_rng, F, auto_reset)
+                got = gogame.batch_untrack(tr).cpu().numpy()
+                ok = np.array_equal(got, ref) and np.array_equal(rng.cpu().numpy().view(np.uint64), ref_rng) and np.array_equal(last.cpu().numpy(), ref_last)
+                ok = ok and torch.equal(gogame.batch_track(torch.from_numpy(ref).to(dev)), tr)
+                if not ok:
+                    bad += 1
+                    print('TRACKED MISMATCH N %d B %d F %d auto_reset %s' % (N, B, F, auto_reset), flush=True)
+    print('tracked parity: %d mismatching launches' % bad, flush=True)
+    return bad
+
+
+def rate_tracked(N, B, F, reps=8):
+    st = gogame.batch_init_state(B, N, device=dev); rng = gogame.rng_seed(B, 20260927, 0, dev)
+    ch = max(1, B // 16)
+    for g in range(1, 16):
+        gogame.batch_rollout(st[g * ch:(g + 1) * ch], rng[g * ch:(g + 1) * ch], g * (8 if N <= 9 else 20 if N <= 13 else 40), True)
+    tr = gogame.batch_track(st)
+    for _ in range(3):
+        gogame.batch_rollout_tracked(tr, rng, F, True)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        gogame.batch_rollout_tracked(tr, rng, F, True)
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    return ms, B * F / ms * 1e3, hashlib.sha1(tr.cpu().numpy().tobytes()).hexdigest()[:10]
+
+
+def tsweep():
+    def both(N, B, F, reps):
+        out = []
+        for lat in ('1000000', '0'):
+            os.environ['GG_AB_LATT_MAX'] = lat
+            os.environ['GG_AB_LATT_PLIES'] = '1'
+            out.append(rate_tracked(N, B, F, reps=reps))
+        print('tracked N %2d B %6d F %3d: lat %.4f ms %.3e steps/s | k_rollout4 %.4f ms %.3e steps/s | x%.2f %s' %
+              (N, B, F, out[0][0], out[0][1], out[1][0], out[1][1], out[0][1] / out[1][1], 'same digest' if out[0][2] == out[1][2] else 'DIGESTS DIFFER'), flush=True)
+    for N, sizes in ((9, (1024, 4096, 8192, 16384, 32768)), (13, (1024, 4096, 8192, 16384)), (19, (1024, 2048, 4096, 8192))):
+        for B in sizes:
+            for F in (1, 4, 64, 256):
+                both(N, B, F, 4 if F >= 64 else 24)
+
+
 if __name__ == '__main__':
     rc = 0
     if MODE in ('all', 'parity'):
@@ -105,4 +164,8 @@ if __name__ == '__main__':
         timing()
     if MODE in ('sweep',):
         sweep()
+    if MODE in ('all', 'tparity'):
+        rc = rc or tracked_parity()
+    if MODE in ('tsweep',):
+        tsweep()
     sys.exit(1 if rc else 0)
