@@ -894,6 +894,32 @@ def extras(dev, back, opts):
         del graph
     except Exception as e:      # no graph support on this stack: the API-loop number above stands alone
         configs['config2_9x9_4096_games']['per_ply_graph_note'] = 'hipGraph capture failed: %s' % (str(e)[:160],)
+    # the same games kept in the TRACKED layout (GoVecEnv's default: the liberty classes travel with the board, no first
+    # analysis per launch) - gg_batch_rollout_tracked: fused, one ply per launch through the API, and as a hipGraph of 64
+    try:
+        tr2 = gogame.batch_track(b2.states)
+        rg2 = b2.rng.clone()
+        for _ in range(3):
+            gogame.batch_rollout_tracked(tr2, rg2, F, True)
+        rt, mst = event_rate(torch, dev, lambda: gogame.batch_rollout_tracked(tr2, rg2, F, True), 4096 * F, 8)
+        rt1, mst1 = event_rate(torch, dev, lambda: gogame.batch_rollout_tracked(tr2, rg2, 1, True), 4096, 64)
+        rec_t = {'layout': 'tracked boards (uint32 [B][5N+1]), gg_batch_rollout_tracked', 'kernel': 'k_rollout_lat<9, true, true, 2>',
+                 'fused_rollout_steps_per_s': round(rt, 1), 'launch_ms': round(mst, 4),
+                 'per_ply_rollout_steps_per_s': round(rt1, 1), 'per_ply_launch_us': round(mst1 * 1e3, 2)}
+        side = torch.cuda.Stream(device=dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            gogame.batch_rollout_tracked(tr2, rg2, 1, True)
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(64):
+                gogame.batch_rollout_tracked(tr2, rg2, 1, True)
+        rg_, msg_ = event_rate(torch, dev, graph.replay, 4096 * 64, 16)
+        rec_t.update({'per_ply_graph_steps_per_s': round(rg_, 1), 'per_ply_graph_launch_us': round(msg_ * 1e3 / 64, 2)})
+        del graph
+        configs['config2_9x9_4096_games']['tracked_layout'] = rec_t
+    except Exception as e:
+        configs['config2_9x9_4096_games']['tracked_layout'] = {'note': 'failed: %s' % (str(e)[:160],)}
     del b2
     # --- config 4's per-GPU batch (131 072 games) on this one GPU: the base for weak-scaling ratios
     if opts['world'] == 1 and N == 19 and count != 131072:
