@@ -5,7 +5,7 @@
 
 Every round draws a board size (2 .. 19), a batch, a layout, a launch length and a mix of game phases, then walks the same
 games on the device (fused rollouts in one to three launches, one env step with rewards, one policy-weighted step with
-float32 / bfloat16 / float16 weights, next_states with drawn - partly illegal - moves, children of a few parents, areas, the invalid-move mask, track_states followed by a fused rollout on the tracked boards)
+float32 / bfloat16 / float16 weights, next_states with drawn - partly illegal - moves, children of a few parents (padded and un-padded), areas, the invalid-move mask, track_states followed by a fused rollout on the tracked boards)
 and through oracle/gg_oracle.c, and compares
 boards, generators, moves, rewards and masks bit for bit.  The seeded tests of the suite pin known cases; this looks for
 the cases nobody wrote down (rare capture / ko / suicide sub-paths of the multi-ply kernel take thousands of plies to hit).
@@ -114,8 +114,16 @@ def main():
         if not (np.array_equal(nxt.cpu().numpy(), wn) and np.array_equal(stat.cpu().numpy(), ws)):
             fail('batch_next_states with arbitrary moves (%d playable)' % int(playable.sum()), params)
         k = min(B, 24)
-        if not np.array_equal(gogame.batch_children(dev[:k]).cpu().numpy(), c_oracle.batch_children_mt(st2[:k])):
+        kids_want = c_oracle.batch_children_mt(st2[:k])
+        if not np.array_equal(gogame.batch_children(dev[:k]).cpu().numpy(), kids_want):
             fail('batch_children', params)
+        # the un-padded form: the slots valid_moves() keeps (plane 3 clear + the pass; every action once the game has ended)
+        keep = np.concatenate([st2[:k, 3].reshape(k, -1) == 0, np.ones((k, 1), bool)], axis=1)
+        keep[st2[:k, 5, 0, 0] == 1] = True
+        ckids, coffs = gogame.batch_children(dev[:k], padded=False)
+        if not (np.array_equal(coffs.cpu().numpy(), np.concatenate([[0], np.cumsum(keep.sum(axis=1))]).astype(np.int32))
+                and np.array_equal(ckids.cpu().numpy(), kids_want[keep])):
+            fail('batch_children(padded=False)', params)
         gb, gw = gogame.batch_areas(dev)
         if not (np.array_equal(gb.cpu().numpy(), b) and np.array_equal(gw.cpu().numpy(), w)):
             fail('batch_areas', params)
