@@ -634,6 +634,7 @@ def children_record(torch, dev, parents, parents_note, by_phase=False, reps=8):
     A, S = N * N + 1, 6 * N * N
     kids = torch.empty((B, A, 6, N, N), dtype=torch.uint8, device=dev)
     offs = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    order = torch.empty(B, dtype=torch.int32, device=dev)
     lib = _lib.lib()
     cur = {'p': parents}
 
@@ -643,10 +644,10 @@ def children_record(torch, dev, parents, parents_note, by_phase=False, reps=8):
 
     def expand_compact():
         _lib.check(lib.gg_batch_children_offsets(_lib.dev_ptr(cur['p'], torch.uint8, 'states'), _lib.dev_ptr(offs, torch.int32, 'offsets'),
-                                                 B, N, _lib.stream_ptr(dev)), 'gg_batch_children_offsets')
+                                                 _lib.dev_ptr(order, torch.int32, 'order'), B, N, _lib.stream_ptr(dev)), 'gg_batch_children_offsets')
         _lib.check(lib.gg_batch_children_compact(_lib.dev_ptr(cur['p'], torch.uint8, 'states'), _lib.dev_ptr(offs, torch.int32, 'offsets'),
-                                                 _lib.dev_ptr(kids, torch.uint8, 'children'), B, N, 0, _lib.stream_ptr(dev)),
-                   'gg_batch_children_compact')
+                                                 _lib.dev_ptr(order, torch.int32, 'order'), _lib.dev_ptr(kids, torch.uint8, 'children'),
+                                                 B, N, 0, _lib.stream_ptr(dev)), 'gg_batch_children_compact')
     r, ms = event_rate(torch, dev, expand, B, reps)
     bytes_per_parent = S + A * S
     rec = {
@@ -671,9 +672,9 @@ def children_record(torch, dev, parents, parents_note, by_phase=False, reps=8):
     # valid_moves() keeps, at their rank - both launches (offsets + children) inside the timed call
     rc, msc = event_rate(torch, dev, expand_compact, B, reps)
     total = int(offs[B].item())
-    moved = total * S + B * (4 * N * N + 4) + 8 * B         # children written + planes 0-3 and flags read + offsets
+    moved = total * S + B * (4 * N * N + 4) + 16 * B        # children written + planes 0-3 and flags read + offsets and order
     rec['compact'] = {
-        'entry': 'gg_batch_children_offsets + gg_batch_children_compact', 'kernel': 'k_children3<%d, false, true>' % N,
+        'entry': 'gg_batch_children_offsets + gg_batch_children_compact (parents handed out by falling child count)', 'kernel': 'k_children3<%d, false, true>' % N,
         'parents_per_s': round(rc, 1), 'child_states_per_s': round(rc * total / B, 1), 'launch_ms': round(msc, 4),
         'mean_children_per_parent': round(total / B, 2), 'of_slots': A,
         'bytes_moved_per_launch': moved, 'bytes_vs_padded': round(moved / (bytes_per_parent * B), 4),

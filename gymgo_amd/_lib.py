@@ -33,8 +33,8 @@ _SIGNATURES = {
     'gg_batch_invalid_mask': ([_vp, _vp, _vp, _i64, _i32, _vp], _i32),
     'gg_batch_areas': ([_vp, _vp, _vp, _i64, _i32, _vp], _i32),
     'gg_batch_children': ([_vp, _vp, _i64, _i32, _i32, _vp], _i32),
-    'gg_batch_children_offsets': ([_vp, _vp, _i64, _i32, _vp], _i32),
-    'gg_batch_children_compact': ([_vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
+    'gg_batch_children_offsets': ([_vp, _vp, _vp, _i64, _i32, _vp], _i32),
+    'gg_batch_children_compact': ([_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
     'gg_batch_rollout': ([_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
     'gg_batch_env_step': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_float, _i32, _i32, _vp], _i32),
     'gg_batch_sample_actions': ([_vp, _vp, _vp, _i64, _i32, _vp], _i32),

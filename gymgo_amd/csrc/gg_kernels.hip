@@ -495,7 +495,7 @@ int32_t gg_batch_children(const uint8_t *states, uint8_t *children, int64_t B, i
 
 // un-padded children (gogame.children(padded=False)): per-parent counts -> exclusive offsets, then the same kernel with every
 // child at the rank of its action among the kept ones
-int32_t gg_batch_children_offsets(const uint8_t *states, int32_t *offsets, int64_t B, int32_t N, void *hip_stream) {
+int32_t gg_batch_children_offsets(const uint8_t *states, int32_t *offsets, int32_t *order, int64_t B, int32_t N, void *hip_stream) {
   if (N >= 2 && N <= GG_MAX_BOARD && B > 0 && B > (int64_t)0x7FFFFFFF / (N * N + 1)) return GG_E_BADSIZE;
   if (B == 0 && offsets && !check(B, N)) {   // an empty batch has offsets[0] = 0
     OnDeviceOf on_dev(offsets);
@@ -504,20 +504,21 @@ int32_t gg_batch_children_offsets(const uint8_t *states, int32_t *offsets, int64
   GG_ENTER(states);
   if (!offsets) return GG_E_NULLPTR;
   k_children_counts<<<grid_for(cus, (B + 3) / 4), 4 * kWave, 0, s>>>(states, offsets, B, N);
+  if (order) k_children_order<<<1, 1024, 0, s>>>(offsets, order, B, N * N + 1);   // (on the counts, before they become offsets)
   k_scan_counts<<<1, 1024, 0, s>>>(offsets, B);
   return (int32_t)hipGetLastError();
 }
 
-int32_t gg_batch_children_compact(const uint8_t *states, const int32_t *offsets, uint8_t *children, int64_t B, int32_t N,
-                                  int32_t canonical, void *hip_stream) {
+int32_t gg_batch_children_compact(const uint8_t *states, const int32_t *offsets, const int32_t *order, uint8_t *children, int64_t B,
+                                  int32_t N, int32_t canonical, void *hip_stream) {
   GG_ENTER(states);
   if (!children || !offsets) return GG_E_NULLPTR;
   if (B > (int64_t)0x7FFFFFFF / (N * N + 1)) return GG_E_BADSIZE;
   const int chunks = children_chunks(cus, B, N * N + 1);
   const int grid = grid_for(cus, B * chunks);
-  GG_DISPATCH(N, (k_children3<9, false, true><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks, offsets)),
-              (k_children3<13, false, true><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks, offsets)),
-              (k_children3<19, false, true><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks, offsets)));
+  GG_DISPATCH(N, (k_children3<9, false, true><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks, offsets, order)),
+              (k_children3<13, false, true><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks, offsets, order)),
+              (k_children3<19, false, true><<<grid, kWave, 0, s>>>(states, children, B, N, inv, canonical, chunks, offsets, order)));
   return (int32_t)hipGetLastError();
 }
 

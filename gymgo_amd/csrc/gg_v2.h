@@ -1053,7 +1053,8 @@ template <int R, bool PACKED = false, bool COMPACT = false>
 __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *__restrict__ states,
                                                         uint8_t *__restrict__ children, int64_t B, int N,
                                                         uint32_t inv, int canonical, int chunks,
-                                                        const int32_t *__restrict__ offsets = nullptr) {
+                                                        const int32_t *__restrict__ offsets = nullptr,
+                                                        const int32_t *__restrict__ order = nullptr) {
   static_assert(!(PACKED && COMPACT), "compact children are byte planes");
   constexpr int RS = Cfg<R>::kRowStride;
   constexpr int RV = (R + 3) / 4;
@@ -1074,8 +1075,12 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
   for (int i = hf.lane; i < (int)kRingWords; i += kWave) ring[i] = 0;   // every flushed block is zeroed again
   const int per = (A + chunks - 1) / chunks;
   for (int64_t w = blockIdx.x; w < B * chunks; w += gridDim.x) {
-    const int64_t b = w / chunks;
-    const int ch = (int)(w - b * chunks);
+    // COMPACT: the work of a parent grows with the children it keeps (57 late in a game, 342 early): in index order a launch
+    // of two rounds of waves ends with a few heavy parents on an emptying machine (56 % mean occupancy measured).  `order`
+    // (k_children_order: the parents by falling count) hands the heavy ones out first - longest processing time first.
+    const int64_t wp = w / chunks;
+    const int64_t b = (COMPACT && order) ? (int64_t)order[wp] : wp;
+    const int ch = (int)(w - wp * chunks);
     const uint8_t *gi = states + b * (int64_t)S;
     uint8_t *gc = COMPACT ? children + (int64_t)offsets[b] * S : children + b * A * (int64_t)S;
     const int W = 3 * N + 1;
@@ -1453,6 +1458,25 @@ static __global__ void k_children_counts(const uint8_t *__restrict__ states, int
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
     if (lane == 0) counts[b] = g[5 * P] ? P + 1 : c + 1;
   }
+}
+
+// order[0 .. B) = the parents sorted by FALLING child count (a counting sort over the <= N*N+1 possible counts; ties in any
+// order: it only decides which work item a parent is, never what is written) - the launch order of the compact expansion.
+// ONE workgroup of 1 024 threads, run on the counts before k_scan_counts turns them into offsets.
+static __global__ __launch_bounds__(1024) void k_children_order(const int32_t *__restrict__ counts, int32_t *__restrict__ order,
+                                                                int64_t B, int A) {
+  __shared__ int32_t bin[512];    // A <= 362
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 512; i += 1024) bin[i] = 0;
+  __syncthreads();
+  for (int64_t i = tid; i < B; i += 1024) atomicAdd(&bin[A - counts[i]], 1);    // bin 0 = the largest count
+  __syncthreads();
+  if (tid == 0) {
+    int32_t acc = 0;
+    for (int i = 0; i <= A; ++i) { const int32_t c = bin[i]; bin[i] = acc; acc += c; }
+  }
+  __syncthreads();
+  for (int64_t i = tid; i < B; i += 1024) order[atomicAdd(&bin[A - counts[i]], 1)] = (int32_t)i;
 }
 
 // counts[0 .. B) -> their exclusive prefix sums in place, counts[B] = the total: ONE workgroup of 1 024 threads walks the

@@ -96,31 +96,34 @@ def _children_dev(states, canonical, out=None):
     return out
 
 
-def _children_offsets_dev(states, offsets=None):
-    """int32 [B+1]: exclusive prefix sums of the number of children valid_moves() keeps per state (gg_batch_children_offsets)."""
+def _children_offsets_dev(states, offsets=None, order=None):
+    """(offsets int32 [B+1], order int32 [B]) of gg_batch_children_offsets: exclusive prefix sums of the number of children
+    valid_moves() keeps per state, and the states by falling count (the launch order of the expansion)."""
     B, C, N, _ = states.shape
     if offsets is None:
         offsets = torch.empty(B + 1, dtype=_I32, device=states.device)
+    if order is None:
+        order = torch.empty(max(B, 1), dtype=_I32, device=states.device)
     code = _lib.lib().gg_batch_children_offsets(_lib.dev_ptr(states, _U8, 'states'), _lib.dev_ptr(offsets, _I32, 'offsets'),
-                                                B, N, _lib.stream_ptr(states.device))
+                                                _lib.dev_ptr(order, _I32, 'order'), B, N, _lib.stream_ptr(states.device))
     _lib.check(code, 'gg_batch_children_offsets')
-    return offsets
+    return offsets, order
 
 
 def _children_compact_dev(states, canonical, offsets=None, out=None):
     """The un-padded children of every state, concatenated (gg_batch_children_compact) -> (children uint8 [total, 6, N, N],
     offsets int32 [B+1]).  `out`: a caller-owned buffer of at least offsets[B] boards (e.g. the upper bound
-    B * (N*N+1)): no device -> host read of the total is then needed and the two launches can be captured in a graph."""
+    B * (N*N+1)): no device -> host read of the total is then needed and the launches can be captured in a graph."""
     B, C, N, _ = states.shape
-    offsets = _children_offsets_dev(states, offsets)
+    offsets, order = _children_offsets_dev(states, offsets)
     if out is None:
         total = int(offsets[B].item())            # (the one host read of the un-padded form: the size of its result)
         out = torch.empty((total, C, N, N), dtype=_U8, device=states.device)
     elif out.dim() != 4 or tuple(out.shape[1:]) != (C, N, N):
         raise ValueError('out must be [n >= total children, 6, N, N]')
     code = _lib.lib().gg_batch_children_compact(_lib.dev_ptr(states, _U8, 'states'), _lib.dev_ptr(offsets, _I32, 'offsets'),
-                                                _lib.dev_ptr(out, _U8, 'children'), B, N, int(bool(canonical)),
-                                                _lib.stream_ptr(states.device))
+                                                _lib.dev_ptr(order, _I32, 'order'), _lib.dev_ptr(out, _U8, 'children'), B, N,
+                                                int(bool(canonical)), _lib.stream_ptr(states.device))
     _lib.check(code, 'gg_batch_children_compact')
     return out, offsets
 

@@ -122,14 +122,18 @@ int32_t gg_batch_children(const uint8_t *states, uint8_t *children, int64_t B, i
  *   1. gg_batch_children_offsets: offsets int32 [B+1] = exclusive prefix sums of the number of children valid_moves() keeps
  *      per parent (:153-161: the points whose plane-3 byte is 0, + the pass; ALL N*N+1 actions once the game has ended),
  *      offsets[B] = the total.  The caller reads offsets[B] back and allocates children: uint8 [offsets[B]][6][N][N].
+ *      order (int32 [B], may be NULL): the parents sorted by falling child count - the order in which the expansion should
+ *      hand them to the machine (a parent's work grows with its children; heaviest first keeps the launch's tail short).
  *      GG_E_BADSIZE if B * (N*N+1) does not fit an int32.
  *   2. gg_batch_children_compact: parent b's children at children[offsets[b] .. offsets[b+1]), ascending action order - exactly
  *      the non-zero-padded slots of gg_batch_children, i.e. children_padded[b][valid_moves(states[b]) == 1] (a kept slot whose
  *      move the reference would have refused - an ended game, plane 3 clear on a stone - is all zero, as in the padded form).
+ *      order: what gg_batch_children_offsets wrote for the same states (any permutation of 0 .. B-1 gives the same result),
+ *      or NULL: index order.
  * On mid-game 19x19 parents a third of the 362 slots is kept: a third of the bytes of the padded expansion. */
-int32_t gg_batch_children_offsets(const uint8_t *states, int32_t *offsets, int64_t B, int32_t N, void *hip_stream);
-int32_t gg_batch_children_compact(const uint8_t *states, const int32_t *offsets, uint8_t *children, int64_t B, int32_t N,
-                                  int32_t canonical, void *hip_stream);
+int32_t gg_batch_children_offsets(const uint8_t *states, int32_t *offsets, int32_t *order, int64_t B, int32_t N, void *hip_stream);
+int32_t gg_batch_children_compact(const uint8_t *states, const int32_t *offsets, const int32_t *order, uint8_t *children, int64_t B,
+                                  int32_t N, int32_t canonical, void *hip_stream);
 
 /*
  * Uniform-random rollout, `plies` steps per game, IN PLACE, board resident on-chip between plies:

@@ -101,14 +101,44 @@ def test_children_compact_argument_checks():
     L = _lib.lib()
     st = torch.zeros((2, 6, 5, 5), dtype=torch.uint8, device='cuda')
     offs = torch.empty(3, dtype=torch.int32, device='cuda')
-    assert L.gg_batch_children_offsets(st.data_ptr(), None, 2, 5, None) == -2
-    assert L.gg_batch_children_offsets(None, offs.data_ptr(), 2, 5, None) == -2
-    assert L.gg_batch_children_offsets(st.data_ptr(), offs.data_ptr(), 2, 1, None) == -1
-    assert L.gg_batch_children_offsets(st.data_ptr(), offs.data_ptr(), 1 << 40, 19, None) == -1     # B (N^2+1) overflows int32
-    assert L.gg_batch_children_compact(st.data_ptr(), None, st.data_ptr(), 2, 5, 0, None) == -2
-    assert L.gg_batch_children_offsets(st.data_ptr(), offs.data_ptr(), 0, 5, None) == 0
+    order = torch.empty(2, dtype=torch.int32, device='cuda')
+    assert L.gg_batch_children_offsets(st.data_ptr(), None, None, 2, 5, None) == -2
+    assert L.gg_batch_children_offsets(None, offs.data_ptr(), None, 2, 5, None) == -2
+    assert L.gg_batch_children_offsets(st.data_ptr(), offs.data_ptr(), None, 2, 1, None) == -1
+    assert L.gg_batch_children_offsets(st.data_ptr(), offs.data_ptr(), None, 1 << 40, 19, None) == -1     # B (N^2+1) overflows int32
+    assert L.gg_batch_children_compact(st.data_ptr(), None, None, st.data_ptr(), 2, 5, 0, None) == -2
+    assert L.gg_batch_children_offsets(st.data_ptr(), offs.data_ptr(), None, 0, 5, None) == 0
     torch.cuda.synchronize()
     assert int(offs[0]) == 0
-    assert L.gg_batch_children_offsets(st.data_ptr(), offs.data_ptr(), 2, 5, None) == 0
+    assert L.gg_batch_children_offsets(st.data_ptr(), offs.data_ptr(), order.data_ptr(), 2, 5, None) == 0
     torch.cuda.synchronize()
-    assert offs.tolist() == [0, 26, 52]
+    assert offs.tolist() == [0, 26, 52] and sorted(order.tolist()) == [0, 1]
+
+
+def test_children_compact_work_order_is_a_permutation_and_does_not_matter():
+    """`order` (the parents by falling child count: heaviest first) decides which work item a parent is, never what is written:
+    the library's order, no order (NULL: index order) and a random permutation give identical bytes."""
+    from gymgo_amd import _lib, gogame
+    L = _lib.lib()
+    B, N = 3001, 9
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, 5, 0, 'cuda')
+    for g in range(3):
+        gogame.batch_rollout(st[g * 1000:(g + 1) * 1000], rng[g * 1000:(g + 1) * 1000], 10 + 35 * g, auto_reset=False)
+    offs = torch.empty(B + 1, dtype=torch.int32, device='cuda')
+    order = torch.empty(B, dtype=torch.int32, device='cuda')
+    assert L.gg_batch_children_offsets(st.data_ptr(), offs.data_ptr(), order.data_ptr(), B, N, None) == 0
+    torch.cuda.synchronize()
+    counts = (offs[1:] - offs[:-1]).cpu().numpy()
+    o = order.cpu().numpy()
+    assert sorted(o.tolist()) == list(range(B))
+    assert (np.diff(counts[o]) <= 0).all()                      # falling child count
+    total = int(offs[B])
+    outs = []
+    for od in (order, None, torch.randperm(B, device='cuda').to(torch.int32)):
+        buf = torch.full((total, 6, N, N), 0x77, dtype=torch.uint8, device='cuda')
+        assert L.gg_batch_children_compact(st.data_ptr(), offs.data_ptr(), None if od is None else od.data_ptr(), buf.data_ptr(),
+                                           B, N, 0, None) == 0
+        torch.cuda.synchronize()
+        outs.append(buf)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
