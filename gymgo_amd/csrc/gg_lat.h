@@ -14,16 +14,22 @@
 //   * a move at q changes the classes of the groups ADJACENT to q only (gg_v4.h): the opponent's group at each of q's four
 //     neighbours and the mover's group G that the stone joins - FIVE floods, run AT THE SAME TIME in bit fields of the same
 //     registers: a 9x9 row is 9 bits, so three floods share a VGPR (10-bit fields, one guard bit; 13x13: two 16-bit fields;
-//     19x19: one).  A flood step is "one row up / down (two DPP moves) + a complete horizontal run fill (carry chain, once per
-//     direction - gg_common.h)", the closure test is the first two instructions of the next step;
+//     19x19: one).  A flood step is "two rows up / down (DPP moves) + a complete horizontal run fill (carry chain, once per
+//     direction - gg_common.h)", the closure test is the head of the next step;
 //   * liberties = dilate & empty per field, counted per lane, summed per board by four DPP rotations (all five counts, the
 //     number of captured stones and "q is boxed in" travel in two words); the class patch and the next mover's mask follow
 //     point-wise exactly as in gg_v4.h (phase 3) - here on one row per lane with the rows above / below one DPP move away.
-// ~300 wave-instructions per ply for FOUR boards, none of them an LDS or memory instruction, so one wave per SIMD already
-// runs at the speed of its dependency chain and a second / third wave fills the issue slots it leaves.
-// Byte planes enter through LDS once per launch (aligned staging as everywhere, gg_common.h); the first classes come from
+// 296 VALU + 17 SALU wave-instructions per ply for FOUR boards (PMC, 9x9), none of them an LDS or memory instruction.  A lone
+// wave issues one instruction per ~4 cycles whether or not it depends on the previous one, so at four boards per SIMD the
+// launch costs instructions per wave-ply x that, and a second / third wave per SIMD fills the slots the first leaves
+// (8 192 games of 9x9: x1.75).  Config 2 (4 096 games of 9x9 x 256 plies): 2.40e9 (k_rollout2) -> 4.5e9 env steps/s.
+// Byte planes enter through LDS once per launch (aligned staging as everywhere, gg_common.h); their first classes come from
 // the constant-weight analysis of gg_v2.h restated in this layout (eleven floods in lock-step, black and white in two fields
-// of one register).  Reference: the loop gym_go/envs/go_env.py:49-81 (uniform_random_action + step) over
+// of one register) - which is why byte-plane launches pay from 3 / 4 / 64 plies on.  TRACKED boards (IO = 2) carry their
+// classes: a lane loads and stores its own five row words, no LDS at all, and the kernel pays from ONE ply per launch
+// (3.5 us per ply as a hipGraph at config 2's size).  Take-over points: gg_kernels.hip, use_lat.
+// tests/devtools/lat_model.py is a lane-by-lane NumPy model of this file (same DPP shuffles, same bit tricks) checked against
+// the C oracle on the CPU.  Reference: the loop gym_go/envs/go_env.py:49-81 (uniform_random_action + step) over
 // gym_go/gogame.py:34-87, gym_go/state_utils.py:24-83,159-180.
 #pragma once
 #include "gg_v2.h"
