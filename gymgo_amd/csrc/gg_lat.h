@@ -29,7 +29,7 @@
 // classes: a lane loads and stores its own five row words, no LDS at all, and the kernel pays from ONE ply per launch
 // (3.5 us per ply as a hipGraph at config 2's size).  Take-over points: gg_kernels.hip, use_lat.
 // tests/devtools/lat_model.py is a lane-by-lane NumPy model of this file (same DPP shuffles, same bit tricks) checked against
-// the C oracle on the CPU.  Reference: the loop gym_go/envs/go_env.py:49-81 (uniform_random_action + step) over
+// oracle/gg_oracle.c on the CPU.  Reference: the loop gym_go/envs/go_env.py:49-81 (uniform_random_action + step) over
 // gym_go/gogame.py:34-87, gym_go/state_utils.py:24-83,159-180.
 #pragma once
 #include "gg_v2.h"
