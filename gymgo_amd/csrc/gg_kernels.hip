@@ -35,6 +35,8 @@ void launch_rollout4(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, 
                      uint32_t inv, int plies, int auto_reset, int nb, int grid, hipStream_t s);
 void launch_rollout_lat(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N, int plies,
                         int auto_reset, hipStream_t s);
+void launch_env_step_lat(uint32_t *tracked, uint64_t *rng, int64_t *steps_done, int64_t B, int32_t N, int auto_reset,
+                         const EnvArgs &env, hipStream_t s);
 }
 
 namespace {
@@ -257,6 +259,20 @@ bool use_lat(int cus, int64_t B, int32_t N, int plies, bool tracked = false) {
   if (const char *e = getenv(tracked ? "GG_AB_LATT_PLIES" : "GG_AB_LAT_PLIES")) min_plies = atoi(e);
 #endif
   return plies >= min_plies && B <= (int64_t)cus * per_cu;
+}
+
+// ... and the tracked env step (k_env_step_lat: one ply + GoEnv.step's outputs + the observation).  A one-ply launch is a
+// latency chain, and more, smaller waves overlap their loads / plies / stores better than sixteen-board waves: measured new /
+// k_rollout4 (profiles/r05k_lat_env_sweep.txt, with the observation): 9x9 4 096 games x1.18, 16 384 x1.43, 65 536 x1.06,
+// 262 144 x1.03; 13x13 4 096 x1.40, 16 384 x1.69, 131 072 x1.22; 19x19 4 096 x1.62, 16 384 x1.38, 32 768 x1.11 (without the
+// observation x0.96), 65 536 x0.98 (x0.78) -> every batch up to 13x13; 19x19 up to 128 games per CU with the observation, 64
+// without.  (A/B builds: GG_AB_LATE_MAX = games per CU.)
+bool use_lat_env(int cus, int64_t B, int32_t N, bool with_observation) {
+  int64_t per_cu = N <= 13 ? (int64_t)1 << 40 : (with_observation ? 128 : 64);
+#ifdef GG_AB
+  if (const char *e = getenv("GG_AB_LATE_MAX")) per_cu = atoll(e);
+#endif
+  return B <= (int64_t)cus * per_cu;
 }
 
 int32_t check(int64_t B, int32_t N) { return (N < 2 || N > GG_MAX_BOARD || B < 0) ? GG_E_BADSIZE : 0; }
@@ -839,6 +855,10 @@ int32_t gg_batch_env_step_tracked(uint32_t *tracked, const int32_t *actions, uin
   env.actions = actions; env.rewards = rewards; env.dones = dones; env.status = status; env.taken = taken_actions;
   env.states_out = states_out; env.komi = komi; env.heuristic = reward_method == GG_REWARD_HEURISTIC;
   env.ws = nullptr; env.canonical = 0; env.weights = nullptr;
+  if (use_lat_env(cus, B, N, states_out != nullptr)) {   // one row per lane, the ply in registers (gg_lat.h)
+    launch_env_step_lat(tracked, rng, steps_done, B, N, auto_reset, env, s);
+    return (int32_t)hipGetLastError();
+  }
   if (actions) {
     GG_DISPATCH4E(N, true, grid, st, nullptr, nullptr, steps_done, B, N, inv, 1, auto_reset, nb, actions, nullptr, env);
   } else {

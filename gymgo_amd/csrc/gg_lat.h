@@ -262,6 +262,99 @@ __device__ __forceinline__ void lat_emit(uint8_t *g, uint32_t black, uint32_t wh
   }
 }
 
+// Phases 2 - 6 of a ply on the boards of the wave: Q = the new stone (one bit in the lane of its row, 0 in every other lane and
+// on a board that passes or does not move), pass (the same in every lane of a board), lv = 0 / ~0: the board moves this ply.
+// me / op / M / inv / fl are updated in place (roles swapped for the boards that moved).
+template <int R>
+__device__ __forceinline__ void lat_play(uint32_t &me, uint32_t &op, uint32_t &M, uint32_t &inv, uint32_t &fl, const uint32_t Q,
+                                         const bool pass, const uint32_t lv, const uint32_t full) {
+  using L = Lat<R>;
+  constexpr int LPB = L::LPB, FW = L::FW, NF = L::NF, NREG = L::NREG;
+  // 2. the stone, its four neighbours, the five floods
+  const uint32_t me1 = me | Q;
+  const uint32_t su = lat_below<LPB>(Q), sd = lat_above<LPB>(Q);   // the point above q lies one row up: that lane takes Q from the lane below it
+  const uint32_t sl = Q >> 1, sr = shl1(Q);
+  const uint32_t open = B3(B3(su, sd, sl, T_OR3) | sr, full, op, T_AND_ANDN);   // on-board neighbours of q that do not hold an opponent stone
+  uint32_t F[NREG], Mk[NREG], Mkr[NREG];
+  {
+    const uint32_t seeds[L::NFL] = {su & op, sd & op, sl & op, sr & op, Q};
+#pragma unroll
+    for (int k2 = 0; k2 < NREG; ++k2) { F[k2] = 0; Mk[k2] = 0; }
+#pragma unroll
+    for (int f = 0; f < L::NFL; ++f) {
+      F[f / NF] |= seeds[f] << ((FW * (f % NF)) & 31);
+      Mk[f / NF] |= (f < 4 ? op : me1) << ((FW * (f % NF)) & 31);
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < NREG; ++k2) Mkr[k2] = __brev(Mk[k2]);
+  }
+  lat_flood<LPB, NREG>(F, Mk, Mkr);
+  uint32_t fr[L::NFL];
+#pragma unroll
+  for (int f = 0; f < L::NFL; ++f) fr[f] = NF == 1 ? F[f] : ((F[f / NF] >> ((FW * (f % NF)) & 31)) & L::FM);
+  const uint32_t U = B3(fr[0], fr[1], fr[2], T_OR3) | fr[3], G = fr[4];
+  const uint32_t C = U & ~M;                          // an opponent group next to q that was in atari: captured
+  // 3. liberties of the five groups: dilate & empty (G's include the captured points), counted per lane, summed per board
+  const uint32_t E1 = full & ~(me1 | op), EG = E1 | C;
+  uint32_t W1 = 0, W2 = 0;
+  {
+    uint32_t Ee[NREG];
+#pragma unroll
+    for (int k2 = 0; k2 < NREG; ++k2) Ee[k2] = 0;
+#pragma unroll
+    for (int f = 0; f < L::NFL; ++f) Ee[f / NF] |= (f < 4 ? E1 : EG) << ((FW * (f % NF)) & 31);
+    uint32_t Lb[NREG];
+#pragma unroll
+    for (int k2 = 0; k2 < NREG; ++k2) Lb[k2] = lat_dilate<LPB>(F[k2]) & Ee[k2];
+#pragma unroll
+    for (int f = 0; f < L::NFL; ++f) {
+      uint32_t c = (uint32_t)__popc(NF == 1 ? Lb[f] : (Lb[f / NF] & (L::FM << ((FW * (f % NF)) & 31))));
+      if (L::kSat) c = c < 2u ? c : 2u;
+      if (f < 4) W1 |= c << (8 * f);
+      else W2 = c;
+    }
+    uint32_t pc = (uint32_t)__popc(C);
+    pc = pc < 2u ? pc : 2u;
+    W2 |= (pc << 8) | (open ? 0x10000u : 0u);
+  }
+  const uint32_t S1 = lat_board_sum<LPB>(W1), S2 = lat_board_sum<LPB>(W2);
+  // 4. class patch: every flooded group leaves M and comes back with >= 2 liberties (count + 126 carries into bit 7)
+  const uint32_t g1 = S1 + 0x7E7E7E7Eu;
+  uint32_t M1 = B3(M, U, G, TA & ~(TB | TC) & 0xFF);
+#pragma unroll
+  for (int f = 0; f < 4; ++f) M1 = B3((uint32_t)((int32_t)(g1 << (24 - 8 * f)) >> 31), fr[f], M1, T_ANDOR);
+  M1 = B3((uint32_t)((int32_t)(1u - (S2 & 0xFFu)) >> 31), G, M1, T_ANDOR);
+  uint32_t K = 0;
+  if (__ballot(C != 0)) {   // some board of the wave captures
+    // ko: exactly one stone died and q is boxed in (gym_go/gogame.py:72-75, state_utils.adj_data)
+    if (((S2 >> 8) & 0xFFu) == 1u && ((S2 >> 16) & 0xFFu) == 0u) K = C;
+    // a mover's group in atari next to a captured stone (not G: its count above includes them) gains a liberty
+    uint32_t X[1], Xm[1], Xr[1];
+    Xm[0] = B3(me1, M, G, TA & ~(TB | TC) & 0xFF);
+    X[0] = lat_dilate<LPB>(C) & Xm[0];
+    if (__ballot(X[0] != 0)) {
+      Xr[0] = __brev(Xm[0]);
+      lat_flood<LPB, 1>(X, Xm, Xr);
+      M1 |= X[0];
+    }
+  }
+  // 5. the next mover's invalid-move mask (state_utils.compute_invalid_moves restated point-wise): an empty
+  // point is playable iff some neighbour is empty, a next-mover stone with >= 2 liberties or a mover's stone in atari
+  const uint32_t op2 = op & ~C;
+  const uint32_t E2 = full & ~(me1 | op2);
+  const uint32_t xs = E2 | B3(M1, op2, me1, T_SEL);
+  const uint32_t nbs = lat_dilate<LPB>(xs);
+  const uint32_t inv2 = B3(full, E2, nbs, TA & ~(TB & TC) & 0xFF) | K;
+  // 6. roles swap for the boards that moved; flags: turn flips, passed = pass, done = two passes in a row
+  me = B3(lv, op2, me1, T_SEL);
+  op = B3(lv, me1, op2, T_SEL);
+  inv = B3(lv, inv2, inv, T_SEL);
+  M = M1;
+  const uint32_t pm = pass ? ~0u : 0u;
+  const uint32_t fl2 = ((fl ^ 1u) & 1u) | (pm & 2u) | (pm & (fl << 1) & 4u);
+  fl = B3(lv, fl2, fl, T_SEL);
+}
+
 template <int R>
 struct LdsLat {
   using L = Lat<R>;
@@ -368,92 +461,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
       }
       played -= (int)lv;
       GG_PROF(0);
-      // 2. the stone, its four neighbours, the five floods
-      const uint32_t me1 = me | Q;
-      const uint32_t su = lat_below<LPB>(Q), sd = lat_above<LPB>(Q);   // the point above q lies one row up: that lane takes Q from the lane below it
-      const uint32_t sl = Q >> 1, sr = shl1(Q);
-      const uint32_t open = B3(B3(su, sd, sl, T_OR3) | sr, full, op, T_AND_ANDN);   // on-board neighbours of q that do not hold an opponent stone
-      uint32_t F[NREG], Mk[NREG], Mkr[NREG];
-      {
-        const uint32_t seeds[L::NFL] = {su & op, sd & op, sl & op, sr & op, Q};
-#pragma unroll
-        for (int k2 = 0; k2 < NREG; ++k2) { F[k2] = 0; Mk[k2] = 0; }
-#pragma unroll
-        for (int f = 0; f < L::NFL; ++f) {
-          F[f / NF] |= seeds[f] << ((FW * (f % NF)) & 31);
-          Mk[f / NF] |= (f < 4 ? op : me1) << ((FW * (f % NF)) & 31);
-        }
-#pragma unroll
-        for (int k2 = 0; k2 < NREG; ++k2) Mkr[k2] = __brev(Mk[k2]);
-      }
-      GG_PROF(1);
-      lat_flood<LPB, NREG>(F, Mk, Mkr);
-      GG_PROF(2);
-      uint32_t fr[L::NFL];
-#pragma unroll
-      for (int f = 0; f < L::NFL; ++f) fr[f] = NF == 1 ? F[f] : ((F[f / NF] >> ((FW * (f % NF)) & 31)) & L::FM);
-      const uint32_t U = B3(fr[0], fr[1], fr[2], T_OR3) | fr[3], G = fr[4];
-      const uint32_t C = U & ~M;                          // an opponent group next to q that was in atari: captured
-      // 3. liberties of the five groups: dilate & empty (G's include the captured points), counted per lane, summed per board
-      const uint32_t E1 = full & ~(me1 | op), EG = E1 | C;
-      uint32_t W1 = 0, W2 = 0;
-      {
-        uint32_t Ee[NREG];
-#pragma unroll
-        for (int k2 = 0; k2 < NREG; ++k2) Ee[k2] = 0;
-#pragma unroll
-        for (int f = 0; f < L::NFL; ++f) Ee[f / NF] |= (f < 4 ? E1 : EG) << ((FW * (f % NF)) & 31);
-        uint32_t Lb[NREG];
-#pragma unroll
-        for (int k2 = 0; k2 < NREG; ++k2) Lb[k2] = lat_dilate<LPB>(F[k2]) & Ee[k2];
-#pragma unroll
-        for (int f = 0; f < L::NFL; ++f) {
-          uint32_t c = (uint32_t)__popc(NF == 1 ? Lb[f] : (Lb[f / NF] & (L::FM << ((FW * (f % NF)) & 31))));
-          if (L::kSat) c = c < 2u ? c : 2u;
-          if (f < 4) W1 |= c << (8 * f);
-          else W2 = c;
-        }
-        uint32_t pc = (uint32_t)__popc(C);
-        pc = pc < 2u ? pc : 2u;
-        W2 |= (pc << 8) | (open ? 0x10000u : 0u);
-      }
-      const uint32_t S1 = lat_board_sum<LPB>(W1), S2 = lat_board_sum<LPB>(W2);
-      GG_PROF(3);
-      // 4. class patch: every flooded group leaves M and comes back with >= 2 liberties (count + 126 carries into bit 7)
-      const uint32_t g1 = S1 + 0x7E7E7E7Eu;
-      uint32_t M1 = B3(M, U, G, TA & ~(TB | TC) & 0xFF);
-#pragma unroll
-      for (int f = 0; f < 4; ++f) M1 = B3((uint32_t)((int32_t)(g1 << (24 - 8 * f)) >> 31), fr[f], M1, T_ANDOR);
-      M1 = B3((uint32_t)((int32_t)(1u - (S2 & 0xFFu)) >> 31), G, M1, T_ANDOR);
-      uint32_t K = 0;
-      if (__ballot(C != 0)) {   // some board of the wave captures
-        // ko: exactly one stone died and q is boxed in (gym_go/gogame.py:72-75, state_utils.adj_data)
-        if (((S2 >> 8) & 0xFFu) == 1u && ((S2 >> 16) & 0xFFu) == 0u) K = C;
-        // a mover's group in atari next to a captured stone (not G: its count above includes them) gains a liberty
-        uint32_t X[1], Xm[1], Xr[1];
-        Xm[0] = B3(me1, M, G, TA & ~(TB | TC) & 0xFF);
-        X[0] = lat_dilate<LPB>(C) & Xm[0];
-        if (__ballot(X[0] != 0)) {
-          Xr[0] = __brev(Xm[0]);
-          lat_flood<LPB, 1>(X, Xm, Xr);
-          M1 |= X[0];
-        }
-      }
-      // 5. the next mover's invalid-move mask (state_utils.compute_invalid_moves restated point-wise): an empty
-      // point is playable iff some neighbour is empty, a next-mover stone with >= 2 liberties or a mover's stone in atari
-      const uint32_t op2 = op & ~C;
-      const uint32_t E2 = full & ~(me1 | op2);
-      const uint32_t xs = E2 | B3(M1, op2, me1, T_SEL);
-      const uint32_t nbs = lat_dilate<LPB>(xs);
-      const uint32_t inv2 = B3(full, E2, nbs, TA & ~(TB & TC) & 0xFF) | K;
-      // 6. roles swap for the boards that moved; flags: turn flips, passed = pass, done = two passes in a row
-      me = B3(lv, op2, me1, T_SEL);
-      op = B3(lv, me1, op2, T_SEL);
-      inv = B3(lv, inv2, inv, T_SEL);
-      M = M1;
-      const uint32_t pm = pass ? ~0u : 0u;
-      const uint32_t fl2 = ((fl ^ 1u) & 1u) | (pm & 2u) | (pm & (fl << 1) & 4u);
-      fl = B3(lv, fl2, fl, T_SEL);
+      lat_play<R>(me, op, M, inv, fl, Q, pass, lv, full);
       GG_PROF(4);
     }
     GG_PROF(5);
@@ -480,6 +488,145 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
     }
     GG_PROF(7);   // write-back
     GG_PROF_FLUSH;
+  }
+}
+
+// Tromp-Taylor areas (gym_go/gogame.py:275-300) of the wave's boards in this layout: a colour owns its stones plus the empty
+// regions that touch only that colour, and a region touches a colour iff the flood of the EMPTY points seeded next to that
+// colour's stones covers it - two floods in two fields of one register (19x19: two registers), summed per board.
+template <int R>
+__device__ __forceinline__ void lat_areas(uint32_t bl, uint32_t wh, uint32_t full, uint32_t &area_b, uint32_t &area_w) {
+  using L = Lat<R>;
+  constexpr int LPB = L::LPB, FW = L::FW, K = L::NF >= 2 ? 1 : 2;
+  const uint32_t E = full & ~(bl | wh);
+  const uint32_t sb = lat_dilate<LPB>(bl) & E, sw = lat_dilate<LPB>(wh) & E;
+  uint32_t F[K], Mk[K], Mkr[K];
+  if (K == 1) {
+    F[0] = sb | (sw << (FW & 31));
+    Mk[0] = E | (E << (FW & 31));
+  } else {
+    F[0] = sb; F[K - 1] = sw;
+    Mk[0] = E; Mk[K - 1] = E;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) Mkr[k] = __brev(Mk[k]);
+  lat_flood<LPB, K>(F, Mk, Mkr);
+  const uint32_t fb = K == 1 ? (F[0] & L::FM) : F[0], fw = K == 1 ? (F[0] >> (FW & 31)) : F[K - 1];
+  const uint32_t cb = (uint32_t)__popc(bl) + (uint32_t)__popc(fb & ~fw), cw = (uint32_t)__popc(wh) + (uint32_t)__popc(fw & ~fb);
+  const uint32_t sum = lat_board_sum<LPB>(cb | (cw << 16));     // (<= 361 each)
+  area_b = sum & 0xFFFFu;
+  area_w = sum >> 16;
+}
+
+// GoEnv.step for every game of a batched env whose boards are kept TRACKED (gg_batch_env_step_tracked; gym_go/envs/go_env.py:49-76)
+// on batches that leave the SIMDs under-filled: ONE ply of the kernel above - the move given (MOVES: env.actions) or drawn -
+// with GoEnv.step's outputs: status, dones, the action used, GoEnv.reward (:128-149; Tromp-Taylor areas of the resulting
+// position when the game has ended or the reward is `heuristic`) and, when asked, the byte-plane observation of every game.
+// Semantics as k_rollout4<R, 2, MOVES, FULLN, true> (gg_v4.h): a finished game is reset first when auto_reset - and the reset
+// stands even when the given move is then refused (GoEnv.reset comes before the action check) - or refuses the step.
+template <int R, bool FULLN, bool MOVES>
+__global__ __launch_bounds__(kWave, 4) void k_env_step_lat(uint32_t *__restrict__ tracked, uint64_t *__restrict__ rng,
+                                                           int64_t *__restrict__ steps_done, int64_t B, int N, int auto_reset,
+                                                           EnvArgs env) {
+  using L = Lat<R>;
+  constexpr int LPB = L::LPB, NBW = L::NBW;
+  if (FULLN) N = R;
+  __shared__ __attribute__((aligned(16))) uint32_t bsv[NBW * L::kBsWords];
+  __shared__ uint2 lut[256];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int r = lane & (LPB - 1), j = lane / LPB;
+  const int P = N * N, S = 6 * P, W = 5 * N + 1;
+  const uint32_t full = r < N ? (1u << N) - 1u : 0u;
+  const bool obs = env.states_out != nullptr;
+  if (obs) load_spread_lut(lut, lane);
+  const int64_t ngroups = (B + NBW - 1) / NBW;
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t b_first = g * NBW;
+    const bool on = b_first + j < B;
+    const int64_t b = on ? b_first + j : B - 1;
+    uint32_t *gp = tracked + b * (int64_t)W;
+    uint32_t me, op, M, inv, fl;
+    {
+      const int rc = r < N ? r : 0;
+      uint32_t bl = gp[rc], wh = gp[N + rc];
+      inv = gp[2 * N + rc];
+      M = gp[3 * N + rc] | gp[4 * N + rc];
+      fl = gp[5 * N] & 7u;
+      if (!on || r >= N) { bl = wh = inv = M = 0; }
+      if (!on) fl = 0;
+      me = (fl & 1u) ? wh : bl;
+      op = (fl & 1u) ? bl : wh;
+    }
+    uint64_t x = (!MOVES && rng) ? rng[b] : 0;
+    const bool done0 = (fl & 4u) != 0;
+    bool live, reset, pass = false;
+    uint32_t Q = 0;
+    int taken = -1;
+    if (MOVES) {
+      const int mv = env.actions[b];
+      reset = on && done0 && auto_reset != 0;
+      const bool inrange = mv >= 0 && mv <= P;
+      const bool point = inrange && mv < P;
+      const int ar = point ? mv / N : 0, ac = point ? mv - ar * N : 0;
+      // the lane that owns row ar tests the mask bit, the board shares the verdict (a board being reset is empty)
+      const uint32_t bad = (point && !reset && r == ar) ? ((inv >> ac) & 1u) : 0u;
+      const bool illegal = lat_board_sum<LPB>(bad) != 0u;
+      live = on && (!done0 || reset) && inrange && !illegal;
+      pass = live && mv == P;
+      Q = (live && point && r == ar) ? (1u << ac) : 0u;
+      taken = mv;
+    } else {
+      live = on && !(done0 && !auto_reset);
+      reset = live && done0;
+    }
+    if (__ballot(reset)) {   // GoEnv.reset: the board is init_state from now on (also when the move is then refused)
+      const uint32_t keep = reset ? 0u : ~0u;
+      me &= keep; op &= keep; M &= keep; inv &= keep; fl &= keep;
+    }
+    const uint32_t lv = live ? ~0u : 0u;
+    if (!MOVES) {   // the draw of k_rollout_lat
+      const uint32_t valid = full & ~inv;
+      const uint32_t cnt = (uint32_t)__popc(valid);
+      const uint32_t incl = lat_board_scan<LPB>(cnt);
+      const uint32_t total = lat_board_sum<LPB>(cnt);
+      uint64_t xn = x;
+      const uint64_t u = splitmix_next(xn);
+      if (live) x = xn;
+      const uint32_t k = __umulhi((uint32_t)(u >> 32), total + 1u);
+      const uint32_t tt = k - (incl - cnt);
+      const bool hit = live && tt < cnt;
+      const uint32_t pos = lat_kth_bit<L::kBits>(valid, tt);
+      Q = hit ? (1u << pos) : 0u;
+      pass = k == total;
+      taken = lat_board_max<LPB>(!live ? -1 : (hit ? r * N + (int)pos : (pass ? P : -1)));
+    }
+    if (__ballot(live)) lat_play<R>(me, op, M, inv, fl, Q, pass, lv, full);
+    // ---- the boards after the step, GoEnv.step's outputs
+    const uint32_t turn = fl & 1u;
+    const uint32_t bl = turn ? op : me, wh = turn ? me : op;
+    const bool doneb = (fl & 4u) != 0;
+    uint32_t area_b = 0, area_w = 0;
+    if (__ballot(on && (env.heuristic != 0 || doneb))) lat_areas<R>(bl, wh, full, area_b, area_w);
+    if (on && r == 0) {
+      const float margin = (float)((int)area_b - (int)area_w) - env.komi;
+      float rwd;   // GoEnv.reward (gym_go/envs/go_env.py:128-149), black's perspective
+      if (env.heuristic) rwd = doneb ? (margin > 0.f ? 1.f : -1.f) * (float)P : margin;
+      else rwd = doneb ? (margin > 0.f ? 1.f : (margin < 0.f ? -1.f : 0.f)) : 0.f;
+      if (env.rewards) env.rewards[b] = rwd;
+      if (env.dones) env.dones[b] = (uint8_t)doneb;
+      if (env.status) env.status[b] = live ? GG_STATUS_OK : GG_STATUS_ILLEGAL;
+      if (env.taken) env.taken[b] = taken;
+      if (!MOVES && live) rng[b] = x;
+      if (steps_done && live) atomicAdd(reinterpret_cast<unsigned long long *>(steps_done) + b, 1ull);
+      if (live || reset) gp[5 * N] = fl;
+    }
+    if (on && (live || reset) && r < N) {
+      gp[r] = bl; gp[N + r] = wh; gp[2 * N + r] = inv;
+      gp[3 * N + r] = M & bl; gp[4 * N + r] = M & wh;
+    }
+    if (obs)   // the observation: every board of the wave as byte planes
+      lat_emit<R>(env.states_out + b * (int64_t)S, bl, wh, inv, turn, (fl >> 1) & 1u, (fl >> 2) & 1u, full, N, r,
+                  bsv + j * L::kBsWords, lut, on);
   }
 }
 

@@ -38,6 +38,24 @@ void launch_rollout_lat(int io, uint8_t *st, uint64_t *rng, int32_t *last_action
 }
 #undef GG_LAT
 
+// gg_batch_env_step_tracked on a batch that leaves the SIMDs under-filled: the same one-ply kernel with GoEnv.step's outputs
+#define GG_LATE(R, F)                                                                                                          \
+  do {                                                                                                                         \
+    const unsigned grid_ = (unsigned)((B + Lat<R>::NBW - 1) / Lat<R>::NBW);                                                    \
+    if (env.actions) k_env_step_lat<R, F, true><<<grid_, kWave, 0, s>>>(tracked, rng, steps_done, B, N, auto_reset, env);      \
+    else k_env_step_lat<R, F, false><<<grid_, kWave, 0, s>>>(tracked, rng, steps_done, B, N, auto_reset, env);                 \
+  } while (0)
+void launch_env_step_lat(uint32_t *tracked, uint64_t *rng, int64_t *steps_done, int64_t B, int32_t N, int auto_reset,
+                         const EnvArgs &env, hipStream_t s) {
+  if (N == 9) GG_LATE(9, true);
+  else if (N < 9) GG_LATE(9, false);
+  else if (N == 13) GG_LATE(13, true);
+  else if (N < 13) GG_LATE(13, false);
+  else if (N == 19) GG_LATE(19, true);
+  else GG_LATE(19, false);
+}
+#undef GG_LATE
+
 }  // namespace gg
 
 #ifdef GG_AB_PROF

@@ -152,3 +152,52 @@ def test_tracked_rollout_same_result_on_both_sides_of_the_take_over(N):
             want, want_rng, _ = c_oracle.batch_rollout_mt(want, want_rng, F, True)
             assert np.array_equal(gogame.batch_untrack(tr).cpu().numpy(), want), (N, B, F)
             assert np.array_equal(rng.cpu().numpy().view(np.uint64), want_rng)
+
+
+def _env_step_vs_oracle(N, B, with_obs, given):
+    """One gg_batch_env_step_tracked launch on mid-game boards (some finished: auto-reset) against one oracle ply."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, 3 * N + B % 7, 0, 'cuda')
+    q = max(1, B // 4)
+    for g in range(4):
+        lo, hi = g * q, (B if g == 3 else (g + 1) * q)
+        if lo < hi:
+            gogame.batch_rollout(st[lo:hi], rng[lo:hi], 5 + (N * N * g) // 3, False)
+    want, want_rng = st.cpu().numpy(), rng.cpu().numpy().view(np.uint64).copy()
+    tr = gogame.batch_track(st)
+    obs = torch.empty_like(st) if with_obs else None
+    sd = torch.zeros(B, dtype=torch.int64, device='cuda')
+    want2, rng2, last2 = c_oracle.batch_rollout_mt(want, want_rng, 1, True)
+    acts = torch.from_numpy(last2).cuda() if given else None        # (the oracle's own moves, handed over as given actions)
+    r_dev = rng.clone()
+    rewards, dones, status, taken = gogame.batch_env_step_tracked(tr, acts, None if given else r_dev, 0.5, 'real', True,
+                                                                  states_out=obs, steps_done=sd)
+    assert np.array_equal(gogame.batch_untrack(tr).cpu().numpy(), want2), (N, B, with_obs, given)
+    if with_obs:
+        assert np.array_equal(obs.cpu().numpy(), want2)
+    assert int(status.abs().sum()) == 0 and np.array_equal(taken.cpu().numpy(), last2) and int(sd.min()) == int(sd.max()) == 1
+    if not given:
+        assert np.array_equal(r_dev.cpu().numpy().view(np.uint64), rng2)
+    over = want2[:, 5, 0, 0] == 1
+    assert np.array_equal(dones.cpu().numpy().astype(bool), over)
+    b, w = c_oracle.batch_areas_mt(want2)
+    assert np.array_equal(rewards.cpu().numpy().astype(np.float64), np.where(over, np.sign(b.astype(np.float64) - w - 0.5), 0.0))
+
+
+@pytest.mark.parametrize('N,B', [(9, 4096), (9, 5), (13, 1001), (19, 511), (19, 3), (5, 77), (16, 33)])
+def test_lat_env_step_vs_oracle(N, B):
+    """GoVecEnv.step's launch on the latency-shaped kernel: drawn and given moves, with and without the observation
+    (tests/test_gpu_env.py drives the same entry point through GoVecEnv: refused / frozen / reset cases, heuristic reward)."""
+    for with_obs in (True, False):
+        for given in (False, True):
+            _env_step_vs_oracle(N, B, with_obs, given)
+
+
+def test_env_step_same_result_on_both_sides_of_the_19x19_take_over():
+    """19x19: k_env_step_lat up to 128 games per CU with the observation (64 without), k_rollout4's env instantiation above."""
+    cus = _cus()
+    for per_cu, with_obs in ((128, True), (64, False)):
+        for B in (cus * per_cu, cus * per_cu + 1):
+            _env_step_vs_oracle(19, B, with_obs, False)

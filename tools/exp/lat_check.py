@@ -156,6 +156,40 @@ def tsweep():
                 both(N, B, F, 4 if F >= 64 else 24)
 
 
+def esweep():
+    """GoVecEnv.step's launch (gg_batch_env_step_tracked: drawn moves, reward `real`, with and without the observation), the
+    latency-shaped kernel forced on / off (A/B build: GG_AB_LATE_MAX)."""
+    big = os.environ.get('BIG')
+    for N, sizes in (((9, (131072, 262144)), (13, (65536, 131072)), (19, (32768, 65536, 131072))) if big else
+                     ((9, (1024, 4096, 16384, 32768, 65536)), (13, (1024, 4096, 16384, 32768)), (19, (1024, 4096, 8192, 16384)))):
+        for B in sizes:
+            st = gogame.batch_init_state(B, N, device=dev); rng = gogame.rng_seed(B, 20260927, 0, dev)
+            ch = max(1, B // 16)
+            for g in range(1, 16):
+                gogame.batch_rollout(st[g * ch:(g + 1) * ch], rng[g * ch:(g + 1) * ch], g * (8 if N <= 9 else 20 if N <= 13 else 40), True)
+            base = gogame.batch_track(st)
+            obs = torch.empty_like(st)
+            env_out = (torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.uint8, device=dev),
+                       torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev))
+            for with_obs in (True, False):
+                res = []
+                for lat in ('1000000', '0'):
+                    os.environ['GG_AB_LATE_MAX'] = lat
+                    tr, rg = base.clone(), rng.clone()
+                    fn = lambda: gogame.batch_env_step_tracked(tr, None, rg, 7.5, 'real', True, out=env_out, states_out=obs if with_obs else None)
+                    for _ in range(3):
+                        fn()
+                    torch.cuda.synchronize()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(32):
+                        fn()
+                    b.record(); torch.cuda.synchronize()
+                    res.append((a.elapsed_time(b) / 32, hashlib.sha1(tr.cpu().numpy().tobytes() + obs.cpu().numpy().tobytes()).hexdigest()[:10]))
+                print('env step N %2d B %6d obs %d: lat %.2f us | k_rollout4 %.2f us | x%.2f %s' %
+                      (N, B, with_obs, res[0][0] * 1e3, res[1][0] * 1e3, res[1][0] / res[0][0], 'same digest' if res[0][1] == res[1][1] else 'DIGESTS DIFFER'), flush=True)
+
+
 if __name__ == '__main__':
     rc = 0
     if MODE in ('all', 'parity'):
@@ -168,4 +202,6 @@ if __name__ == '__main__':
         rc = rc or tracked_parity()
     if MODE in ('tsweep',):
         tsweep()
+    if MODE in ('esweep',):
+        esweep()
     sys.exit(1 if rc else 0)
