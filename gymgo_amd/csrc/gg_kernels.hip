@@ -253,6 +253,10 @@ bool use_lat(int cus, int64_t B, int32_t N, int plies, bool tracked = false) {
   if (tracked) {
     per_cu = N <= 13 ? 64 : 16;
     min_plies = 1;
+    // ONE ply per launch is a latency chain that many small waves overlap better than sixteen-board ones, at every batch size
+    // measured (9x9 65 536 / 262 144 games x1.14 / 1.12, 13x13 32 768 / 131 072 x1.53 / 1.23, 19x19 16 384 / 32 768 / 65 536
+    // x1.34 / 1.03 / 0.81; two plies per launch: x0.94 - 1.03 up to 13x13, 0.59 - 0.99 at 19x19)
+    if (plies == 1) per_cu = N <= 13 ? (int64_t)1 << 40 : 128;
   }
 #ifdef GG_AB
   if (const char *e = getenv(tracked ? "GG_AB_LATT_MAX" : "GG_AB_LAT_MAX")) per_cu = atoll(e);

@@ -150,6 +150,12 @@ def tsweep():
             out.append(rate_tracked(N, B, F, reps=reps))
         print('tracked N %2d B %6d F %3d: lat %.4f ms %.3e steps/s | k_rollout4 %.4f ms %.3e steps/s | x%.2f %s' %
               (N, B, F, out[0][0], out[0][1], out[1][0], out[1][1], out[0][1] / out[1][1], 'same digest' if out[0][2] == out[1][2] else 'DIGESTS DIFFER'), flush=True)
+    if os.environ.get('BIG'):
+        for N, sizes in ((9, (65536, 262144)), (13, (32768, 65536, 131072)), (19, (16384, 32768, 65536))):
+            for B in sizes:
+                for F in (1, 2, 4):
+                    both(N, B, F, 24)
+        return
     for N, sizes in ((9, (1024, 4096, 8192, 16384, 32768)), (13, (1024, 4096, 8192, 16384)), (19, (1024, 2048, 4096, 8192))):
         for B in sizes:
             for F in (1, 4, 64, 256):
