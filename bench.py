@@ -426,7 +426,7 @@ def rollout_kernel_name(n, games, plies, cus, auto_reset=True):
     serves this launch."""
     rcap = 9 if n <= 9 else 13 if n <= 13 else 19
     full = 'true' if n == rcap else 'false'
-    lat_per_cu, lat_plies = {9: (64, 3), 13: (32, 4), 19: (8, 64)}[rcap]
+    lat_per_cu, lat_plies = {9: (64, 3), 13: (32, 3 if games >= 16 * cus else 4), 19: (8, 8)}[rcap]
     if plies >= lat_plies and games <= lat_per_cu * cus:
         return 'k_rollout_lat<%d, %s, %s, 0>' % (rcap, full, 'true' if auto_reset else 'false')
     if plies >= 2 and games >= 32 * cus:

@@ -241,7 +241,7 @@ bool use_multi_ply(int cus, int64_t B, int plies) {
 //   19x19 (14 .. 19)   1 024 x1.07, 2 048 x1.05, 4 096 x0.89                           -> up to 8 games per CU
 // and per launch length at 4 096 games: 9x9 1 / 2 / 4 / 16 plies x0.87 / 0.97 / 1.13 / 1.49, 13x13 x0.78 / 0.87 / 1.03 / 1.32,
 // 19x19 x0.50 / 0.59 / 0.73 / 0.82 (the launch pays the first classes of every board: eleven lock-step floods), so from
-// 3 / 4 / 64 plies per launch on.  (A/B builds: GG_AB_LAT_MAX = games per CU, GG_AB_LAT_PLIES = plies.)
+// 3 / 3 - 4 / 8 plies per launch on.  (A/B builds: GG_AB_LAT_MAX = games per CU, GG_AB_LAT_PLIES = plies.)
 // Tracked boards carry their classes - no first analysis on either kernel, a lane loads and stores its own five row words - so
 // the kernel pays from ONE ply per launch on and up to larger batches (profiles/r05e_lat_tracked_sweep.txt, new / k_rollout4
 // at 1 / 4 / 64 / 256 plies per launch): 9x9 4 096 games x1.06 / 2.06 / 2.33 / 2.54, 16 384 x1.61 / 1.41 / 1.16 / 1.14, 32 768
@@ -249,7 +249,10 @@ bool use_multi_ply(int cus, int64_t B, int plies) {
 // 1.11 / 1.14, 8 192 x1.52 / 1.03 / 0.76 / 0.72 -> up to 64 / 64 / 16 games per CU.  (A/B builds: GG_AB_LATT_MAX, GG_AB_LATT_PLIES.)
 bool use_lat(int cus, int64_t B, int32_t N, int plies, bool tracked = false) {
   int64_t per_cu = N <= 9 ? 64 : N <= 13 ? 32 : 8;
-  int min_plies = N <= 9 ? 3 : N <= 13 ? 4 : 64;
+  // (second sweep, with every read of either kernel's prologue in flight together - profiles/r05n_lat_fsweep.txt, hipGraph nodes,
+  // new / two-board: 9x9 4 096 games 1 / 2 / 3 / 4 / 16 plies x0.86 / 0.98 / 1.12 / 1.22 / 1.66; 13x13 4 096 x0.81 / 0.95 / 1.09 /
+  // 1.19 / 1.57, 1 024 x0.71 / 0.82 / 0.93 / 1.01 / 1.33; 19x19 2 048 games 4 / 8 / 16 / 64 plies x0.92 / 1.04 / 1.12 / 1.19)
+  int min_plies = N <= 9 ? 3 : N <= 13 ? (B >= (int64_t)cus * 16 ? 3 : 4) : 8;
   if (tracked) {
     per_cu = N <= 13 ? 64 : 16;
     min_plies = 1;
@@ -346,13 +349,9 @@ uint32_t recip16(int32_t N) {
 extern "C" {
 
 #ifdef GG_AB_PROF
-// A/B builds only: read and clear the phase clocks of k_rollout4
-int32_t gg_ab_prof_read(unsigned long long *out8) {
-  if (hipDeviceSynchronize() != hipSuccess) return 1;
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gg::gg_prof), sizeof(z)) != hipSuccess) return 2;
-  return hipMemcpyToSymbol(HIP_SYMBOL(gg::gg_prof), z, sizeof(z)) == hipSuccess ? 0 : 3;
-}
+// A/B builds only: read and clear the phase clocks of THIS translation unit's launches (k_rollout2, env steps of k_rollout4;
+// gg_prof has internal linkage; [8] / [9] = first entry / last exit on the 100 MHz wall clock)
+GG_PROF_READ(gg_ab_prof_read_kernels)
 #endif
 
 #ifdef GG_AB_WHERE

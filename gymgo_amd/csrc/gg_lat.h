@@ -172,15 +172,16 @@ __device__ __forceinline__ void lat_flood(uint32_t (&F)[K], const uint32_t (&Mk)
 // The stones (of either colour) whose group has >= 2 liberties, from the stones alone: the constant-weight code of gg_v2.h
 // (point q gets the q-th 11-bit word of weight 5; flood i is seeded next to the empty points whose word has bit i; a group
 // with one liberty is reached by exactly 5 floods, with two or more by >= 6) in the row-per-lane layout - eleven floods in
-// lock-step, black and white in two fields of a register (19x19: two passes).  r = the lane's row.
+// lock-step, black and white in two fields of a register (19x19: two passes).  cwm[i] = kCw.m[i][the lane's row], read by the
+// caller together with the boards (one round trip for all of the launch's first reads: cw_table_issue, gg_v2.h).
 template <int R>
-__device__ __forceinline__ uint32_t lat_classes(uint32_t bl, uint32_t wh, uint32_t full, int r) {
+__device__ __forceinline__ uint32_t lat_classes(uint32_t bl, uint32_t wh, uint32_t full, const uint32_t (&cwm)[kCwClasses]) {
   using L = Lat<R>;
   constexpr int NC = L::NF >= 2 ? 1 : 2;
   const uint32_t E = full & ~(bl | wh);
   uint32_t d[kCwClasses];
 #pragma unroll
-  for (int i = 0; i < kCwClasses; ++i) d[i] = lat_dilate<L::LPB>(E & kCw.m[i][r < 19 ? r : 19]);
+  for (int i = 0; i < kCwClasses; ++i) d[i] = lat_dilate<L::LPB>(E & cwm[i]);
   uint32_t multi_all = 0;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -387,7 +388,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
   static_assert(IO == 0 || IO == 2, "byte planes or tracked boards");
   constexpr bool TRACKED = IO == 2;
   const int W = 5 * N + 1;
-  if (!TRACKED) load_spread_lut(lut, lane);
+  GG_PROF_DECL;
+  bool tables = TRACKED;
   const int64_t ngroups = (B + NBW - 1) / NBW;
   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const int64_t b_first = g * NBW;
@@ -395,36 +397,58 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
     const int64_t b = on ? b_first + j : B - 1;
     uint8_t *gs = states + b * (int64_t)S;
     // ---------------------------------------------------------------- load: all boards of the wave staged, then one row per lane
-    GG_PROF_DECL;
     uint32_t *gp = reinterpret_cast<uint32_t *>(states) + b * (int64_t)W;   // TRACKED: this lane's board
     uint64_t x;
     uint32_t me, op, M, inv, fl;
     if (TRACKED) {
       const int rc = r < N ? r : 0;
+      x = rng[b];   // (first: every read of the prologue is in flight before the first one is consumed)
       uint32_t bl = gp[rc], wh = gp[N + rc];
       inv = gp[2 * N + rc];
       M = gp[3 * N + rc] | gp[4 * N + rc];
       fl = gp[5 * N] & 7u;
-      x = rng[b];
       if (!on || r >= N) { bl = wh = inv = M = 0; }
       if (!on) fl = 0;
       me = (fl & 1u) ? wh : bl;
       op = (fl & 1u) ? bl : wh;
     } else {
-      WAVE_SYNC();
+      // the boards of the wave are ONE contiguous slice of HBM: its aligned 16-byte vectors, the class masks of the lane's row
+      // and the generator are read together (one round trip; each helper waiting for its own reads cost a one-ply launch
+      // 3 500 of its 11 300 cycles per wave: tools/exp/oneply_where.py), the spread table is built while they are in flight
+      constexpr int NVL = (((15 + NBW * 6 * R * R + 15) >> 4) + kWave - 1) / kWave;
+      typedef uint32_t Vec __attribute__((ext_vector_type(4)));
+      const uint8_t *g0 = states + b_first * (int64_t)S;
+      const int64_t nb = B - b_first < NBW ? B - b_first : NBW;
+      const uint32_t mis = (uint32_t)((uintptr_t)g0 & 15u);
+      const int nv = (int)((mis + (uint32_t)(nb * S) + 15u) >> 4);
+      uint32_t cwm[kCwClasses];
+      int rr = r < 19 ? r : 19;
+      asm volatile("" : "+v"(rr));   // (loop-variant for the compiler: hoisted out of the loop, the reads would be waited for before the loop)
 #pragma unroll
-      for (int i = 0; i < NBW; ++i) {
-        const int64_t bi = b_first + i < B ? b_first + i : B - 1;
-        stage_in(states + bi * (int64_t)S, S, reinterpret_cast<uint8_t *>(lds + LdsLat<R>::kIo) + i * L::kIoBytes, lane);
+      for (int i = 0; i < kCwClasses; ++i) cwm[i] = kCw.m[i][rr];
+      Vec sv[NVL];
+#pragma unroll
+      for (int k = 0; k < NVL; ++k) {
+        const int v = lane + kWave * k;
+        sv[k] = *reinterpret_cast<const Vec *>(g0 - mis + 16 * (v < nv ? v : nv - 1));
       }
       x = rng[b];
+      if (!tables) { load_spread_lut(lut, lane); tables = true; }
       WAVE_SYNC();
-      const uint8_t *io = reinterpret_cast<const uint8_t *>(lds + LdsLat<R>::kIo) + j * L::kIoBytes + ((uintptr_t)gs & 15u);
+      uint8_t *iob = reinterpret_cast<uint8_t *>(lds + LdsLat<R>::kIo);
+#pragma unroll
+      for (int k = 0; k < NVL; ++k) {
+        const int v = lane + kWave * k;
+        if (v < nv) *reinterpret_cast<Vec *>(iob + 16 * v) = sv[k];
+      }
+      WAVE_SYNC();
+      const uint8_t *io = iob + mis + j * S;
       uint32_t bl = plane_to_row<R>(io, N, r), wh = plane_to_row<R>(io + P, N, r);
       inv = plane_to_row<R>(io + 3 * P, N, r);
       fl = (io[2 * P] ? 1u : 0u) | (io[4 * P] ? 2u : 0u) | (io[5 * P] ? 4u : 0u);   // turn, passed, done
       if (!on) { bl = wh = inv = 0; fl = 0; }
-      M = lat_classes<R>(bl, wh, full, r);
+      GG_PROF(2);   // bytes -> rows
+      M = lat_classes<R>(bl, wh, full, cwm);
       me = (fl & 1u) ? wh : bl;
       op = (fl & 1u) ? bl : wh;
     }
@@ -487,8 +511,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
       }
     }
     GG_PROF(7);   // write-back
-    GG_PROF_FLUSH;
   }
+  GG_PROF_FLUSH;
 }
 
 // Tromp-Taylor areas (gym_go/gogame.py:275-300) of the wave's boards in this layout: a colour owns its stones plus the empty
@@ -545,6 +569,9 @@ __global__ __launch_bounds__(kWave, 4) void k_env_step_lat(uint32_t *__restrict_
     const bool on = b_first + j < B;
     const int64_t b = on ? b_first + j : B - 1;
     uint32_t *gp = tracked + b * (int64_t)W;
+    // (the generator / the given move first: every read of the prologue is in flight before the first one is consumed)
+    uint64_t x = MOVES ? 0 : rng[b];
+    const int mv_in = MOVES ? env.actions[b] : 0;
     uint32_t me, op, M, inv, fl;
     {
       const int rc = r < N ? r : 0;
@@ -557,13 +584,12 @@ __global__ __launch_bounds__(kWave, 4) void k_env_step_lat(uint32_t *__restrict_
       me = (fl & 1u) ? wh : bl;
       op = (fl & 1u) ? bl : wh;
     }
-    uint64_t x = (!MOVES && rng) ? rng[b] : 0;
     const bool done0 = (fl & 4u) != 0;
     bool live, reset, pass = false;
     uint32_t Q = 0;
     int taken = -1;
     if (MOVES) {
-      const int mv = env.actions[b];
+      const int mv = mv_in;
       reset = on && done0 && auto_reset != 0;
       const bool inrange = mv >= 0 && mv <= P;
       const bool point = inrange && mv < P;

@@ -60,10 +60,5 @@ void launch_env_step_lat(uint32_t *tracked, uint64_t *rng, int64_t *steps_done, 
 
 #ifdef GG_AB_PROF
 // A/B builds only: read and clear the phase clocks of THIS translation unit's launches (gg_prof has internal linkage)
-extern "C" int32_t gg_ab_prof_read_lat(unsigned long long *out8) {
-  if (hipDeviceSynchronize() != hipSuccess) return 1;
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gg::gg_prof), sizeof(z)) != hipSuccess) return 2;
-  return hipMemcpyToSymbol(HIP_SYMBOL(gg::gg_prof), z, sizeof(z)) == hipSuccess ? 0 : 3;
-}
+GG_PROF_READ(gg_ab_prof_read_lat)
 #endif

@@ -40,10 +40,5 @@ void launch_rollout4(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, 
 
 #ifdef GG_AB_PROF
 // A/B builds only: read and clear the phase clocks of THIS translation unit's k_rollout4 launches (gg_prof has internal linkage)
-extern "C" int32_t gg_ab_prof_read_rollout(unsigned long long *out8) {
-  if (hipDeviceSynchronize() != hipSuccess) return 1;
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gg::gg_prof), sizeof(z)) != hipSuccess) return 2;
-  return hipMemcpyToSymbol(HIP_SYMBOL(gg::gg_prof), z, sizeof(z)) == hipSuccess ? 0 : 3;
-}
+GG_PROF_READ(gg_ab_prof_read_rollout)
 #endif

@@ -24,6 +24,40 @@ constexpr int kCwClasses = 11, kCwWeight = 5, kCwLanes = 2 * kCwClasses;
 static __device__ unsigned int gg_where[3 * 16384];
 #endif
 
+#ifdef GG_AB_PROF
+// A/B builds only: shader-clock time of the phases of a ply as one wave experiences them (incl. waiting for the SIMD), one
+// record per (single-wave) workgroup - plain stores into its own slots, nothing shared; [8] / [9] = the workgroup's entry /
+// exit on the 100 MHz wall clock.  GG_PROF_READ reduces them on the host: sums, earliest entry, latest exit.
+constexpr int kProfSlots = 16384;
+static __device__ unsigned long long gg_prof[kProfSlots * 10];
+#define GG_PROF_DECL unsigned long long tph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tw_ = (unsigned long long)wall_clock64(), tc_ = clock64()
+#define GG_PROF(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    const unsigned long long n_ = clock64(); __builtin_amdgcn_sched_barrier(0); tph_[k] += n_ - tc_; tc_ = n_; } while (0)
+#define GG_PROF_FLUSH do { if (threadIdx.x == 0 && blockIdx.x < kProfSlots) { unsigned long long *o_ = gg_prof + 10 * blockIdx.x; \
+    for (int k_ = 0; k_ < 8; ++k_) o_[k_] += tph_[k_]; \
+    if (o_[9] == 0 || tw_ < o_[8]) o_[8] = tw_; o_[9] = (unsigned long long)wall_clock64(); \
+    for (int k_ = 0; k_ < 8; ++k_) tph_[k_] = 0; } } while (0)
+#define GG_PROF_READ(name) extern "C" int32_t name(unsigned long long *out10) { \
+    if (hipDeviceSynchronize() != hipSuccess) return 1; \
+    static unsigned long long h_[gg::kProfSlots * 10]; \
+    if (hipMemcpyFromSymbol(h_, HIP_SYMBOL(gg::gg_prof), sizeof(h_)) != hipSuccess) return 2; \
+    for (int k = 0; k < 10; ++k) out10[k] = k == 8 ? ~0ull : 0; \
+    for (int i = 0; i < gg::kProfSlots; ++i) { const unsigned long long *r = h_ + 10 * i; if (!r[9]) continue; \
+      for (int k = 0; k < 8; ++k) out10[k] += r[k]; \
+      if (r[8] < out10[8]) out10[8] = r[8]; if (r[9] > out10[9]) out10[9] = r[9]; } \
+    for (int i = 0; i < gg::kProfSlots * 10; ++i) h_[i] = 0; \
+    return hipMemcpyToSymbol(HIP_SYMBOL(gg::gg_prof), h_, sizeof(h_)) == hipSuccess ? 0 : 3; }
+#elif defined(GG_AB_MARK)
+// A/B builds only: phase markers in the assembly listing (tools/isa_mix.py --phases)
+#define GG_PROF_DECL do {} while (0)
+#define GG_PROF(k) asm volatile("; GGMARK " #k ::: "memory")
+#define GG_PROF_FLUSH do {} while (0)
+#else
+#define GG_PROF_DECL do {} while (0)
+#define GG_PROF(k) do {} while (0)
+#define GG_PROF_FLUSH do {} while (0)
+#endif
+
 struct CwTable { uint32_t m[kCwClasses + 1][20]; };  // [class][row] -> columns of the class; last row = zeros
 
 constexpr CwTable make_cw_table() {
@@ -431,12 +465,102 @@ __device__ __forceinline__ Half make_half(int lane, int N, uint32_t inv, bool ar
   return hf;
 }
 
+// The class table, constant memory -> LDS.  A launch's first global reads are a LATENCY chain when each helper waits for its
+// own (tools/exp/oneply_where.py: a one-ply launch of k_rollout2<9> spent 2 300 of its 10 900 cycles per wave in a loop of
+// five load - wait - ds_write rounds here, another 3 200 in flags -> planes -> generators, one round trip each), so the table
+// comes in two halves: cw_table_issue puts ALL its reads in flight, the caller issues whatever else the prologue reads
+// (stage_issue_h, flags_issue_h, the generators), and cw_table_commit / stage_commit_h / flags_commit_h consume them in
+// issue order - one round trip for the lot.
+constexpr int kCwWords = (kCwClasses + 2) * 20, kCwRounds = (kCwWords + kWave - 1) / kWave;
+struct CwRegs { uint32_t t[kCwRounds]; };
+__device__ __forceinline__ void cw_table_issue(CwRegs &c, int lane) {
+  const uint32_t *src = &kCw.m[0][0];
+#pragma unroll
+  for (int k = 0; k < kCwRounds; ++k) {
+    const int i = lane + kWave * k;
+    c.t[k] = src[i < (kCwClasses + 1) * 20 ? i : (kCwClasses + 1) * 20 - 1];
+  }
+}
+template <int R>
+__device__ __forceinline__ void cw_table_commit(uint32_t *lds, const CwRegs &c, int lane) {
+  uint32_t *cwt = lds + Lds2<R>::kCwt;
+#pragma unroll
+  for (int k = 0; k < kCwRounds; ++k) {
+    const int i = lane + kWave * k;
+    if (i < kCwWords) cwt[i] = i < (kCwClasses + 1) * 20 ? c.t[k] : 0xFFFFFFFFu;
+  }
+  WAVE_SYNC();
+}
 template <int R>
 __device__ __forceinline__ void load_cw_table(uint32_t *lds, int lane) {
-  uint32_t *cwt = lds + Lds2<R>::kCwt;
-  for (int i = lane; i < (kCwClasses + 2) * 20; i += kWave)
-    cwt[i] = i < (kCwClasses + 1) * 20 ? kCw.m[i / 20][i % 20] : 0xFFFFFFFFu;
+  CwRegs c;
+  cw_table_issue(c, lane);
+  cw_table_commit<R>(lds, c, lane);
+}
+
+// stage_in_h / load_flags_h in two halves (see cw_table_issue): the aligned 16-byte vectors of one half's board slice into
+// registers (a lane past the slice re-reads its last vector: always mapped, never stored), then registers -> LDS
+template <int R>
+struct StageRegs {
+  static constexpr int NV = (((15 + 4 * R * R + 15) >> 4) + 31) / 32;
+  typedef uint32_t Vec __attribute__((ext_vector_type(4)));   // (a register quadruple: a struct would live in scratch)
+  Vec v[NV];
+};
+template <int R>
+__device__ __forceinline__ void stage_issue_h(const uint8_t *g, int nbytes, int hl, StageRegs<R> &s) {
+  const uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
+  const uint8_t *ga = g - mis;
+  const int nv = (int)(mis + nbytes + 15) >> 4;
+#pragma unroll
+  for (int k = 0; k < StageRegs<R>::NV; ++k) {
+    const int v = hl + 32 * k;
+    s.v[k] = *reinterpret_cast<const typename StageRegs<R>::Vec *>(ga + 16 * (v < nv ? v : nv - 1));
+  }
+}
+template <int R>
+__device__ __forceinline__ uint32_t stage_commit_h(const uint8_t *g, int nbytes, uint8_t *lds, int hl, const StageRegs<R> &s) {
+  const uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
+  const int nv = (int)(mis + nbytes + 15) >> 4;
+#pragma unroll
+  for (int k = 0; k < StageRegs<R>::NV; ++k) {
+    const int v = hl + 32 * k;
+    if (v < nv) *reinterpret_cast<typename StageRegs<R>::Vec *>(lds + 16 * v) = s.v[k];
+  }
+  return mis;
+}
+__device__ __forceinline__ uint8_t flags_issue_h(const uint8_t *g, int P, int pt, const Half &hf) {
+  const int l = hf.hl & 3;
+  return g[l == 0 ? 2 * P : l == 1 ? 3 * P + pt : l == 2 ? 4 * P : 5 * P];   // (every lane reads one of the four bytes: no branch)
+}
+__device__ __forceinline__ uint32_t flags_commit_h(uint8_t fb, const Half &hf) {
+  return half_of(__ballot(fb != 0 && hf.hl < 4), hf.h) & 0xFu;
+}
+
+// One pair's byte planes: pair_issue puts the half's flag bytes and plane vectors in flight - and, on a wave's first pair
+// (`tables` false), the class table; the caller adds its own reads (actions, generators, ko points); pair_commit builds the
+// tables if they are still missing (the spread table `lut` when the kernel emits boards), hands the flags back and leaves the
+// planes at io + (return value).
+template <int R>
+struct PairRegs { StageRegs<R> sr; CwRegs cw; uint8_t fb; };
+template <int R>
+__device__ __forceinline__ void pair_issue(PairRegs<R> &pr, const uint8_t *g, int nbytes, const Half &hf, bool tables) {
+  if (!tables) cw_table_issue(pr.cw, hf.lane);
+  pr.fb = flags_issue_h(g, hf.P, 0, hf);
+  stage_issue_h<R>(g, nbytes, hf.hl, pr.sr);
+}
+template <int R>
+__device__ __forceinline__ uint32_t pair_commit(const PairRegs<R> &pr, const uint8_t *g, int nbytes, uint8_t *io, const Half &hf,
+                                                uint32_t *lds, uint2 *lut, bool &tables, uint32_t &flags) {
+  if (!tables) {
+    if (lut) load_spread_lut(lut, hf.lane);
+    cw_table_commit<R>(lds, pr.cw, hf.lane);
+    tables = true;
+  }
+  flags = flags_commit_h(pr.fb, hf);
   WAVE_SYNC();
+  const uint32_t mi = stage_commit_h<R>(g, nbytes, io, hf.hl, pr.sr);
+  WAVE_SYNC();
+  return mi;
 }
 
 // inclusive prefix sum of v over the 32 lanes of each half: 4 DPP row shifts + 1 row broadcast
@@ -593,8 +717,8 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_next_states2(const uint8_t
   __shared__ __attribute__((aligned(16))) uint32_t meta[kWave];
   const Half hf = make_half(threadIdx.x, N, inv);
   __shared__ uint2 lut[256];
-  load_cw_table<R>(lds, hf.lane);
-  load_spread_lut(lut, hf.lane);
+  CwRegs cw;
+  cw_table_issue(cw, hf.lane);   // (in flight with the first action and, behind it, the first pair's DMA: see cw_table_issue)
   const int S = 6 * hf.P;
   const int64_t npairs = (B + 1) >> 1;
   // Which pairs a wave takes.  The grid is the resident set: `cols` SIMDs x 3 waves, and the dispatcher places workgroups
@@ -644,6 +768,8 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_next_states2(const uint8_t
 #endif
   int a = actions[board_of(p)];
   issue(p, a);
+  load_spread_lut(lut, hf.lane);             // both tables are built while the first pair's DMA is in flight
+  cw_table_commit<R>(lds, cw, hf.lane);
   bool have_prev = false;
   uint32_t pb = 0, pw = 0, pi = 0, pm = 0;   // previous pair's result rows + {turn, passed, done, illegal} bits
   for (;;) {
@@ -733,10 +859,12 @@ __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_
   if (FULLN) { N = R; inv = (65536u + R - 1u) / R; }   // N == R: compile-time constants (see k_env_step2)
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   __shared__ uint32_t fair_mates[16];
+  GG_PROF_DECL;
   const Half hf = make_half(threadIdx.x, N, inv);
   __shared__ uint2 lut[256];
-  load_cw_table<R>(lds, hf.lane);
-  load_spread_lut(lut, hf.lane);
+  // the prologue's global reads - class table, the first pair's flags, planes and generators - are in flight TOGETHER
+  // (cw_table_issue): one round trip instead of eight (9x9 x 4 096 games, one ply per launch as a hipGraph node: 7.15 -> 6.07 us)
+  bool tables = false;
   const int S = 6 * hf.P;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
@@ -749,21 +877,27 @@ __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_
     uint32_t *gp = reinterpret_cast<uint32_t *>(states) + b * (int64_t)(3 * N + 1);
     uint32_t black, white, invalid;
     int turn, passed, done;
+    PairRegs<R> pr;
+    if (PACKED) {
+      if (!tables) { load_cw_table<R>(lds, hf.lane); load_spread_lut(lut, hf.lane); tables = true; }
+    } else {
+      pair_issue<R>(pr, gs, 4 * hf.P, hf, tables);
+    }
+    const uint64_t ra = rng[bA], rb = rng[bB];
     if (PACKED) {
       uint32_t fw;
       load_packed_h(gp, N, hf, black, white, invalid, fw);
       turn = fw & 1u; passed = (fw >> 1) & 1u; done = (fw >> 2) & 1u;
     } else {
-      const uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
-      WAVE_SYNC();
-      const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
-      WAVE_SYNC();
+      uint32_t flags;
+      const uint32_t mi = pair_commit<R>(pr, gs, 4 * hf.P, io, hf, lds, lut, tables, flags);
       black = plane_to_row<R>(io + mi, N, hf.hl);
       white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
       invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
       turn = flags & 1u; passed = (flags >> 2) & 1u; done = (flags >> 3) & 1u;
     }
-    uint64_t xa = uniform64(rng[bA]), xb = uniform64(rng[bB]);  // generator states live in SGPRs
+    GG_PROF(5);   // tables + load
+    uint64_t xa = uniform64(ra), xb = uniform64(rb);  // generator states live in SGPRs
     int last = -1, played = 0;
     uint32_t atari = 0;   // next mover's opponents in atari, known from the previous ply of this launch
     bool have_atari = false;
@@ -795,7 +929,9 @@ __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_
       int a = pick_action2(valid, incl, hf.h ? kb : ka, hf);
       uint32_t mine = turn ? white : black, opp = turn ? black : white;
       uint32_t natari;
+      GG_PROF(0);
       uint32_t ninv = step_core2<R, false>(mine, opp, live ? a : hf.P, hf, lds, atari, have_atari, natari);
+      GG_PROF(4);
       have_atari = true;   // from now on every live half carries its atari set (frozen halves only ever pass)
       if (live) {
         atari = natari;
@@ -820,7 +956,9 @@ __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_
       if (last_actions) last_actions[b] = last;
       if (steps_done && played) atomicAdd(reinterpret_cast<unsigned long long *>(steps_done) + b, (unsigned long long)played);
     }
+    GG_PROF(7);   // write-back
   }
+  GG_PROF_FLUSH;
 }
 
 // Replay of given move sequences with the boards resident on-chip: state = next_state(state, moves[b][t]) for
@@ -834,8 +972,7 @@ __global__ __launch_bounds__(kWave, 4) void k_play_moves2(uint8_t *__restrict__ 
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv);
   __shared__ uint2 lut[256];
-  load_cw_table<R>(lds, hf.lane);
-  load_spread_lut(lut, hf.lane);
+  bool tables = false;
   const int S = 6 * hf.P;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
@@ -848,14 +985,15 @@ __global__ __launch_bounds__(kWave, 4) void k_play_moves2(uint8_t *__restrict__ 
     uint32_t black, white, invalid;
     int turn, passed, done;
     if (PACKED) {
+      if (!tables) { load_cw_table<R>(lds, hf.lane); load_spread_lut(lut, hf.lane); tables = true; }
       uint32_t fw;
       load_packed_h(gp, N, hf, black, white, invalid, fw);
       turn = fw & 1u; passed = (fw >> 1) & 1u; done = (fw >> 2) & 1u;
     } else {
-      const uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
-      WAVE_SYNC();
-      const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
-      WAVE_SYNC();
+      PairRegs<R> pr;
+      pair_issue<R>(pr, gs, 4 * hf.P, hf, tables);
+      uint32_t flags;
+      const uint32_t mi = pair_commit<R>(pr, gs, 4 * hf.P, io, hf, lds, lut, tables, flags);
       black = plane_to_row<R>(io + mi, N, hf.hl);
       white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
       invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
@@ -928,8 +1066,7 @@ __global__ __launch_bounds__(kWave, PACKED ? 4 : GG_LB_PLY) void k_env_step2(uin
   const Half hf = make_half(threadIdx.x, N, inv, HEUR);
   const Half hfa = make_half(threadIdx.x, N, inv, true);   // lanes 22 / 23 of each half flood the empty points
   __shared__ uint2 lut[256];
-  load_cw_table<R>(lds, hf.lane);
-  load_spread_lut(lut, hf.lane);
+  bool tables = false;
   const int S = 6 * hf.P;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
@@ -942,15 +1079,22 @@ __global__ __launch_bounds__(kWave, PACKED ? 4 : GG_LB_PLY) void k_env_step2(uin
     uint32_t *gp = reinterpret_cast<uint32_t *>(states) + b * (int64_t)(3 * N + 1);
     uint32_t black, white, invalid;
     int turn, passed, done;
+    PairRegs<R> pr;
+    if (PACKED) {
+      if (!tables) { load_cw_table<R>(lds, hf.lane); load_spread_lut(lut, hf.lane); tables = true; }
+    } else {
+      pair_issue<R>(pr, gs, 4 * hf.P, hf, tables);
+    }
+    // (the given action or the generators: in flight with the planes)
+    const int a_given = actions ? actions[b] : 0;
+    const uint64_t rga = actions ? 0 : rng[bA], rgb = actions ? 0 : rng[bB];
     if (PACKED) {
       uint32_t fw;
       load_packed_h(gp, N, hf, black, white, invalid, fw);
       turn = fw & 1u; passed = (fw >> 1) & 1u; done = (fw >> 2) & 1u;
     } else {
-      const uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
-      WAVE_SYNC();
-      const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
-      WAVE_SYNC();
+      uint32_t flags;
+      const uint32_t mi = pair_commit<R>(pr, gs, 4 * hf.P, io, hf, lds, lut, tables, flags);
       black = plane_to_row<R>(io + mi, N, hf.hl);
       white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
       invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
@@ -965,9 +1109,9 @@ __global__ __launch_bounds__(kWave, PACKED ? 4 : GG_LB_PLY) void k_env_step2(uin
     }
     int a;
     if (actions) {
-      a = actions[b];
+      a = a_given;
     } else {
-      uint64_t xa = uniform64(rng[bA]), xb = uniform64(rng[bB]);
+      uint64_t xa = uniform64(rga), xb = uniform64(rgb);
       const uint32_t valid = hf.full_l1 & ~invalid;
       const uint32_t incl = half_scan((uint32_t)__popc(valid));
       const uint32_t cnt_a = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
@@ -1516,7 +1660,7 @@ __global__ __launch_bounds__(kWave, 4) void k_invalid_mask2(const uint8_t *__res
   if (FULLN) { N = R; inv = (65536u + R - 1u) / R; }   // N == R: compile-time constants (see k_env_step2)
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv);
-  load_cw_table<R>(lds, hf.lane);
+  bool tables = false;
   const int S = 6 * hf.P;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
@@ -1525,11 +1669,11 @@ __global__ __launch_bounds__(kWave, 4) void k_invalid_mask2(const uint8_t *__res
     const bool on = 2 * p + hf.h < B;
     const int64_t b = on ? 2 * p + hf.h : B - 1;
     const uint8_t *gi = states + b * (int64_t)S;
-    const uint32_t flags = load_flags_h(gi, hf.P, 0, hf);
+    PairRegs<R> pr;
+    pair_issue<R>(pr, gi, 2 * hf.P, hf, tables);
     const int k = ko ? ko[b] : -1;
-    WAVE_SYNC();
-    const uint32_t mi = stage_in_h(gi, 2 * hf.P, io, hf.hl);
-    WAVE_SYNC();
+    uint32_t flags;
+    const uint32_t mi = pair_commit<R>(pr, gi, 2 * hf.P, io, hf, lds, nullptr, tables, flags);
     const uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
     const uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
     const int nx = flags & 1u;  // side to move

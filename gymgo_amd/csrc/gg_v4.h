@@ -58,24 +58,6 @@ template <int NJ> __device__ __forceinline__ void wmask_from_bits(const uint32_t
 #define GG_WHERE_END do {} while (0)
 #endif
 
-#ifdef GG_AB_PROF
-// A/B builds only: shader-clock time of the phases of a ply as one wave experiences them (incl. waiting for the SIMD)
-static __device__ unsigned long long gg_prof[8];
-#define GG_PROF_DECL unsigned long long tph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc_ = clock64()
-#define GG_PROF(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); \
-    const unsigned long long n_ = clock64(); __builtin_amdgcn_sched_barrier(0); tph_[k] += n_ - tc_; tc_ = n_; } while (0)
-#define GG_PROF_FLUSH do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&gg_prof[k_], tph_[k_]); } while (0)
-#elif defined(GG_AB_MARK)
-// A/B builds only: phase markers in the assembly listing (tools/isa_mix.py --phases)
-#define GG_PROF_DECL do {} while (0)
-#define GG_PROF(k) asm volatile("; GGMARK " #k ::: "memory")
-#define GG_PROF_FLUSH do {} while (0)
-#else
-#define GG_PROF_DECL do {} while (0)
-#define GG_PROF(k) do {} while (0)
-#define GG_PROF_FLUSH do {} while (0)
-#endif
-
 template <int R>
 struct Lds4 {
   static constexpr int RS = Cfg<R>::kRowStride;
@@ -1206,7 +1188,7 @@ __global__ __launch_bounds__(kWave, 4) void k_track(const uint8_t *__restrict__ 
                                                      int64_t B, int N, uint32_t inv, AgeSplit age) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
   const Half hf = make_half(threadIdx.x, N, inv);
-  load_cw_table<R>(lds, hf.lane);
+  bool tables = false;
   const int S = 6 * hf.P, W = 5 * N + 1;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
@@ -1215,10 +1197,10 @@ __global__ __launch_bounds__(kWave, 4) void k_track(const uint8_t *__restrict__ 
     const bool on = 2 * p + hf.h < B;
     const int64_t b = on ? 2 * p + hf.h : B - 1;
     const uint8_t *gs = states + b * (int64_t)S;
-    const uint32_t flags = load_flags_h(gs, hf.P, 0, hf);
-    WAVE_SYNC();
-    const uint32_t mi = stage_in_h(gs, 4 * hf.P, io, hf.hl);
-    WAVE_SYNC();
+    PairRegs<R> pr;
+    pair_issue<R>(pr, gs, 4 * hf.P, hf, tables);
+    uint32_t flags;
+    const uint32_t mi = pair_commit<R>(pr, gs, 4 * hf.P, io, hf, lds, nullptr, tables, flags);
     const uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
     const uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
     const uint32_t invalid = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);

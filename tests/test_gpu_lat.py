@@ -64,10 +64,13 @@ def test_rollout_same_result_on_both_sides_of_every_take_over(N):
     """The games-per-launch and plies-per-launch thresholds of use_lat (and of use_multi_ply above them): the batch sizes /
     launch lengths right at, below and above each take-over point, every launch against the oracle."""
     cus = _cus()
-    per_cu, min_plies = (64, 3) if N <= 9 else (32, 4) if N <= 13 else (8, 64)
+    per_cu, min_plies = (64, 3) if N <= 9 else (32, 3) if N <= 13 else (8, 8)
     edge = cus * per_cu
     for B in (edge - 3, edge, edge + 1, edge + 5):
         _run(N, B, (min_plies - 1, min_plies, min_plies + 1, 40 if N <= 13 else 90), True, seed=B)
+    if 9 < N <= 13:   # (13x13: from 4 plies per launch below 16 games per CU, from 3 above)
+        for B in (cus * 16 - 1, cus * 16):
+            _run(N, B, (2, 3, 4, 5), True, seed=B)
     # below / above the multi-ply kernel's own take-over (32 games per CU), launches the new kernel does not take
     for B in (cus * 32 - 2, cus * 32 + 2):
         _run(N, B, (1, 2), True, seed=B + 1)

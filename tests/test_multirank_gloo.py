@@ -145,6 +145,8 @@ def test_bench_argument_plumbing():
     assert bench.rollout_kernel_name(9, 16385, 256, 256) == 'k_rollout4<9, 0, false, true, false, false>'
     assert bench.rollout_kernel_name(13, 8192, 4, 256) == 'k_rollout_lat<13, true, true, 0>'
     assert bench.rollout_kernel_name(19, 2048, 64, 256) == 'k_rollout_lat<19, true, true, 0>' and bench.rollout_kernel_name(19, 2049, 64, 256).startswith('k_rollout2<19')
+    assert bench.rollout_kernel_name(19, 2048, 8, 256).startswith('k_rollout_lat<19') and bench.rollout_kernel_name(19, 2048, 7, 256).startswith('k_rollout2<19')
+    assert bench.rollout_kernel_name(13, 4096, 3, 256).startswith('k_rollout_lat<13') and bench.rollout_kernel_name(13, 4095, 3, 256).startswith('k_rollout2<13')
     assert bench.rollout_symbol_prefix('k_rollout_lat<9, true, true, 0>') == '_ZN2gg13k_rollout_latILi9ELb1ELb1ELi0EEE'
     assert bench.rollout_kernel_name(19, 65536, 1, 256) == 'k_env_step16<19, false>'        # (gg_kernels.hip: use_ns16, 3 groups per SIMD)
     assert bench.rollout_kernel_name(19, 32768, 1, 256) == 'k_rollout2<19, true, false, true>'

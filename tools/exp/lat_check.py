@@ -97,6 +97,42 @@ def sweep():
             both(N, B, F, 32)
 
 
+def rate_graph(N, B, F, nodes=32, reps=8):
+    """us per launch inside a hipGraph of `nodes` launches (no host launch cost)."""
+    st = gogame.batch_init_state(B, N, device=dev); rng = gogame.rng_seed(B, 20260927, 0, dev)
+    ch = max(1, B // 16)
+    for g in range(1, 16):
+        gogame.batch_rollout(st[g * ch:(g + 1) * ch], rng[g * ch:(g + 1) * ch], g * (8 if N <= 9 else 20 if N <= 13 else 40), True)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(); graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        gogame.batch_rollout(st, rng, F, True)
+    side.synchronize()
+    with torch.cuda.graph(graph, stream=side):
+        for _ in range(nodes):
+            gogame.batch_rollout(st, rng, F, True)
+    graph.replay(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        graph.replay()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / (reps * nodes) * 1e3, hashlib.sha1(st.cpu().numpy().tobytes()).hexdigest()[:10]
+
+
+def fsweep():
+    """A/B build only: byte-plane launches of 1 .. 16 plies as hipGraph nodes, the latency-shaped kernel forced on / off."""
+    for N, B in ((9, 1024), (9, 4096), (9, 8192), (13, 1024), (13, 4096), (19, 512), (19, 2048), (19, 4096)):
+        for F in (1, 2, 3, 4, 6, 8, 16, 64):
+            out = []
+            for lat in ('1000000', '0'):
+                os.environ['GG_AB_LAT_MAX'] = lat
+                os.environ['GG_AB_LAT_PLIES'] = '1'
+                out.append(rate_graph(N, B, F))
+            print('N %2d B %6d F %3d: lat %.2f us | two-board %.2f us per launch | x%.2f %s' %
+                  (N, B, F, out[0][0], out[1][0], out[1][0] / out[0][0], 'same digest' if out[0][1] == out[1][1] else 'DIGESTS DIFFER'), flush=True)
+
+
 def tracked_parity():
     """Tracked boards through gg_batch_rollout_tracked (lat below its take-over point, k_rollout4 above): untracked == oracle,
     and the tracked words == track(states) bit for bit (the classes are canonical)."""
@@ -204,6 +240,8 @@ if __name__ == '__main__':
         timing()
     if MODE in ('sweep',):
         sweep()
+    if MODE in ('fsweep',):
+        fsweep()
     if MODE in ('all', 'tparity'):
         rc = rc or tracked_parity()
     if MODE in ('tsweep',):

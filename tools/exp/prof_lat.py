@@ -16,7 +16,7 @@ ch = max(1, B // 16)
 for g in range(1, 16):
     gogame.batch_rollout(st[g*ch:(g+1)*ch], rng[g*ch:(g+1)*ch], g * 8, True)
 gogame.batch_rollout(st, rng, F, True)
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 10)()
 L.gg_ab_prof_read(buf)
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
@@ -24,9 +24,9 @@ reps = 4
 for _ in range(reps): gogame.batch_rollout(st, rng, F, True)
 b.record(); torch.cuda.synchronize()
 L.gg_ab_prof_read(buf)
-v = list(buf); tot = sum(v)
+v = list(buf)[:8]; tot = sum(v)
 per = (B + (4 if N <= 13 else 2) - 1) // (4 if N <= 13 else 2) * reps * F   # wave-plies
-names = ['1 draw', '2 stone + seeds', '2 flood', '3 liberties + board sums', '4 patch + mask + flags', '-', 'load + first classes', 'write-back']
+names = ['draw', 'tables (lut)', 'load bytes -> rows', '-', 'ply (lat_play)', '-', 'first classes / tracked load', 'write-back']
 print('N %d B %d F %d: %.4f ms per launch (instrumented)' % (N, B, F, a.elapsed_time(b) / reps))
 for n, x in zip(names, v):
     print('  %-26s %5.1f %%  %8.1f cycles per wave-ply' % (n, 100.0 * x / tot, x / per))

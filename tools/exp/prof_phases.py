@@ -15,14 +15,14 @@ ch = B // 16
 for g in range(1, 16):
     gogame.batch_rollout(st[g*ch:(g+1)*ch], rng[g*ch:(g+1)*ch], g * 40, True)
 gogame.batch_rollout(st, rng, F, True)
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 10)()
 L.gg_ab_prof_read(buf)
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
 for _ in range(4): gogame.batch_rollout(st, rng, F, True)
 b.record(); torch.cuda.synchronize()
 L.gg_ab_prof_read(buf)
-v = list(buf); tot = sum(v)
+v = list(buf)[:8]; tot = sum(v)
 names = ['phase1 sampling', 'phase2 roles+setup', 'phase2 flood', 'phase2 liberties+cls', 'phase3 class patch', '-', 'load', 'write-back']
 print('B %d: %.3f ms per launch (instrumented)' % (B, a.elapsed_time(b) / 4))
 wave_plies = ((B + 15) // 16) * 4 * F
