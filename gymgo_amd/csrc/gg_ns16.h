@@ -219,9 +219,11 @@ __global__ __launch_bounds__(kWave, Ns16Waves<R>::value) void k_next_states16(co
   uint2 *lut = reinterpret_cast<uint2 *>(lds + Lds16<R>::kGrpLut);
   {
     const int l0 = threadIdx.x;
-    for (int i = l0; i < (kCwClasses + 1) * 20; i += kWave) cwt[i] = kCw.m[i / 20][i % 20];
+    CwRegs cw_;   // (all reads of the class rows in flight at once, the spread table built meanwhile: cw_table_issue, gg_v2.h)
+    cw_table_issue(cw_, l0);
     for (int e_ = l0; e_ < 256; e_ += kWave)
       lut[e_] = make_uint2(__umul24((uint32_t)e_ & 15u, 0x204081u) & 0x01010101u, __umul24((uint32_t)e_ >> 4, 0x204081u) & 0x01010101u);
+    cw_rows_commit(cwt, cw_, l0);
   }
   WAVE_SYNC();
 #ifdef GG_AB
@@ -464,9 +466,11 @@ __global__ __launch_bounds__(kWave, Ns16Waves<R>::value) void k_invalid_mask16(c
   uint2 *lut = reinterpret_cast<uint2 *>(lds + Lds16<R>::kGrpLut);
   {
     const int l0 = threadIdx.x;
-    for (int i = l0; i < (kCwClasses + 1) * 20; i += kWave) cwt[i] = kCw.m[i / 20][i % 20];
+    CwRegs cw_;   // (all reads of the class rows in flight at once, the spread table built meanwhile: cw_table_issue, gg_v2.h)
+    cw_table_issue(cw_, l0);
     for (int e_ = l0; e_ < 256; e_ += kWave)
       lut[e_] = make_uint2(__umul24((uint32_t)e_ & 15u, 0x204081u) & 0x01010101u, __umul24((uint32_t)e_ >> 4, 0x204081u) & 0x01010101u);
+    cw_rows_commit(cwt, cw_, l0);
   }
   WAVE_SYNC();
   const int64_t ngroups = (B + kNB16 - 1) / kNB16;
@@ -577,7 +581,9 @@ __global__ __launch_bounds__(kWave, Ns16Waves<R>::value) void k_track16(const ui
   __shared__ __attribute__((aligned(16))) uint32_t cwt[(kCwClasses + 1) * 20];
   {
     const int l0 = threadIdx.x;
-    for (int i = l0; i < (kCwClasses + 1) * 20; i += kWave) cwt[i] = kCw.m[i / 20][i % 20];
+    CwRegs cw_;
+    cw_table_issue(cw_, l0);
+    cw_rows_commit(cwt, cw_, l0);
   }
   WAVE_SYNC();
   const int64_t ngroups = (B + kNB16 - 1) / kNB16;
@@ -692,9 +698,11 @@ __global__ __launch_bounds__(kWave, Ns16Waves<R>::value) void k_env_step16(uint8
   uint2 *lut = reinterpret_cast<uint2 *>(lds + Lds16<R>::kGrpLut);
   {
     const int l0 = threadIdx.x;
-    for (int i = l0; i < (kCwClasses + 1) * 20; i += kWave) cwt[i] = kCw.m[i / 20][i % 20];
+    CwRegs cw_;   // (all reads of the class rows in flight at once, the spread table built meanwhile: cw_table_issue, gg_v2.h)
+    cw_table_issue(cw_, l0);
     for (int e_ = l0; e_ < 256; e_ += kWave)
       lut[e_] = make_uint2(__umul24((uint32_t)e_ & 15u, 0x204081u) & 0x01010101u, __umul24((uint32_t)e_ >> 4, 0x204081u) & 0x01010101u);
+    cw_rows_commit(cwt, cw_, l0);
   }
   WAVE_SYNC();
   const int64_t ngroups = (B + kNB16 - 1) / kNB16;

@@ -491,6 +491,14 @@ __device__ __forceinline__ void cw_table_commit(uint32_t *lds, const CwRegs &c, 
   }
   WAVE_SYNC();
 }
+// (the sixteen-board kernels keep the bare class rows: [kCwClasses + 1][20] words)
+__device__ __forceinline__ void cw_rows_commit(uint32_t *cwt, const CwRegs &c, int lane) {
+#pragma unroll
+  for (int k = 0; k < kCwRounds; ++k) {
+    const int i = lane + kWave * k;
+    if (i < (kCwClasses + 1) * 20) cwt[i] = c.t[k];
+  }
+}
 template <int R>
 __device__ __forceinline__ void load_cw_table(uint32_t *lds, int lane) {
   CwRegs c;
@@ -1236,10 +1244,10 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
       flags = (fw & 1u) | ((fw & 6u) << 1);
       WAVE_SYNC();
     } else {
-      flags = load_flags_h(gi, hf.P, 0, hf);
-      WAVE_SYNC();
-      const uint32_t mi = stage_in_h(gi, 4 * hf.P, io, hf.hl);  // both halves hold the same parent
-      WAVE_SYNC();
+      PairRegs<R> pr;   // (flags and planes in flight together; both halves hold the same parent)
+      bool no_tables = true;
+      pair_issue<R>(pr, gi, 4 * hf.P, hf, true);
+      const uint32_t mi = pair_commit<R>(pr, gi, 4 * hf.P, io, hf, nullptr, nullptr, no_tables, flags);
       black = plane_to_row<R>(io + mi, N, hf.hl);
       white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
       invd = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);

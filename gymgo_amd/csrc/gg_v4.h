@@ -305,6 +305,11 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
     for (int r = 0; r < RPL; ++r) inv_r[r] = M[r] = 0u;
     GG_PROF_DECL;
     // ---------------------------------------------------------------- load
+    // (given moves: the first one is requested with the boards, so that it does not cost the first ply a round trip of its own;
+    // the env step hands it back as the action taken)
+    int mv_next = 0;
+    if (MOVES && !WTS) mv_next = moves[((b_first + q4 < B) ? b_first + q4 : B - 1) * (int64_t)plies];
+    const int mv_first = mv_next;
     WAVE_SYNC();
     if (TRACKED) {
       // the group's boards are ONE contiguous block of nb x (5 N + 1) words: a flat, fully coalesced copy (all loads in
@@ -582,7 +587,6 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
 #define GG_AB_EARLY4 false
 #endif
     const uint32_t fair_lag = plies >= 192 ? GG_AB_FAIRLAG : (plies >= 16 ? (uint32_t)plies >> 3 : 2u);
-    int mv_next = 0;
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
       // fair share of the SIMD (gg_common.h): every fourth ply the wave publishes the ply it has reached and sets its issue
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
           // the move of this ply was fetched during the previous one (mv_next), the next one is requested now
           const int64_t bm = (b_first + s4 < B) ? b_first + s4 : B - 1;
           constexpr bool drawn = WTS;   // the move was drawn from the policy weights above
-          const int mv = drawn ? wact[s4] : (t == 0 ? moves[bm * (int64_t)plies] : mv_next);
+          const int mv = drawn ? wact[s4] : mv_next;
           if (!drawn && t + 1 < plies) mv_next = moves[bm * (int64_t)plies + t + 1];
           // (gg_batch_play_moves passes auto_reset = 0: a finished game stops; the env step may reset it first, and the
           // reset stands even when the move is then refused - GoEnv.reset comes before the action check)
@@ -1112,7 +1116,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         if (env.rewards) env.rewards[b] = rwd;
         if (env.dones) env.dones[b] = (uint8_t)doneb;
         if (env.status) env.status[b] = ((fl >> 4) & 1u) ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
-        if (env.taken) env.taken[b] = MOVES ? (WTS ? wact[q4s] : env.actions[b]) : lastv[q4s];
+        if (env.taken) env.taken[b] = MOVES ? (WTS ? wact[q4s] : mv_first) : lastv[q4s];   // (one ply per launch: the move of the ply)
       }
       if (env.states_out) {
         // the observation: every board of the group as byte planes, one contiguous write
