@@ -437,6 +437,8 @@ def rollout_kernel_name(n, games, plies, cus, auto_reset=True):
         per_simd = {19: 3, 13: 2, 9: 1}[n]
         if (games + 15) // 16 >= cus * 4 * per_simd:
             return 'k_env_step16<%d, false>' % n
+    if plies <= 2 and (games + 1) // 2 <= cus * (16 if n <= 9 else 8):
+        return 'k_rollout2_w4<%d, %s>' % (rcap, full)        # small one- / two-ply launches: four waves per workgroup
     return 'k_rollout2<%d, %s, false, %s>' % (rcap, 'true' if plies <= 2 else 'false', full)
 
 
@@ -521,6 +523,9 @@ def rollout_symbol_prefix(kernel):
     m = re.match(r'k_rollout_lat<(\d+), (\w+), (\w+), (\d+)>', kernel)
     if m:
         return '_ZN2gg13k_rollout_latILi%sE%s%sLi%sEEE' % (m.group(1), b(m.group(2)), b(m.group(3)), m.group(4))
+    m = re.match(r'k_rollout2_w4<(\d+), (\w+)>', kernel)
+    if m:
+        return '_ZN2gg13k_rollout2_w4ILi%sE%sEE' % (m.group(1), b(m.group(2)))
     m = re.match(r'k_rollout2<(\d+), (\w+), (\w+), (\w+)>', kernel)
     if m:
         return '_ZN2gg10k_rollout2ILi%sE%s%s%sEE' % (m.group(1), b(m.group(2)), b(m.group(3)), b(m.group(4)))

@@ -411,7 +411,11 @@ struct FairShare {
   unsigned int slot;      // this wave's slot
   uint32_t *mates;        // 16 words of LDS: the row as it was at the previous check
   uint32_t mates_lds;
-  __device__ __forceinline__ explicit FairShare(uint32_t *lds16) : mates(lds16), mates_lds(lds_addr_of(lds16)) {
+  // active = false (a compile-time constant at the call): the launch never calls update / release, nothing is set up
+  __device__ __forceinline__ explicit FairShare(uint32_t *lds16, bool active = true) : mates(lds16), mates_lds(lds_addr_of(lds16)) {
+    row = nullptr;
+    slot = 0;
+    if (!active) return;
     unsigned int hw, xc;
     asm volatile("s_getreg_b32 %0, hwreg(4)" : "=s"(hw));    // HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]
     asm volatile("s_getreg_b32 %0, hwreg(20)" : "=s"(xc));   // XCC_ID

@@ -34,9 +34,9 @@ namespace gg {
 void launch_rollout4(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N,
                      uint32_t inv, int plies, int auto_reset, int nb, int grid, hipStream_t s);
 void launch_rollout_lat(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N, int plies,
-                        int auto_reset, hipStream_t s);
+                        int auto_reset, bool w4, hipStream_t s);
 void launch_env_step_lat(uint32_t *tracked, uint64_t *rng, int64_t *steps_done, int64_t B, int32_t N, int auto_reset,
-                         const EnvArgs &env, hipStream_t s);
+                         const EnvArgs &env, bool w4, hipStream_t s);
 }
 
 namespace {
@@ -282,6 +282,21 @@ bool use_lat_env(int cus, int64_t B, int32_t N, bool with_observation) {
   return B <= (int64_t)cus * per_cu;
 }
 
+// Short launches of the one-row-per-lane kernels on tracked boards go out as four-wave workgroups: single-wave workgroups
+// enter the machine over ~0.26 ns each (tools/exp/oneply_ramp.py), a tenth of a one-ply launch of a thousand of them.
+// (A/B builds: GG_AB_WPB = 1 / 4 forces the form.)
+// hipGraph node, single-wave -> four-wave workgroups (profiles/r05p_wpb_tracked.txt): 9x9 x 4 096 games one-ply rollout 3.45 -> 3.10
+// us, env step with / without the observation 4.70 -> 4.44 / 3.79 -> 3.52; 16 384 games 5.34 -> 4.80, 7.57 -> 7.17; 13x13 x 4 096 3.99
+// -> 3.65; 5x5 / 7x7 / 11x11 alike; four plies per launch still -0.3 us; from 65 536 games of 9x9 on and at 19x19 nothing moves.
+bool lat_w4(int cus, int64_t B, int32_t N, int plies) {
+  const int64_t groups = (B + 3) / 4;
+  bool w4 = N <= 13 && plies <= 4 && groups <= (int64_t)cus * 16;
+#ifdef GG_AB
+  if (const char *e = getenv("GG_AB_WPB")) w4 = atoi(e) == 4;
+#endif
+  return w4;
+}
+
 int32_t check(int64_t B, int32_t N) { return (N < 2 || N > GG_MAX_BOARD || B < 0) ? GG_E_BADSIZE : 0; }
 
 // reciprocal for the in-kernel action -> (row, col) split; exactness is verified for every action
@@ -352,6 +367,7 @@ extern "C" {
 // A/B builds only: read and clear the phase clocks of THIS translation unit's launches (k_rollout2, env steps of k_rollout4;
 // gg_prof has internal linkage; [8] / [9] = first entry / last exit on the 100 MHz wall clock)
 GG_PROF_READ(gg_ab_prof_read_kernels)
+GG_PROF_RAW(gg_ab_prof_raw_kernels)
 #endif
 
 #ifdef GG_AB_WHERE
@@ -548,7 +564,7 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
   if (plies == 0) return 0;
   if (!rng) return GG_E_NULLPTR;
   if (use_lat(cus, B, N, plies)) {   // an under-filled machine: one row per lane, the ply in registers (gg_lat.h, launched from gg_rollout.hip)
-    launch_rollout_lat(0, states, rng, last_actions, steps_done, B, N, plies, auto_reset, s);
+    launch_rollout_lat(0, states, rng, last_actions, steps_done, B, N, plies, auto_reset, false, s);
     return (int32_t)hipGetLastError();
   }
   if (use_multi_ply(cus, B, plies)) {   // liberty classes carried across the plies, 16 boards per wave
@@ -571,6 +587,22 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
   }
   const int64_t npairs = (B + 1) / 2;
   if (plies <= 2) {
+    // small launches go out as four-wave workgroups: the dispatcher's ramp is per workgroup (k_rollout2, WPB).  hipGraph node,
+    // one ply, single-wave -> four-wave workgroups (profiles/r05p_wpb.txt): 9x9 4 096 / 8 192 games 6.02 -> 5.82 / 7.97 -> 7.61 us,
+    // 13x13 4 096 6.98 -> 6.80 (8 192: 9.67 -> 10.66, the four waves' LDS no longer fits three times per CU), 19x19 4 096 8.49 ->
+    // 8.37; 1 024 games: no change -> up to two waves per SIMD (9x9: four)
+    int wpb = npairs <= (int64_t)cus * (N <= 9 ? 16 : 8) ? 4 : 1;
+#ifdef GG_AB
+    if (const char *e = getenv("GG_AB_WPB")) wpb = atoi(e) == 4 && npairs < (int64_t)cus * 24 ? 4 : 1;
+#endif
+    if (wpb == 4) {
+      const AgeSplit none = {0, {0, 0, 0}};
+      const unsigned grid4 = (unsigned)((npairs + 3) / 4);
+#define GG_K(R, F) k_rollout2_w4<R, F><<<grid4, 4 * kWave, 0, s>>>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, none)
+      GG_DISPATCH_N(N);
+#undef GG_K
+      return (int32_t)hipGetLastError();
+    }
 #define GG_K(R, F) launch_pairs(k_rollout2<R, true, false, F>, cus, npairs, true, s, states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset)
     GG_DISPATCH_N(N);
 #undef GG_K
@@ -823,7 +855,7 @@ int32_t gg_batch_rollout_tracked(uint32_t *tracked, uint64_t *rng, int32_t *last
   if (!rng) return GG_E_NULLPTR;
   uint8_t *st = reinterpret_cast<uint8_t *>(tracked);
   if (use_lat(cus, B, N, plies, true)) {   // an under-filled machine: one row per lane, the ply in registers (gg_lat.h)
-    launch_rollout_lat(2, st, rng, last_actions, steps_done, B, N, plies, auto_reset, s);
+    launch_rollout_lat(2, st, rng, last_actions, steps_done, B, N, plies, auto_reset, lat_w4(cus, B, N, plies), s);
     return (int32_t)hipGetLastError();
   }
   int grid3;
@@ -859,7 +891,7 @@ int32_t gg_batch_env_step_tracked(uint32_t *tracked, const int32_t *actions, uin
   env.states_out = states_out; env.komi = komi; env.heuristic = reward_method == GG_REWARD_HEURISTIC;
   env.ws = nullptr; env.canonical = 0; env.weights = nullptr;
   if (use_lat_env(cus, B, N, states_out != nullptr)) {   // one row per lane, the ply in registers (gg_lat.h)
-    launch_env_step_lat(tracked, rng, steps_done, B, N, auto_reset, env, s);
+    launch_env_step_lat(tracked, rng, steps_done, B, N, auto_reset, env, lat_w4(cus, B, N, 1), s);
     return (int32_t)hipGetLastError();
   }
   if (actions) {

@@ -370,17 +370,22 @@ struct LdsLat {
 // IO: 0 = byte planes (uint8 [B][6][N][N]); 2 = TRACKED boards (uint32 [B][5N+1]: the rows of black, white, invalid,
 // multi_black, multi_white + the flag word, gg_v4.h) - a lane reads and writes its own five row words, the classes travel with
 // the board: no LDS, no first analysis, so even a one-ply launch is just the ply
-template <int R, bool FULLN, bool AUTO, int IO = 0>
-__global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
-                                                          int32_t *__restrict__ last_actions,
-                                                          int64_t *__restrict__ steps_done, int64_t B, int N, int plies,
-                                                          int auto_reset) {
+// WPB: waves per workgroup, each wave an independent group of boards (a launch of single-wave workgroups enters the machine over
+// ~0.26 ns per workgroup - tools/exp/oneply_ramp.py - which a ONE-ply launch of a thousand workgroups feels: k_rollout_lat_w4)
+template <int R, bool FULLN, bool AUTO, int IO, int WPB>
+__device__ __forceinline__ void rollout_lat_body(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+                                                 int32_t *__restrict__ last_actions,
+                                                 int64_t *__restrict__ steps_done, int64_t B, int N, int plies,
+                                                 int auto_reset) {
   using L = Lat<R>;
   constexpr int LPB = L::LPB, NBW = L::NBW, FW = L::FW, NF = L::NF, NREG = L::NREG;
   if (FULLN) N = R;
   if (AUTO) auto_reset = 1;
-  __shared__ __attribute__((aligned(16))) uint32_t lds[LdsLat<R>::kTotal];
-  __shared__ uint2 lut[256];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_[WPB][LdsLat<R>::kTotal];
+  __shared__ uint2 lut_[WPB][256];
+  const int wv = WPB > 1 ? (int)(threadIdx.x >> 6) : 0;
+  uint32_t *lds = lds_[wv];
+  uint2 *lut = lut_[wv];
   const int lane = threadIdx.x & (kWave - 1);
   const int r = lane & (LPB - 1), j = lane / LPB;      // row, board of the wave
   const int P = N * N, S = 6 * P;
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
   GG_PROF_DECL;
   bool tables = TRACKED;
   const int64_t ngroups = (B + NBW - 1) / NBW;
-  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+  for (int64_t g = (int64_t)blockIdx.x * WPB + wv; g < ngroups; g += (int64_t)gridDim.x * WPB) {
     const int64_t b_first = g * NBW;
     const bool on = b_first + j < B;
     const int64_t b = on ? b_first + j : B - 1;
@@ -514,6 +519,21 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ 
   }
   GG_PROF_FLUSH;
 }
+template <int R, bool FULLN, bool AUTO, int IO = 0>
+__global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+                                                          int32_t *__restrict__ last_actions,
+                                                          int64_t *__restrict__ steps_done, int64_t B, int N, int plies,
+                                                          int auto_reset) {
+  rollout_lat_body<R, FULLN, AUTO, IO, 1>(states, rng, last_actions, steps_done, B, N, plies, auto_reset);
+}
+// tracked boards, a few plies per launch: four waves per workgroup
+template <int R, bool FULLN, bool AUTO>
+__global__ __launch_bounds__(4 * kWave, 4) void k_rollout_lat_w4(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+                                                                 int32_t *__restrict__ last_actions,
+                                                                 int64_t *__restrict__ steps_done, int64_t B, int N, int plies,
+                                                                 int auto_reset) {
+  rollout_lat_body<R, FULLN, AUTO, 2, 4>(states, rng, last_actions, steps_done, B, N, plies, auto_reset);
+}
 
 // Tromp-Taylor areas (gym_go/gogame.py:275-300) of the wave's boards in this layout: a colour owns its stones plus the empty
 // regions that touch only that colour, and a region touches a colour iff the flood of the EMPTY points seeded next to that
@@ -548,15 +568,18 @@ __device__ __forceinline__ void lat_areas(uint32_t bl, uint32_t wh, uint32_t ful
 // position when the game has ended or the reward is `heuristic`) and, when asked, the byte-plane observation of every game.
 // Semantics as k_rollout4<R, 2, MOVES, FULLN, true> (gg_v4.h): a finished game is reset first when auto_reset - and the reset
 // stands even when the given move is then refused (GoEnv.reset comes before the action check) - or refuses the step.
-template <int R, bool FULLN, bool MOVES>
-__global__ __launch_bounds__(kWave, 4) void k_env_step_lat(uint32_t *__restrict__ tracked, uint64_t *__restrict__ rng,
-                                                           int64_t *__restrict__ steps_done, int64_t B, int N, int auto_reset,
-                                                           EnvArgs env) {
+template <int R, bool FULLN, bool MOVES, int WPB>
+__device__ __forceinline__ void env_step_lat_body(uint32_t *__restrict__ tracked, uint64_t *__restrict__ rng,
+                                                  int64_t *__restrict__ steps_done, int64_t B, int N, int auto_reset,
+                                                  const EnvArgs &env) {
   using L = Lat<R>;
   constexpr int LPB = L::LPB, NBW = L::NBW;
   if (FULLN) N = R;
-  __shared__ __attribute__((aligned(16))) uint32_t bsv[NBW * L::kBsWords];
-  __shared__ uint2 lut[256];
+  __shared__ __attribute__((aligned(16))) uint32_t bsv_[WPB][NBW * L::kBsWords];
+  __shared__ uint2 lut_[WPB][256];
+  const int wv = WPB > 1 ? (int)(threadIdx.x >> 6) : 0;
+  uint32_t *bsv = bsv_[wv];
+  uint2 *lut = lut_[wv];
   const int lane = threadIdx.x & (kWave - 1);
   const int r = lane & (LPB - 1), j = lane / LPB;
   const int P = N * N, S = 6 * P, W = 5 * N + 1;
@@ -564,7 +587,7 @@ __global__ __launch_bounds__(kWave, 4) void k_env_step_lat(uint32_t *__restrict_
   const bool obs = env.states_out != nullptr;
   if (obs) load_spread_lut(lut, lane);
   const int64_t ngroups = (B + NBW - 1) / NBW;
-  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+  for (int64_t g = (int64_t)blockIdx.x * WPB + wv; g < ngroups; g += (int64_t)gridDim.x * WPB) {
     const int64_t b_first = g * NBW;
     const bool on = b_first + j < B;
     const int64_t b = on ? b_first + j : B - 1;
@@ -654,6 +677,19 @@ __global__ __launch_bounds__(kWave, 4) void k_env_step_lat(uint32_t *__restrict_
       lat_emit<R>(env.states_out + b * (int64_t)S, bl, wh, inv, turn, (fl >> 1) & 1u, (fl >> 2) & 1u, full, N, r,
                   bsv + j * L::kBsWords, lut, on);
   }
+}
+template <int R, bool FULLN, bool MOVES>
+__global__ __launch_bounds__(kWave, 4) void k_env_step_lat(uint32_t *__restrict__ tracked, uint64_t *__restrict__ rng,
+                                                           int64_t *__restrict__ steps_done, int64_t B, int N, int auto_reset,
+                                                           EnvArgs env) {
+  env_step_lat_body<R, FULLN, MOVES, 1>(tracked, rng, steps_done, B, N, auto_reset, env);
+}
+// ... four waves per workgroup (small batches: the dispatcher's ramp, rollout_lat_body)
+template <int R, bool FULLN, bool MOVES>
+__global__ __launch_bounds__(4 * kWave, 4) void k_env_step_lat_w4(uint32_t *__restrict__ tracked, uint64_t *__restrict__ rng,
+                                                                  int64_t *__restrict__ steps_done, int64_t B, int N, int auto_reset,
+                                                                  EnvArgs env) {
+  env_step_lat_body<R, FULLN, MOVES, 4>(tracked, rng, steps_done, B, N, auto_reset, env);
 }
 
 }  // namespace gg

@@ -22,13 +22,18 @@ namespace gg {
     if (io == 0) {                                                                                                              \
       if (auto_reset) k_rollout_lat<R, F, true, 0><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 1);  \
       else k_rollout_lat<R, F, false, 0><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 0);            \
+    } else if (w4) {                                                                                                            \
+      const unsigned grid4_ = (grid_ + 3u) / 4u;                                                                                \
+      if (auto_reset) k_rollout_lat_w4<R, F, true><<<grid4_, 4 * kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 1); \
+      else k_rollout_lat_w4<R, F, false><<<grid4_, 4 * kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 0);       \
     } else {                                                                                                                    \
       if (auto_reset) k_rollout_lat<R, F, true, 2><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 1);  \
       else k_rollout_lat<R, F, false, 2><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 0);            \
     }                                                                                                                           \
   } while (0)
+// w4 (tracked boards only): four waves per workgroup (k_rollout_lat_w4: short launches of few workgroups)
 void launch_rollout_lat(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N, int plies,
-                        int auto_reset, hipStream_t s) {
+                        int auto_reset, bool w4, hipStream_t s) {
   if (N == 9) GG_LAT(9, true);
   else if (N < 9) GG_LAT(9, false);
   else if (N == 13) GG_LAT(13, true);
@@ -42,11 +47,15 @@ void launch_rollout_lat(int io, uint8_t *st, uint64_t *rng, int32_t *last_action
 #define GG_LATE(R, F)                                                                                                          \
   do {                                                                                                                         \
     const unsigned grid_ = (unsigned)((B + Lat<R>::NBW - 1) / Lat<R>::NBW);                                                    \
-    if (env.actions) k_env_step_lat<R, F, true><<<grid_, kWave, 0, s>>>(tracked, rng, steps_done, B, N, auto_reset, env);      \
+    const unsigned grid4_ = (grid_ + 3u) / 4u;                                                                                 \
+    if (w4) {                                                                                                                  \
+      if (env.actions) k_env_step_lat_w4<R, F, true><<<grid4_, 4 * kWave, 0, s>>>(tracked, rng, steps_done, B, N, auto_reset, env); \
+      else k_env_step_lat_w4<R, F, false><<<grid4_, 4 * kWave, 0, s>>>(tracked, rng, steps_done, B, N, auto_reset, env);       \
+    } else if (env.actions) k_env_step_lat<R, F, true><<<grid_, kWave, 0, s>>>(tracked, rng, steps_done, B, N, auto_reset, env); \
     else k_env_step_lat<R, F, false><<<grid_, kWave, 0, s>>>(tracked, rng, steps_done, B, N, auto_reset, env);                 \
   } while (0)
 void launch_env_step_lat(uint32_t *tracked, uint64_t *rng, int64_t *steps_done, int64_t B, int32_t N, int auto_reset,
-                         const EnvArgs &env, hipStream_t s) {
+                         const EnvArgs &env, bool w4, hipStream_t s) {
   if (N == 9) GG_LATE(9, true);
   else if (N < 9) GG_LATE(9, false);
   else if (N == 13) GG_LATE(13, true);
@@ -61,4 +70,5 @@ void launch_env_step_lat(uint32_t *tracked, uint64_t *rng, int64_t *steps_done, 
 #ifdef GG_AB_PROF
 // A/B builds only: read and clear the phase clocks of THIS translation unit's launches (gg_prof has internal linkage)
 GG_PROF_READ(gg_ab_prof_read_lat)
+GG_PROF_RAW(gg_ab_prof_raw_lat)
 #endif

@@ -27,15 +27,16 @@ static __device__ unsigned int gg_where[3 * 16384];
 #ifdef GG_AB_PROF
 // A/B builds only: shader-clock time of the phases of a ply as one wave experiences them (incl. waiting for the SIMD), one
 // record per (single-wave) workgroup - plain stores into its own slots, nothing shared; [8] / [9] = the workgroup's entry /
-// exit on the 100 MHz wall clock.  GG_PROF_READ reduces them on the host: sums, earliest entry, latest exit.
+// exit on the 100 MHz wall clock (of its latest launch).  GG_PROF_READ reduces them on the host: sums, earliest entry, latest exit.
 constexpr int kProfSlots = 16384;
 static __device__ unsigned long long gg_prof[kProfSlots * 10];
 #define GG_PROF_DECL unsigned long long tph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tw_ = (unsigned long long)wall_clock64(), tc_ = clock64()
 #define GG_PROF(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); \
     const unsigned long long n_ = clock64(); __builtin_amdgcn_sched_barrier(0); tph_[k] += n_ - tc_; tc_ = n_; } while (0)
-#define GG_PROF_FLUSH do { if (threadIdx.x == 0 && blockIdx.x < kProfSlots) { unsigned long long *o_ = gg_prof + 10 * blockIdx.x; \
+#define GG_PROF_FLUSH do { const unsigned int ws_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
+    if ((threadIdx.x & 63) == 0 && ws_ < kProfSlots) { unsigned long long *o_ = gg_prof + 10 * ws_; \
     for (int k_ = 0; k_ < 8; ++k_) o_[k_] += tph_[k_]; \
-    if (o_[9] == 0 || tw_ < o_[8]) o_[8] = tw_; o_[9] = (unsigned long long)wall_clock64(); \
+    o_[8] = tw_; o_[9] = (unsigned long long)wall_clock64(); \
     for (int k_ = 0; k_ < 8; ++k_) tph_[k_] = 0; } } while (0)
 #define GG_PROF_READ(name) extern "C" int32_t name(unsigned long long *out10) { \
     if (hipDeviceSynchronize() != hipSuccess) return 1; \
@@ -47,6 +48,10 @@ static __device__ unsigned long long gg_prof[kProfSlots * 10];
       if (r[8] < out10[8]) out10[8] = r[8]; if (r[9] > out10[9]) out10[9] = r[9]; } \
     for (int i = 0; i < gg::kProfSlots * 10; ++i) h_[i] = 0; \
     return hipMemcpyToSymbol(HIP_SYMBOL(gg::gg_prof), h_, sizeof(h_)) == hipSuccess ? 0 : 3; }
+#define GG_PROF_RAW(name) extern "C" int32_t name(unsigned long long *out, int slots) { \
+    if (hipDeviceSynchronize() != hipSuccess) return 1; \
+    if (slots > gg::kProfSlots) slots = gg::kProfSlots; \
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(gg::gg_prof), sizeof(unsigned long long) * 10 * (size_t)slots) == hipSuccess ? 0 : 2; }
 #elif defined(GG_AB_MARK)
 // A/B builds only: phase markers in the assembly listing (tools/isa_mix.py --phases)
 #define GG_PROF_DECL do {} while (0)
@@ -859,24 +864,35 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_next_states2(const uint8_t
 // PERPLY = instantiation for 1-2 plies per launch: the board I/O dominates there and the kernel runs best spill-free
 // at 3 waves per SIMD; the fused instantiation keeps its hot ply loop spill-free at 4 waves per SIMD.
 // PACKED: `states` holds packed boards (uint32 [B][3 N + 1]).
-template <int R, bool PERPLY, bool PACKED = false, bool FULLN = false>
-__global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_rollout2(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
-                                                    int32_t *__restrict__ last_actions,
-                                                    int64_t *__restrict__ steps_done, int64_t B, int N, uint32_t inv,
-                                                    int plies, int auto_reset, AgeSplit age) {
+// WPB: waves per workgroup (each wave an independent pair of boards with its own LDS).  A launch of a few thousand single-wave
+// workgroups is DISPATCHED over ~0.26 ns per workgroup (tools/exp/oneply_ramp.py: 2 048 workgroups enter the machine over
+// 0.54 us, 512 over 0.22), which is a tenth of a one-ply launch of config 2's size: small launches go out as WPB-wave workgroups.
+template <int R, bool PERPLY, bool PACKED, bool FULLN, int WPB>
+__device__ __forceinline__ void rollout2_body(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+                                              int32_t *__restrict__ last_actions,
+                                              int64_t *__restrict__ steps_done, int64_t B, int N, uint32_t inv,
+                                              int plies, int auto_reset, const AgeSplit &age) {
   if (FULLN) { N = R; inv = (65536u + R - 1u) / R; }   // N == R: compile-time constants (see k_env_step2)
-  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
-  __shared__ uint32_t fair_mates[16];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_[WPB][Lds2<R>::kTotal];
+  __shared__ uint32_t fair_mates_[WPB][16];
+  __shared__ uint2 lut_[WPB][256];
+  const int wv = WPB > 1 ? (int)(threadIdx.x >> 6) : 0;
+  uint32_t *lds = lds_[wv], *fair_mates = fair_mates_[wv];
+  uint2 *lut = lut_[wv];
   GG_PROF_DECL;
-  const Half hf = make_half(threadIdx.x, N, inv);
-  __shared__ uint2 lut[256];
+  const Half hf = make_half((int)(threadIdx.x & (kWave - 1)), N, inv);
   // the prologue's global reads - class table, the first pair's flags, planes and generators - are in flight TOGETHER
   // (cw_table_issue): one round trip instead of eight (9x9 x 4 096 games, one ply per launch as a hipGraph node: 7.15 -> 6.07 us)
   bool tables = false;
   const int S = 6 * hf.P;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
-  const PairSpan span = pair_span(npairs, age);
+  PairSpan span = pair_span(npairs, age);
+  if (WPB > 1) {   // (launched without an age split: wave w of workgroup g is "workgroup" g WPB + w of the single-wave form)
+    span.first = (int64_t)blockIdx.x * WPB + wv;
+    span.stride = (int64_t)gridDim.x * WPB;
+    span.end = npairs;
+  }
   for (int64_t p = span.first; p < span.end; p += span.stride) {
     const int64_t bA = 2 * p, bB = (2 * p + 1 < B) ? 2 * p + 1 : B - 1;
     const bool on = 2 * p + hf.h < B;
@@ -909,7 +925,7 @@ __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_
     int last = -1, played = 0;
     uint32_t atari = 0;   // next mover's opponents in atari, known from the previous ply of this launch
     bool have_atari = false;
-    FairShare fair(fair_mates);   // a fused launch: the waves of a SIMD advance together (gg_common.h)
+    FairShare fair(fair_mates, !PERPLY);   // a fused launch: the waves of a SIMD advance together (gg_common.h)
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
       if (!PERPLY && (t & 3) == 0 && plies >= 8) {   // (the band of k_rollout4: never wider than the plies that are left)
@@ -967,6 +983,21 @@ __global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_
     GG_PROF(7);   // write-back
   }
   GG_PROF_FLUSH;
+}
+template <int R, bool PERPLY, bool PACKED = false, bool FULLN = false>
+__global__ __launch_bounds__(kWave, (PERPLY && !PACKED) ? GG_LB_PLY : 4) void k_rollout2(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+                                                    int32_t *__restrict__ last_actions,
+                                                    int64_t *__restrict__ steps_done, int64_t B, int N, uint32_t inv,
+                                                    int plies, int auto_reset, AgeSplit age) {
+  rollout2_body<R, PERPLY, PACKED, FULLN, 1>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, age);
+}
+// one / two plies per launch on byte planes, four waves per workgroup (WPB above)
+template <int R, bool FULLN>
+__global__ __launch_bounds__(4 * kWave, GG_LB_PLY) void k_rollout2_w4(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+                                                    int32_t *__restrict__ last_actions,
+                                                    int64_t *__restrict__ steps_done, int64_t B, int N, uint32_t inv,
+                                                    int plies, int auto_reset, AgeSplit age) {
+  rollout2_body<R, true, false, FULLN, 4>(states, rng, last_actions, steps_done, B, N, inv, plies, auto_reset, age);
 }
 
 // Replay of given move sequences with the boards resident on-chip: state = next_state(state, moves[b][t]) for

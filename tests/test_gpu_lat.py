@@ -204,3 +204,31 @@ def test_env_step_same_result_on_both_sides_of_the_19x19_take_over():
     for per_cu, with_obs in ((128, True), (64, False)):
         for B in (cus * per_cu, cus * per_cu + 1):
             _env_step_vs_oracle(19, B, with_obs, False)
+
+
+@pytest.mark.parametrize('N', [9, 13, 19, 6])
+def test_four_wave_workgroups_ragged_and_at_their_take_over(N):
+    """Short launches go out as FOUR-wave workgroups (k_rollout2_w4 on byte planes up to 16 / 8 pairs per CU; k_rollout_lat_w4 /
+    k_env_step_lat_w4 on tracked boards up to 13x13 and 16 groups of four per CU, <= 4 plies): batches that leave the last
+    workgroup with one, two or three waves (and the last wave ragged), and the batch sizes on both sides of each take-over -
+    rollouts, tracked rollouts and env steps against the oracle."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    cus = _cus()
+    edge_bytes = 2 * cus * (16 if N <= 9 else 8)          # games = 2 x pairs
+    edge_tracked = 4 * cus * 16
+    for B in (1, 2, 3, 7, 8, 9, 13, 17, 31, 33, edge_bytes - 1, edge_bytes, edge_bytes + 1, edge_bytes + 2):
+        _run(N, B, (1, 2, 1), True, seed=B + 3)
+    for B in (1, 4, 5, 9, 15, 16, 17, 29, edge_tracked - 1, edge_tracked, edge_tracked + 1):
+        st = gogame.batch_init_state(B, N, device='cuda')
+        tr = gogame.batch_track(st)
+        rng = gogame.rng_seed(B, B + 11, 0, 'cuda')
+        want, want_rng = st.cpu().numpy(), rng.cpu().numpy().view(np.uint64).copy()
+        for F in (1, 4, 5, 2, 33, 1):
+            gogame.batch_rollout_tracked(tr, rng, F, True)
+            want, want_rng, _ = c_oracle.batch_rollout_mt(want, want_rng, F, True)
+            assert np.array_equal(gogame.batch_untrack(tr).cpu().numpy(), want), (N, B, F)
+            assert np.array_equal(rng.cpu().numpy().view(np.uint64), want_rng)
+    for B in (1, 5, 13, 17, edge_tracked, edge_tracked + 1):
+        for with_obs, given in ((True, False), (False, True)):
+            _env_step_vs_oracle(N, B, with_obs, given)

@@ -141,7 +141,8 @@ def test_bench_argument_plumbing():
     assert bench.algo_bytes_per_step(19) == 4336 and bench.fused_bytes_per_game(19) == 4348
     assert bench.rollout_kernel_name(19, 65536, 256, 256) == 'k_rollout4<19, 0, false, true, false, false>'
     assert bench.rollout_kernel_name(9, 4096, 256, 256) == 'k_rollout_lat<9, true, true, 0>'      # config 2 (use_lat: <= 64 games per CU, >= 3 plies)
-    assert bench.rollout_kernel_name(9, 4096, 2, 256) == 'k_rollout2<9, true, false, true>'
+    assert bench.rollout_kernel_name(9, 4096, 2, 256) == 'k_rollout2_w4<9, true>' and bench.rollout_kernel_name(9, 8194, 1, 256) == 'k_rollout2<9, true, false, true>'
+    assert bench.rollout_kernel_name(19, 4096, 1, 256) == 'k_rollout2_w4<19, true>' and bench.rollout_kernel_name(19, 4098, 1, 256) == 'k_rollout2<19, true, false, true>'
     assert bench.rollout_kernel_name(9, 16385, 256, 256) == 'k_rollout4<9, 0, false, true, false, false>'
     assert bench.rollout_kernel_name(13, 8192, 4, 256) == 'k_rollout_lat<13, true, true, 0>'
     assert bench.rollout_kernel_name(19, 2048, 64, 256) == 'k_rollout_lat<19, true, true, 0>' and bench.rollout_kernel_name(19, 2049, 64, 256).startswith('k_rollout2<19')
