@@ -432,6 +432,20 @@ int32_t gg_batch_next_states(const uint8_t *in, const int32_t *actions, uint8_t 
     }
   }
   const int64_t npairs = (B + 1) / 2;
+  // up to two waves per SIMD (9x9: four) there is no pipeline to fill: one pair per wave, every read of the pair in flight at
+  // once, four-wave workgroups (k_next_states2s; hipGraph node, 9x9 / 13x13 / 19x19 x 4 096 games 6.53 -> 5.88 / 7.82 -> 6.96 / 9.18 -> 8.66 us:
+  // profiles/r05p_perply_nodes.txt)
+  bool straight = npairs <= (int64_t)cus * (N <= 9 ? 16 : 8);
+#ifdef GG_AB
+  if (const char *e = getenv("GG_AB_NS_STRAIGHT")) straight = atoi(e) != 0 && npairs <= (int64_t)cus * 24;
+#endif
+  if (straight) {
+    const unsigned grid4 = (unsigned)((npairs + 3) / 4);
+    GG_DISPATCH(N, (k_next_states2s<9, 4><<<grid4, 4 * kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+                (k_next_states2s<13, 4><<<grid4, 4 * kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)),
+                (k_next_states2s<19, 4><<<grid4, 4 * kWave, 0, s>>>(in, actions, out, status, B, N, inv, canonical)));
+    return (int32_t)hipGetLastError();
+  }
   int grid = grid_resident(cus, npairs, GG_LB_PLY);
   // from six pairs per resident wave on, the three waves of a SIMD share its pairs unevenly (k_next_states2): fractions
   // of a SIMD's pairs taken by its oldest / by its two oldest waves, 16.16 fixed point
@@ -640,6 +654,24 @@ int32_t gg_batch_env_step(uint8_t *states, const int32_t *actions, uint64_t *rng
     }
   }
   const int64_t npairs = (B + 1) / 2;
+  bool w4 = npairs <= (int64_t)cus * (N <= 9 ? 16 : 8);   // small launches: four-wave workgroups (gg_batch_rollout, k_rollout2_w4)
+#ifdef GG_AB
+  if (const char *e = getenv("GG_AB_WPB")) w4 = atoi(e) == 4 && npairs < (int64_t)cus * 24;
+#endif
+  if (w4) {
+    const AgeSplit none = {0, {0, 0, 0}};
+    const unsigned grid4 = (unsigned)((npairs + 3) / 4);
+    if (reward_method == GG_REWARD_HEURISTIC) {
+#define GG_K(R, F) k_env_step2_w4<R, true, F><<<grid4, 4 * kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset, none)
+      GG_DISPATCH_N(N);
+#undef GG_K
+    } else {
+#define GG_K(R, F) k_env_step2_w4<R, false, F><<<grid4, 4 * kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset, none)
+      GG_DISPATCH_N(N);
+#undef GG_K
+    }
+    return (int32_t)hipGetLastError();
+  }
   if (reward_method == GG_REWARD_HEURISTIC) {
 #define GG_K(R, F) launch_pairs(k_env_step2<R, true, false, F>, cus, npairs, true, s, states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset)
     GG_DISPATCH_N(N);

@@ -861,6 +861,70 @@ __global__ __launch_bounds__(kWave, GG_LB_PLY) void k_next_states2(const uint8_t
 #endif
 }
 
+// gogame.batch_next_states on a batch that leaves the machine under-filled (<= two waves per SIMD): one pair per wave, no
+// pipeline to fill - so every read of the pair (class table, flag bytes, planes 0 - 3, the action) is in flight together
+// (cw_table_issue), the legality of the move is read off the staged invalid-move plane instead of a dependent INVD[action]
+// load, and the launch goes out as WPB-wave workgroups (rollout2_body).  Same results as k_next_states2: next_state's
+// semantics per game, an illegal / out-of-range move passes its row through with status 1.
+template <int R, int WPB>
+__global__ __launch_bounds__(kWave * WPB, GG_LB_PLY) void k_next_states2s(const uint8_t *__restrict__ in,
+                                                        const int32_t *__restrict__ actions,
+                                                        uint8_t *__restrict__ out, int32_t *__restrict__ status,
+                                                        int64_t B, int N, uint32_t inv, int canonical) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_[WPB][Lds2<R>::kTotal];
+  __shared__ uint2 lut_[WPB][256];
+  const int wv = WPB > 1 ? (int)(threadIdx.x >> 6) : 0;
+  uint32_t *lds = lds_[wv];
+  uint2 *lut = lut_[wv];
+  const Half hf = make_half((int)(threadIdx.x & (kWave - 1)), N, inv);
+  const int S = 6 * hf.P;
+  uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
+  bool tables = false;
+  const int64_t npairs = (B + 1) >> 1;
+  for (int64_t p = (int64_t)blockIdx.x * WPB + wv; p < npairs; p += (int64_t)gridDim.x * WPB) {
+    const bool on = 2 * p + hf.h < B;
+    const int64_t b = on ? 2 * p + hf.h : B - 1;
+    const uint8_t *gi = in + b * (int64_t)S;
+    uint8_t *go = out + b * (int64_t)S;
+    PairRegs<R> pr;
+    pair_issue<R>(pr, gi, 4 * hf.P, hf, tables);
+    const int a = actions[b];
+    uint32_t flags;   // bit 0 turn, (bit 1: not used here), bit 2 previous move was a pass, bit 3 game over
+    const uint32_t mi = pair_commit<R>(pr, gi, 4 * hf.P, io, hf, lds, lut, tables, flags);
+    uint32_t black = plane_to_row<R>(io + mi, N, hf.hl);
+    uint32_t white = plane_to_row<R>(io + mi + hf.P, N, hf.hl);
+    const uint32_t invd = plane_to_row<R>(io + mi + 3 * hf.P, N, hf.hl);
+    const bool in_range = a >= 0 && a <= hf.P;
+    const bool is_pass = a == hf.P;
+    int ar = 0, ac = 0;
+    if (in_range && !is_pass) split_action(a, N, hf.inv, ar, ac);
+    // the lane that holds row ar of the half's board tests the mask bit (gym_go/gogame.py:59), the half shares the verdict
+    const bool bad = half_of(__ballot(in_range && !is_pass && hf.hl == ar && ((invd >> ac) & 1u)), hf.h) != 0;
+    const bool illegal = !in_range || bad;
+    const int pl = flags & 1u;
+    uint32_t invalid = 0;
+    if (__ballot(!illegal)) {
+      uint32_t mine = pl ? white : black, opp = pl ? black : white;
+      uint32_t atari_unused;   // (an illegal half runs the wave-wide analysis on a harmless pass, its result is discarded)
+      invalid = step_core2<R, false>(mine, opp, illegal ? hf.P : a, hf, lds, 0u, false, atari_unused);
+      black = pl ? opp : mine;
+      white = pl ? mine : opp;
+    }
+    const uint32_t passed = is_pass ? 1 : 0;
+    const uint32_t done = ((flags & 8u) || (is_pass && (flags & 4u))) ? 1 : 0;
+    int nturn = 1 - pl;
+    if (canonical && nturn == 1) {
+      const uint32_t t = black; black = white; white = t;
+      nturn = 0;
+    }
+    WAVE_SYNC();
+    if (__ballot(!illegal))
+      emit_store_h<R>(go, black, white, invalid, (uint32_t)nturn, passed, done, hf, reinterpret_cast<uint32_t *>(io), lut, on && !illegal);
+    if (illegal) copy_row_h(gi, go, S, hf.hl, on);
+    if (status && on && hf.hl == 0) status[b] = illegal ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
+  }
+}
+
 // PERPLY = instantiation for 1-2 plies per launch: the board I/O dominates there and the kernel runs best spill-free
 // at 3 waves per SIMD; the fused instantiation keeps its hot ply loop spill-free at 4 waves per SIMD.
 // PACKED: `states` holds packed boards (uint32 [B][3 N + 1]).
@@ -1092,24 +1156,32 @@ __global__ __launch_bounds__(kWave, 4) void k_play_moves2(uint8_t *__restrict__ 
 // position ride in the idle flood lanes of the liberty analysis.  !HEUR (reward_method real): the areas only matter
 // when a game ends, so the step runs the plain analysis and a wave whose pair just finished a game (two passes: no
 // stone moved, the liberty classes are not needed again) runs one more analysis for the territory.
-template <int R, bool HEUR, bool PACKED = false, bool FULLN = false>
-__global__ __launch_bounds__(kWave, PACKED ? 4 : GG_LB_PLY) void k_env_step2(uint8_t *__restrict__ states, const int32_t *__restrict__ actions,
-                                                        uint64_t *__restrict__ rng, float *__restrict__ rewards,
-                                                        uint8_t *__restrict__ dones, int32_t *__restrict__ status,
-                                                        int32_t *__restrict__ taken, int64_t B, int N, uint32_t inv,
-                                                        float komi, int auto_reset, AgeSplit age) {
+template <int R, bool HEUR, bool PACKED, bool FULLN, int WPB>
+__device__ __forceinline__ void env_step2_body(uint8_t *__restrict__ states, const int32_t *__restrict__ actions,
+                                               uint64_t *__restrict__ rng, float *__restrict__ rewards,
+                                               uint8_t *__restrict__ dones, int32_t *__restrict__ status,
+                                               int32_t *__restrict__ taken, int64_t B, int N, uint32_t inv,
+                                               float komi, int auto_reset, const AgeSplit &age) {
   // FULLN: the board fills the row capacity (N == R) - N, N * N and the reciprocal become compile-time constants
   // (GoVecEnv.step 19x19: 7.9e8 against 7.6e8 steps/s; the same on k_next_states2 costs registers: 7.0e8 against 1.0e9)
   if (FULLN) { N = R; inv = (65536u + R - 1u) / R; }
-  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds2<R>::kTotal];
-  const Half hf = make_half(threadIdx.x, N, inv, HEUR);
-  const Half hfa = make_half(threadIdx.x, N, inv, true);   // lanes 22 / 23 of each half flood the empty points
-  __shared__ uint2 lut[256];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_[WPB][Lds2<R>::kTotal];
+  __shared__ uint2 lut_[WPB][256];
+  const int wv = WPB > 1 ? (int)(threadIdx.x >> 6) : 0;   // (WPB waves per workgroup: rollout2_body)
+  uint32_t *lds = lds_[wv];
+  uint2 *lut = lut_[wv];
+  const Half hf = make_half((int)(threadIdx.x & (kWave - 1)), N, inv, HEUR);
+  const Half hfa = make_half((int)(threadIdx.x & (kWave - 1)), N, inv, true);   // lanes 22 / 23 of each half flood the empty points
   bool tables = false;
   const int S = 6 * hf.P;
   uint8_t *io = reinterpret_cast<uint8_t *>(lds) + hf.h * Cfg<R>::kIoBytes;
   const int64_t npairs = (B + 1) >> 1;
-  const PairSpan span = pair_span(npairs, age);
+  PairSpan span = pair_span(npairs, age);
+  if (WPB > 1) {
+    span.first = (int64_t)blockIdx.x * WPB + wv;
+    span.stride = (int64_t)gridDim.x * WPB;
+    span.end = npairs;
+  }
   for (int64_t p = span.first; p < span.end; p += span.stride) {
     const int64_t bA = 2 * p, bB = (2 * p + 1 < B) ? 2 * p + 1 : B - 1;
     const bool on = 2 * p + hf.h < B;
@@ -1207,6 +1279,23 @@ __global__ __launch_bounds__(kWave, PACKED ? 4 : GG_LB_PLY) void k_env_step2(uin
       if (taken) taken[b] = a;
     }
   }
+}
+template <int R, bool HEUR, bool PACKED = false, bool FULLN = false>
+__global__ __launch_bounds__(kWave, PACKED ? 4 : GG_LB_PLY) void k_env_step2(uint8_t *__restrict__ states, const int32_t *__restrict__ actions,
+                                                        uint64_t *__restrict__ rng, float *__restrict__ rewards,
+                                                        uint8_t *__restrict__ dones, int32_t *__restrict__ status,
+                                                        int32_t *__restrict__ taken, int64_t B, int N, uint32_t inv,
+                                                        float komi, int auto_reset, AgeSplit age) {
+  env_step2_body<R, HEUR, PACKED, FULLN, 1>(states, actions, rng, rewards, dones, status, taken, B, N, inv, komi, auto_reset, age);
+}
+// byte planes, small batches: four waves per workgroup (rollout2_body)
+template <int R, bool HEUR, bool FULLN>
+__global__ __launch_bounds__(4 * kWave, GG_LB_PLY) void k_env_step2_w4(uint8_t *__restrict__ states, const int32_t *__restrict__ actions,
+                                                        uint64_t *__restrict__ rng, float *__restrict__ rewards,
+                                                        uint8_t *__restrict__ dones, int32_t *__restrict__ status,
+                                                        int32_t *__restrict__ taken, int64_t B, int N, uint32_t inv,
+                                                        float komi, int auto_reset, AgeSplit age) {
+  env_step2_body<R, HEUR, false, FULLN, 4>(states, actions, rng, rewards, dones, status, taken, B, N, inv, komi, auto_reset, age);
 }
 
 

@@ -244,6 +244,41 @@ def test_illegal_moves_status_and_passthrough(gg, oracle):
         gg.batch_next_states(st, dev(acts))
 
 
+@pytest.mark.parametrize('size', [9, 13, 19, 7])
+def test_next_states_and_env_step_on_both_sides_of_the_small_batch_take_over(gg, oracle, size):
+    """Up to 16 / 8 pairs per CU (9x9 / larger) gg_batch_next_states runs the straight one-pair-per-wave kernel and
+    gg_batch_env_step goes out as four-wave workgroups; above, the pipelined / single-wave forms: mid-game boards with a mix
+    of legal points, occupied points, passes and out-of-range moves (canonical on and off) at the batch sizes around the
+    take-over and at ragged workgroups - states and status against the oracle; one env step against the oracle's ply."""
+    from gymgo_amd import _lib
+    cus = int(_lib.lib().gg_device_cus())
+    edge = 2 * cus * (16 if size <= 9 else 8)
+    for B in (1, 2, 3, 5, 7, 8, 9, 15, 17, edge - 1, edge, edge + 1, edge + 2, edge + 9):
+        rng = gg.rng_seed(B, 17 + B)
+        st = torch.zeros((B, 6, size, size), dtype=torch.uint8, device='cuda')
+        gg.batch_rollout(st, rng, 3 * size, False)
+        s_np = st.cpu().numpy()
+        acts = gg.batch_sample_actions(st, rng).cpu().numpy().astype(np.int32)
+        r = np.random.RandomState(B)
+        for b in range(0, B, 3):      # every third game: an occupied / invalid point where there is one
+            occ = np.flatnonzero(s_np[b, 3].ravel() == 1)
+            if len(occ):
+                acts[b] = occ[r.randint(len(occ))]
+        acts[::7] = size * size       # passes
+        if B > 4:
+            acts[1], acts[4] = -1, size * size + 1
+        for canonical in (False, True):
+            out, status = gg.batch_next_states(st, dev(acts), canonical=canonical, check=False)
+            want, wst = oracle.batch_next_states_mt(s_np, acts, canonical)
+            assert np.array_equal(status.cpu().numpy(), wst), (size, B, canonical)
+            assert np.array_equal(out.cpu().numpy(), want), (size, B, canonical)
+        es, er = st.clone(), rng.clone()
+        want2, rng2, last2 = oracle.batch_rollout_mt(s_np, rng.cpu().numpy().view(np.uint64).copy(), 1, True)
+        rewards, dones, status, taken = gg.batch_env_step(es, None, er, 0.5, 'real', True)
+        assert np.array_equal(es.cpu().numpy(), want2) and np.array_equal(taken.cpu().numpy(), last2), (size, B)
+        assert np.array_equal(er.cpu().numpy().view(np.uint64), rng2) and int(status.abs().sum()) == 0
+
+
 def test_unaligned_views(gg, oracle):
     """Boards that start at odd byte offsets / non-16-byte-aligned bases (head and tail byte paths)."""
     size, B = 19, 33
