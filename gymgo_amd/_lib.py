@@ -78,7 +78,7 @@ def build(force=False):
     srcs.append(os.path.join(os.path.dirname(_HERE), 'include', 'gymgo_amd.h'))
     stale = not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
-        subprocess.check_call(['make', '-C', os.path.join(_HERE, 'csrc'), '-s', '-B'])
+        subprocess.check_call(['make', '-C', os.path.join(_HERE, 'csrc'), '-s', '-B', '-j3'])
     return LIB_PATH
 
 
