@@ -14,7 +14,7 @@ Three resident layouts (`layout=`):
 """
 import torch
 
-from gymgo_amd import gogame, govars
+from gymgo_amd import _lib, gogame, govars
 
 
 def shard(total_games, rank, world_size):
@@ -50,6 +50,7 @@ class GoVecEnv:
         self.last_actions = torch.full((batch_size,), -1, dtype=torch.int32, device=self.device)
         # step() outputs live in fixed buffers (rewards, dones, status; the action taken goes to last_actions): no
         # allocation per step, and the step can be captured in a hipGraph.  They are overwritten by the next step.
+        self._prep = None   # step(): the validated pointers of the tracked step (see there)
         self._step_out = (torch.empty(batch_size, dtype=torch.float32, device=self.device),
                           torch.empty(batch_size, dtype=torch.uint8, device=self.device),
                           torch.empty(batch_size, dtype=torch.int32, device=self.device), self.last_actions)
@@ -132,6 +133,22 @@ class GoVecEnv:
                 torch.where(over, rng_before, self.rng, out=self.rng)
                 actions.masked_fill_(over, -1)
             probs = None
+        if self.layout == 'tracked' and probs is None:
+            # the hot call of a self-play loop: the env's own buffers are validated ONCE (gogame.batch_env_step_tracked's
+            # checks, through _lib.dev_ptr), their pointers kept; a step is then the launch itself (8.6 -> 5.4 us of host time
+            # per call).  Re-validated whenever one of the buffers is re-bound; they must not be resized in place.
+            key = (id(self.tracked), id(self.rng), id(self._obs), id(self.steps_done), self.komi, self.reward_method, self.auto_reset)
+            prep = self._prep
+            if prep is None or prep[0] != key:
+                prep = self._prep = (key, self._prepare_tracked_step())
+            fn, head, tail = prep[1]
+            a = 0 if actions is None else _lib.dev_ptr(actions, torch.int32, 'actions')
+            _lib.check(fn(head, a, *tail, _lib.stream_ptr(self.device)), 'gg_batch_env_step_tracked')
+            rewards, dones, status, taken = self._step_out
+            self._obs_fresh = True
+            if check and bool((status != 0).any()):
+                raise AssertionError('illegal move in batch')
+            return self._obs, rewards, dones, status
         if self.layout == 'tracked':
             rewards, dones, status, taken = gogame.batch_env_step_tracked(
                 self.tracked, actions, self.rng, self.komi, self.reward_method, self.auto_reset, out=self._step_out,
@@ -150,6 +167,23 @@ class GoVecEnv:
             raise AssertionError('illegal move in batch')
         self.steps_done += (status == 0)
         return obs, rewards, dones, status
+
+    def _prepare_tracked_step(self):
+        """(entry point, first argument, the arguments after `actions` up to the stream) of gg_batch_env_step_tracked on this
+        env's buffers, every tensor checked as gogame.batch_env_step_tracked checks it."""
+        rewards, dones, status, taken = self._step_out
+        B, N = self.batch_size, self.size
+        if gogame._tracked_size(self.tracked) != N or self.tracked.shape[0] != B or tuple(self._obs.shape) != (B, 6, N, N):
+            raise ValueError('the env\'s tracked boards / observation buffer do not have its batch and board size')
+        for t, n in ((self.rng, B), (rewards, B), (dones, B), (status, B), (taken, B), (self.steps_done, B)):
+            if t.numel() != n:
+                raise ValueError('a step buffer of the env does not have one entry per game')
+        tail = (_lib.dev_ptr(self.rng, torch.int64, 'rng'), _lib.dev_ptr(rewards, torch.float32, 'rewards'),
+                _lib.dev_ptr(dones, torch.uint8, 'dones'), _lib.dev_ptr(status, torch.int32, 'status'),
+                _lib.dev_ptr(taken, torch.int32, 'taken'), _lib.dev_ptr(self._obs, torch.uint8, 'states_out'),
+                _lib.dev_ptr(self.steps_done, torch.int64, 'steps_done'), B, N, float(self.komi),
+                gogame.REWARD_METHODS[self.reward_method], int(bool(self.auto_reset)))
+        return _lib.lib().gg_batch_env_step_tracked, _lib.dev_ptr(self.tracked, torch.int32, 'tracked'), tail
 
     def step_unfused(self, actions, check=False):
         """The same step as separate launches (reset, next_states, areas + torch reward arithmetic); float64 rewards."""

@@ -364,3 +364,35 @@ def test_vecenv_parts_step_captured_in_hipgraph():
     gogame.batch_rollout(want, wr, K, True)
     assert torch.equal(env.gather('states'), want) and torch.equal(env.gather('rng'), wr)
     assert int(torch.cat([o[3] for o in outs]).sum()) == 0
+
+
+def test_vecenv_step_follows_rebound_buffers_and_refuses_bad_ones():
+    """GoVecEnv.step() (tracked layout) keeps the validated pointers of the env's buffers between steps: re-binding a buffer
+    (generator states, tracked boards, step counters, komi / reward method) is picked up by the next step - two envs, one of
+    them re-bound to clones and changed settings between steps, walk the same games - and a buffer of the wrong type is
+    refused exactly as gogame.batch_env_step_tracked refuses it."""
+    from gymgo_amd import _lib, gogame
+    from gymgo_amd.envs import GoVecEnv
+    a = GoVecEnv(777, 9, komi=0.5, reward_method='real', seed=5)
+    b = GoVecEnv(777, 9, komi=0.5, reward_method='real', seed=5)
+    for i in range(60):
+        if i % 7 == 3:
+            b.rng = b.rng.clone()
+            b.tracked = b.tracked.clone()
+            b.steps_done = b.steps_done.clone()
+        if i == 30:
+            a.komi = b.komi = 6.5
+            a.reward_method = b.reward_method = 'heuristic'
+        acts = None if i % 3 else gogame.batch_sample_actions(a.states, gogame.rng_seed(777, 1000 + i))   # (a throw-away generator)
+        oa, ra, da, sa = a.step(acts)
+        ob, rb, db, sb = b.step(None if acts is None else acts.clone())
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(sa, sb), i
+        assert torch.equal(a.rng, b.rng) and torch.equal(a.tracked, b.tracked) and torch.equal(a.steps_done, b.steps_done)
+    assert int(a.steps_done.min()) > 0
+    b.rng = b.rng.to(torch.float64)
+    with pytest.raises(_lib.GymGoNativeError):
+        b.step()
+    b.rng = a.rng.clone()
+    b.tracked = b.tracked[:-1]
+    with pytest.raises(ValueError):
+        b.step()
