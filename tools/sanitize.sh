@@ -28,7 +28,9 @@ case $KIND in
   undefined) FLAGS="-fsanitize=undefined -fno-sanitize-recover=undefined"; RT=$CLANG_LIB/libclang_rt.ubsan_standalone-x86_64.so
            export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 ;;
   thread)  FLAGS="-fsanitize=thread"; RT=$CLANG_LIB/libclang_rt.tsan-x86_64.so
-           export TSAN_OPTIONS=halt_on_error=1:report_signal_unsafe=0 ;;
+           # (the suppressions name the uninstrumented GPU runtime: test_host_abi.py's GYMGO_AMD_CUS test initialises HIP in a
+           # child process when a GPU is visible, and libhsa-runtime64's own start-up threads race among themselves)
+           export TSAN_OPTIONS=suppressions=$R/tools/sanitize/tsan.supp:halt_on_error=1:report_signal_unsafe=0 ;;
   *) echo "usage: $0 [address|undefined|thread]"; exit 2 ;;
 esac
 [ -f "$RT" ] || { echo "sanitizer runtime $RT not found"; exit 2; }
