@@ -553,8 +553,7 @@ int32_t gg_batch_children_offsets(const uint8_t *states, int32_t *offsets, int32
   GG_ENTER(states);
   if (!offsets) return GG_E_NULLPTR;
   k_children_counts<<<grid_for(cus, (B + 3) / 4), 4 * kWave, 0, s>>>(states, offsets, B, N);
-  if (order) k_children_order<<<1, 1024, 0, s>>>(offsets, order, B, N * N + 1);   // (on the counts, before they become offsets)
-  k_scan_counts<<<1, 1024, 0, s>>>(offsets, B);
+  k_children_order_scan<<<1, 1024, 0, s>>>(offsets, order, B, N * N + 1);   // the launch order from the counts, then counts -> offsets
   return (int32_t)hipGetLastError();
 }
 

@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(4 * kWave, GG_LB_PLY) void k_env_step2_w4(uint8_t *
 // COMPACT (byte planes): gogame.children(..., padded=False) - gym_go/gogame.py:179, the un-padded result the reference
 // computes first - for a whole batch: only the slots of the actions valid_moves() keeps (plane 3 clear, + the pass; every
 // action once the game has ended, :155-156), in ascending action order, parent b's first child at offsets[b] (exclusive
-// scan of the per-parent counts, k_children_counts + k_scan_counts below).  The same analysis and the same streaming
+// scan of the per-parent counts, k_children_counts + k_children_order_scan below).  The same analysis and the same streaming
 // emitter: a child's place in the stream is the RANK of its action among the kept ones instead of the action itself, so the
 // zero slots of the illegal actions - two thirds of the padded bytes on mid-game 19x19 parents - are never written.
 template <int R, bool PACKED = false, bool COMPACT = false>
@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(kWave, GG_LB_CH3) void k_children3(const uint8_t *_
   for (int64_t w = blockIdx.x; w < B * chunks; w += gridDim.x) {
     // COMPACT: the work of a parent grows with the children it keeps (57 late in a game, 342 early): in index order a launch
     // of two rounds of waves ends with a few heavy parents on an emptying machine (56 % mean occupancy measured).  `order`
-    // (k_children_order: the parents by falling count) hands the heavy ones out first - longest processing time first.
+    // (k_children_order_scan: the parents by falling count) hands the heavy ones out first - longest processing time first.
     const int64_t wp = w / chunks;
     const int64_t b = (COMPACT && order) ? (int64_t)order[wp] : wp;
     const int ch = (int)(w - wp * chunks);
@@ -1732,31 +1732,60 @@ static __global__ void k_children_counts(const uint8_t *__restrict__ states, int
   }
 }
 
-// order[0 .. B) = the parents sorted by FALLING child count (a counting sort over the <= N*N+1 possible counts; ties in any
-// order: it only decides which work item a parent is, never what is written) - the launch order of the compact expansion.
-// ONE workgroup of 1 024 threads, run on the counts before k_scan_counts turns them into offsets.
-static __global__ __launch_bounds__(1024) void k_children_order(const int32_t *__restrict__ counts, int32_t *__restrict__ order,
-                                                                int64_t B, int A) {
+// The per-parent counts of a children batch -> what the compact expansion needs, in ONE workgroup of 1 024 threads and one
+// launch (round 5 ran two: a counting sort whose bin scan was one thread walking 363 LDS words, 11.9 us, and a tiled scan
+// with three barriers per 1 024 parents, 8.8 us - together 6 % of the compact call on 8 192 parents):
+//   * order[0 .. B) (optional) = the parents by FALLING child count (a counting sort over the <= N*N+1 possible counts; ties in
+//     any order: it only decides which work item a parent is, never what is written) - the launch order of the expansion;
+//   * v[0 .. B) = the counts' exclusive prefix sums in place, v[B] = the total: every thread owns a contiguous run of parents
+//     (serial inside the run, one scan of the 1 024 run totals across the workgroup).
+static __global__ __launch_bounds__(1024) void k_children_order_scan(int32_t *__restrict__ v, int32_t *__restrict__ order,
+                                                                     int64_t B, int A) {
   __shared__ int32_t bin[512];    // A <= 362
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 512; i += 1024) bin[i] = 0;
-  __syncthreads();
-  for (int64_t i = tid; i < B; i += 1024) atomicAdd(&bin[A - counts[i]], 1);    // bin 0 = the largest count
-  __syncthreads();
-  if (tid == 0) {
-    int32_t acc = 0;
-    for (int i = 0; i <= A; ++i) { const int32_t c = bin[i]; bin[i] = acc; acc += c; }
-  }
-  __syncthreads();
-  for (int64_t i = tid; i < B; i += 1024) order[atomicAdd(&bin[A - counts[i]], 1)] = (int32_t)i;
-}
-
-// counts[0 .. B) -> their exclusive prefix sums in place, counts[B] = the total: ONE workgroup of 1 024 threads walks the
-// array in tiles (the per-parent counts of a children batch: microseconds even for a million parents)
-static __global__ __launch_bounds__(1024) void k_scan_counts(int32_t *__restrict__ v, int64_t B) {
   __shared__ int32_t wsum[16];
-  __shared__ int32_t carry_s;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  if (order) {
+    if (tid < 512) bin[tid] = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < B; i += 1024) atomicAdd(&bin[A - v[i]], 1);    // bin 0 = the largest count
+    __syncthreads();
+    {   // exclusive scan of the 512 bins: eight waves, then the wave totals
+      const int32_t c = tid < 512 ? bin[tid] : 0;
+      int32_t incl = c;
+      for (int d = 1; d < kWave; d <<= 1) {
+        const int32_t y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+      }
+      if (lane == kWave - 1) wsum[wv] = incl;
+      __syncthreads();
+      int32_t before = 0;
+      for (int k = 0; k < wv; ++k) before += wsum[k];
+      if (tid < 512) bin[tid] = before + incl - c;
+      __syncthreads();
+    }
+    for (int64_t i = tid; i < B; i += 1024) order[atomicAdd(&bin[A - v[i]], 1)] = (int32_t)i;
+    __syncthreads();   // (the counts are read above and overwritten below)
+  }
+  const int64_t run = (B + 1023) / 1024;
+  if (run <= 16) {   // a children batch of up to 16 384 parents: one pass, two barriers
+    const int64_t lo = (int64_t)tid * run, hi = lo + run < B ? lo + run : B;
+    int32_t sum = 0;
+    for (int64_t i = lo; i < hi; ++i) sum += v[i];
+    int32_t incl = sum;
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int32_t y = __shfl_up(incl, d);
+      if (lane >= d) incl += y;
+    }
+    if (lane == kWave - 1) wsum[wv] = incl;
+    __syncthreads();
+    int32_t acc = incl - sum;
+    for (int k = 0; k < wv; ++k) acc += wsum[k];
+    for (int64_t i = lo; i < hi; ++i) { const int32_t x = v[i]; v[i] = acc; acc += x; }
+    if (tid == 1023) v[B] = acc;   // (the last thread's run ends at B - or is empty, then acc is the total before it)
+    return;
+  }
+  // larger batches: tiles of 1 024 consecutive parents (coalesced), the running total carried from tile to tile
+  __shared__ int32_t carry_s;
   if (tid == 0) carry_s = 0;
   __syncthreads();
   for (int64_t base = 0; base < B; base += 1024) {

@@ -36,7 +36,7 @@ def test_children_unpadded_golden(golden):
             assert offs.tolist() == [0, len(want)] and np.array_equal(kids.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize('N,B', [(19, 8192), (9, 3000), (13, 1001), (5, 257), (2, 5), (19, 1)])
+@pytest.mark.parametrize('N,B', [(19, 8192), (9, 3000), (13, 1001), (5, 257), (2, 5), (19, 1), (5, 16384), (5, 16385), (4, 40001)])   # (the last: the tiled scan of the offsets)
 def test_batch_children_compact_vs_padded_and_oracle(N, B):
     """Mid-game parents (a few finished games among them - every action is "valid" there, gogame.py:155-156): offsets ==
     the exclusive scan of the valid counts; the concatenation == the padded kernel's kept slots for EVERY parent; == the C
