@@ -501,6 +501,8 @@ def _mask_pc_relative(code):
             j = i + 1
             while j < min(n - 1, i + 8):
                 d = w[j]
+                if (d & 0xFF80FF00) == 0xBE801C00:                   # the next s_getpc_b64 (sites can be 7 words apart): its own turn
+                    break
                 if (d & 0xFF800000) in (0x80000000, 0x82000000) and (((d >> 8) & 0xFF) == 0xFF or (d & 0xFF) == 0xFF):
                     w[j + 1] = 0                                     # s_add_u32 / s_addc_u32 with a 32-bit literal
                     j += 2

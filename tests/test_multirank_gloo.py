@@ -168,3 +168,24 @@ def test_speed_calibration_file():
     assert bench.speed_calibration() == rec
     assert bench._two_digits(40871.3) == 41000.0 and bench._two_digits(0) == 0
     assert not hasattr(bench, 'PORT_STEPS_PER_S_PER_CORE_BUILD_BOX')
+
+
+def test_kernel_hash_masks_every_pc_relative_literal():
+    """bench._mask_pc_relative: the `symbol - pc` literals after EVERY s_getpc_b64 are zeroed - also when two sites are only
+    seven words apart (the scan of one site must stop at the next) - and nothing else is."""
+    import struct
+    import bench
+
+    def site(lo):   # s_getpc_b64 s[0:1]; s_add_u32 s0, s0, <lit>; s_addc_u32 s1, s1, <lit>; a 2-word load
+        return [0xBE801C00, 0x8000FF00, lo, 0x8201FF01, 0xFFFFFFFF, 0xDC508000, 0x027F0000]
+
+    def code(offsets, tail):
+        w = [0x7E000280]
+        for o in offsets:
+            w += site(o)
+        return struct.pack('<%dI' % (len(w) + 1), *(w + [tail]))
+
+    a = bench._mask_pc_relative(code([0xFFFFDAD8, 0xFFFFDB00, 0xFFFFDB34, 0xFFFFDB68], 0xBF810000))
+    b = bench._mask_pc_relative(code([0xFFFFD418, 0xFFFFD440, 0xFFFFD474, 0xFFFFD4A8], 0xBF810000))
+    assert a == b and len(a) == 4 * (1 + 4 * 7 + 1)
+    assert bench._mask_pc_relative(code([1, 2, 3, 4], 0xBF810000)) != bench._mask_pc_relative(code([1, 2, 3, 4], 0xBF800000))   # an instruction differs
