@@ -140,7 +140,8 @@ class GoVecEnv:
             key = (id(self.tracked), id(self.rng), id(self._obs), id(self.steps_done), self.komi, self.reward_method, self.auto_reset)
             prep = self._prep
             if prep is None or prep[0] != key:
-                prep = self._prep = (key, self._prepare_tracked_step())
+                # (the record keeps the tensors themselves: an object that is alive cannot hand its id() to a new one)
+                prep = self._prep = (key, self._prepare_tracked_step(), (self.tracked, self.rng, self._obs, self.steps_done))
             fn, head, tail = prep[1]
             a = 0 if actions is None else _lib.dev_ptr(actions, torch.int32, 'actions')
             _lib.check(fn(head, a, *tail, _lib.stream_ptr(self.device)), 'gg_batch_env_step_tracked')
