@@ -306,30 +306,49 @@ def run_rank(rank, world, backend, opts, dist=None):
                 backend.rollout(g * opts['desync'] // 16, lo, hi)
     for _ in range(opts['burn_in_steps']):      # same launch shape as the timed ones (rocprof averages then agree)
         backend.rollout(F, count_steps=False)
-    # THE clock of the line: >= 0.3 s of back-to-back untimed launches of the timed shape BEFORE warm-up + timed region, sampled
-    # through amdsmi; the mean of the second half of the samples (the SMU's read-out is smoothed over tens of ms: it has
-    # settled by then) is the one figure `clocks.sclk_mhz` and `roofline.measured_clock` both carry.  The samples taken
-    # INSIDE the ~50 ms timed region lag (they still show the ramp) and are kept apart, labelled.
+    # THE clock of the line, and a machine that has stopped ramping.  Untimed back-to-back launches of the timed shape run
+    # BEFORE warm-up + timed region until the launch time has settled: windows of 8 launches (HIP events where the backend
+    # has them), at least `clock_settle_s` (0.35 s) of them, until three consecutive windows agree within 0.5 % - capped at
+    # `clock_settle_max_s` (3 s).  Why adaptive (round 6, tools/exp/timing_split.py, profiles/r06a_timing_split.txt): after an
+    # idle gap the first ~10 launches of this shape run 5 % slow on one lease (1.96 -> 1.86 ms) and the driver's round-5 box
+    # still ran 7 % slow after 0.35 s (1.98 ms timed, 1.85 ms for the same shape seconds later) - the clock ramp is per box.
+    # The shader clock is sampled through amdsmi DURING this phase only (mean of the second half of the samples =
+    # `clocks.sclk_mhz`); the timed region itself runs with no sampler thread (it cost 0.2 - 0.4 % there).
     settle, n_s = None, 0
-    if hasattr(backend, 'clock_sampler') and opts.get('clock_settle_s', 0.35) > 0:
-        with backend.clock_sampler() as probe:
-            t_s, n_s = time.perf_counter(), 0
-            while time.perf_counter() - t_s < opts.get('clock_settle_s', 0.35):
-                for _ in range(4):
-                    backend.rollout(F, count_steps=False)
-                backend.sync()
-                n_s += 4
-        settle = probe.record()
-        if probe.mhz:
+    if hasattr(backend, 'clock_sampler') and opts.get('clock_settle_s', 0.35) > 0:      # (the CPU test backend has neither)
+        probe = backend.clock_sampler()
+        if probe is not None:
+            probe.__enter__()
+        t_s, windows = time.perf_counter(), []
+        lo_s, hi_s = opts.get('clock_settle_s', 0.35), opts.get('clock_settle_max_s', 3.0)
+        while True:
+            w0, w1, w_ms = backend.timer()
+            w0()
+            for _ in range(8):
+                backend.rollout(F, count_steps=False)
+            w1()
+            backend.sync()
+            n_s += 8
+            windows.append(w_ms() / 8)
+            el = time.perf_counter() - t_s
+            last = windows[-3:]
+            flat = len(last) == 3 and max(last) - min(last) <= 0.005 * min(last)
+            if (el >= lo_s and flat) or el >= hi_s:
+                break
+        if probe is not None:
+            probe.__exit__(None, None, None)
+        settle = {'sclk_mhz': None, 'launches': n_s, 'seconds': round(time.perf_counter() - t_s, 3),
+                  'first_window_launch_ms': round(windows[0], 5), 'last_window_launch_ms': round(windows[-1], 5),
+                  'settled': bool(flat),
+                  'how': 'untimed back-to-back launches of the timed shape right before warm-up, in windows of 8, until three '
+                         'windows agree within 0.5 %% (>= %.2f s, <= %.1f s); sclk = mean of the second half of the amdsmi '
+                         'samples taken meanwhile; no sampler thread runs inside the timed region' % (lo_s, hi_s)}
+        if probe is not None and probe.mhz:
             tail = probe.mhz[len(probe.mhz) // 2:]
-            settle = {'sclk_mhz': round(sum(tail) / len(tail), 1), 'samples': len(probe.mhz), 'launches': n_s,
-                      'seconds': round(time.perf_counter() - t_s, 3), 'min': min(probe.mhz), 'max': max(probe.mhz),
-                      'power_raw': settle.get('power_raw'),
-                      'how': 'mean of the second half of the amdsmi samples over %d back-to-back untimed launches of the timed shape, '
-                             'right before warm-up and the timed region' % n_s}
-    sampler = backend.clock_sampler() if hasattr(backend, 'clock_sampler') else None
-    if sampler is not None:
-        sampler.__enter__()
+            settle.update({'sclk_mhz': round(sum(tail) / len(tail), 1), 'samples': len(probe.mhz), 'min': min(probe.mhz),
+                           'max': max(probe.mhz), 'power_raw': probe.record().get('power_raw')})
+        elif probe is not None:
+            settle['note'] = probe.record().get('note')
     for _ in range(W):
         backend.rollout(F, count_steps=False)
 
@@ -349,25 +368,13 @@ def run_rank(rank, world, backend, opts, dist=None):
     stop()
     fence()
     wall = time.perf_counter() - t0
-    if sampler is not None:
-        sampler.__exit__(None, None, None)
     kernel_ms = elapsed_ms()
     played = backend.played() - before
     assert played == K * F * count, 'work was skipped inside the timed region (%d != %d)' % (played, K * F * count)
     red = backend.comm_tensor([wall, float(played)])
     comm = {'backend': None, 'world_size': 1, 'ranks_counted': 1}
     per_rank_ms = [kernel_ms / K]
-    clocks = None
-    if sampler is not None:
-        inreg = sampler.record()
-        if settle and settle.get('sclk_mhz') and not isinstance(settle['sclk_mhz'], dict):
-            clocks = dict(settle)
-            clocks['in_region_samples_smu_smoothed'] = {'sclk_mhz': inreg.get('sclk_mhz'),
-                                                        'note': 'polled during warm-up + the ~50 ms timed region: the SMU read-out '
-                                                                'lags, NOT the clock of the timed region - use sclk_mhz above'}
-        else:       # no settle phase / no amdsmi: say so instead of passing the lagging samples off as the clock
-            clocks = {'sclk_mhz': None, 'note': (settle or inreg).get('note', 'no settled clock sample'),
-                      'in_region_samples_smu_smoothed': {'sclk_mhz': inreg.get('sclk_mhz')}}
+    clocks = settle      # (None when the settle phase is switched off)
     sclk = (clocks or {}).get('sclk_mhz') or 0.0
     # what every rank reports about itself: the first global game index of its shard, the steps it played, the device it
     # ran on (index + a 48-bit digest of its uuid / name: two ranks on ONE device show up as equal pairs) and its clock
@@ -984,8 +991,11 @@ def extras(dev, back, opts):
             chunk = max(1, games // 16)
             for g in range(1, 16):
                 bs.rollout(g * (40 if n_s == 19 else 8), g * chunk, min(games, (g + 1) * chunk))
-            bs.rollout(F, count_steps=False)
-            rf_, msf = event_rate(torch, dev, lambda: bs.rollout(F, count_steps=False), games * F, 3 if games >= 32768 else 6)
+            t_up = time.perf_counter()          # (the launches after an idle gap run slow - clock ramp: 40 ms of the shape first)
+            while time.perf_counter() - t_up < 0.04:
+                bs.rollout(F, count_steps=False)
+                bs.sync()
+            rf_, msf = event_rate(torch, dev, lambda: bs.rollout(F, count_steps=False), games * F, 4 if games >= 32768 else 8)
             r1_, ms1_ = event_rate(torch, dev, lambda: bs.rollout(1, count_steps=False), games, 24)
             rows.append({'games': games, 'fused_steps_per_s': round(rf_, 1), 'fused_launch_ms': round(msf, 4),
                          'fused_kernel': rollout_kernel_name(n_s, games, F, cus_lib),
@@ -999,6 +1009,53 @@ def extras(dev, back, opts):
     out['note'] = ('per-ply rates: HIP events over back-to-back calls through the Python API on the resident config-3 batch; '
                    'configs: one driver-timed number per BASELINE config that is not the headline')
     return out, per_ply
+
+
+def flat_config_scalars(line, also, res):
+    """One flat scalar per BASELINE config and per protocol fact, INSIDE `roofline` (the driver's record keeps `roofline`,
+    `config` and `cpu_baseline` whole and drops every other nested dict of the line - round 5's config 1 / 2 / 5 numbers and
+    the clock only survived in builder-run profiles/).  Every figure is measured in this run; None = that part did not run."""
+    def dig(d, *path):
+        for k in path:
+            d = d.get(k) if isinstance(d, dict) else None
+        return d
+    clocks = res.get('clocks') or {}
+    cfg = (also or {}).get('configs') or {}
+    c2, c5, c1 = cfg.get('config2_9x9_4096_games'), cfg.get('config5_children_8192_parents'), cfg.get('config1_7x7_single_game_GoEnv_step')
+    c4 = cfg.get('config4_per_gpu_batch_131072_games_on_one_gpu')
+    flat = {
+        'sclk_mhz': clocks.get('sclk_mhz'),
+        'settle_launches': clocks.get('launches'), 'settle_seconds': clocks.get('seconds'),
+        'settle_first_window_launch_ms': clocks.get('first_window_launch_ms'),
+        'settle_last_window_launch_ms': clocks.get('last_window_launch_ms'),
+        'timed_launch_ms': line['roofline'].get('launch_ms'),
+        'per_ply_frac': dig(line['roofline'], 'per_ply', 'frac'),
+        'per_ply_steps_per_s': dig(line['roofline'], 'per_ply', 'env_steps_per_s'),
+        'config1_steps_per_s': dig(c1, 'steps_per_s'),
+        'config2_fused_steps_per_s': dig(c2, 'fused_rollout_steps_per_s'), 'config2_fused_launch_ms': dig(c2, 'launch_ms'),
+        'config2_frac': dig(c2, 'roofline', 'frac'),
+        'config2_per_ply_us': dig(c2, 'per_ply_graph_launch_us'), 'config2_per_ply_steps_per_s': dig(c2, 'per_ply_graph_steps_per_s'),
+        'config2_per_ply_hbm_frac': dig(c2, 'per_ply_graph_hbm_frac'),
+        'config2_tracked_fused_steps_per_s': dig(c2, 'tracked_layout', 'fused_rollout_steps_per_s'),
+        'config2_tracked_per_ply_us': dig(c2, 'tracked_layout', 'per_ply_graph_launch_us'),
+        'config4_per_gpu_batch_steps_per_s': dig(c4, 'fused_rollout_steps_per_s'),
+        'config5_parents_per_s': dig(c5, 'parents_per_s'), 'config5_launch_ms': dig(c5, 'launch_ms'),
+        'config5_frac': dig(c5, 'roofline', 'frac'),
+        'config5_compact_parents_per_s': dig(c5, 'compact', 'parents_per_s'), 'config5_compact_frac': dig(c5, 'compact', 'frac'),
+        'env_step_tracked_steps_per_s': (also or {}).get('gg_batch_env_step_steps_per_s'),
+        'env_step_policy_weighted_vs_uniform': (also or {}).get('gg_batch_env_step_policy_weighted_vs_uniform'),
+    }
+    # the same launch shape elsewhere in this run (the batch sweep times it seconds later, after other work): round 5's
+    # driver run had the two 7 % apart; with the settle phase they must agree
+    for row in dig(also, 'batch_sweep', 'sizes', '%dx%d' % (line['config']['board'], line['config']['board'])) or []:
+        if row.get('games') == line['config']['games_per_gpu'] and line['n_gpus'] == 1:
+            flat['sweep_same_shape_launch_ms'] = row.get('fused_launch_ms')
+            if flat['timed_launch_ms']:
+                flat['timed_vs_sweep'] = round(flat['timed_launch_ms'] / row['fused_launch_ms'], 4)
+        if row.get('games') == 4096:
+            flat['mid_batch_4096_games_fused_steps_per_s'] = row.get('fused_steps_per_s')
+            flat['mid_batch_4096_games_fused_launch_ms'] = row.get('fused_launch_ms')
+    return flat
 
 
 # ------------------------------------------------------------------------------------------------ entry
@@ -1148,6 +1205,7 @@ def main(argv=None):
             'per_rank': res.get('per_rank'), 'distinct_devices': res.get('distinct_devices'),
             'per_gpu_steps_per_s': [round(F * res['games_per_gpu'] / (x * 1e-3), 1) for x in res['per_rank_launch_ms']],
         }
+        line['roofline'].update(flat_config_scalars(line, also, res))
         if numa is not None:
             line['rank0_numa'] = numa
         if solo:

@@ -61,7 +61,7 @@ def test_bench_one_gpu_plain_invocation():
     mc, ck = line['roofline']['measured_clock'], line['clocks']
     if ck and ck.get('sclk_mhz'):      # ONE clock: the settled figure sampled before the timed region prices the fraction
         assert mc and abs(mc['sclk_mhz'] - ck['sclk_mhz']) <= 0.02 * ck['sclk_mhz'] and ck['seconds'] >= 0.3
-        assert 'in_region_samples_smu_smoothed' in ck
+        assert ck['launches'] >= 24 and ck['first_window_launch_ms'] > 0 and ck['last_window_launch_ms'] > 0      # the adaptive settle phase (round 6)
     assert line['config']['games'] == 65536 and line['config']['board'] == 19 and line['config']['plies_per_step'] == 256
     assert line['roofline']['frac'] is not None                       # the committed PMC record matches the default shape
     assert 0 < line['roofline']['per_ply']['frac'] <= 1
