@@ -12,7 +12,7 @@ import torch  # must be imported before the library so both share ONE HIP runtim
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgymgo_amd.so')   # always the in-tree build: no override, no search path
-ABI_VERSION = 4                                      # GG_ABI_VERSION of include/gymgo_amd.h
+ABI_VERSION = 5                                      # GG_ABI_VERSION of include/gymgo_amd.h
 
 EXPORTS = (
     'gg_version', 'gg_device_cus', 'gg_batch_next_states', 'gg_batch_next_states_ws', 'gg_batch_invalid_mask', 'gg_batch_areas',
@@ -21,7 +21,7 @@ EXPORTS = (
     'gg_batch_children_packed', 'gg_batch_play_moves', 'gg_batch_play_moves_packed', 'gg_tracked_words', 'gg_batch_track_states',
     'gg_batch_untrack_states', 'gg_batch_rollout_tracked', 'gg_batch_play_moves_tracked', 'gg_batch_env_step_tracked',
     'gg_rng_seed', 'gg_batch_env_step_tracked_weighted', 'gg_batch_sample_weighted', 'gg_batch_sample_weighted_rows',
-    'gg_batch_symmetry', 'gg_batch_symmetry_rows',
+    'gg_batch_symmetry', 'gg_batch_symmetry_rows', 'gg_batch_env_step_scored',
 )
 
 _vp, _i64, _i32, _u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64
@@ -37,6 +37,7 @@ _SIGNATURES = {
     'gg_batch_children_compact': ([_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp], _i32),
     'gg_batch_rollout': ([_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp], _i32),
     'gg_batch_env_step': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_float, _i32, _i32, _vp], _i32),
+    'gg_batch_env_step_scored': ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_float, _i32, _i32, _vp], _i32),
     'gg_batch_sample_actions': ([_vp, _vp, _vp, _i64, _i32, _vp], _i32),
     'gg_batch_update_pieces': ([_vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp], _i32),
     'gg_batch_reset_finished': ([_vp, _i64, _i32, _vp], _i32),
@@ -170,7 +171,10 @@ def hip_runtime():
         try:
             with open('/proc/self/maps') as f:
                 for line in f:
-                    path = line.rsplit(None, 1)[-1] if '/' in line else ''
+                    # (the path is everything from the first '/' on: it may hold spaces; a '(deleted)' suffix cannot be opened)
+                    path = line[line.index('/'):].rstrip('\n') if '/' in line else ''
+                    if path.endswith(' (deleted)'):
+                        continue
                     if 'libamdhip64' in os.path.basename(path) and path not in paths:
                         paths.append(path)
         except OSError:
@@ -190,11 +194,15 @@ def hip_runtime():
         H.hipStreamQuery.argtypes, H.hipStreamQuery.restype = [_vp], _i32
         H.hipStreamIsCapturing.argtypes, H.hipStreamIsCapturing.restype = [_vp, ctypes.POINTER(ctypes.c_int)], _i32
         if torch.cuda.is_available():
-            # the same runtime as torch's: a torch stream must be a stream it knows (0 = idle, 600 = hipErrorNotReady)
-            rc = H.hipStreamQuery(current_raw_stream(None))
-            if rc not in (0, 600):
+            # the same runtime as torch's: a torch stream must be a stream it knows.  Probed with hipStreamIsCapturing,
+            # which is legal on a capturing stream (hipStreamQuery would invalidate the capture) and reports an unknown
+            # handle (400 hipErrorInvalidHandle / 709 hipErrorContextIsDestroyed) - any other code (a sticky asynchronous
+            # error of earlier work, say) is not a statement about the runtime and is left to the call that caused it
+            cap = ctypes.c_int(0)
+            rc = H.hipStreamIsCapturing(current_raw_stream(None), ctypes.byref(cap))
+            if rc in (400, 709):
                 raise GymGoNativeError('the HIP runtime opened for stream ordering (%s) does not know torch\'s stream '
-                                       '(hipStreamQuery -> %d): two runtimes in one process?' % (getattr(H, '_name', '?'), rc))
+                                       '(hipStreamIsCapturing -> %d): two runtimes in one process?' % (getattr(H, '_name', '?'), rc))
         _hip = H
     return _hip
 

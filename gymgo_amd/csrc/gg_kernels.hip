@@ -181,7 +181,10 @@ template <typename... KArgs, typename... Args>
 void launch_pairs(void (*kern)(KArgs...), int cus, int64_t npairs, bool split, hipStream_t s, Args... args) {
   int grid;
   const AgeSplit as = age_split(reinterpret_cast<const void *>(kern), cus, npairs, split, grid);
-  kern<<<grid, kWave, 0, s>>>(args..., as);
+  // (the env-step kernels take two more trailing arguments - the areas output and the reward formula of
+  // gg_batch_env_step_scored - which every other caller leaves at "none"; function pointers carry no default arguments)
+  if constexpr (sizeof...(KArgs) == sizeof...(Args) + 3) kern<<<grid, kWave, 0, s>>>(args..., as, nullptr, 0);
+  else kern<<<grid, kWave, 0, s>>>(args..., as);
 }
 
 // The sixteen-boards-per-wave kernels of gg_ns16.h serve batches of exactly 9x9 / 13x13 / 19x19 boards from a number of
@@ -680,6 +683,37 @@ int32_t gg_batch_env_step(uint8_t *states, const int32_t *actions, uint64_t *rng
     GG_DISPATCH_N(N);
 #undef GG_K
   }
+  return (int32_t)hipGetLastError();
+}
+
+// gg_batch_env_step + the Tromp-Taylor areas of every resulting position, ONE launch: the instantiation that scores every
+// game every step (the two area floods ride in idle flood lanes of the liberty analysis) with the reward formula of the
+// caller's choice.  GoEnv.step (gymgo_amd/envs/go_env.py) is this launch at B = 1.
+int32_t gg_batch_env_step_scored(uint8_t *states, const int32_t *actions, uint64_t *rng, float *rewards, uint8_t *dones,
+                                 int32_t *status, int32_t *taken_actions, int32_t *areas, int64_t B, int32_t N, float komi,
+                                 int32_t reward_method, int32_t auto_reset, void *hip_stream) {
+  if (reward_method != GG_REWARD_REAL && reward_method != GG_REWARD_HEURISTIC) return GG_E_BADARG;
+  GG_ENTER(states);
+  if (!actions && !rng) return GG_E_NULLPTR;
+  if (!areas) return GG_E_NULLPTR;
+  const int real = reward_method == GG_REWARD_REAL ? 1 : 0;
+  const int64_t npairs = (B + 1) / 2;
+  if (npairs <= (int64_t)cus * (N <= 9 ? 16 : 8)) {   // small launches: four-wave workgroups (gg_batch_env_step)
+    const AgeSplit none = {0, {0, 0, 0}};
+    const unsigned grid4 = (unsigned)((npairs + 3) / 4);
+#define GG_K(R, F) k_env_step2_w4<R, true, F><<<grid4, 4 * kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset, none, areas, real)
+    GG_DISPATCH_N(N);
+#undef GG_K
+    return (int32_t)hipGetLastError();
+  }
+#define GG_K(R, F)                                                                                                          \
+  do {                                                                                                                      \
+    int grid;                                                                                                               \
+    const AgeSplit as = age_split(reinterpret_cast<const void *>(k_env_step2<R, true, false, F>), cus, npairs, true, grid); \
+    k_env_step2<R, true, false, F><<<grid, kWave, 0, s>>>(states, actions, rng, rewards, dones, status, taken_actions, B, N, inv, komi, auto_reset, as, areas, real); \
+  } while (0)
+  GG_DISPATCH_N(N);
+#undef GG_K
   return (int32_t)hipGetLastError();
 }
 

@@ -1161,7 +1161,11 @@ __device__ __forceinline__ void env_step2_body(uint8_t *__restrict__ states, con
                                                uint64_t *__restrict__ rng, float *__restrict__ rewards,
                                                uint8_t *__restrict__ dones, int32_t *__restrict__ status,
                                                int32_t *__restrict__ taken, int64_t B, int N, uint32_t inv,
-                                               float komi, int auto_reset, const AgeSplit &age) {
+                                               float komi, int auto_reset, const AgeSplit &age,
+                                               int32_t *__restrict__ areas = nullptr, int real_formula = 0) {
+  // areas (HEUR instantiations, nullable): int32 [B][2], the black / white Tromp-Taylor areas of the resulting position
+  // (gg_batch_env_step_scored: GoEnv.step in ONE launch); real_formula: the HEUR instantiation (areas every step) pays
+  // out GG_REWARD_REAL's reward
   // FULLN: the board fills the row capacity (N == R) - N, N * N and the reciprocal become compile-time constants
   // (GoVecEnv.step 19x19: 7.9e8 against 7.6e8 steps/s; the same on k_next_states2 costs registers: 7.0e8 against 1.0e9)
   if (FULLN) { N = R; inv = (65536u + R - 1u) / R; }
@@ -1271,12 +1275,13 @@ __device__ __forceinline__ void env_step2_body(uint8_t *__restrict__ states, con
     if (on && hf.hl == 31) {
       const float margin = (float)((int)ab - (int)aw) - komi;
       float rwd;
-      if (HEUR) rwd = done ? (margin > 0.f ? 1.f : -1.f) * (float)hf.P : margin;
+      if (HEUR && !real_formula) rwd = done ? (margin > 0.f ? 1.f : -1.f) * (float)hf.P : margin;
       else rwd = done ? (margin > 0.f ? 1.f : margin < 0.f ? -1.f : 0.f) : 0.f;
       if (rewards) rewards[b] = rwd;
       if (dones) dones[b] = (uint8_t)done;
       if (status) status[b] = bad ? GG_STATUS_ILLEGAL : GG_STATUS_OK;
       if (taken) taken[b] = a;
+      if (HEUR && areas) { areas[2 * b] = (int32_t)ab; areas[2 * b + 1] = (int32_t)aw; }
     }
   }
 }
@@ -1285,8 +1290,9 @@ __global__ __launch_bounds__(kWave, PACKED ? 4 : GG_LB_PLY) void k_env_step2(uin
                                                         uint64_t *__restrict__ rng, float *__restrict__ rewards,
                                                         uint8_t *__restrict__ dones, int32_t *__restrict__ status,
                                                         int32_t *__restrict__ taken, int64_t B, int N, uint32_t inv,
-                                                        float komi, int auto_reset, AgeSplit age) {
-  env_step2_body<R, HEUR, PACKED, FULLN, 1>(states, actions, rng, rewards, dones, status, taken, B, N, inv, komi, auto_reset, age);
+                                                        float komi, int auto_reset, AgeSplit age,
+                                                        int32_t *__restrict__ areas = nullptr, int real_formula = 0) {
+  env_step2_body<R, HEUR, PACKED, FULLN, 1>(states, actions, rng, rewards, dones, status, taken, B, N, inv, komi, auto_reset, age, areas, real_formula);
 }
 // byte planes, small batches: four waves per workgroup (rollout2_body)
 template <int R, bool HEUR, bool FULLN>
@@ -1294,8 +1300,9 @@ __global__ __launch_bounds__(4 * kWave, GG_LB_PLY) void k_env_step2_w4(uint8_t *
                                                         uint64_t *__restrict__ rng, float *__restrict__ rewards,
                                                         uint8_t *__restrict__ dones, int32_t *__restrict__ status,
                                                         int32_t *__restrict__ taken, int64_t B, int N, uint32_t inv,
-                                                        float komi, int auto_reset, AgeSplit age) {
-  env_step2_body<R, HEUR, false, FULLN, 4>(states, actions, rng, rewards, dones, status, taken, B, N, inv, komi, auto_reset, age);
+                                                        float komi, int auto_reset, AgeSplit age,
+                                                        int32_t *__restrict__ areas = nullptr, int real_formula = 0) {
+  env_step2_body<R, HEUR, false, FULLN, 4>(states, actions, rng, rewards, dones, status, taken, B, N, inv, komi, auto_reset, age, areas, real_formula);
 }
 
 
@@ -1726,7 +1733,7 @@ static __global__ void k_children_counts(const uint8_t *__restrict__ states, int
   for (int64_t b = wave; b < B; b += nwaves) {
     const uint8_t *g = states + b * (int64_t)(6 * P);
     int c = 0;
-    for (int i = lane; i < P; i += kWave) c += g[3 * P + i] == 0 ? 1 : 0;
+    for (int i = lane; i < P; i += kWave) c += (g[3 * P + i] & 1) == 0 ? 1 : 0;   // (bit 0, like plane_to_row: the expansion must keep exactly what is counted here)
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
     if (lane == 0) counts[b] = g[5 * P] ? P + 1 : c + 1;
   }

@@ -1,10 +1,12 @@
 """GoEnv with the reference's interface (gym_go/envs/go_env.py:19-152) on the HIP backend.
 
-One game, NumPy float64 states in and out like the reference (config 1 "plumbing").  The board lives on the device;
-one step() is one host->device copy (the action), two launches (gg_batch_env_step: legality, transition, game-over
-flag; gg_batch_areas: the Tromp-Taylor score the reward needs) and ONE device->host copy of a small record (state,
-areas, done, status) from which the reward, `info()` and the returned state are read - nothing is computed on the host
-and nothing is copied twice.  Rendering (pyglet UI, gym_go/envs/go_env.py:160-243) is out of scope; render('terminal') prints.
+One game, NumPy float64 states in and out like the reference (config 1 "plumbing").  The game's record - action, state,
+areas, status, done - lives in ONE block of pinned host memory that the device maps (hipHostMalloc through torch's
+pinned allocator): step() writes the action into it, enqueues ONE launch (gg_batch_env_step_scored: legality, transition,
+game-over flag and the Tromp-Taylor score the reward needs; the kernel reads and writes the record in place over the host
+link) and waits for the stream - no host<->device copy in either direction, nothing computed on the host.  (Round 5: one
+H2D copy, two launches and one D2H copy per step.)  Rendering (pyglet UI, gym_go/envs/go_env.py:160-243) is out of scope;
+render('terminal') prints.
 """
 from enum import Enum
 
@@ -53,22 +55,33 @@ class GoEnv(spaces.Env):
     def _same(self, snap):
         return snap is not None and snap.shape == np.shape(self.state_) and np.array_equal(snap, self.state_)
 
-    # ---- the resident device record: [state 6 N^2 | pad | black i32 | white i32 | status i32 | done u8 ...]
+    # ---- the record the kernel works on, in pinned (device-mapped) host memory:
+    #      [64 B pad | state 6 N^2 | pad to 16 | black i32 | white i32 | status i32 | done u8 ... | action i32 | 64 B pad]
+    # (the kernels read whole aligned 16-byte vectors around a board: the pads keep those reads inside the block)
     def _record(self):
         import torch
         if self._dev is None:
+            from gymgo_amd import _lib
+            dev = gogame._device()
+            if dev.type != 'cuda' or not torch.cuda.is_available():
+                raise _lib.GymGoNativeError('GoEnv needs a ROCm device (gymgo_amd has no CPU path)')
             n2 = govars.NUM_CHNLS * self.size * self.size
-            off = (n2 + 15) & ~15
-            buf = torch.zeros(off + 16, dtype=torch.uint8, device=gogame._device())
+            off = 64 + ((n2 + 15) & ~15)
+            with torch.cuda.device(dev):
+                buf = torch.zeros(off + 32 + 64, dtype=torch.uint8).pin_memory()
+            host = buf.numpy()
+            base = buf.data_ptr()       # pinned host memory is mapped into the device's address space at the same address
             self._dev = {
-                'buf': buf, 'off': off,
-                'states': buf[:n2].view(1, govars.NUM_CHNLS, self.size, self.size),
-                'black': buf[off:off + 4].view(torch.int32), 'white': buf[off + 4:off + 8].view(torch.int32),
-                'status': buf[off + 8:off + 12].view(torch.int32), 'done': buf[off + 12:off + 13],
+                'buf': buf, 'host': host, 'device': dev,
+                'state': host[64:64 + n2].reshape(govars.NUM_CHNLS, self.size, self.size),
+                'words': host[off:off + 12].view(np.int32),       # black, white, status
+                'done': host[off + 12:off + 13], 'action': host[off + 16:off + 20].view(np.int32),
+                'p_state': base + 64, 'p_areas': base + off, 'p_status': base + off + 8, 'p_done': base + off + 12,
+                'p_action': base + off + 16,
             }
-        if not self._same(self._dev_of):      # replaced or edited in place by the caller: upload it
+        if not self._same(self._dev_of):      # replaced or edited in place by the caller: hand the kernel the new bytes
             snap = self._snapshot()
-            self._dev['states'].copy_(torch.from_numpy(snap).view(1, govars.NUM_CHNLS, self.size, self.size))
+            self._dev['state'][...] = snap
             self._dev_of = snap
         return self._dev
 
@@ -91,25 +104,20 @@ class GoEnv(spaces.Env):
         from gymgo_amd import _lib
         rec = self._record()
         n = self.size
-        act = torch.tensor([int(action)], dtype=torch.int32, device=rec['buf'].device)
-        gogame.batch_env_step(rec['states'], act, None, 0.0, 'real', False,
-                              out=(None, rec['done'], rec['status'], None))
-        L = _lib.lib()
-        _lib.check(L.gg_batch_areas(_lib.dev_ptr(rec['states'], torch.uint8, 'states'),
-                                    _lib.dev_ptr(rec['black'], torch.int32, 'black'),
-                                    _lib.dev_ptr(rec['white'], torch.int32, 'white'), 1, n,
-                                    _lib.stream_ptr(rec['buf'].device)), 'gg_batch_areas')
-        host = rec['buf'].cpu().numpy()           # the one device->host copy of the step
-        off = rec['off']
-        black, white, status = (int(x) for x in host[off:off + 12].view(np.int32))
+        rec['action'][0] = int(action)
+        stream = _lib.stream_ptr(rec['device'])
+        _lib.check(_lib.lib().gg_batch_env_step_scored(rec['p_state'], rec['p_action'], None, None, rec['p_done'], rec['p_status'],
+                                                       None, rec['p_areas'], 1, n, 0.0, 0, 0, stream), 'gg_batch_env_step_scored')
+        torch.cuda.current_stream(rec['device']).synchronize()      # the kernel's writes to the record are visible from here on
+        black, white, status = (int(x) for x in rec['words'])
         if status != 0:                           # gym_go/gogame.py:59: the position is unchanged
             a = int(action)
             raise AssertionError(('Invalid move', (a // n, a % n)))
-        snap = host[:off][:govars.NUM_CHNLS * n * n].reshape(govars.NUM_CHNLS, n, n).copy()
+        snap = rec['state'].copy()
         self.state_ = snap.astype(np.float64)
         self._dev_of = snap
         self._areas, self._areas_of = (float(black), float(white)), snap
-        self.done = int(host[off + 12])
+        self.done = int(rec['done'][0])
         return np.copy(self.state_), self.reward(), self.done, self.info()
 
     def game_ended(self):

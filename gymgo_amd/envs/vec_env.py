@@ -30,6 +30,10 @@ class GoVecEnv:
         self.batch_size, self.size, self.komi = batch_size, size, komi
         self.reward_method = reward_method
         self.device = torch.device(device) if device is not None else gogame._device()
+        if self.device.type == 'cuda' and self.device.index is None:
+            # an INDEXED device from here on: 'cuda' means "whatever is current NOW" - resolved again at every step it would
+            # name another device's stream once the caller switches devices, while the kernels follow the tensors
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.auto_reset = auto_reset
         if packed and layout not in (None, 'packed'):
             raise ValueError("packed=True is the legacy spelling of layout='packed'; it contradicts layout=%r" % (layout,))
@@ -261,6 +265,10 @@ class GoVecEnvParts:
             raise ValueError('parts must be in [1, batch_size]')
         self.batch_size, self.size, self.parts = batch_size, size, parts
         self.device = torch.device(device) if device is not None else gogame._device()
+        if self.device.type == 'cuda' and self.device.index is None:
+            # an INDEXED device from here on: 'cuda' means "whatever is current NOW" - resolved again at every step it would
+            # name another device's stream once the caller switches devices, while the kernels follow the tensors
+            self.device = torch.device('cuda', torch.cuda.current_device())
         from gymgo_amd import _lib
         self._lib = _lib
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(parts)]

@@ -102,8 +102,12 @@ def _children_offsets_dev(states, offsets=None, order=None):
     B, C, N, _ = states.shape
     if offsets is None:
         offsets = torch.empty(B + 1, dtype=_I32, device=states.device)
+    elif offsets.numel() < B + 1:          # the launch writes offsets[0 .. B]
+        raise ValueError('offsets must hold at least B + 1 = %d int32 (got %d)' % (B + 1, offsets.numel()))
     if order is None:
         order = torch.empty(max(B, 1), dtype=_I32, device=states.device)
+    elif order.numel() < B:
+        raise ValueError('order must hold at least B = %d int32 (got %d)' % (B, order.numel()))
     code = _lib.lib().gg_batch_children_offsets(_lib.dev_ptr(states, _U8, 'states'), _lib.dev_ptr(offsets, _I32, 'offsets'),
                                                 _lib.dev_ptr(order, _I32, 'order'), B, N, _lib.stream_ptr(states.device))
     _lib.check(code, 'gg_batch_children_offsets')
@@ -112,8 +116,9 @@ def _children_offsets_dev(states, offsets=None, order=None):
 
 def _children_compact_dev(states, canonical, offsets=None, out=None):
     """The un-padded children of every state, concatenated (gg_batch_children_compact) -> (children uint8 [total, 6, N, N],
-    offsets int32 [B+1]).  `out`: a caller-owned buffer of at least offsets[B] boards (e.g. the upper bound
-    B * (N*N+1)): no device -> host read of the total is then needed and the launches can be captured in a graph."""
+    offsets int32 [B+1]).  `out`: a caller-owned buffer of at least offsets[B] boards; with the upper bound
+    B * (N*N+1) no device -> host read of the total is needed and the launches can be captured in a graph, a smaller buffer
+    is checked against the total (one host read) and refused when it is too short."""
     B, C, N, _ = states.shape
     offsets, order = _children_offsets_dev(states, offsets)
     if out is None:
@@ -121,6 +126,11 @@ def _children_compact_dev(states, canonical, offsets=None, out=None):
         out = torch.empty((total, C, N, N), dtype=_U8, device=states.device)
     elif out.dim() != 4 or tuple(out.shape[1:]) != (C, N, N):
         raise ValueError('out must be [n >= total children, 6, N, N]')
+    elif out.shape[0] < B * (N * N + 1):
+        # smaller than the upper bound: the true total has to be read back once, or the launch could write past the end
+        total = int(offsets[B].item())
+        if out.shape[0] < total:
+            raise ValueError('out holds %d boards, the un-padded children of this batch are %d' % (out.shape[0], total))
     code = _lib.lib().gg_batch_children_compact(_lib.dev_ptr(states, _U8, 'states'), _lib.dev_ptr(offsets, _I32, 'offsets'),
                                                 _lib.dev_ptr(order, _I32, 'order'), _lib.dev_ptr(out, _U8, 'children'), B, N,
                                                 int(bool(canonical)), _lib.stream_ptr(states.device))

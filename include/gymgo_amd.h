@@ -30,6 +30,10 @@
  *     `gg_oracle_*`, linked by tests and the bench's cpu_baseline only), and a product library that could fall back
  *     to it would void every parity claim.  A missing GPU is an error (hipErrorNoDevice / GymGoNativeError).
  *   - Which kernel serves a call depends on its arguments only (board size, batch size, plies per launch).
+ *   - Alignment.  Boards may start at any byte offset, but HBM is only touched with naturally aligned 16-byte accesses:
+ *     a state / children / tracked buffer must be READABLE from its start rounded down to 16 bytes to its end rounded
+ *     up to 16 bytes (always true for a whole allocation and for any slice of one; bytes outside the buffer are read,
+ *     never written).
  *   - 2 <= N <= 19.  Actions are int32 in [0, N*N]; N*N = pass (gym_go/gogame.py:40-42).
  *   - Return value: 0 on success, a hipError_t (> 0) for launch/runtime errors, or a negative
  *     GG_E_* code for bad arguments.  Re-entrant; safe from several threads / one process per GPU.
@@ -43,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 4
+#define GG_ABI_VERSION 5
 #define GG_MAX_BOARD 19
 #define GG_NUM_CHNLS 6
 
@@ -169,6 +173,18 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
 int32_t gg_batch_env_step(uint8_t *states, const int32_t *actions, uint64_t *rng, float *rewards, uint8_t *dones,
                           int32_t *status, int32_t *taken_actions, int64_t B, int32_t N, float komi,
                           int32_t reward_method, int32_t auto_reset, void *hip_stream);
+
+/*
+ * gg_batch_env_step + the score of every resulting position, ONE launch         gym_go/envs/go_env.py:49-76, :128-149
+ * areas: int32 [B][2] (required) = gogame.areas (gym_go/gogame.py:275-300) of the position each game is left in: black, white -
+ * what GoEnv.reward / winning / winner read after the step.  Everything else as gg_batch_env_step (the reward follows
+ * `reward_method`).  GoEnv.step of the Python package is this call at B = 1 on a record in pinned, device-mapped host
+ * memory (hipHostMalloc: the kernel reads the action and writes state, areas, status and done in place - no copy either way);
+ * like every entry point it accepts any device-accessible pointer whose 16-byte-aligned superset is readable.
+ */
+int32_t gg_batch_env_step_scored(uint8_t *states, const int32_t *actions, uint64_t *rng, float *rewards, uint8_t *dones,
+                                 int32_t *status, int32_t *taken_actions, int32_t *areas, int64_t B, int32_t N, float komi,
+                                 int32_t reward_method, int32_t auto_reset, void *hip_stream);
 
 /*
  * One sampling pass only (no step): actions[b] ~ Uniform{valid actions of states[b] incl. pass},

@@ -142,3 +142,35 @@ def test_children_compact_work_order_is_a_permutation_and_does_not_matter():
         torch.cuda.synchronize()
         outs.append(buf)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_children_compact_refuses_short_buffers_and_counts_bit_0_of_plane_3():
+    """caller-owned `out` / `offsets` / `order` that are too short are refused on the host (they were silent
+    out-of-bounds device writes), and a plane-3 byte such as 2 (a caller-edited state) counts by bit 0 in BOTH the offsets and
+    the expansion, so a parent never emits more children than its slot holds."""
+    from gymgo_amd import gogame
+    B, N = 40, 5
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, 11, 0, 'cuda')
+    gogame.batch_rollout(st, rng, 9, auto_reset=False)
+    full, offs = gogame._children_compact_dev(st, False)
+    total = int(offs[B])
+    with pytest.raises(ValueError):
+        gogame._children_compact_dev(st, False, out=torch.empty((total - 1, 6, N, N), dtype=torch.uint8, device='cuda'))
+    with pytest.raises(ValueError):
+        gogame._children_compact_dev(st, False, offsets=torch.empty(B, dtype=torch.int32, device='cuda'))
+    with pytest.raises(ValueError):
+        gogame._children_offsets_dev(st, order=torch.empty(B - 1, dtype=torch.int32, device='cuda'))
+    exact = torch.full((total, 6, N, N), 7, dtype=torch.uint8, device='cuda')     # exactly the total: accepted after one host read
+    got, _ = gogame._children_compact_dev(st, False, out=exact)
+    assert torch.equal(got, full)
+    # plane-3 bytes of 2: bit 0 clear = a kept point, for the count and for the expansion alike
+    odd = st.clone()
+    odd[:, 3] = odd[:, 3] * 3          # set points become 3 (bit 0 set), clear ones stay 0
+    odd[:, 3][st[:, 3] == 0] = 2       # ... and the clear ones become 2 (bit 0 clear)
+    guard = torch.full((total + 8, 6, N, N), 9, dtype=torch.uint8, device='cuda')
+    got2, offs2 = gogame._children_compact_dev(odd, False, out=guard[:total])
+    torch.cuda.synchronize()
+    assert torch.equal(offs2, offs) and bool((guard[total:] == 9).all())
+    # (plane 3 of a child is recomputed by the expansion; planes 0 / 1 and the flags come from the move)
+    assert torch.equal(got2[:, :2], full[:, :2])

@@ -396,3 +396,91 @@ def test_vecenv_step_follows_rebound_buffers_and_refuses_bad_ones():
     b.tracked = b.tracked[:-1]
     with pytest.raises(ValueError):
         b.step()
+
+
+@pytest.mark.parametrize('N,B,method,komi', [(7, 1, 'real', 0.0), (9, 300, 'heuristic', 6.5), (19, 5000, 'real', 7.5), (13, 33, 'real', 0.5),
+                                             (5, 4099, 'heuristic', 0.0)])
+def test_env_step_scored_areas_rewards_and_states_match_oracle(N, B, method, komi):
+    """gg_batch_env_step_scored (round 6: GoEnv.step in ONE launch): the step of gg_batch_env_step plus the Tromp-Taylor areas
+    (gym_go/gogame.py:275-300) of every resulting position - states, drawn actions, dones, rewards by either formula and the
+    areas vs the oracle, over game ends and auto-resets, on both sides of the four-wave-workgroup threshold."""
+    from gymgo_amd import _lib, gogame
+    from oracle import c_oracle
+    L = _lib.lib()
+    st = gogame.batch_init_state(B, N, device='cuda')
+    rng = gogame.rng_seed(B, 99, 0, 'cuda')
+    want = np.zeros((B, 6, N, N), np.uint8)
+    wrng = c_oracle.rng_seed(99, B)
+    rew = torch.empty(B, dtype=torch.float32, device='cuda')
+    dones = torch.empty(B, dtype=torch.uint8, device='cuda')
+    status = torch.empty(B, dtype=torch.int32, device='cuda')
+    taken = torch.empty(B, dtype=torch.int32, device='cuda')
+    areas = torch.empty((B, 2), dtype=torch.int32, device='cuda')
+    m = 0 if method == 'real' else 1
+    seen_done = 0
+    for t in range(12 if N == 19 else 120):
+        assert L.gg_batch_env_step_scored(st.data_ptr(), None, rng.data_ptr(), rew.data_ptr(), dones.data_ptr(), status.data_ptr(),
+                                          taken.data_ptr(), areas.data_ptr(), B, N, komi, m, 1, None) == 0
+        want, wrng, last = c_oracle.batch_rollout(want, wrng, 1, True)
+        assert np.array_equal(st.cpu().numpy(), want), t
+        assert np.array_equal(taken.cpu().numpy(), last), t
+        b, w = c_oracle.batch_areas(want)
+        assert np.array_equal(areas.cpu().numpy(), np.stack([b, w], axis=1)), t
+        assert np.array_equal(rew.cpu().numpy().astype(np.float64), _ref_reward(want, komi, method, N)), t
+        assert np.array_equal(dones.cpu().numpy(), want[:, 5, 0, 0]) and int(status.sum()) == 0
+        seen_done += int(dones.sum())
+    assert np.array_equal(rng.cpu().numpy().view(np.uint64), wrng)
+    if N <= 9 and B > 1:
+        assert seen_done > 0
+    # given actions incl. an illegal one: status 1, the row and its areas are those of the untouched position
+    acts = torch.full((B,), N * N, dtype=torch.int32, device='cuda')
+    occupied = np.flatnonzero(want[0, 3].reshape(-1))
+    if len(occupied):
+        acts[0] = int(occupied[0])
+    before = st.clone()
+    assert L.gg_batch_env_step_scored(st.data_ptr(), acts.data_ptr(), None, None, dones.data_ptr(), status.data_ptr(), None,
+                                      areas.data_ptr(), B, N, komi, m, 1, None) == 0
+    if len(occupied) and not want[0, 5, 0, 0]:
+        assert int(status[0]) == 1 and torch.equal(st[0], before[0])
+        b0, w0 = c_oracle.batch_areas(want[:1])
+        assert areas[0].tolist() == [int(b0[0]), int(w0[0])]
+    assert L.gg_batch_env_step_scored(st.data_ptr(), None, None, None, None, None, None, areas.data_ptr(), B, N, komi, m, 1, None) == -2
+    assert L.gg_batch_env_step_scored(st.data_ptr(), acts.data_ptr(), None, None, None, None, None, None, B, N, komi, m, 1, None) == -2
+    assert L.gg_batch_env_step_scored(st.data_ptr(), acts.data_ptr(), None, None, None, None, None, areas.data_ptr(), B, N, komi, 5, 1, None) == -3
+
+
+def test_goenv_step_is_one_launch_on_a_pinned_record():
+    """GoEnv.step (config 1): the game's record lives in pinned, device-mapped host memory; one step = one launch of
+    gg_batch_env_step_scored and a stream wait - a game replayed against the oracle incl. captures, the end of the game, a
+    caller who replaces / edits `state_` between steps, and an illegal move that leaves everything untouched."""
+    from gymgo_amd.envs import make
+    from oracle import c_oracle
+    env = make('gym_go:go-v0', size=7, komi=0.5, reward_method='heuristic')
+    state = env.reset()
+    want = np.zeros((6, 7, 7), np.uint8)
+    rs = np.random.default_rng(3)
+    for t in range(400):
+        if env.done:
+            break
+        valid = np.flatnonzero(env.valid_moves())
+        a = int(rs.choice(valid))
+        state, reward, done, info = env.step(a)
+        want = c_oracle.next_state(want, a)
+        assert np.array_equal(state, want.astype(np.float64)), t
+        b, w = c_oracle.batch_areas(want[None])
+        margin = float(b[0]) - float(w[0]) - 0.5
+        assert reward == ((1 if margin > 0 else -1) * 49 if done else margin), t
+        assert done == int(want[5, 0, 0]) and info['turn'] == int(want[2, 0, 0])
+    assert env._dev is not None and env._dev['buf'].is_pinned() and not env._dev['buf'].is_cuda
+    # an illegal move: AssertionError, nothing changes
+    env.reset()
+    env.step(8)
+    snap = env.state()
+    with pytest.raises(AssertionError):
+        env.step(8)
+    assert np.array_equal(env.state(), snap) and not env.done
+    # the caller edits state_ in place: the next step starts from the edited position (gym_go recomputes from state_)
+    env.state_[0, 3, 3] = 1
+    edited = env.state().astype(np.uint8)
+    s2, *_ = env.step(0)
+    assert np.array_equal(s2, c_oracle.next_state(edited, 0).astype(np.float64))

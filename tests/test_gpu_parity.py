@@ -307,7 +307,7 @@ def test_unaligned_views(gg, oracle):
 def test_empty_batch_and_bad_args(gg):
     from gymgo_amd import _lib
     L = _lib.lib()
-    assert L.gg_version() == _lib.ABI_VERSION == 4
+    assert L.gg_version() == _lib.ABI_VERSION == 5
     assert L.gg_batch_next_states(None, None, None, None, 0, 9, 0, None) == 0
     assert L.gg_batch_next_states(None, None, None, None, 4, 9, 0, None) == -2
     assert L.gg_batch_next_states(None, None, None, None, 4, 20, 0, None) == -1

@@ -24,7 +24,7 @@ def test_header_symbols_exported(built):
     L = ctypes.CDLL(built.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert built.lib().gg_version() == built.ABI_VERSION == 4
+    assert built.lib().gg_version() == built.ABI_VERSION == 5
 
 
 def test_integration_doc_names_every_entry_point():
