@@ -433,7 +433,7 @@ def rollout_kernel_name(n, games, plies, cus, auto_reset=True):
     serves this launch."""
     rcap = 9 if n <= 9 else 13 if n <= 13 else 19
     full = 'true' if n == rcap else 'false'
-    lat_per_cu, lat_plies = {9: (64, 3), 13: (32, 3 if games >= 16 * cus else 4), 19: (8, 8)}[rcap]
+    lat_per_cu, lat_plies = {9: (128, 3), 13: (80, 3 if games >= 16 * cus else 4), 19: (31, 8)}[rcap]
     if plies >= lat_plies and games <= lat_per_cu * cus:
         return 'k_rollout_lat<%d, %s, %s, 0>' % (rcap, full, 'true' if auto_reset else 'false')
     if plies >= 2 and games >= 32 * cus:
@@ -531,7 +531,7 @@ def rollout_symbol_prefix(kernel):
         return '_ZN2gg10k_rollout4ILi%sELi%sE%s%s%s%sEE' % (m.group(1), m.group(2), b(m.group(3)), b(m.group(4)), b(m.group(5)), b(m.group(6)))
     m = re.match(r'k_rollout_lat<(\d+), (\w+), (\w+), (\d+)>', kernel)
     if m:
-        return '_ZN2gg13k_rollout_latILi%sE%s%sLi%sEEE' % (m.group(1), b(m.group(2)), b(m.group(3)), m.group(4))
+        return '_ZN2gg13k_rollout_latILi%sE%s%sLi%sELb0EEE' % (m.group(1), b(m.group(2)), b(m.group(3)), m.group(4))      # (+ SHORT = false)
     m = re.match(r'k_rollout2_w4<(\d+), (\w+)>', kernel)
     if m:
         return '_ZN2gg13k_rollout2_w4ILi%sE%sEE' % (m.group(1), b(m.group(2)))

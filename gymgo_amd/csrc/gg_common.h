@@ -64,6 +64,14 @@ __device__ __forceinline__ uint32_t dpp0(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
 }
 
+// OR-accumulation of a compile-time-indexed series of terms, two per v_bitop3_b32: `acc |= a; acc |= b` is fused by the compiler
+// into v_or3_b32 (4 issue cycles), the same truth table as a bitop3 issues in 2.  idx & 1 == 0: the term is parked in `pend`,
+// == 1: acc = acc | pend | term; a series of odd length ORs the last parked term in itself.
+__device__ __forceinline__ void or_pairs(uint32_t &acc, uint32_t &pend, int odd, uint32_t term) {
+  if (odd) acc = B3(acc, pend, term, T_OR3);
+  else pend = term;
+}
+
 // complete horizontal run fill of seeds s (subset of m), 6 ops: 2 carry fills, 2 bit reversals
 __device__ __forceinline__ uint32_t run_fill2(uint32_t m, uint32_t mrev, uint32_t s) {
   uint32_t t = m + s;
@@ -157,7 +165,7 @@ __device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint
     for (int r = 0; r < R; ++r) FLOOD_VISIT(r, r - 1, (r & 1) != 0);       // down: domain (r&1) -> ((r+1)&1)
     if (it > 0) {
       // normal-order copy streamed into `out` (speculatively: it is the result if the test passes)
-      uint32_t open = 0, above = 0;  // a filled stone whose upper neighbour is fillable but not filled
+      uint32_t open = 0, pend = 0, above = 0;  // a filled stone whose upper neighbour is fillable but not filled
       uint32_t q[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int r = R - 1; r >= 0; --r) {
@@ -168,15 +176,16 @@ __device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint
         } else {
           out[r] = g;
         }
-        if (r < R - 1) open |= B3(above, m[r], g, T_AND_ANDN);
+        if (r < R - 1) or_pairs(open, pend, (R - 2 - r) & 1, B3(above, m[r], g, T_AND_ANDN));
         above = g;
       }
+      if ((R - 1) & 1) open |= pend;
       if (__ballot(open != 0) == 0) return;
     }
 #pragma unroll
     for (int r = R - 1; r >= 0; --r) FLOOD_VISIT(r, r + 1, ((r + 1) & 1) != 0);  // up: domain ((r+1)&1) -> (r&1)
     if (it > 0 || EARLY) {
-      uint32_t open = 0, below = 0;
+      uint32_t open = 0, pend = 0, below = 0;
       uint32_t q[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -190,9 +199,10 @@ __device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint
         } else {
           out[r] = g;
         }
-        if (r > 0) open |= B3(below, m[r], g, T_AND_ANDN);
+        if (r > 0) or_pairs(open, pend, (r - 1) & 1, B3(below, m[r], g, T_AND_ANDN));
         below = g;
       }
+      if ((R - 1) & 1) open |= pend;
       if (__ballot(open != 0) == 0) return;
     }
   }

@@ -241,7 +241,7 @@ bool use_multi_ply(int cus, int64_t B, int plies) {
 // board size (profiles/r05a_lat_sweep.txt, A/B build, 256 plies per launch, new / old kernel):
 //   9x9 (and smaller)  4 096 games x1.77, 8 192 x1.69, 16 384 x1.10, 32 768 x0.73     -> up to 64 games per CU
 //   13x13 (10 .. 13)   4 096 x1.50, 8 192 x1.39, 16 384 x0.87                          -> up to 32 games per CU
-//   19x19 (14 .. 19)   1 024 x1.07, 2 048 x1.05, 4 096 x0.89                           -> up to 8 games per CU
+//   19x19 (14 .. 19)   1 024 x1.07, 2 048 x1.05, 4 096 x0.89                           -> up to 8 games per CU (round 5; see below)
 // and per launch length at 4 096 games: 9x9 1 / 2 / 4 / 16 plies x0.87 / 0.97 / 1.13 / 1.49, 13x13 x0.78 / 0.87 / 1.03 / 1.32,
 // 19x19 x0.50 / 0.59 / 0.73 / 0.82 (the launch pays the first classes of every board: eleven lock-step floods), so from
 // 3 / 3 - 4 / 8 plies per launch on.  (A/B builds: GG_AB_LAT_MAX = games per CU, GG_AB_LAT_PLIES = plies.)
@@ -251,7 +251,13 @@ bool use_multi_ply(int cus, int64_t B, int plies) {
 // x1.35 / 1.04 / 0.76 / 0.76; 13x13 8 192 x1.77 / 1.74 / 1.55 / 1.61, 16 384 x1.86 / 1.37 / 1.00 / 1.01; 19x19 4 096 x1.65 / 1.27 /
 // 1.11 / 1.14, 8 192 x1.52 / 1.03 / 0.76 / 0.72 -> up to 64 / 64 / 16 games per CU.  (A/B builds: GG_AB_LATT_MAX, GG_AB_LATT_PLIES.)
 bool use_lat(int cus, int64_t B, int32_t N, int plies, bool tracked = false) {
-  int64_t per_cu = N <= 9 ? 64 : N <= 13 ? 32 : 8;
+  // (round 6, three floods per ply instead of five - profiles/r06c_mid_batch.txt, 19x19 x 256 plies, new / best other family:
+  // 2 048 games 0.414 / 0.637 ms, 4 096 0.557 / 0.736, 6 144 0.713 / 0.889, 8 192 0.874 / 0.888 (k_rollout4, eight boards per
+  // wave), 12 288 1.31 / 0.95 -> up to 31 games per CU; the launch time is now monotone in the batch size)
+  // (9x9 / 13x13 with the three-flood ply, profiles/r06c_mid_batch_9.txt / _13.txt, new / k_rollout4: 9x9 16 384 games 0.42 /
+  // 0.64 ms, 24 576 0.58 / 0.73, 32 768 0.735 / 0.746, 49 152 1.04 / 0.89; 13x13 16 384 0.58 / 0.75, 24 576 0.90 / 0.90, 32 768
+  // 1.11 / 0.92 -> up to 128 / 80 games per CU)
+  int64_t per_cu = N <= 9 ? 128 : N <= 13 ? 80 : 31;
   // (second sweep, with every read of either kernel's prologue in flight together - profiles/r05n_lat_fsweep.txt, hipGraph nodes,
   // new / two-board: 9x9 4 096 games 1 / 2 / 3 / 4 / 16 plies x0.86 / 0.98 / 1.12 / 1.22 / 1.66; 13x13 4 096 x0.81 / 0.95 / 1.09 /
   // 1.19 / 1.57, 1 024 x0.71 / 0.82 / 0.93 / 1.01 / 1.33; 19x19 2 048 games 4 / 8 / 16 / 64 plies x0.92 / 1.04 / 1.12 / 1.19)

@@ -44,7 +44,9 @@ struct Lat {
   static constexpr int FW = R <= 9 ? 10 : (R <= 15 ? 16 : 32);    // bits per flood field (one guard bit above the row unless the field is the register)
   static constexpr int NF = 32 / FW;                              // fields per register: 3 / 2 / 1
   static constexpr int NFL = 5;                                   // floods per ply: up, down, left, right (opponent), G (mover)
-  static constexpr int NREG = (NFL + NF - 1) / NF;                // 2 / 3 / 5
+  static constexpr int NREG = (NFL + NF - 1) / NF;                // 2 / 3 / 5 (the five-flood ply: lat_play_full)
+  static constexpr int NFL3 = 3;                                  // floods of the usual ply (lat_play): two opponent slots + G
+  static constexpr int NREG3 = (NFL3 + NF - 1) / NF;              // 1 / 2 / 3
   static constexpr uint32_t FM = FW >= 32 ? 0xFFFFFFFFu : ((1u << (FW & 31)) - 1u);
   static constexpr int kBits = R <= 16 ? 16 : 32;                 // width of the k-th-set-bit search
   static constexpr bool kSat = R > 9;                             // per-lane liberty counts saturated at 2 (the board sums are 8-bit fields)
@@ -96,14 +98,15 @@ template <int LPB> __device__ __forceinline__ uint32_t lat_board_scan(uint32_t v
 // position of the tt-th (0-based) set bit of v (tt < popc(v); anything otherwise): binary search on popcounts, branch-free
 // on 0 / ~0 masks (kth_set_bit of gg_v4.h for one row)
 template <int BITS> __device__ __forceinline__ uint32_t lat_kth_bit(uint32_t v, uint32_t tt) {
-  uint32_t ps = 0;
+  // five instructions per level (a lone wave pays per instruction, whatever it is): the field by v_bfe, its popcount added to
+  // ~tt by the same v_bcnt (c + ~tt = c - tt - 1 is negative iff tt >= c: the bit is in the upper half - and is ~(tt - c) then)
+  uint32_t ps = 0, ntt = ~tt;
 #pragma unroll
   for (int sh = BITS / 2; sh >= 1; sh >>= 1) {
-    const uint32_t c = (uint32_t)__popc((v >> ps) & ((1u << sh) - 1u));
-    const uint32_t d = tt - c;
-    const uint32_t lt = (uint32_t)((int32_t)d >> 31);                   // tt < c: the bit is in the lower half
-    tt = B3(lt, tt, d, T_SEL);
-    ps = B3(ps, (uint32_t)sh, lt, TA | (TB & ~TC & 0xFF));              // ps | (sh & ~lt)
+    const uint32_t e = (uint32_t)__popc(__builtin_amdgcn_ubfe(v, ps, (uint32_t)sh)) + ntt;
+    const uint32_t ge = (uint32_t)((int32_t)e >> 31);
+    ntt = B3(ge, e, ntt, T_SEL);
+    ps = B3((uint32_t)sh, ge, ps, T_ANDOR);                             // ps | (sh & ge)
   }
   return ps;
 }
@@ -266,9 +269,10 @@ __device__ __forceinline__ void lat_emit(uint8_t *g, uint32_t black, uint32_t wh
 // Phases 2 - 6 of a ply on the boards of the wave: Q = the new stone (one bit in the lane of its row, 0 in every other lane and
 // on a board that passes or does not move), pass (the same in every lane of a board), lv = 0 / ~0: the board moves this ply.
 // me / op / M / inv / fl are updated in place (roles swapped for the boards that moved).
+// FIVE floods (round 5's ply): one per neighbour of q + G.  Since round 6 the rare path of lat_play below.
 template <int R>
-__device__ __forceinline__ void lat_play(uint32_t &me, uint32_t &op, uint32_t &M, uint32_t &inv, uint32_t &fl, const uint32_t Q,
-                                         const bool pass, const uint32_t lv, const uint32_t full) {
+__device__ __forceinline__ void lat_play_full(uint32_t &me, uint32_t &op, uint32_t &M, uint32_t &inv, uint32_t &fl, const uint32_t Q,
+                                           const bool pass, const uint32_t lv, const uint32_t full) {
   using L = Lat<R>;
   constexpr int LPB = L::LPB, FW = L::FW, NF = L::NF, NREG = L::NREG;
   // 2. the stone, its four neighbours, the five floods
@@ -356,6 +360,151 @@ __device__ __forceinline__ void lat_play(uint32_t &me, uint32_t &op, uint32_t &M
   fl = B3(lv, fl2, fl, T_SEL);
 }
 
+// The usual ply (round 6): THREE floods.  An opponent group next to q that is NOT in M had q as its only liberty - it is
+// captured whatever its shape - so only the neighbours of q that are in M (>= 2 liberties before the move) need a liberty
+// count of their own, and more than two DISTINCT such groups next to one point are rare (1.2 % of the moves, measured on
+// stationary 9x9 and 19x19 positions; two: 10 - 13 %).  Slot A floods every atari neighbour + the FIRST neighbour in M
+// (priority up, down, left, right), slot B the SECOND one, the third field is G: a 9x9 ply is ONE flood register instead of
+// two, 13x13 two instead of three, 19x19 three instead of five, and all the board sums travel in one word.  Neighbours in M
+// beyond the second must lie in A | B (they are stones of the same groups); when one does not, a second round floods the
+// left-over neighbours (4 % of the wave-plies at four 9x9 boards per wave).  tests/devtools/lat_model.py: the same in NumPy.
+template <int R>
+__device__ __forceinline__ void lat_play(uint32_t &me, uint32_t &op, uint32_t &M, uint32_t &inv, uint32_t &fl, const uint32_t Q,
+                                         const bool pass, const uint32_t lv, const uint32_t full) {
+  using L = Lat<R>;
+  constexpr int LPB = L::LPB, FW = L::FW, NF = L::NF, NREG = L::NREG3, NFL = L::NFL3;
+  // 2. the stone, its four neighbours, the three floods
+  const uint32_t me1 = me | Q;
+  const uint32_t su = lat_below<LPB>(Q), sd = lat_above<LPB>(Q);   // the point above q lies one row up: that lane takes Q from the lane below it
+  const uint32_t sl = Q >> 1, sr = shl1(Q);
+  const uint32_t nbr = B3(su, sd, sl, T_OR3) | sr;
+  const uint32_t open = B3(nbr, full, op, T_AND_ANDN);   // on-board neighbours of q that do not hold an opponent stone
+  const uint32_t mAll = B3(nbr, op, M, TA & TB & TC);    // the opponent's stones next to q whose group had >= 2 liberties
+  const uint32_t aAll = B3(nbr, op, M, T_AND_ANDN);      // ... and the ones in atari: captured
+  uint32_t seedA, seedB;
+  {
+    const uint32_t mUl = su & mAll, mDl = sd & mAll, mL = sl & mAll, mR = sr & mAll;   // in the lanes of their rows
+    const uint32_t fU = lat_above<LPB>(mUl), fD = lat_below<LPB>(mDl);                 // ... and as flags at q's own bit, in q's lane
+    const uint32_t gU = lat_above<LPB>(fU);                                            // the lane below q learns about the point above q
+    const uint32_t fL = shl1(mL), fR = mR >> 1;
+    const uint32_t p1L = B3(fL, fU, fD, TA & ~(TB | TC) & 0xFF);      // left is the first neighbour in M
+    const uint32_t p2L = B3(fL, fU, fD, TA & (TB ^ TC));              // ... the second
+    const uint32_t udl = B3(fU, fD, fL, T_OR3);
+    const uint32_t p1R = fR & ~udl;
+    const uint32_t p2R = fR & B3(fU, fD, fL, 0x16);                   // exactly one of up / down / left
+    seedA = B3(aAll, mUl, B3(mDl, gU, p1L >> 1, (TA & ~TB & 0xFF) | TC), T_OR3) | shl1(p1R);
+    seedB = B3(mDl & gU, p2L >> 1, shl1(p2R), T_OR3);
+  }
+  uint32_t F[NREG], Mk[NREG], Mkr[NREG];
+  {
+    const uint32_t seeds[NFL] = {seedA, seedB, Q};
+#pragma unroll
+    for (int k2 = 0; k2 < NREG; ++k2) { F[k2] = 0; Mk[k2] = 0; }
+#pragma unroll
+    for (int f = 0; f < NFL; ++f) {
+      F[f / NF] |= seeds[f] << ((FW * (f % NF)) & 31);
+      Mk[f / NF] |= (f < 2 ? op : me1) << ((FW * (f % NF)) & 31);
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < NREG; ++k2) Mkr[k2] = __brev(Mk[k2]);
+  }
+  lat_flood<LPB, NREG>(F, Mk, Mkr);
+  uint32_t fr[NFL];
+#pragma unroll
+  for (int f = 0; f < NFL; ++f) fr[f] = NF == 1 ? F[f] : ((F[f / NF] >> ((FW * (f % NF)) & 31)) & L::FM);
+  uint32_t U = fr[0] | fr[1];
+  const uint32_t G = fr[2];
+  const uint32_t C = fr[0] & ~M;                      // the opponent groups next to q that were in atari: captured
+  // 3. liberties of the three groups: dilate & empty (G's include the captured points; the captured part of slot A has none
+  // among the empty points - q was its only liberty), counted per lane, summed per board in ONE word: 8-bit fields A, B, G,
+  // then the number of captured stones (6 bits) and "some on-board neighbour of q is not the opponent's" (2 bits)
+  const uint32_t E1 = full & ~(me1 | op), EG = E1 | C;
+  uint32_t W = 0;
+  {
+    uint32_t Ee[NREG];
+#pragma unroll
+    for (int k2 = 0; k2 < NREG; ++k2) Ee[k2] = 0;
+#pragma unroll
+    for (int f = 0; f < NFL; ++f) Ee[f / NF] |= (f < 2 ? E1 : EG) << ((FW * (f % NF)) & 31);
+    uint32_t Lb[NREG];
+#pragma unroll
+    for (int k2 = 0; k2 < NREG; ++k2) Lb[k2] = lat_dilate<LPB>(F[k2]) & Ee[k2];
+#pragma unroll
+    for (int f = 0; f < NFL; ++f) {
+      uint32_t c = (uint32_t)__popc(NF == 1 ? Lb[f] : (Lb[f / NF] & (L::FM << ((FW * (f % NF)) & 31))));
+      if (L::kSat) c = c < 2u ? c : 2u;
+      W |= c << (8 * f);
+    }
+    uint32_t pc = (uint32_t)__popc(C);
+    pc = pc < 2u ? pc : 2u;
+    W |= (pc << 24) | (open ? 0x40000000u : 0u);
+  }
+  const uint32_t S = lat_board_sum<LPB>(W);
+  // ... and the rare second round: a neighbour of q in M that A | B do not cover is a THIRD (fourth) distinct group.  Up and
+  // down are always first or second, so only the left and the right neighbour can be left over - each in a slot of its own:
+  // one more flood of the two opponent fields (the masks of round one serve again; G's field stays empty), their liberties,
+  // their board sums.  (4 % of the wave-plies at four 9x9 boards per wave, 3 % at two 19x19 boards.)
+  uint32_t M1x = 0;   // round-two groups that keep >= 2 liberties
+  if (__builtin_expect(__ballot((mAll & ~U) != 0u) != 0ull, 0)) {
+    constexpr int K2 = NF == 1 ? 2 : 1;
+    const uint32_t s2[2] = {(uint32_t)B3(sl, mAll, U, T_AND_ANDN), (uint32_t)B3(sr, mAll, U, T_AND_ANDN)};
+    uint32_t F2[K2], Mk2[K2], Mkr2[K2];
+#pragma unroll
+    for (int k2 = 0; k2 < K2; ++k2) { Mk2[k2] = Mk[k2]; Mkr2[k2] = Mkr[k2]; }
+    if (NF == 1) { F2[0] = s2[0]; F2[K2 - 1] = s2[1]; }
+    else F2[0] = s2[0] | (s2[1] << (FW & 31));
+    lat_flood<LPB, K2>(F2, Mk2, Mkr2);
+    uint32_t Lb2[K2], W2 = 0, f2[2];
+#pragma unroll
+    for (int k2 = 0; k2 < K2; ++k2) Lb2[k2] = lat_dilate<LPB>(F2[k2]) & (NF == 1 ? E1 : (E1 | (E1 << (FW & 31))));
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      f2[f] = NF == 1 ? F2[f < K2 ? f : 0] : ((F2[0] >> ((FW * f) & 31)) & L::FM);
+      uint32_t c = (uint32_t)__popc(NF == 1 ? Lb2[f < K2 ? f : 0] : (Lb2[0] & (L::FM << ((FW * f) & 31))));
+      if (L::kSat) c = c < 2u ? c : 2u;
+      W2 |= c << (8 * f);
+    }
+    const uint32_t g2 = lat_board_sum<LPB>(W2) + 0x00007E7Eu;
+    M1x = ((uint32_t)((int32_t)(g2 << 24) >> 31) & f2[0]) | ((uint32_t)((int32_t)(g2 << 16) >> 31) & f2[1]);
+    U |= f2[0] | f2[1];
+  }
+  // 4. class patch: every flooded group leaves M and comes back with >= 2 liberties (count + 126 carries into bit 7)
+  const uint32_t g1 = S + 0x007E7E7Eu;
+  uint32_t M1 = B3(M, U, G, TA & ~(TB | TC) & 0xFF) | M1x;
+  M1 = B3((uint32_t)((int32_t)(g1 << 24) >> 31), fr[0] & M, M1, T_ANDOR);
+  M1 = B3((uint32_t)((int32_t)(g1 << 16) >> 31), fr[1], M1, T_ANDOR);
+  M1 = B3((uint32_t)((int32_t)(g1 << 8) >> 31), G, M1, T_ANDOR);
+  uint32_t K = 0;
+  if (__ballot(C != 0)) {   // some board of the wave captures
+    // ko: exactly one stone died and q is boxed in (gym_go/gogame.py:72-75, state_utils.adj_data)
+    if (((S >> 24) & 0x3Fu) == 1u && (S >> 30) == 0u) K = C;
+    // a mover's group in atari next to a captured stone (not G: its count above includes them) gains a liberty
+    uint32_t X[1], Xm[1], Xr[1];
+    Xm[0] = B3(me1, M, G, TA & ~(TB | TC) & 0xFF);
+    X[0] = lat_dilate<LPB>(C) & Xm[0];
+    if (__ballot(X[0] != 0)) {
+      Xr[0] = __brev(Xm[0]);
+      lat_flood<LPB, 1>(X, Xm, Xr);
+      M1 |= X[0];
+    }
+  }
+  // 5. the next mover's invalid-move mask (state_utils.compute_invalid_moves restated point-wise): an empty
+  // point is playable iff some neighbour is empty, a next-mover stone with >= 2 liberties or a mover's stone in atari
+  const uint32_t op2 = op & ~C;
+  const uint32_t E2 = full & ~(me1 | op2);
+  const uint32_t xs = E2 | B3(M1, op2, me1, T_SEL);
+  const uint32_t nbs = lat_dilate<LPB>(xs);
+  const uint32_t inv2 = B3(full, E2, nbs, TA & ~(TB & TC) & 0xFF) | K;
+  // 6. roles swap for the boards that moved; flags: turn flips, passed = pass, done = two passes in a row
+  me = B3(lv, op2, me1, T_SEL);
+  op = B3(lv, me1, op2, T_SEL);
+  inv = B3(lv, inv2, inv, T_SEL);
+  M = M1;
+  const uint32_t pm = pass ? ~0u : 0u;
+  const uint32_t fl2 = ((fl ^ 1u) & 1u) | (pm & 2u) | (pm & (fl << 1) & 4u);
+  fl = B3(lv, fl2, fl, T_SEL);
+}
+
 template <int R>
 struct LdsLat {
   using L = Lat<R>;
@@ -370,9 +519,13 @@ struct LdsLat {
 // IO: 0 = byte planes (uint8 [B][6][N][N]); 2 = TRACKED boards (uint32 [B][5N+1]: the rows of black, white, invalid,
 // multi_black, multi_white + the flag word, gg_v4.h) - a lane reads and writes its own five row words, the classes travel with
 // the board: no LDS, no first analysis, so even a one-ply launch is just the ply
+// SHORT: the launch is one or two plies long (tracked boards only) - a latency chain that lasts as long as its slowest wave, and
+// with so few plies SOME wave of the launch takes the rare second flood round of the three-flood ply, so a short launch runs the
+// five-flood ply and mixes its draws lane by lane; as an instantiation of its own (not a branch) because a one-ply launch
+// also pays for every instruction-cache line it has to jump to (3.19 us per hipGraph node at config 2's size against 3.36)
 // WPB: waves per workgroup, each wave an independent group of boards (a launch of single-wave workgroups enters the machine over
 // ~0.26 ns per workgroup - tools/exp/oneply_ramp.py - which a ONE-ply launch of a thousand workgroups feels: k_rollout_lat_w4)
-template <int R, bool FULLN, bool AUTO, int IO, int WPB>
+template <int R, bool FULLN, bool AUTO, int IO, int WPB, bool SHORT>
 __device__ __forceinline__ void rollout_lat_body(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                  int32_t *__restrict__ last_actions,
                                                  int64_t *__restrict__ steps_done, int64_t B, int N, int plies,
@@ -459,6 +612,13 @@ __device__ __forceinline__ void rollout_lat_body(uint8_t *__restrict__ states, u
     }
     int lastv = -1, played = 0;
     const int rN = r * N;
+    // The draws of a board, LPB plies at a time: the generator is a counter (x += c per draw) and a board draws once per ply
+    // from ply 0 until it freezes for good, so the draw of ply t is mix(x0 + (t + 1) c) - lane r of the board computes the one
+    // of ply t0 + r every LPB plies, a ply fetches its own with one ds_bpermute (in flight under the popcounts and board scans),
+    // and the generator the launch leaves behind is x0 + played c.  (19 VALU instructions per ply -> 2.)
+    const uint64_t x0 = x;
+    uint32_t uq = 0;
+    const int lane_b0 = lane & ~(LPB - 1);
     GG_PROF(6);   // load + first classes
     // ---------------------------------------------------------------- plies
 #pragma unroll 1
@@ -471,14 +631,22 @@ __device__ __forceinline__ void rollout_lat_body(uint8_t *__restrict__ states, u
       }
       const uint32_t lv = live ? ~0u : 0u;
       // 1. the draw: uniform over the valid points + the pass (GoEnv.uniform_random_action; oracle/gg_oracle.c rollout_ply)
+      uint32_t uh;
+      if (SHORT) {   // (a one- or two-ply launch is a latency chain: every lane mixes the ply's draw itself, no hand-off)
+        uint64_t xx = x0 + (uint64_t)(uint32_t)t * 0x9E3779B97F4A7C15ull;
+        uh = (uint32_t)(splitmix_next(xx) >> 32);
+      } else {
+        if ((t & (LPB - 1)) == 0) {
+          uint64_t xx = x0 + (uint64_t)(uint32_t)(t + r) * 0x9E3779B97F4A7C15ull;   // (splitmix_next adds the (t + r + 1)-th c itself)
+          uq = (uint32_t)(splitmix_next(xx) >> 32);
+        }
+        uh = (uint32_t)__builtin_amdgcn_ds_bpermute((lane_b0 + (t & (LPB - 1))) << 2, (int)uq);
+      }
       const uint32_t valid = full & ~inv;
       const uint32_t cnt = (uint32_t)__popc(valid);
       const uint32_t incl = lat_board_scan<LPB>(cnt);
       const uint32_t total = lat_board_sum<LPB>(cnt);
-      uint64_t xn = x;
-      const uint64_t u = splitmix_next(xn);
-      if (live) x = xn;
-      const uint32_t k = __umulhi((uint32_t)(u >> 32), total + 1u);
+      const uint32_t k = __umulhi(uh, total + 1u);
       const uint32_t tt = k - (incl - cnt);
       const bool hit = live && tt < cnt;                 // this lane's row holds the k-th valid point
       const uint32_t pos = lat_kth_bit<L::kBits>(valid, tt);
@@ -490,7 +658,8 @@ __device__ __forceinline__ void rollout_lat_body(uint8_t *__restrict__ states, u
       }
       played -= (int)lv;
       GG_PROF(0);
-      lat_play<R>(me, op, M, inv, fl, Q, pass, lv, full);
+      if (SHORT) lat_play_full<R>(me, op, M, inv, fl, Q, pass, lv, full);
+      else lat_play<R>(me, op, M, inv, fl, Q, pass, lv, full);
       GG_PROF(4);
     }
     GG_PROF(5);
@@ -510,7 +679,7 @@ __device__ __forceinline__ void rollout_lat_body(uint8_t *__restrict__ states, u
                     lds + LdsLat<R>::kBs + j * L::kBsWords, lut, on && played != 0);
       }
       if (on && r == 0) {
-        rng[b] = x;
+        rng[b] = x0 + (uint64_t)(uint32_t)played * 0x9E3779B97F4A7C15ull;
         if (last_actions) last_actions[b] = lastb;
         if (steps_done && played) atomicAdd(reinterpret_cast<unsigned long long *>(steps_done) + b, (unsigned long long)played);
       }
@@ -519,20 +688,20 @@ __device__ __forceinline__ void rollout_lat_body(uint8_t *__restrict__ states, u
   }
   GG_PROF_FLUSH;
 }
-template <int R, bool FULLN, bool AUTO, int IO = 0>
+template <int R, bool FULLN, bool AUTO, int IO = 0, bool SHORT = false>
 __global__ __launch_bounds__(kWave, 4) void k_rollout_lat(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                           int32_t *__restrict__ last_actions,
                                                           int64_t *__restrict__ steps_done, int64_t B, int N, int plies,
                                                           int auto_reset) {
-  rollout_lat_body<R, FULLN, AUTO, IO, 1>(states, rng, last_actions, steps_done, B, N, plies, auto_reset);
+  rollout_lat_body<R, FULLN, AUTO, IO, 1, SHORT>(states, rng, last_actions, steps_done, B, N, plies, auto_reset);
 }
 // tracked boards, a few plies per launch: four waves per workgroup
-template <int R, bool FULLN, bool AUTO>
+template <int R, bool FULLN, bool AUTO, bool SHORT>
 __global__ __launch_bounds__(4 * kWave, 4) void k_rollout_lat_w4(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                                  int32_t *__restrict__ last_actions,
                                                                  int64_t *__restrict__ steps_done, int64_t B, int N, int plies,
                                                                  int auto_reset) {
-  rollout_lat_body<R, FULLN, AUTO, 2, 4>(states, rng, last_actions, steps_done, B, N, plies, auto_reset);
+  rollout_lat_body<R, FULLN, AUTO, 2, 4, SHORT>(states, rng, last_actions, steps_done, B, N, plies, auto_reset);
 }
 
 // Tromp-Taylor areas (gym_go/gogame.py:275-300) of the wave's boards in this layout: a colour owns its stones plus the empty
@@ -649,7 +818,7 @@ __device__ __forceinline__ void env_step_lat_body(uint32_t *__restrict__ tracked
       pass = k == total;
       taken = lat_board_max<LPB>(!live ? -1 : (hit ? r * N + (int)pos : (pass ? P : -1)));
     }
-    if (__ballot(live)) lat_play<R>(me, op, M, inv, fl, Q, pass, lv, full);
+    if (__ballot(live)) lat_play_full<R>(me, op, M, inv, fl, Q, pass, lv, full);   // (one ply per launch: see rollout_lat_body)
     // ---- the boards after the step, GoEnv.step's outputs
     const uint32_t turn = fl & 1u;
     const uint32_t bl = turn ? op : me, wh = turn ? me : op;

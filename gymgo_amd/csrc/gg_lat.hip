@@ -19,13 +19,19 @@ namespace gg {
 #define GG_LAT(R, F)                                                                                                            \
   do {                                                                                                                          \
     const unsigned grid_ = (unsigned)((B + Lat<R>::NBW - 1) / Lat<R>::NBW);                                                     \
+    const unsigned grid4_ = (grid_ + 3u) / 4u;                                                                                  \
     if (io == 0) {                                                                                                              \
       if (auto_reset) k_rollout_lat<R, F, true, 0><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 1);  \
       else k_rollout_lat<R, F, false, 0><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 0);            \
+    } else if (w4 && plies <= 2) {                                                                                              \
+      if (auto_reset) k_rollout_lat_w4<R, F, true, true><<<grid4_, 4 * kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 1); \
+      else k_rollout_lat_w4<R, F, false, true><<<grid4_, 4 * kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 0); \
     } else if (w4) {                                                                                                            \
-      const unsigned grid4_ = (grid_ + 3u) / 4u;                                                                                \
-      if (auto_reset) k_rollout_lat_w4<R, F, true><<<grid4_, 4 * kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 1); \
-      else k_rollout_lat_w4<R, F, false><<<grid4_, 4 * kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 0);       \
+      if (auto_reset) k_rollout_lat_w4<R, F, true, false><<<grid4_, 4 * kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 1); \
+      else k_rollout_lat_w4<R, F, false, false><<<grid4_, 4 * kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 0); \
+    } else if (plies <= 2) {                                                                                                    \
+      if (auto_reset) k_rollout_lat<R, F, true, 2, true><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 1); \
+      else k_rollout_lat<R, F, false, 2, true><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 0);      \
     } else {                                                                                                                    \
       if (auto_reset) k_rollout_lat<R, F, true, 2><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 1);  \
       else k_rollout_lat<R, F, false, 2><<<grid_, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, N, plies, 0);            \

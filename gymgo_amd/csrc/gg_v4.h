@@ -109,7 +109,7 @@ __device__ __forceinline__ uint32_t quad_sum(uint32_t x) { x += dpp0<QP_X1>(x); 
 template <int RPL>
 __device__ __forceinline__ void kth_set_bit(const uint32_t (&v)[RPL], const uint32_t (&p)[RPL], uint32_t tt, int &rr,
                                             uint32_t &pos) {
-  const uint32_t ntt = ~tt;
+  uint32_t ntt = ~tt;
   uint32_t vr = v[0], base = 0, row = 0;
 #pragma unroll
   for (int r = 1; r < RPL; ++r) {
@@ -118,15 +118,16 @@ __device__ __forceinline__ void kth_set_bit(const uint32_t (&v)[RPL], const uint
     base = B3(ge, p[r - 1], base, T_SEL);
     row -= ge;
   }
-  tt -= base;
+  ntt += base;                                                          // ~(tt - base)
   uint32_t ps = 0;
 #pragma unroll
   for (int sh = 16; sh >= 1; sh >>= 1) {
-    const uint32_t c = (uint32_t)__popc((vr >> ps) & ((1u << sh) - 1u));
-    const uint32_t d = tt - c;
-    const uint32_t lt = (uint32_t)((int32_t)d >> 31);                   // tt < c: the bit is in the lower half
-    tt = B3(lt, tt, d, T_SEL);
-    ps = B3(ps, (uint32_t)sh, lt, TA | (TB & ~TC & 0xFF));              // ps | (sh & ~lt)
+    // c + ~tt = c - tt - 1 is negative iff tt >= c (the bit is in the upper half) - and is ~(tt - c) then: the popcount is added
+    // to ~tt by the v_bcnt itself
+    const uint32_t e = (uint32_t)__popc((vr >> ps) & ((1u << sh) - 1u)) + ntt;
+    const uint32_t ge = (uint32_t)((int32_t)e >> 31);
+    ntt = B3(ge, e, ntt, T_SEL);
+    ps = B3((uint32_t)sh, ge, ps, T_ANDOR);                             // ps | (sh & ge)
   }
   rr = (int)row;
   pos = ps;
@@ -587,6 +588,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
 #define GG_AB_EARLY4 false
 #endif
     const uint32_t fair_lag = plies >= 192 ? GG_AB_FAIRLAG : (plies >= 16 ? (uint32_t)plies >> 3 : 2u);
+    uint32_t uq = 0;   // (drawn moves) this lane's pre-mixed draw: lane j of a quad holds the one of ply (t & ~3) + j, rotated by one lane per ply
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
       // fair share of the SIMD (gg_common.h): every fourth ply the wave publishes the ply it has reached and sets its issue
@@ -672,9 +674,18 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
           const uint32_t sh2 = dpp0<QP_SHR2>(x1);
           const uint32_t Sx = x1 + (t5 >= 2 ? sh2 : 0u);
           const uint32_t n = dpp0<QP_B3>(Sx), P = Sx - T;
-          x = ((uint64_t)rngv[2 * s4 + 1] << 32) | rngv[2 * s4];
-          const uint64_t u = splitmix_next(x);
-          const uint32_t k = (uint32_t)(((u >> 32) * (uint64_t)(n + 1)) >> 32);   // k == n: the pass
+          // The draws of a board, FOUR plies at a time: the generator is a counter (x += c per draw) and a board draws once per
+          // ply from ply 0 until it freezes for good, so the draw of ply t is mix(x0 + (t + 1) c) with x0 the generator the launch
+          // found (it stays in LDS untouched until the write-back, which leaves x0 + played c).  Lane j of the quad mixes the
+          // draw of ply t + j every fourth ply; a ply takes lane 0's and the quad rotates by one lane: 2 DPP moves instead of
+          // the 64-bit mix (19 VALU instructions, six of them multiplies) + an LDS round trip of the generator per ply.
+          if ((t & 3) == 0) {
+            uint64_t xx = (((uint64_t)rngv[2 * s4 + 1] << 32) | rngv[2 * s4]) + (uint64_t)(uint32_t)(t + t5) * 0x9E3779B97F4A7C15ull;
+            uq = (uint32_t)(splitmix_next(xx) >> 32);
+          }
+          const uint32_t uh = dpp0<QP_B0>(uq);
+          uq = dpp0<0x39>(uq);   // quad_perm [1,2,3,0]: lane i takes lane i + 1's
+          const uint32_t k = __umulhi(uh, n + 1u);   // k == n: the pass
           const bool hit = k >= P && k < P + T;        // this lane holds the k-th valid point
           int rr;
           kth_set_bit<RPL>(v, p, (k - P) & 0x3FFu, rr, pos);   // (only the hit lane's result is used; the mask keeps tt small elsewhere)
@@ -686,11 +697,9 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
           place = bl && live && hit;
           if (ENV && on && !live && t5 == 0) flagsv[s4] = fl | 16u;   // a frozen game refuses the step
         }
-        if (wr_act) actv[s4] = a;
         // (one lane of a board announces the move - the one that holds the point, or the first: a quad OR hands it round)
         a_q = MOVES ? a : (int)quad_or(wr_act ? (uint32_t)(a + 2) : 0u) - 2;
         fl_q = reset ? 40u : fl;   // a board being reset: on, dirty, black to move
-        if (!MOVES && bl && t5 == 0 && live) { rngv[2 * s4] = (uint32_t)x; rngv[2 * s4 + 1] = (uint32_t)(x >> 32); }
         // (a finished game whose move is refused is still reset when auto_reset - GoEnv.reset comes before the action
         // check - also when no board of the wave moves: the resets are applied before the early exit)
         uint64_t resetm = __ballot(reset && t5 == 0);
@@ -1063,7 +1072,8 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         if (CACHED) {
           if (env.status) env.status[b] = played ? GG_STATUS_OK : GG_STATUS_ILLEGAL;
         } else {
-          if (!MOVES || WTS) rng[b] = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
+          // (drawn moves: the generator the launch found + one step per ply played - see the draw; policy-weighted moves: as the draw block left it)
+          if (!MOVES || WTS) rng[b] = (((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb]) + (MOVES ? 0ull : (uint64_t)(uint32_t)played * 0x9E3779B97F4A7C15ull);
           if (last_actions) last_actions[b] = lastv[sb];
           if (steps_done && played) atomicAdd(reinterpret_cast<unsigned long long *>(steps_done) + b, (unsigned long long)played);   // (no read-back: nothing to wait for)
           if (MOVES && played_out) played_out[b] = played;
@@ -1138,7 +1148,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
         const int sb = hs.lane;
         const int64_t b = b_first + sb;
         const int played = playedv[sb];
-        if (!MOVES) rng[b] = ((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb];
+        if (!MOVES) rng[b] = (((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb]) + (uint64_t)(uint32_t)played * 0x9E3779B97F4A7C15ull;
         if (last_actions) last_actions[b] = lastv[sb];
         if (steps_done && played) atomicAdd(reinterpret_cast<unsigned long long *>(steps_done) + b, (unsigned long long)played);
         if (MOVES && played_out) played_out[b] = played;
@@ -1173,7 +1183,7 @@ __global__ __launch_bounds__(kWave, 4) void k_rollout4(uint8_t *__restrict__ sta
                         v2 + hs.h * 128, lut, wr);
       }
       if (on && hs.hl == 0) {
-        if (!MOVES) rng[b] = ((uint64_t)rngv[2 * s + 1] << 32) | rngv[2 * s];
+        if (!MOVES) rng[b] = (((uint64_t)rngv[2 * s + 1] << 32) | rngv[2 * s]) + (uint64_t)(uint32_t)played * 0x9E3779B97F4A7C15ull;
         if (last_actions) last_actions[b] = lastv[s];
         if (steps_done && played) atomicAdd(reinterpret_cast<unsigned long long *>(steps_done) + b, (unsigned long long)played);
         if (MOVES && played_out) played_out[b] = played;

@@ -60,7 +60,10 @@ class Model:
         self.NBW = 64 // self.LPB
         self.FW = 10 if R <= 9 else (16 if R <= 15 else 32)
         self.NF = 32 // self.FW
-        self.NREG = (5 + self.NF - 1) // self.NF
+        self.NREG = (5 + self.NF - 1) // self.NF      # the five-flood fallback
+        self.NREG3 = (3 + self.NF - 1) // self.NF     # the fast path: two opponent slots + G
+        self.fallbacks = 0
+        self.plays = 0
         self.FM = 0xFFFFFFFF if self.FW >= 32 else (1 << self.FW) - 1
         self.kBits = 16 if R <= 16 else 32
         self.kSat = R > 9
@@ -276,76 +279,190 @@ class Model:
             pas = k == total
             lastv = np.where(live, np.where(hit, r * N + pos.astype(np.int64), np.where(pas, P, -1)), lastv)
             played += live
-            me1 = me | Q
-            su, sd = self.below(Q), self.above(Q)
-            sl, sr = Q >> U32(1), Q + Q
-            opn = B3(B3(su, sd, sl, T_OR3) | sr, full, op, T_AND_ANDN)
-            seeds = [su & op, sd & op, sl & op, sr & op, Q]
-            F = [np.zeros(64, U32) for _ in range(NREG)]
-            Mk = [np.zeros(64, U32) for _ in range(NREG)]
-            for f in range(5):
-                sh = U32((FW * (f % NF)) & 31)
-                F[f // NF] |= seeds[f] << sh
-                Mk[f // NF] |= (op if f < 4 else me1) << sh
-            Mkr = [brev(m) for m in Mk]
-            F = self.flood(F, Mk, Mkr)
-            fr = [F[f] if NF == 1 else (F[f // NF] >> U32((FW * (f % NF)) & 31)) & U32(self.FM) for f in range(5)]
-            U = B3(fr[0], fr[1], fr[2], T_OR3) | fr[3]
-            G = fr[4]
-            C = U & ~M
-            E1 = full & ~(me1 | op)
-            EG = E1 | C
-            Ee = [np.zeros(64, U32) for _ in range(NREG)]
-            for f in range(5):
-                Ee[f // NF] |= (E1 if f < 4 else EG) << U32((FW * (f % NF)) & 31)
-            Lb = [self.dilate(F[k2]) & Ee[k2] for k2 in range(NREG)]
-            W1 = np.zeros(64, U32)
-            W2 = np.zeros(64, U32)
-            for f in range(5):
-                c = popc(Lb[f] if NF == 1 else Lb[f // NF] & U32((self.FM << ((FW * (f % NF)) & 31)) & 0xFFFFFFFF))
-                if self.kSat:
-                    c = np.minimum(c, U32(2))
-                if f < 4:
-                    W1 |= c << U32(8 * f)
-                else:
-                    W2 = c.copy()
-            pc = np.minimum(popc(C), U32(2))
-            W2 |= (pc << U32(8)) | np.where(opn != 0, U32(0x10000), U32(0)).astype(U32)
-            S1, S2 = self.board_sum(W1), self.board_sum(W2)
-            g1 = S1 + U32(0x7E7E7E7E)
-            M1 = B3(M, U, G, TA & ~(TB | TC) & 0xFF)
-            for f in range(4):
-                ge = ((g1 << U32(24 - 8 * f)).astype(np.int32) >> 31).astype(U32)
-                M1 = B3(ge, fr[f], M1, T_ANDOR)
-            geG = ((U32(1) - (S2 & U32(0xFF))).astype(np.int32) >> 31).astype(U32)
-            M1 = B3(geG, G, M1, T_ANDOR)
-            K = np.zeros(64, U32)
-            if (C != 0).any():
-                kc = (((S2 >> U32(8)) & U32(0xFF)) == 1) & (((S2 >> U32(16)) & U32(0xFF)) == 0)
-                K = np.where(kc, C, U32(0)).astype(U32)
-                Xm = B3(me1, M, G, TA & ~(TB | TC) & 0xFF)
-                X = self.dilate(C) & Xm
-                if (X != 0).any():
-                    X = self.flood([X], [Xm], [brev(Xm)])[0]
-                    M1 = M1 | X
-            op2 = op & ~C
-            E2 = full & ~(me1 | op2)
-            xs = E2 | B3(M1, op2, me1, T_SEL)
-            nbs = self.dilate(xs)
-            inv2 = B3(full, E2, nbs, TA & ~(TB & TC) & 0xFF) | K
-            me = B3(lv, op2, me1, T_SEL)
-            op = B3(lv, me1, op2, T_SEL)
-            inv = B3(lv, inv2, inv, T_SEL)
-            M = M1
-            pm = np.where(pas, U32(0xFFFFFFFF), U32(0)).astype(U32)
-            fl2 = ((fl ^ U32(1)) & U32(1)) | (pm & U32(2)) | (pm & (fl << U32(1)) & U32(4))
-            fl = B3(lv, fl2, fl, T_SEL)
+            me, op, M, inv, fl = self.play(me, op, M, inv, fl, Q, pas, lv, full)
             if check is not None:
                 check(t, self._emit(me, op, inv, fl, N, nb, r, j, on), M, full)
         out = self._emit(me, op, inv, fl, N, nb, r, j, on)
         lastb = self.board_max(lastv)
         return out, np.array([x[jj * LPB] for jj in range(nb)], np.uint64), np.array([lastb[jj * LPB] for jj in range(nb)]), \
             np.array([played[jj * LPB] for jj in range(nb)])
+
+    def play_full(self, me, op, M, inv, fl, Q, pas, lv, full):
+        """the five-flood ply (round 5): the fallback of play() when q touches three distinct opponent groups with >= 2 liberties"""
+        me1 = me | Q
+        su, sd = self.below(Q), self.above(Q)
+        sl, sr = Q >> U32(1), Q + Q
+        opn = B3(B3(su, sd, sl, T_OR3) | sr, full, op, T_AND_ANDN)
+        seeds = [su & op, sd & op, sl & op, sr & op, Q]
+        F = [np.zeros(64, U32) for _ in range(self.NREG)]
+        Mk = [np.zeros(64, U32) for _ in range(self.NREG)]
+        for f in range(5):
+            sh = U32((self.FW * (f % self.NF)) & 31)
+            F[f // self.NF] |= seeds[f] << sh
+            Mk[f // self.NF] |= (op if f < 4 else me1) << sh
+        Mkr = [brev(m) for m in Mk]
+        F = self.flood(F, Mk, Mkr)
+        fr = [F[f] if self.NF == 1 else (F[f // self.NF] >> U32((self.FW * (f % self.NF)) & 31)) & U32(self.FM) for f in range(5)]
+        U = B3(fr[0], fr[1], fr[2], T_OR3) | fr[3]
+        G = fr[4]
+        C = U & ~M
+        E1 = full & ~(me1 | op)
+        EG = E1 | C
+        Ee = [np.zeros(64, U32) for _ in range(self.NREG)]
+        for f in range(5):
+            Ee[f // self.NF] |= (E1 if f < 4 else EG) << U32((self.FW * (f % self.NF)) & 31)
+        Lb = [self.dilate(F[k2]) & Ee[k2] for k2 in range(self.NREG)]
+        W1 = np.zeros(64, U32)
+        W2 = np.zeros(64, U32)
+        for f in range(5):
+            c = popc(Lb[f] if self.NF == 1 else Lb[f // self.NF] & U32((self.FM << ((self.FW * (f % self.NF)) & 31)) & 0xFFFFFFFF))
+            if self.kSat:
+                c = np.minimum(c, U32(2))
+            if f < 4:
+                W1 |= c << U32(8 * f)
+            else:
+                W2 = c.copy()
+        pc = np.minimum(popc(C), U32(2))
+        W2 |= (pc << U32(8)) | np.where(opn != 0, U32(0x10000), U32(0)).astype(U32)
+        S1, S2 = self.board_sum(W1), self.board_sum(W2)
+        g1 = S1 + U32(0x7E7E7E7E)
+        M1 = B3(M, U, G, TA & ~(TB | TC) & 0xFF)
+        for f in range(4):
+            ge = ((g1 << U32(24 - 8 * f)).astype(np.int32) >> 31).astype(U32)
+            M1 = B3(ge, fr[f], M1, T_ANDOR)
+        geG = ((U32(1) - (S2 & U32(0xFF))).astype(np.int32) >> 31).astype(U32)
+        M1 = B3(geG, G, M1, T_ANDOR)
+        K = np.zeros(64, U32)
+        if (C != 0).any():
+            kc = (((S2 >> U32(8)) & U32(0xFF)) == 1) & (((S2 >> U32(16)) & U32(0xFF)) == 0)
+            K = np.where(kc, C, U32(0)).astype(U32)
+            Xm = B3(me1, M, G, TA & ~(TB | TC) & 0xFF)
+            X = self.dilate(C) & Xm
+            if (X != 0).any():
+                X = self.flood([X], [Xm], [brev(Xm)])[0]
+                M1 = M1 | X
+        op2 = op & ~C
+        E2 = full & ~(me1 | op2)
+        xs = E2 | B3(M1, op2, me1, T_SEL)
+        nbs = self.dilate(xs)
+        inv2 = B3(full, E2, nbs, TA & ~(TB & TC) & 0xFF) | K
+        me = B3(lv, op2, me1, T_SEL)
+        op = B3(lv, me1, op2, T_SEL)
+        inv = B3(lv, inv2, inv, T_SEL)
+        M = M1
+        pm = np.where(pas, U32(0xFFFFFFFF), U32(0)).astype(U32)
+        fl2 = ((fl ^ U32(1)) & U32(1)) | (pm & U32(2)) | (pm & (fl << U32(1)) & U32(4))
+        fl = B3(lv, fl2, fl, T_SEL)
+        return me, op, M, inv, fl
+
+    def play(self, me, op, M, inv, fl, Q, pas, lv, full):
+        """lat_play (round 6): at most TWO distinct opponent groups next to q keep their class question open (the ones in M: an
+        opponent group NOT in M had q as its only liberty and is captured whatever its shape), so three floods do: slot A = every
+        atari neighbour + the FIRST neighbour in M (priority up, down, left, right), slot B = the SECOND one, G = the mover's
+        group through q.  Further neighbours in M must be covered by A | B (the same groups); if not (1.2 % of the moves) a
+        second round floods the left-over (left / right) neighbours in slots of their own."""
+        NF, FW = self.NF, self.FW
+        self.plays += 1
+        me1 = me | Q
+        su, sd = self.below(Q), self.above(Q)
+        sl, sr = Q >> U32(1), Q + Q
+        nbr = B3(su, sd, sl, T_OR3) | sr
+        opn = B3(nbr, full, op, T_AND_ANDN)
+        nbo = nbr & op
+        mAll = nbo & M
+        aAll = nbo & ~M
+        mUl, mDl, mL, mR = su & mAll, sd & mAll, sl & mAll, sr & mAll
+        fU = self.above(mUl)          # lane r: the point above q is an opponent stone in M (bit c)
+        fD = self.below(mDl)
+        gU = self.above(fU)           # lane r + 1 learns about the point above q
+        fL, fR = mL + mL, mR >> U32(1)
+        ud = fU | fD
+        p1L = fL & ~ud
+        p2L = fL & (fU ^ fD)
+        p1R = fR & ~(ud | fL)
+        one3 = B3(fU, fD, fL, 0x16)
+        p2R = fR & one3
+        seedA = aAll | mUl | (mDl & ~gU) | (p1L >> U32(1)) | (p1R + p1R)
+        seedB = (mDl & gU) | (p2L >> U32(1)) | (p2R + p2R)
+        NR = self.NREG3
+        seeds = [seedA, seedB, Q]
+        F = [np.zeros(64, U32) for _ in range(NR)]
+        Mk = [np.zeros(64, U32) for _ in range(NR)]
+        for f in range(3):
+            sh = U32((FW * (f % NF)) & 31)
+            F[f // NF] |= seeds[f] << sh
+            Mk[f // NF] |= (op if f < 2 else me1) << sh
+        Mkr = [brev(m) for m in Mk]
+        F = self.flood(F, Mk, Mkr)
+        fr = [F[f] if NF == 1 else (F[f // NF] >> U32((FW * (f % NF)) & 31)) & U32(self.FM) for f in range(3)]
+        U = fr[0] | fr[1]
+        G = fr[2]
+        C = fr[0] & ~M
+        E1 = full & ~(me1 | op)
+        EG = E1 | C
+        Ee = [np.zeros(64, U32) for _ in range(NR)]
+        for f in range(3):
+            Ee[f // NF] |= (E1 if f < 2 else EG) << U32((FW * (f % NF)) & 31)
+        Lb = [self.dilate(F[k2]) & Ee[k2] for k2 in range(NR)]
+        W = np.zeros(64, U32)
+        for f in range(3):
+            c = popc(Lb[f] if NF == 1 else Lb[f // NF] & U32((self.FM << ((FW * (f % NF)) & 31)) & 0xFFFFFFFF))
+            if self.kSat:
+                c = np.minimum(c, U32(2))
+            W |= c << U32(8 * f)
+        pc = np.minimum(popc(C), U32(2))
+        W |= (pc << U32(24)) | np.where(opn != 0, U32(0x40000000), U32(0)).astype(U32)
+        S = self.board_sum(W)
+        M1x = np.zeros(64, U32)
+        if (mAll & ~U).any():         # a third distinct group in M (only the left / right neighbour can be left over): round two
+            self.fallbacks += 1
+            s2 = [B3(sl, mAll, U, T_AND_ANDN), B3(sr, mAll, U, T_AND_ANDN)]
+            K2 = 2 if NF == 1 else 1
+            F2 = [s2[0], s2[1]] if NF == 1 else [s2[0] | (s2[1] << U32(FW & 31))]
+            F2 = self.flood(F2, Mk[:K2], Mkr[:K2])
+            Eb = E1 if NF == 1 else (E1 | (E1 << U32(FW & 31)))
+            Lb2 = [self.dilate(F2[k]) & Eb for k in range(K2)]
+            W2 = np.zeros(64, U32)
+            f2 = []
+            for f in range(2):
+                f2.append(F2[f] if NF == 1 else (F2[0] >> U32((FW * f) & 31)) & U32(self.FM))
+                c = popc(Lb2[f] if NF == 1 else Lb2[0] & U32((self.FM << ((FW * f) & 31)) & 0xFFFFFFFF))
+                if self.kSat:
+                    c = np.minimum(c, U32(2))
+                W2 |= c << U32(8 * f)
+            g2 = self.board_sum(W2) + U32(0x00007E7E)
+            for f in range(2):
+                ge = ((g2 << U32(24 - 8 * f)).astype(np.int32) >> 31).astype(U32)
+                M1x |= ge & f2[f]
+            U = U | f2[0] | f2[1]
+        g1 = S + U32(0x007E7E7E)
+        M1 = B3(M, U, G, TA & ~(TB | TC) & 0xFF) | M1x
+        frm = [fr[0] & M, fr[1], G]
+        for f in range(3):
+            ge = ((g1 << U32(24 - 8 * f)).astype(np.int32) >> 31).astype(U32)
+            M1 = B3(ge, frm[f], M1, T_ANDOR)
+        K = np.zeros(64, U32)
+        if (C != 0).any():
+            kc = (((S >> U32(24)) & U32(0x3F)) == 1) & ((S >> U32(30)) == 0)
+            K = np.where(kc, C, U32(0)).astype(U32)
+            Xm = B3(me1, M, G, TA & ~(TB | TC) & 0xFF)
+            X = self.dilate(C) & Xm
+            if (X != 0).any():
+                X = self.flood([X], [Xm], [brev(Xm)])[0]
+                M1 = M1 | X
+        op2 = op & ~C
+        E2 = full & ~(me1 | op2)
+        xs = E2 | B3(M1, op2, me1, T_SEL)
+        nbs = self.dilate(xs)
+        inv2 = B3(full, E2, nbs, TA & ~(TB & TC) & 0xFF) | K
+        me = B3(lv, op2, me1, T_SEL)
+        op = B3(lv, me1, op2, T_SEL)
+        inv = B3(lv, inv2, inv, T_SEL)
+        M = M1
+        pm = np.where(pas, U32(0xFFFFFFFF), U32(0)).astype(U32)
+        fl2 = ((fl ^ U32(1)) & U32(1)) | (pm & U32(2)) | (pm & (fl << U32(1)) & U32(4))
+        fl = B3(lv, fl2, fl, T_SEL)
+        return me, op, M, inv, fl
 
     def _emit(self, me, op, inv, fl, N, nb, r, j, on):
         out = np.zeros((nb, 6, N, N), np.uint8)
@@ -393,7 +510,8 @@ def main():
                         break
             states, rng = ref, ref_rng
         print('wave %d done (%s)' % (w, 'ok' if not bad else 'MISMATCH'), flush=True)
-    print('model vs oracle: N=%d, %d waves x 2 launches x %d plies: %s' % (N, waves, plies, 'OK' if not bad else '%d mismatching launches' % bad))
+    print('model vs oracle: N=%d, %d waves x 2 launches x %d plies: %s  (second flood round on %d of %d wave-plies)'
+          % (N, waves, plies, 'OK' if not bad else '%d mismatching launches' % bad, m.fallbacks, m.plays))
     return 1 if bad else 0
 
 

@@ -64,7 +64,7 @@ def test_rollout_same_result_on_both_sides_of_every_take_over(N):
     """The games-per-launch and plies-per-launch thresholds of use_lat (and of use_multi_ply above them): the batch sizes /
     launch lengths right at, below and above each take-over point, every launch against the oracle."""
     cus = _cus()
-    per_cu, min_plies = (64, 3) if N <= 9 else (32, 3) if N <= 13 else (8, 8)
+    per_cu, min_plies = (128, 3) if N <= 9 else (80, 3) if N <= 13 else (31, 8)     # (64 / 32 / 8 games per CU until round 6)
     edge = cus * per_cu
     for B in (edge - 3, edge, edge + 1, edge + 5):
         _run(N, B, (min_plies - 1, min_plies, min_plies + 1, 40 if N <= 13 else 90), True, seed=B)

@@ -143,12 +143,12 @@ def test_bench_argument_plumbing():
     assert bench.rollout_kernel_name(9, 4096, 256, 256) == 'k_rollout_lat<9, true, true, 0>'      # config 2 (use_lat: <= 64 games per CU, >= 3 plies)
     assert bench.rollout_kernel_name(9, 4096, 2, 256) == 'k_rollout2_w4<9, true>' and bench.rollout_kernel_name(9, 8194, 1, 256) == 'k_rollout2<9, true, false, true>'
     assert bench.rollout_kernel_name(19, 4096, 1, 256) == 'k_rollout2_w4<19, true>' and bench.rollout_kernel_name(19, 4098, 1, 256) == 'k_rollout2<19, true, false, true>'
-    assert bench.rollout_kernel_name(9, 16385, 256, 256) == 'k_rollout4<9, 0, false, true, false, false>'
+    assert bench.rollout_kernel_name(9, 32769, 256, 256) == 'k_rollout4<9, 0, false, true, false, false>' and bench.rollout_kernel_name(9, 32768, 256, 256).startswith('k_rollout_lat<9')
     assert bench.rollout_kernel_name(13, 8192, 4, 256) == 'k_rollout_lat<13, true, true, 0>'
-    assert bench.rollout_kernel_name(19, 2048, 64, 256) == 'k_rollout_lat<19, true, true, 0>' and bench.rollout_kernel_name(19, 2049, 64, 256).startswith('k_rollout2<19')
+    assert bench.rollout_kernel_name(19, 7936, 64, 256) == 'k_rollout_lat<19, true, true, 0>' and bench.rollout_kernel_name(19, 7937, 64, 256).startswith('k_rollout2<19')
     assert bench.rollout_kernel_name(19, 2048, 8, 256).startswith('k_rollout_lat<19') and bench.rollout_kernel_name(19, 2048, 7, 256).startswith('k_rollout2<19')
     assert bench.rollout_kernel_name(13, 4096, 3, 256).startswith('k_rollout_lat<13') and bench.rollout_kernel_name(13, 4095, 3, 256).startswith('k_rollout2<13')
-    assert bench.rollout_symbol_prefix('k_rollout_lat<9, true, true, 0>') == '_ZN2gg13k_rollout_latILi9ELb1ELb1ELi0EEE'
+    assert bench.rollout_symbol_prefix('k_rollout_lat<9, true, true, 0>') == '_ZN2gg13k_rollout_latILi9ELb1ELb1ELi0ELb0EEE'
     assert bench.rollout_kernel_name(19, 65536, 1, 256) == 'k_env_step16<19, false>'        # (gg_kernels.hip: use_ns16, 3 groups per SIMD)
     assert bench.rollout_kernel_name(19, 32768, 1, 256) == 'k_rollout2<19, true, false, true>'
     assert bench.rollout_kernel_name(9, 16384, 1, 256) == 'k_env_step16<9, false>'

@@ -11,6 +11,7 @@ if os.environ.get('LIB'):
     _lib.LIB_PATH = os.path.join(ROOT, os.environ['LIB'])
 from gymgo_amd import gogame
 N, F = int(os.environ.get('GGN', '19')), int(os.environ.get('PLIES', '256'))
+SIZES = [int(x) for x in os.environ.get('SIZES', '1024,2048,3072,4096,6144,8192,12288,16384,32768').split(',')]
 
 
 def rate(B, env, reps=6):
@@ -20,7 +21,7 @@ def rate(B, env, reps=6):
     st = gogame.batch_init_state(B, N, device='cuda'); rng = gogame.rng_seed(B, 20260927, 0, 'cuda')
     ch = max(1, B // 16)
     for g in range(1, 16):
-        gogame.batch_rollout(st[g * ch:(g + 1) * ch], rng[g * ch:(g + 1) * ch], g * 40, True)
+        gogame.batch_rollout(st[g * ch:(g + 1) * ch], rng[g * ch:(g + 1) * ch], g * (8 if N <= 9 else 20 if N <= 13 else 40), True)
     for _ in range(12):
         gogame.batch_rollout(st, rng, F, True)
     torch.cuda.synchronize()
@@ -37,7 +38,7 @@ variants = [('lat', {'GG_AB_LAT_MAX': '1000000', 'GG_AB_LAT_PLIES': '1'}),
 for nb in (2, 4, 8, 16):
     variants.append(('rollout4 nb=%d' % nb, {'GG_AB_LAT_MAX': '0', 'GG_AB_MULTI_MIN': '1', 'GG_AB_NB': str(nb)}))
 print('N %d, %d plies per launch: ms per launch (steps/s)' % (N, F))
-for B in (1024, 2048, 3072, 4096, 6144, 8192, 12288, 16384, 32768):
+for B in SIZES:
     row, digs = [], set()
     for name, env in variants:
         ms, dg = rate(B, env)
