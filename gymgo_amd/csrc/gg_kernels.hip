@@ -254,7 +254,7 @@ bool use_lat(int cus, int64_t B, int32_t N, int plies, bool tracked = false) {
   // (round 6, three floods per ply instead of five - profiles/r06c_mid_batch.txt, 19x19 x 256 plies, new / best other family:
   // 2 048 games 0.414 / 0.637 ms, 4 096 0.557 / 0.736, 6 144 0.713 / 0.889, 8 192 0.874 / 0.888 (k_rollout4, eight boards per
   // wave), 12 288 1.31 / 0.95 -> up to 31 games per CU; the launch time is now monotone in the batch size)
-  // (9x9 / 13x13 with the three-flood ply, profiles/r06c_mid_batch_9.txt / _13.txt, new / k_rollout4: 9x9 16 384 games 0.42 /
+  // (9x9 / 13x13 with the three-flood ply, profiles/r06c_mid_batch_9_13.txt, new / k_rollout4: 9x9 16 384 games 0.42 /
   // 0.64 ms, 24 576 0.58 / 0.73, 32 768 0.735 / 0.746, 49 152 1.04 / 0.89; 13x13 16 384 0.58 / 0.75, 24 576 0.90 / 0.90, 32 768
   // 1.11 / 0.92 -> up to 128 / 80 games per CU)
   int64_t per_cu = N <= 9 ? 128 : N <= 13 ? 80 : 31;
