@@ -59,8 +59,12 @@ def main():
                 env = GoVecEnv(B, N, komi=7.5, reward_method=method, layout=layout)
                 env.rollout(plies)
                 t = timed(lambda: env.step(), 50)
+                # the bytes THIS launch moves per game: a tracked board in and out (2 x 4 (5 N + 1) B) + the observation (S B) + the
+                # generator and the per-game outputs (25 B); in place on byte planes: the board in and out + the same 25 B.
+                # (round 5 priced the tracked step against the 2 S + 29 B of an out-of-place byte-plane step: 0.915 instead of 0.62)
+                moved = (8 * (5 * N + 1) + S + 25) if layout == 'tracked' else (2 * S + 25)
                 out['GoVecEnv_step_%s_reward_%s_%dx%d_B%d' % (method, layout, N, N, B)] = {
-                    'steps_per_s': B / t, 'algorithmic_GBps': B * (2 * S + 29) / t / 1e9, 'roofline_frac': B * (2 * S + 29) / t / PEAK,
+                    'steps_per_s': B / t, 'bytes_moved_per_step': moved, 'moved_GBps': B * moved / t / 1e9, 'hbm_frac': B * moved / t / PEAK,
                     'note': 'one launch: sample + auto-reset + step + areas + rewards + dones + the uint8 observation (tracked: '
                             'gg_batch_env_step_tracked on resident tracked boards; bytes: gg_batch_env_step in place)'}
             env = GoVecEnv(B, N, komi=7.5, reward_method=method, layout='bytes')

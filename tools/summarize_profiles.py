@@ -57,10 +57,18 @@ md.append('bench line: value = %.4g %s, ms_per_step = %.5f (one step = one launc
           % (bench['value'], bench['unit'], bench['ms_per_step'], F, rf['bound'], rf.get('achieved'), rf['unit'], rf['peak'],
              rf.get('frac'), rf['hbm']['frac'], rf.get('per_ply', {}).get('kernel'), rf.get('per_ply', {}).get('frac')))
 md.append('## rocprofv3 --kernel-trace --stats (same command, extras and CPU baseline off)\n')
-md.append('| kernel | calls | avg ns | total % |\n|---|---|---|---|')
-for r in stats[:5]:
-    md.append('| `%s` | %s | %.0f | %s |' % (r['Name'][:80], r['Calls'], float(r['AverageNs']), r['Percentage']))
-trace = [r for r in csv.DictReader(open(os.path.join(src, 'kt', 'kt_kernel_trace.csv'))) if kshort in r['Kernel_Name']]
+# one row per launch SHAPE (kernel x grid): rocprofv3's own stats file averages over every launch of a kernel NAME, and a bench
+# run launches most kernels in several shapes (round 5's `k_children3` row averaged 8 192-parent launches with smaller ones and
+# read as 8.2 TB/s)
+all_trace = list(csv.DictReader(open(os.path.join(src, 'kt', 'kt_kernel_trace.csv'))))
+shapes = collections.defaultdict(list)
+for r in all_trace:
+    shapes[(r['Kernel_Name'], int(r['Grid_Size_X']), int(r.get('Workgroup_Size_X') or 0))].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+total_ns = float(sum(sum(v) for v in shapes.values())) or 1.0
+md.append('| kernel | grid (threads) x workgroup | calls | avg ns | total % |\n|---|---|---|---|---|')
+for (name, grid, wg), d in sorted(shapes.items(), key=lambda kv: -sum(kv[1]))[:8]:
+    md.append('| `%s` | %d x %d | %d | %.0f | %.1f |' % (name[:80], grid, wg, len(d), mean(d), 100.0 * sum(d) / total_ns))
+trace = [r for r in all_trace if kshort in r['Kernel_Name']]
 full = max(int(r['Grid_Size_X']) for r in trace)
 fullrows = [r for r in trace if int(r['Grid_Size_X']) == full]
 durs = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in fullrows]
@@ -209,8 +217,17 @@ if os.path.exists(ops_stats):
     shutil.copy(ops_stats, os.path.join(dst, tag + '_ops_kernel_stats.csv'))
     shutil.copy(os.path.join(src, 'ops.json'), os.path.join(dst, tag + '_ops.json'))
     md.append('\n## the other entry points (`tools/bench_ops.py`, rocprofv3 --kernel-trace --stats; %s_ops.json has the rates)\n' % tag)
-    md.append('| kernel | calls | avg ns |\n|---|---|---|')
-    for r in list(csv.DictReader(open(ops_stats)))[:16]:
-        md.append('| `%s` | %s | %.0f |' % (r['Name'][:80], r['Calls'], float(r['AverageNs'])))
+    ops_trace = os.path.join(src, 'kt_ops', 'kt_kernel_trace.csv')
+    if os.path.exists(ops_trace):     # one row per launch shape, as above
+        oshapes = collections.defaultdict(list)
+        for r in csv.DictReader(open(ops_trace)):
+            oshapes[(r['Kernel_Name'], int(r['Grid_Size_X']), int(r.get('Workgroup_Size_X') or 0))].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+        md.append('| kernel | grid (threads) x workgroup | calls | avg ns |\n|---|---|---|---|')
+        for (name, grid, wg), d in sorted(oshapes.items(), key=lambda kv: -sum(kv[1]))[:24]:
+            md.append('| `%s` | %d x %d | %d | %.0f |' % (name[:80], grid, wg, len(d), mean(d)))
+    else:
+        md.append('| kernel | calls | avg ns (all launch shapes of the name together) |\n|---|---|---|')
+        for r in list(csv.DictReader(open(ops_stats)))[:16]:
+            md.append('| `%s` | %s | %.0f |' % (r['Name'][:80], r['Calls'], float(r['AverageNs'])))
 open(os.path.join(dst, tag + '_summary.md'), 'w').write('\n'.join(md) + '\n')
 print('\n'.join(md))
