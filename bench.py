@@ -957,14 +957,17 @@ def extras(dev, back, opts):
     env.reset()
     rs = np.random.default_rng(1)
     n_steps, t0 = 0, time.perf_counter()
-    while n_steps < 300:
+    while n_steps < 600:
         if env.done:
             env.reset()
-        env.step(int(rs.choice(np.flatnonzero(env.valid_moves()))))
+        valid = np.flatnonzero(env.valid_moves())
+        env.step(int(valid[rs.integers(len(valid))]))
         n_steps += 1
     configs['config1_7x7_single_game_GoEnv_step'] = {
         'steps_per_s': round(n_steps / (time.perf_counter() - t0), 1),
-        'note': 'one H2D action + two launches + one D2H record per step; latency-bound plumbing by construction'}
+        'note': 'GoEnv.step through the reference-style API (NumPy in / out) driven by a uniform-random policy on the host: one '
+                'launch (gg_batch_env_step_scored) on a record in pinned, device-mapped host memory + a stream wait per step, no '
+                'copy in either direction; latency-bound plumbing by construction'}
     out['configs'] = configs
     # --- what this box streams ("also report against a measured device-copy bandwidth on the box")
     big = torch.empty(1 << 30, dtype=torch.uint8, device=dev)

@@ -161,7 +161,8 @@ _hip = None
 
 def hip_runtime():
     """The HIP runtime torch and the library already share, bound for the three stream-ordering calls GoVecEnvParts
-    makes per step (torch's Stream.wait_stream creates and destroys an event per call: 8 us of host time against 2)."""
+    makes per step (torch's Stream.wait_stream creates and destroys an event per call: 8 us of host time against 2) and the
+    stream wait of GoEnv.step."""
     global _hip
     if _hip is None:
         # The runtime ALREADY in the process (torch's and the library's): its path is read from /proc/self/maps and that exact
@@ -192,6 +193,7 @@ def hip_runtime():
         H.hipStreamWaitEvent.argtypes, H.hipStreamWaitEvent.restype = [_vp, _vp, ctypes.c_uint], _i32
         H.hipEventDestroy.argtypes, H.hipEventDestroy.restype = [_vp], _i32
         H.hipStreamQuery.argtypes, H.hipStreamQuery.restype = [_vp], _i32
+        H.hipStreamSynchronize.argtypes, H.hipStreamSynchronize.restype = [_vp], _i32
         H.hipStreamIsCapturing.argtypes, H.hipStreamIsCapturing.restype = [_vp, ctypes.POINTER(ctypes.c_int)], _i32
         if torch.cuda.is_available():
             # the same runtime as torch's: a torch stream must be a stream it knows.  Probed with hipStreamIsCapturing,

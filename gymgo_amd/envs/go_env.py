@@ -100,7 +100,6 @@ class GoEnv(spaces.Env):
             action = self.size * action[0] + action[1]
         elif action is None:
             action = self.size ** 2
-        import torch
         from gymgo_amd import _lib
         rec = self._record()
         n = self.size
@@ -108,7 +107,7 @@ class GoEnv(spaces.Env):
         stream = _lib.stream_ptr(rec['device'])
         _lib.check(_lib.lib().gg_batch_env_step_scored(rec['p_state'], rec['p_action'], None, None, rec['p_done'], rec['p_status'],
                                                        None, rec['p_areas'], 1, n, 0.0, 0, 0, stream), 'gg_batch_env_step_scored')
-        torch.cuda.current_stream(rec['device']).synchronize()      # the kernel's writes to the record are visible from here on
+        _lib.check(_lib.hip_runtime().hipStreamSynchronize(stream), 'hipStreamSynchronize')   # the kernel's writes to the record are visible from here on
         black, white, status = (int(x) for x in rec['words'])
         if status != 0:                           # gym_go/gogame.py:59: the position is unchanged
             a = int(action)

@@ -232,3 +232,50 @@ def test_four_wave_workgroups_ragged_and_at_their_take_over(N):
     for B in (1, 5, 13, 17, edge_tracked, edge_tracked + 1):
         for with_obs, given in ((True, False), (False, True)):
             _env_step_vs_oracle(N, B, with_obs, given)
+
+
+@pytest.mark.parametrize('N', [9, 13, 19, 6])
+def test_three_flood_ply_second_round_on_a_point_between_three_groups(N):
+    """Round 6: the usual ply of the one-row-per-lane kernels floods THREE sets (two opponent slots + the mover's group) and
+    runs a second round when the new stone touches a THIRD distinct opponent group with >= 2 liberties (four are impossible:
+    a point whose four neighbours are opponent stones is only playable when one of them is in atari).  Crafted positions put
+    an empty point between three separate white groups of different shapes - every choice of the fourth, empty, side, so that
+    the left-over neighbour of round two is the left or the right one - on every board of a batch; the boards differ only in
+    their generators, so a known share of them plays that point on the first ply.  Byte planes (first classes from scratch)
+    and tracked boards, long launches (the three-flood ply) and short ones (the five-flood ply), all against the oracle."""
+    from gymgo_amd import gogame
+    from oracle import c_oracle
+    B = 768 if N <= 13 else 4096
+    c = N // 2
+    sides = ((c - 1, c), (c + 1, c), (c, c - 1), (c, c + 1))          # up, down, left, right of (c, c)
+    for skip in range(4):
+        s0 = np.zeros((6, N, N), np.uint8)
+        for i, (r, q) in enumerate(sides):
+            if i != skip:
+                s0[1, r, q] = 1                     # three white stones around (c, c), pairwise not adjacent
+        if N >= 9:                                  # different shapes: the upper one grows upwards, the right one to the right
+            if skip != 0:
+                s0[1, c - 2, c] = s0[1, c - 3, c] = 1
+            if skip != 3:
+                s0[1, c, c + 2] = 1
+            s0[0, 0, 0] = s0[0, N - 1, N - 1] = 1   # black stones elsewhere
+        s0[3] = c_oracle.compute_invalid_moves(s0, 0)
+        assert s0[3, c, c] == 0                     # the point between the three groups is playable for black
+        states = np.repeat(s0[None], B, axis=0)
+        for tracked in (False, True):
+            for launches in ((40, 3, 64), (1, 2, 1, 50)):
+                st = torch.from_numpy(states).cuda()
+                rng = gogame.rng_seed(B, 1234 + N + skip, 0, 'cuda')
+                want, want_rng = states.copy(), rng.cpu().numpy().view(np.uint64).copy()
+                _, _, last1 = c_oracle.batch_rollout_mt(want, want_rng, 1, True)
+                assert int((last1 == c * N + c).sum()) >= 3     # some boards play that point on the first ply
+                tr = gogame.batch_track(st) if tracked else None
+                for F in launches:
+                    if tracked:
+                        gogame.batch_rollout_tracked(tr, rng, F, True)
+                    else:
+                        gogame.batch_rollout(st, rng, F, True)
+                    want, want_rng, _ = c_oracle.batch_rollout_mt(want, want_rng, F, True)
+                    got = gogame.batch_untrack(tr).cpu().numpy() if tracked else st.cpu().numpy()
+                    assert np.array_equal(got, want), (N, skip, tracked, F)
+                    assert np.array_equal(rng.cpu().numpy().view(np.uint64), want_rng), (N, skip, tracked, F)
