@@ -23,6 +23,7 @@
 #include "gg_common.h"
 #include "gg_v2.h"
 #include "gg_v4.h"
+#include "gg_v5.h"
 #include "gg_aux.h"
 #include "gg_ws.h"
 #include "gg_sym.h"
@@ -33,6 +34,8 @@ namespace gg {
 // gg_rollout.hip: the fused multi-ply launches with drawn moves, a translation unit of their own (one code-generation switch differs)
 void launch_rollout4(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N,
                      uint32_t inv, int plies, int auto_reset, int nb, int grid, hipStream_t s);
+void launch_rollout5(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, uint32_t inv,
+                     int plies, int auto_reset, int nb, int grid, hipStream_t s);
 void launch_rollout_lat(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N, int plies,
                         int auto_reset, bool w4, hipStream_t s);
 void launch_env_step_lat(uint32_t *tracked, uint64_t *rng, int64_t *steps_done, int64_t B, int32_t N, int auto_reset,
@@ -234,6 +237,35 @@ bool use_multi_ply(int cus, int64_t B, int plies) {
   if (const char *e = getenv("GG_AB_MULTI_MIN")) min_games = atoll(e);
 #endif
   return plies >= 2 && B >= min_games;
+}
+
+// The thirty-two-board multi-ply kernel (gg_v5.h: a pair of lanes per board, the floods of a ply as a compacted job list) serves
+// the fused launches of full-size 19x19 batches that give every SIMD two of its waves: 20 KB of LDS per wave = eight waves per CU.
+// Boards per wave: as many as keep the rounds of resident waves full (65 536 games on 256 CUs: 32 boards x 2 048 waves).
+// (A/B builds: GG_AB_R5 = 0 / 1 forces the choice, GG_AB_R5_MIN = games per CU, GG_AB_R5_PLIES, GG_AB_NB5 = boards per wave.)
+bool use_rollout5(int cus, int64_t B, int32_t N, int plies) {
+  int64_t per_cu = 8 * kNB5;
+  int min_plies = 8;
+  bool ok = N == 19;
+#ifdef GG_AB
+  if (const char *e = getenv("GG_AB_R5_MIN")) per_cu = atoll(e);
+  if (const char *e = getenv("GG_AB_R5_PLIES")) min_plies = atoi(e);
+  if (const char *e = getenv("GG_AB_R5")) { if (atoi(e) == 0) ok = false; else { per_cu = 0; min_plies = 1; } }
+#endif
+  return ok && plies >= min_plies && B >= (int64_t)cus * per_cu;
+}
+int boards_per_wave5(int cus, int64_t B, int &grid) {
+  const int64_t resident = (int64_t)cus * 8;
+  const int64_t waves = (B + kNB5 - 1) / kNB5, rounds = (waves + resident - 1) / resident;
+  int64_t nb = (B + rounds * resident - 1) / (rounds * resident);
+#ifdef GG_AB
+  if (const char *e = getenv("GG_AB_NB5")) nb = atoi(e);
+#endif
+  nb = (nb + 1) & ~(int64_t)1;
+  if (nb > kNB5) nb = kNB5;
+  if (nb < 2) nb = 2;
+  grid = grid_for(cus, (B + nb - 1) / nb);
+  return (int)nb;
 }
 
 // The latency-shaped multi-ply kernel (gg_lat.h: one row per lane, four 9x9 / 13x13 boards or two 19x19 boards per wave, the
@@ -589,6 +621,12 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
     launch_rollout_lat(0, states, rng, last_actions, steps_done, B, N, plies, auto_reset, false, s);
     return (int32_t)hipGetLastError();
   }
+  if (use_rollout5(cus, B, N, plies)) {   // a full machine: 32 boards per wave, the floods of a ply as a job list (gg_v5.h)
+    int grid;
+    const int nb = boards_per_wave5(cus, B, grid);
+    launch_rollout5(0, states, rng, last_actions, steps_done, B, inv, plies, auto_reset, nb, grid, s);
+    return (int32_t)hipGetLastError();
+  }
   if (use_multi_ply(cus, B, plies)) {   // liberty classes carried across the plies, 16 boards per wave
     int grid;
     const int nb = boards_per_wave(cus, B, grid);
@@ -927,6 +965,12 @@ int32_t gg_batch_rollout_tracked(uint32_t *tracked, uint64_t *rng, int32_t *last
   uint8_t *st = reinterpret_cast<uint8_t *>(tracked);
   if (use_lat(cus, B, N, plies, true)) {   // an under-filled machine: one row per lane, the ply in registers (gg_lat.h)
     launch_rollout_lat(2, st, rng, last_actions, steps_done, B, N, plies, auto_reset, lat_w4(cus, B, N, plies), s);
+    return (int32_t)hipGetLastError();
+  }
+  if (use_rollout5(cus, B, N, plies)) {
+    int grid5;
+    const int nb5 = boards_per_wave5(cus, B, grid5);
+    launch_rollout5(2, st, rng, last_actions, steps_done, B, inv, plies, auto_reset, nb5, grid5, s);
     return (int32_t)hipGetLastError();
   }
   int grid3;

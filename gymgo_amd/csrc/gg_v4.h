@@ -152,14 +152,15 @@ __device__ __forceinline__ void dilate_rows(const uint32_t (&x)[RPL], uint32_t (
 // planes, the mask from its registers, the three uniform planes from the flag word) - and leaves as aligned 1 KB blocks,
 // 64 lanes x 16 B through the 8 bits -> 8 bytes table: one hand-off instead of one per pair of boards, two ragged edges
 // per group instead of two per board, and the store pattern that streams best (tools/ubench/write_patterns.hip).
-template <int R, int RPL>
+// LPB = lanes per board (4: the quads of k_rollout4; 2: the pairs of k_rollout5, gg_v5.h), RPL rows per lane
+template <int R, int RPL, int LPB = 4>
 __device__ __forceinline__ void emit_group(uint8_t *g, int nbrd, int N, const uint32_t *st, int PL, int RS,
                                            const uint32_t (&inv_r)[RPL], const uint32_t *flagsv, uint32_t *bs, uint2 *lut,
                                            int lane) {
   const int P = N * N, S = 6 * P;
   const uint32_t mo = (uint32_t)((uintptr_t)g & 15u);
   const int nbits = (int)mo + nbrd * S;
-  const int q4 = lane >> 2, r04 = RPL * (lane & 3);
+  const int q4 = lane / LPB, r04 = RPL * (lane % LPB);
   WAVE_SYNC();
   for (int i = lane; i < (nbits + 31) / 32 + 1; i += kWave) bs[i] = 0;
   for (int e = lane; e < 256; e += kWave)

@@ -1,0 +1,691 @@
+// gg_v5.h - the multi-ply kernel for batches that fill the machine: THIRTY-TWO BOARDS PER WAVEFRONT (one pair of lanes per
+// board), the floods of a ply compacted into a job list.
+#pragma once
+#include "gg_v4.h"
+
+namespace gg {
+
+// ===================================================================== v5: 32 boards per wave, flood jobs
+// k_rollout4 (gg_v4.h) gives every board a quad of lanes: lane t floods whatever q's neighbour in direction t holds, and
+// 39 % of those flood lanes carry a flood (1.56 per board and ply) - the flood batch, the liberty count and the seed set-up,
+// 54 % of a ply's instructions, cost the same whatever their lanes carry.  Here a board is a PAIR of lanes (lane t owns
+// the RPL = ceil(R / 2) adjacent rows RPL t ..), a wave holds 32 boards, and a ply is
+//   1.  sampling, as in k_rollout4 (the pair scan is one DPP swap);
+//   2a. the board's own lanes look at q's four neighbours (two directions each) and post the floods the ply needs as JOBS:
+//       one per opponent stone next to q, and ONE for the mover's group G when q has a friendly neighbour (k_rollout4 runs
+//       that flood in every friendly lane); the slots come from two ballots (v_mbcnt prefix), the descriptors go to LDS;
+//   2b. lane L runs job L - 32 boards x 1.56 = 50 jobs in 64 lanes (a second batch when a ply posts more than 64: < 1 %);
+//   3.  class patch, captures, ko and the next mover's mask on the pair lanes: the flood of direction d is read through the
+//       slot the board posted it in, an absent one through an all-zero block.
+// Instructions per board: the flood batch is shared by twice the boards, and so is everything in phases 1 and 3 that does not
+// scale with the rows a lane holds (the draw, the k-th-bit search, the capture / ko logic, addresses): ~44 VALU per env step
+// against 73.  65 536 games are 2 048 waves = TWO per SIMD (20 KB of LDS, up to 256 VGPRs per wave): what the SIMD loses in
+// waves to switch between it gets back as independent rows inside each wave (ten per lane in phases 1 and 3).
+// Scope: drawn moves on full-size boards (N == R), byte planes or tracked boards - the fused rollout of big batches; every
+// other form stays on k_rollout4.
+constexpr int kNB5 = 32;
+constexpr int kJobCap = 128;   // jobs of one ply: <= 4 per board (four opponent neighbours leave no friendly one)
+
+template <int R>
+struct Lds5 {
+  static constexpr int RS = Cfg<R>::kRowStride;
+  static constexpr int RPL = (R + 1) / 2;                        // rows per lane in phases 1 and 3
+  static_assert(2 * RPL <= RS, "a pair's rows must fit the row stride");
+  static constexpr int kPad = 4;                                 // zero words in front of the planes: "row -1" / "row -2" of the first board
+  static constexpr int kState = kPad;                            // [2][kNB5][RS]: black, white
+  static constexpr int kMeta = kState + 2 * kNB5 * RS;           // flags[32], last[32], played[32], rng[64]
+  static constexpr int kFair = kMeta + 5 * kNB5;                 // [16]: FairShare
+  static constexpr int kTmp = kFair + 16;                        // [2][2][RS]: layout change of one pair at load
+  static constexpr int kUnion = kTmp + 4 * RS;
+  // ply loop: per job its class word and descriptor, per board the block of the mover's group, per job its flood block
+  static constexpr int kZero = kJobCap, kDump = kJobCap + 1;     // slot of an absent job (all zero, never written) / of a write nobody reads
+  static constexpr int kCls = kUnion;                            // [kJobCap + 4]
+  static constexpr int kJob = kCls + kJobCap + 4;                // [kJobCap + 4]
+  static constexpr int kG = kJob + kJobCap + 4;                  // [kNB5][RS]
+  static constexpr int kSc = kG + kNB5 * RS;                     // [kJobCap + 2][RS]
+  static constexpr int kLoopEnd = kSc + (kJobCap + 2) * RS;
+  // load: the v2 analysis in its compact form (region 0 only); tracked boards: the DMA landing area, the parked rows
+  static constexpr int kV2 = kUnion;
+  static constexpr int kIoEnd = kV2 + (Lds2<R>::kRegion0 > 768 ? Lds2<R>::kRegion0 : 768);
+  static constexpr int kDmaWords = (((kNB5 * (5 * R + 1) * 4 + 12 + 15) / 16 + kWave - 1) / kWave) * 256;
+  static constexpr int kDmaEnd = kUnion + kDmaWords;
+  // byte-plane write-back of a whole group (emit_group)
+  static constexpr int kGrpBits = kUnion;
+  static constexpr int kGrpWords = ((15 + kNB5 * 6 * R * R + 31) / 32 + 4) & ~3;
+  static constexpr int kGrpLut = kGrpBits + kGrpWords;           // uint2[256]
+  static constexpr int kGrpEnd = kGrpLut + 512;
+  static constexpr int kMax2(int a, int b) { return a > b ? a : b; }
+  static constexpr int kTotal = kMax2(kMax2(kLoopEnd, kIoEnd), kMax2(kDmaEnd, kGrpEnd));
+  static_assert(kTotal * 4 <= 20480, "two waves per SIMD: 20 KB of LDS per wave");
+  static_assert(kUnion % 4 == 0 && kG % 4 == 0 && kSc % 4 == 0, "16-byte alignment of the flood blocks");
+  static_assert(3 * kNB5 * RS <= kLoopEnd - kUnion, "parked tracked rows fit the loop area");
+};
+
+// set bits of a ballot in the lanes below this one
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+constexpr int QP_L0 = 0xA0;   // quad_perm [0,0,2,2]: the even lane of each pair
+
+// job descriptor: bits 0-4 board, 5-9 seed row, 10-14 seed column, 15 the colour flooded, 16 the job floods G, 17 the seed
+// is a one-stone group (ko needs it), 18 the job exists
+template <int R, int IO>
+__global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
+                                                       int32_t *__restrict__ last_actions, int64_t *__restrict__ steps_done,
+                                                       int64_t B, uint32_t inv, int plies, int auto_reset, int nb) {
+  static_assert(IO == 0 || IO == 2, "byte planes or tracked boards");
+  constexpr int N = R;
+  constexpr int RS = Lds5<R>::RS;
+  constexpr int RV = (R + 3) / 4;
+  constexpr int RPL = Lds5<R>::RPL;
+  constexpr int PL = kNB5 * RS;   // words per plane of all boards
+  constexpr int ZERO = Lds5<R>::kZero, DUMP = Lds5<R>::kDump;
+  constexpr bool TRACKED = IO == 2;
+  constexpr int P = N * N, S = 6 * P, W = 5 * N + 1;
+  constexpr uint32_t FULLROW = (1u << N) - 1u;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[Lds5<R>::kTotal];
+  uint32_t *st = lds + Lds5<R>::kState;     // st[colour * PL + board * RS + row]
+  uint32_t *flagsv = lds + Lds5<R>::kMeta;  // bit 0 turn, 1 passed, 2 done, 3 on, 5 reset (dirty)
+  int *lastv = reinterpret_cast<int *>(lds + Lds5<R>::kMeta + kNB5);
+  int *playedv = reinterpret_cast<int *>(lds + Lds5<R>::kMeta + 2 * kNB5);
+  uint32_t *rngv = lds + Lds5<R>::kMeta + 3 * kNB5;   // [2 * s], [2 * s + 1]
+  uint32_t *tmp = lds + Lds5<R>::kTmp;      // tmp[(half * 2 + set) * RS + row], set 0 = invalid, 1 = M
+  uint32_t *clsv = lds + Lds5<R>::kCls;
+  uint32_t *jobv = lds + Lds5<R>::kJob;
+  uint32_t *gblk = lds + Lds5<R>::kG;
+  uint32_t *sc = lds + Lds5<R>::kSc;
+  uint32_t *v2 = lds + Lds5<R>::kV2;
+  uint32_t *park = lds + Lds5<R>::kUnion;   // tracked I/O: park[set * PL + board * RS + row], set 0 invalid, 1 mb, 2 mw
+  const int64_t ngroups = (B + nb - 1) / nb;
+
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t b_first = g * nb;
+    int ln0;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln0));
+    const Half hf = make_half(ln0, N, inv);
+    const bool row = hf.hl < RS;
+    const int s5 = hf.lane >> 1, t2 = hf.lane & 1, r05 = RPL * t2;   // board / lane of the pair / first row of this lane
+    // the next mover's invalid-move mask and the stones of groups with >= 2 liberties, rows r05 .. r05 + RPL - 1 of board
+    // s5: in registers from here to the write-back
+    uint32_t inv_r[RPL], M[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) inv_r[r] = M[r] = 0u;
+    GG_PROF_DECL;
+    // ---------------------------------------------------------------- load
+    WAVE_SYNC();
+    if (TRACKED) {
+      // the group's boards are ONE contiguous block of nb x (5 N + 1) words: global -> LDS by LDS-DMA, all of it in flight
+      // at once, sorted from the landing area (as k_rollout4 does)
+      const int64_t nbrd = (B - b_first) < nb ? (B - b_first) : nb;
+      const int nw = (int)nbrd * W;
+      const uint32_t *gp = reinterpret_cast<const uint32_t *>(states) + b_first * (int64_t)W;
+      constexpr int KD = Lds5<R>::kDmaWords / 256;   // DMA instructions per lane
+      const uint8_t *gb = reinterpret_cast<const uint8_t *>(gp);
+      const uint32_t mis = (uint32_t)((uintptr_t)gb & 15u);
+      const int nvec = (int)((mis + (uint32_t)nw * 4u + 15u) >> 4);
+      WAVE_SYNC();
+      lds_drain();
+      {
+        const uint32_t stage_lds = lds_addr(park);
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+          const int v = hf.lane + kWave * k;
+          if (v < nvec) dma16(gb - mis + 16 * v, stage_lds + 1024u * (uint32_t)k);
+        }
+      }
+      uint64_t xg = 0;
+      if (hf.lane < kNB5) xg = rng[(hf.lane < nb && b_first + hf.lane < B) ? b_first + hf.lane : B - 1];
+      for (int i = hf.lane; i < 2 * PL; i += kWave) st[i] = 0;      // rows N .. RS-1 and absent boards read as zero
+      if (hf.lane < Lds5<R>::kPad) lds[hf.lane] = 0;
+      dma_wait();
+      WAVE_SYNC();
+      const uint32_t *stg = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(park) + mis);   // word i of the block
+      for (int i = hf.lane; i < (int)nbrd * 2 * N; i += kWave) {
+        const int sb = i / (2 * N), w = i - sb * (2 * N);
+        const int pl = w >= N ? 1 : 0;
+        st[pl * PL + sb * RS + (w - pl * N)] = stg[sb * W + w];
+      }
+      if (hf.lane < kNB5) {
+        const int sb = hf.lane;
+        const bool on = sb < nb && b_first + sb < B;
+        flagsv[sb] = on ? ((stg[sb * W + 5 * N] & 7u) | 8u) : 0u;
+        lastv[sb] = -1;
+        playedv[sb] = 0;
+        rngv[2 * sb] = (uint32_t)xg;
+        rngv[2 * sb + 1] = (uint32_t)(xg >> 32);
+      }
+      {
+        const bool have = s5 < (int)nbrd;
+        const uint32_t *bq = stg + (have ? s5 : 0) * W;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          const int rw = r05 + r;
+          const bool ok = have && rw < N;
+          const int rc = ok ? rw : 0;
+          const uint32_t iv = bq[2 * N + rc], mb = bq[3 * N + rc], mw = bq[4 * N + rc];
+          inv_r[r] = ok ? iv : 0u;
+          M[r] = ok ? (mb | mw) : 0u;
+        }
+      }
+      WAVE_SYNC();
+    } else {
+      if (hf.lane < kNB5) flagsv[hf.lane] = 0;                       // boards beyond nb: off
+      for (int i = hf.lane; i < 2 * PL; i += kWave) st[i] = 0;
+      if (hf.lane < Lds5<R>::kPad) lds[hf.lane] = 0;
+      WAVE_SYNC();
+      // Byte planes: pairs of boards, first classes by the per-ply analysis (analyze2); the global loads of pair i + 1 are
+      // issued before pair i is converted
+      constexpr int NVL = (4 * R * R + 15 + 15) / 512 + 1;   // 16-byte vectors per lane
+      static_assert(NVL <= 3, "vectors per lane of a staged board");
+      if (hf.lane < kNB5) {   // the generator states of the whole group: one coalesced load
+        const uint64_t x = rng[(b_first + hf.lane < B) ? b_first + hf.lane : B - 1];
+        rngv[2 * hf.lane] = (uint32_t)x;
+        rngv[2 * hf.lane + 1] = (uint32_t)(x >> 32);
+      }
+      uint4 cv0 = make_uint4(0, 0, 0, 0), cv1 = cv0, cv2 = cv0, nv0 = cv0, nv1 = cv0, nv2 = cv0;
+      uint32_t cfb = 0, nfb = 0;
+#define GG_ISSUE_PAIR5(I, V0, V1, V2, FB)                                                                              \
+      do {                                                                                                             \
+        const int s_ = 2 * (I) + hf.h;                                                                                 \
+        const int64_t b_ = (b_first + s_ < B) ? b_first + s_ : B - 1;                                                  \
+        const uint8_t *gs_ = states + b_ * (int64_t)S;                                                                 \
+        FB = 0;                                                                                                        \
+        if (hf.hl < 4) {                                                                                               \
+          const int off_ = hf.hl == 0 ? 2 * P : hf.hl == 1 ? 3 * P : hf.hl == 2 ? 4 * P : 5 * P;                       \
+          FB = gs_[off_];                                                                                              \
+        }                                                                                                              \
+        const uint32_t mis_ = (uint32_t)((uintptr_t)gs_ & 15u);                                                        \
+        const uint4 *ga_ = reinterpret_cast<const uint4 *>(gs_ - mis_);                                                \
+        const int nv_ = (int)(mis_ + 4 * P + 15) >> 4;                                                                 \
+        if (hf.hl < nv_) V0 = ga_[hf.hl];                                                                              \
+        if (NVL > 1 && hf.hl + 32 < nv_) V1 = ga_[hf.hl + 32];                                                         \
+        if (NVL > 2 && hf.hl + 64 < nv_) V2 = ga_[hf.hl + 64];                                                         \
+      } while (0)
+      if (nb >= 2) GG_ISSUE_PAIR5(0, cv0, cv1, cv2, cfb);
+#pragma unroll 1
+      for (int i = 0; i < nb / 2; ++i) {
+        if (i + 1 < nb / 2) GG_ISSUE_PAIR5(i + 1, nv0, nv1, nv2, nfb);
+        const int s = 2 * i + hf.h;
+        const bool on = b_first + s < B;
+        const int64_t b = on ? b_first + s : B - 1;
+        uint32_t black, white, invalid, mb = 0, mw = 0;
+        const uint8_t *gs = states + b * (int64_t)S;
+        uint8_t *io = reinterpret_cast<uint8_t *>(v2) + hf.h * Cfg<R>::kIoBytes;
+        const uint32_t mi = (uint32_t)((uintptr_t)gs & 15u);
+        const int nv = (int)(mi + 4 * P + 15) >> 4;
+        const uint32_t flags = half_of(__ballot(cfb != 0), hf.h) & 0xFu;   // bit 0 turn, 1 (unused), 2 passed, 3 done
+        WAVE_SYNC();
+        uint4 *iov = reinterpret_cast<uint4 *>(io);
+        if (hf.hl < nv) iov[hf.hl] = cv0;
+        if (NVL > 1 && hf.hl + 32 < nv) iov[hf.hl + 32] = cv1;
+        if (NVL > 2 && hf.hl + 64 < nv) iov[hf.hl + 64] = cv2;
+        WAVE_SYNC();
+        black = plane_to_row<R>(io + mi, N, hf.hl);
+        white = plane_to_row<R>(io + mi + P, N, hf.hl);
+        invalid = plane_to_row<R>(io + mi + 3 * P, N, hf.hl);
+        const uint32_t turn = flags & 1u, passed = (flags >> 2) & 1u, done = (flags >> 3) & 1u;
+        uint32_t ab;
+        analyze2<R, false>(black, white, hf.full_l1 & ~(black | white), hf, v2, mb, ab, mw, nullptr, nullptr, true);
+        if (row) {
+          st[0 * PL + s * RS + hf.hl] = black;
+          st[1 * PL + s * RS + hf.hl] = white;
+          tmp[(hf.h * 2 + 0) * RS + hf.hl] = invalid;
+          tmp[(hf.h * 2 + 1) * RS + hf.hl] = mb | mw;
+        }
+        if (hf.hl == 0) {
+          flagsv[s] = turn | (passed << 1) | (done << 2) | (on ? 8u : 0u);
+          lastv[s] = -1;
+          playedv[s] = 0;
+        }
+        WAVE_SYNC();
+        if ((hf.lane >> 2) == i) {   // the two pairs of lanes that own these boards pick their rows up
+          const uint32_t *tp = tmp + ((s5 & 1) * 2) * RS + r05;
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) {
+            inv_r[r] = tp[r];
+            M[r] = tp[RS + r];
+          }
+        }
+        WAVE_SYNC();
+        cv0 = nv0; cv1 = nv1; cv2 = nv2; cfb = nfb;
+      }
+#undef GG_ISSUE_PAIR5
+    }
+    // the slot of an absent job: an all-zero block and class word (the loop area was the load's scratch)
+    WAVE_SYNC();
+    if (hf.lane < RS) sc[ZERO * RS + hf.lane] = 0u;
+    if (hf.lane == 0) clsv[ZERO] = 0u;
+    WAVE_SYNC();
+
+    // ---------------------------------------------------------------- the plies
+    GG_PROF(6);   // load
+    FairShare fair(lds + Lds5<R>::kFair);
+    const uint32_t fair_lag = plies >= 192 ? 24u : (plies >= 16 ? (uint32_t)plies >> 3 : 2u);
+    uint32_t uq = 0;   // this lane's pre-mixed draw: lane j of a pair holds the one of ply (t & ~1) + j, swapped every ply
+#pragma unroll 1
+    for (int t = 0; t < plies; ++t) {
+      if ((t & 3) == 0 && plies >= 8) {
+        const uint32_t left = (uint32_t)(plies - t);
+        fair.update((uint32_t)t, left < fair_lag ? (left > 2u ? left : 2u) : fair_lag);
+      }
+      int ln;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      const int s4 = (ln >> 1) & 31, t5 = ln & 1, r0 = RPL * t5;   // board, lane of the pair, first row of this lane
+      const bool bl = s4 < nb;
+      uint32_t full[RPL];   // the N-bit row mask of the lane's rows that exist
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) full[r] = (r0 + r < N) ? FULLROW : 0u;
+
+      int a_q;
+      uint32_t fl_q;
+      // phase 1 - two lanes per board, RPL rows each: liveness, the draw, the k-th valid point of the mask
+      {
+        const uint32_t fl = flagsv[s4];
+        const bool on = bl && ((fl >> 3) & 1u);
+        const bool done = (fl >> 2) & 1u;
+        const bool live = on && !(done && !auto_reset);
+        const bool reset = live && done;           // auto-reset: the board is init_state from now on
+        uint32_t v[RPL], p[RPL];
+        const uint32_t rm = reset ? ~0u : 0u;   // a board being reset plays on the empty board
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          v[r] = B3(full[r], rm, inv_r[r], TA & (TB | (~TC & 0xFF)));
+          p[r] = (uint32_t)__popc(v[r]) + (r ? p[r - 1] : 0u);
+        }
+        const uint32_t T = p[RPL - 1];
+        // valid points of the board before this lane's rows (Pb) and on the whole board (n): one swap inside the pair
+        const uint32_t oth = dpp0<QP_X1>(T);
+        const uint32_t Pb = t5 ? oth : 0u, n = T + oth;
+        // The draws of a board, TWO plies at a time: the draw of ply t is mix(x0 + (t + 1) c) with x0 the generator the
+        // launch found; lane j of the pair mixes the draw of ply t + j every second ply, a ply takes the even lane's and
+        // the pair swaps
+        if ((t & 1) == 0) {
+          uint64_t xx = (((uint64_t)rngv[2 * s4 + 1] << 32) | rngv[2 * s4]) + (uint64_t)(uint32_t)(t + t5) * 0x9E3779B97F4A7C15ull;
+          uq = (uint32_t)(splitmix_next(xx) >> 32);
+        }
+        const uint32_t uh = dpp0<QP_L0>(uq);
+        uq = dpp0<QP_X1>(uq);
+        const uint32_t k = __umulhi(uh, n + 1u);   // k == n: the pass
+        const bool hit = k >= Pb && k < Pb + T;       // this lane holds the k-th valid point
+        int rr;
+        uint32_t pos;
+        kth_set_bit<RPL>(v, p, (k - Pb) & 0x3FFu, rr, pos);
+        const int rabs = r0 + rr;
+        const int a = !live ? -1 : (k < n ? rabs * N + (int)pos : P);
+        const bool wr_act = bl && (live && k < n ? hit : t5 == 0);
+        const bool place = bl && live && hit;
+        a_q = (int)(((wr_act ? (uint32_t)(a + 2) : 0u) | dpp0<QP_X1>(wr_act ? (uint32_t)(a + 2) : 0u))) - 2;
+        fl_q = reset ? 40u : fl;   // a board being reset: on, dirty, black to move
+        uint64_t resetm = __ballot(reset && t5 == 0);
+        const bool none_live = __ballot(live) == 0;
+        if (none_live && resetm == 0) break;
+        if (resetm) {   // rare
+          if (reset) {
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) inv_r[r] = M[r] = 0u;
+          }
+          while (resetm) {
+            const int s = (__ffsll((unsigned long long)resetm) - 1) >> 1;   // lane 2 s -> board s
+            resetm &= resetm - 1;
+            for (int i = hf.lane; i < 2 * RS; i += kWave) st[(i / RS) * PL + s * RS + (i % RS)] = 0;
+            if (hf.lane == 0) flagsv[s] = 8u | 32u;   // on, reset (written back even if nothing is played)
+          }
+          if (none_live) break;
+        }
+        WAVE_SYNC();
+        // the new stone goes into the mover's plane right away, and - as the group G it forms on its own - into the board's
+        // G block (a job floods over it when q has a friendly neighbour)
+        if (place) {
+          const int turn = reset ? 0 : (int)(fl & 1u);
+          st[turn * PL + s4 * RS + rabs] |= 1u << pos;
+          uint32_t *gb = gblk + s4 * RS;
+          uint4 *pz = reinterpret_cast<uint4 *>(gb);
+#pragma unroll
+          for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
+          asm volatile("" ::: "memory");
+          gb[rabs] = 1u << pos;
+        }
+      }
+      WAVE_SYNC();
+      GG_PROF(0);
+
+      // phase 2a - the board's lanes look at q's neighbours: lane 0 of the pair at the ones above / below, lane 1 at the ones
+      // to the left / right; what the board-level tests need (empty neighbours of q, is any of them friendly, is q boxed
+      // in) is one packed pair sum; the floods become jobs
+      uint32_t qs;                 // bits 0-2 empty neighbours of q, 11 q has a friendly neighbour, 19 q is NOT boxed in
+      int slA0, slA1, slG;         // job slots of this lane's two directions and of G (ZERO: no such job)
+      int njobs;
+      {
+        const int a = a_q;
+        const uint32_t turn = fl_q & 1u;
+        const uint32_t mv1 = ((uint32_t)a < (uint32_t)P) ? 1u : 0u;   // a stone was placed
+        int ar, ac;
+        split_action(mv1 ? a : 0, N, inv, ar, ac);
+        const uint32_t *pm = st + turn * PL + s4 * RS, *po = st + (1u - turn) * PL + s4 * RS;
+        uint32_t obit[2], single[2], packed = 0;
+        int nrv[2], ncv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int sg = 2 * j - 1;
+          const int dr = t5 ? 0 : sg, dc = t5 ? sg : 0;
+          const int nr = ar + dr, nc = ac + dc;   // row -1 .. N, column -1 .. N
+          // (row -1 / -2 of a board is a zero row of the board before it or the pad, row N a zero row, row N + 1 - read for
+          // an off-board neighbour only - whatever follows: masked by obit)
+          const uint32_t rowm = pm[nr], rowo = po[nr], oup = po[nr - 1], odn = po[nr + 1];
+          const uint32_t ncs = (uint32_t)nc & 31u;   // column -1 reads bit 31, column N bit N: never set in a row
+          const uint32_t mbit = (rowm >> ncs) & mv1, ob = (rowo >> ncs) & mv1;
+          const uint32_t onb = ((uint32_t)nr < (uint32_t)N && (uint32_t)nc < (uint32_t)N) ? mv1 : 0u;
+          const uint32_t ex = mbit | ob;
+          packed += (onb & ~ex) | (mbit << 8) | ((onb & ~ob) << 16);
+          const uint32_t onbr = B3(oup, odn, rowo >> 1, T_OR3) | shl1(rowo);
+          obit[j] = ob;
+          single[j] = ob & ~(onbr >> ncs);
+          nrv[j] = nr; ncv[j] = nc;
+        }
+        qs = packed + dpp0<QP_X1>(packed) + 0x70700u;
+        const uint32_t friendly = (qs >> 11) & 1u;
+        const uint32_t gf = t5 ? 0u : friendly;             // the pair's even lane posts the G job
+        const uint32_t c = gf + obit[0] + obit[1];
+        const uint64_t b0 = __ballot((c & 1u) != 0u), b1 = __ballot((c & 2u) != 0u);
+        const uint32_t base = mbcnt64(b0) + 2u * mbcnt64(b1);
+        njobs = (int)__popcll(b0) + 2 * (int)__popcll(b1);
+        const uint32_t sG = base, s0 = base + gf, s1 = s0 + obit[0];
+        const uint32_t common = (uint32_t)s4 | (1u << 18);
+        const uint32_t oc = (turn ^ 1u) << 15;
+        jobv[gf ? sG : (uint32_t)DUMP] = common | ((uint32_t)ar << 5) | ((uint32_t)ac << 10) | (turn << 15) | (1u << 16);
+        jobv[obit[0] ? s0 : (uint32_t)DUMP] = common | (((uint32_t)nrv[0] & 31u) << 5) | (((uint32_t)ncv[0] & 31u) << 10) | oc | (single[0] << 17);
+        jobv[obit[1] ? s1 : (uint32_t)DUMP] = common | (((uint32_t)nrv[1] & 31u) << 5) | (((uint32_t)ncv[1] & 31u) << 10) | oc | (single[1] << 17);
+        slA0 = obit[0] ? (int)s0 : ZERO;
+        slA1 = obit[1] ? (int)s1 : ZERO;
+        slG = (int)dpp0<QP_L0>(gf ? sG : (uint32_t)ZERO);
+      }
+      WAVE_SYNC();
+
+      // phase 2b - lane L runs job L: the flood (seed staged through the job's cleared block), then the liberties of the
+      // group (dilate & empty, saturated at 2), all rows in registers; the class word: bits 0-1 liberties, 2 the group is
+      // one stone, 5 an opponent group without a liberty (captured).  An opponent group that keeps >= 2 liberties zeroes
+      // its block: phase 3 never sees it.
+#pragma unroll 1
+      for (int jb = 0; jb < njobs; jb += kWave) {
+        const int j = jb + ln;
+        const bool have = j < njobs;
+        const uint32_t d = jobv[have ? j : DUMP];
+        const uint32_t ex = have ? 1u : 0u;
+        const int sj = (int)(d & 31u), sr = (int)((d >> 5) & 31u), scol = (int)((d >> 10) & 31u);
+        const uint32_t ownc = (d >> 15) & 1u;
+        const uint32_t isG = have ? (d >> 16) & 1u : 0u;
+        const uint32_t single = have ? (d >> 17) & 1u : 0u;
+        uint32_t *blk = sc + (have ? j : DUMP) * RS;
+        {
+          uint4 *pz = reinterpret_cast<uint4 *>(blk);
+#pragma unroll
+          for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        const uint4 *lds4 = reinterpret_cast<const uint4 *>(lds);
+        const uint4 *pmv = lds4 + (Lds5<R>::kState + (int)ownc * PL + sj * RS) / 4;
+        const uint4 *pov = lds4 + (Lds5<R>::kState + (int)(ownc ^ 1u) * PL + sj * RS) / 4;
+        uint32_t *out = isG ? gblk + sj * RS : blk;
+        uint32_t cnt = 0;
+        {
+          uint32_t m[R];
+          {
+            uint32_t mrev[R], f[R];
+            uint32_t mt[RV * 4], ft[RV * 4];
+#pragma unroll
+            for (int i = 0; i < RV; ++i) {
+              const uint4 x = pmv[i];
+              mt[4 * i] = x.x; mt[4 * i + 1] = x.y; mt[4 * i + 2] = x.z; mt[4 * i + 3] = x.w;
+            }
+            {
+              const int srw = sr & (int)(0u - ex);
+              asm volatile("" ::: "memory");
+              blk[srw] = ex << (((uint32_t)scol ^ (0u - ((uint32_t)sr & 1u))) & 31u);   // odd rows: bit 31 - scol
+              asm volatile("" ::: "memory");
+              const uint4 *pf = reinterpret_cast<const uint4 *>(blk);
+#pragma unroll
+              for (int i = 0; i < RV; ++i) {
+                const uint4 x = pf[i];
+                ft[4 * i] = x.x; ft[4 * i + 1] = x.y; ft[4 * i + 2] = x.z; ft[4 * i + 3] = x.w;
+              }
+              asm volatile("" ::: "memory");
+              blk[srw] = 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              m[r] = mt[r];
+              mrev[r] = __brev(m[r]);
+              f[r] = ft[r];
+            }
+            GG_PROF(1);
+            flood2_serial<R, true, true, false>(m, mrev, f, out);
+            GG_PROF(2);
+          }
+          uint32_t gt[RV * 4], ot[RV * 4];
+          const uint4 *pg = reinterpret_cast<const uint4 *>(out);
+#pragma unroll
+          for (int i = 0; i < RV; ++i) {
+            const uint4 x = pg[i], y = pov[i];
+            gt[4 * i] = x.x; gt[4 * i + 1] = x.y; gt[4 * i + 2] = x.z; gt[4 * i + 3] = x.w;
+            ot[4 * i] = y.x; ot[4 * i + 1] = y.y; ot[4 * i + 2] = y.z; ot[4 * i + 3] = y.w;
+          }
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const uint32_t e = B3(ot[r], m[r], FULLROW, ~(TA | TB) & TC & 0xFF);   // empty points
+            const uint32_t up = r > 0 ? gt[r - 1] : 0u, dn = r + 1 < R ? gt[r + 1] : 0u;
+            const uint32_t dd = B3(shl1(gt[r]), gt[r] >> 1, up, T_OR3);
+            const uint32_t l = B3(dd, dn, e, (TA | TB) & TC);
+            cnt += (uint32_t)__popc(l);
+          }
+        }
+        const uint32_t lib2 = cnt < 2u ? cnt : 2u;
+        const uint32_t dead = (cnt == 0u && have && !isG) ? CL_CAPT : 0u;
+        clsv[have ? j : DUMP] = lib2 | (single << 2) | dead;
+        if (!isG && cnt >= 2u) {
+          uint4 *pz = reinterpret_cast<uint4 *>(blk);
+#pragma unroll
+          for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
+      WAVE_SYNC();
+      GG_PROF(3);
+
+      // phase 3 - all thirty-two boards in ONE pass, RPL adjacent rows per lane: patch the classes, resolve captures and
+      // ko, the next mover's mask (k_rollout4's phase 3 on pairs; A = this lane's two directions, B = its partner's)
+      {
+        const int a = a_q;
+        const uint32_t fl = fl_q;
+        const int slB0 = (int)dpp0<QP_X1>((uint32_t)slA0), slB1 = (int)dpp0<QP_X1>((uint32_t)slA1);
+        const uint32_t cA0 = clsv[slA0], cA1 = clsv[slA1], cB0 = clsv[slB0], cB1 = clsv[slB1], cG = clsv[slG];
+        const int turn0 = fl & 1u;
+        uint32_t *pmine = st + turn0 * PL + s4 * RS + r0;
+        uint32_t *popp = st + (1 - turn0) * PL + s4 * RS + r0;
+        const uint32_t *gA0 = sc + slA0 * RS + r0, *gA1 = sc + slA1 * RS + r0, *gB0 = sc + slB0 * RS + r0, *gB1 = sc + slB1 * RS + r0;
+        const uint32_t *gG = gblk + s4 * RS + r0;
+        uint32_t mine1[RPL], opp0[RPL], b0[RPL], b1[RPL], b2[RPL], b3[RPL], bg[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          mine1[r] = pmine[r];   // (rows >= N are zero)
+          opp0[r] = popp[r];
+          b0[r] = gA0[r]; b1[r] = gA1[r]; b2[r] = gB0[r]; b3[r] = gB1[r];
+          bg[r] = gG[r];
+        }
+        const bool moves_now = a >= 0;
+        const bool is_pass = a == P;
+        const uint32_t stone_m = (moves_now && !is_pass) ? ~0u : 0u;
+        int ar, ac;
+        split_action(a, N, inv, ar, ac);                       // (garbage for a pass / an idle board: masked below)
+        const uint32_t km0 = (uint32_t)__builtin_amdgcn_sbfe((int)cA0, 5, 1), km1 = (uint32_t)__builtin_amdgcn_sbfe((int)cA1, 5, 1),
+                       km2 = (uint32_t)__builtin_amdgcn_sbfe((int)cB0, 5, 1), km3 = (uint32_t)__builtin_amdgcn_sbfe((int)cB1, 5, 1);
+        const uint32_t capt_m = km0 | km1 | km2 | km3;
+        uint32_t g0[RPL], gch[RPL], cap[RPL], Mm_fix[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          g0[r] = bg[r] & stone_m;   // the G block: the flood of G, or the stone alone as phase 1 left it there
+          gch[r] = B3(b0[r], b1[r], b2[r], T_OR3) | b3[r];   // the opponent groups whose class changes
+          cap[r] = B3(b3[r], km3, B3(b2[r], km2, B3(b1[r], km1, b0[r] & km0, T_ANDOR), T_ANDOR), T_ANDOR);
+          Mm_fix[r] = 0u;
+        }
+        // liberties of G among the empty points (saturated at 2): G's own count, or the empty neighbours of q when the
+        // stone stands alone
+        const uint32_t ne = qs & 7u, ne2 = ne < 2u ? ne : 2u;
+        uint32_t libsG = ((qs >> 11) & 1u) ? (cG & 3u) : ne2;
+        uint32_t kor[RPL];   // the ko point as rows of this lane (almost always none)
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) kor[r] = 0u;
+        if (__ballot(capt_m != 0u)) {   // a capture on some board of the wave
+          const uint32_t ncapn = 0u - (km0 + km1 + km2 + km3);    // masks are 0 / -1
+          if (__ballot(ncapn == 1u && libsG == 0u)) {
+            uint32_t dg[RPL];
+            dilate_rows<RPL>(g0, dg);
+            uint32_t cntc = 0;
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) cntc += (uint32_t)__popc(dg[r] & cap[r]);
+            const uint32_t c2 = cntc < 2u ? cntc : 2u;
+            const uint32_t tot = c2 + dpp0<QP_X1>(c2);
+            libsG += (ncapn == 1u && libsG == 0u) ? (tot < 2u ? tot : 2u) : ncapn;
+          } else {
+            libsG += ncapn;
+          }
+          // gogame.py:72-75: ko iff exactly one stone died and the new stone is boxed in
+          const uint32_t ncap1 = ((cA0 >> 2) & km0 & 1u) + ((cA1 >> 2) & km1 & 1u) + ((cB0 >> 2) & km2 & 1u) + ((cB1 >> 2) & km3 & 1u);
+          const bool ko = !(qs & CL_OPEN) && ncapn == 1u && ncap1 == 1u;
+          // the one captured stone is q's neighbour in the direction of its job: up / down are lane 0's directions, left / right lane 1's
+          const uint32_t kmU = t5 ? km2 : km0, kmD = t5 ? km3 : km1, kmL = t5 ? km0 : km2, kmR = t5 ? km1 : km3;
+          const uint32_t kr = (uint32_t)ar + kmU - kmD - (uint32_t)r0;
+          const uint32_t ko_oh = (ko && kr < (uint32_t)RPL) ? (1u << (kr & 31)) : 0u;
+          if (__ballot(ko_oh != 0u)) {
+            const uint32_t ko_bit = 1u << (((uint32_t)ac + kmL - kmR) & 31u);
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) kor[r] = (uint32_t)__builtin_amdgcn_sbfe((int)ko_oh, r, 1) & ko_bit;
+          }
+          // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties
+          uint32_t atari[RPL], f[RPL];
+          uint32_t anya = 0;
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) { atari[r] = B3(mine1[r], M[r], g0[r], TA & ~(TB | TC) & 0xFF); f[r] = 0u; anya |= atari[r]; }
+          uint32_t anyf = 0;
+          if (__ballot(anya != 0u && capt_m != 0u)) {
+            dilate_rows<RPL>(cap, f);
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) { f[r] &= atari[r]; anyf |= f[r]; }
+          }
+          if (__ballot(anyf != 0)) {
+#pragma unroll 1
+            for (int it = 0; it < R * R; ++it) {
+              uint32_t dd[RPL], chg = 0;
+              dilate_rows<RPL>(f, dd);
+#pragma unroll
+              for (int r = 0; r < RPL; ++r) {
+                const uint32_t nw = B3(dd[r], atari[r], f[r], T_ANDOR);
+                chg |= nw ^ f[r];
+                f[r] = nw;
+              }
+              if (__ballot(chg != 0) == 0) break;
+            }
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) Mm_fix[r] = f[r];
+          }
+        }
+        const uint32_t gsel = libsG >= 2u ? ~0u : 0u;
+        uint32_t Mo2[RPL], opp1[RPL], Mm2[RPL], e[RPL], x[RPL], nbr[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          Mo2[r] = B3(M[r], opp0[r], gch[r], TA & TB & ~TC & 0xFF);         // (a captured group was in atari: never in M)
+          opp1[r] = opp0[r] & ~cap[r];
+          const uint32_t Mm = B3(M[r], mine1[r], g0[r], TA & TB & ~TC & 0xFF);
+          Mm2[r] = B3(gsel, g0[r], Mm, T_ANDOR) | Mm_fix[r];               // (M & mine & ~g0) | (gsel & g0)
+          e[r] = B3(full[r], opp1[r], mine1[r], TA & ~(TB | TC) & 0xFF);
+          x[r] = B3(mine1[r], Mm2[r], e[r], (TA & ~TB & 0xFF) | TC) | Mo2[r];
+        }
+        dilate_rows<RPL>(x, nbr);
+        const uint32_t mv_m = moves_now ? ~0u : 0u;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          const uint32_t invalid = B3(e[r], nbr[r], full[r], ~(TA & TB) & TC & 0xFF) | kor[r];
+          inv_r[r] = B3(mv_m, invalid, inv_r[r], T_SEL);
+          M[r] = Mm2[r] | Mo2[r];
+        }
+        if (capt_m) {
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) popp[r] = opp1[r];
+        }
+        if (moves_now && t5 == 0) {
+          const uint32_t passed0 = (fl >> 1) & 1u, done0 = (fl >> 2) & 1u;
+          const uint32_t passed = is_pass ? 1u : 0u, done = done0 | (passed & passed0);
+          flagsv[s4] = (uint32_t)(turn0 ^ 1) | (passed << 1) | (done << 2) | 8u | (fl & 32u);
+          lastv[s4] = a;
+          playedv[s4] += 1;
+        }
+      }
+      WAVE_SYNC();
+      GG_PROF(4);
+    }
+    if (plies >= 8) fair.release();
+    GG_PROF(5);
+
+    // ---------------------------------------------------------------- store
+    int lnS;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lnS));
+    const int s5s = lnS >> 1, r05s = RPL * (lnS & 1);
+    WAVE_SYNC();
+    if (TRACKED) {
+      // park the register rows, then one flat coalesced copy of the group's contiguous block
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        if (r05s + r < RS) {
+          const uint32_t bk = st[0 * PL + s5s * RS + r05s + r], wh = st[1 * PL + s5s * RS + r05s + r];
+          park[0 * PL + s5s * RS + r05s + r] = inv_r[r];
+          park[1 * PL + s5s * RS + r05s + r] = M[r] & bk;
+          park[2 * PL + s5s * RS + r05s + r] = M[r] & wh;
+        }
+      }
+      WAVE_SYNC();
+      const int64_t nbrd = (B - b_first) < nb ? (B - b_first) : nb;
+      const int nw = (int)nbrd * W;
+      uint32_t *gp = reinterpret_cast<uint32_t *>(states) + b_first * (int64_t)W;
+      for (int i = lnS; i < nw; i += kWave) {
+        const int sb = i / W, w = i - sb * W;
+        if (playedv[sb] == 0 && !(flagsv[sb] & 32u)) continue;   // untouched boards are not rewritten
+        uint32_t v;
+        if (w == 5 * N) {
+          v = flagsv[sb] & 7u;
+        } else {
+          const int pl = w / N, rw = w - pl * N;
+          v = pl < 2 ? st[pl * PL + sb * RS + rw] : park[(pl - 2) * PL + sb * RS + rw];
+        }
+        gp[i] = v;
+      }
+      if (lnS < nb && b_first + lnS < B) {
+        const int sb = lnS;
+        const int64_t b = b_first + sb;
+        const int played = playedv[sb];
+        rng[b] = (((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb]) + (uint64_t)(uint32_t)played * 0x9E3779B97F4A7C15ull;
+        if (last_actions) last_actions[b] = lastv[sb];
+        if (steps_done && played) atomicAdd(reinterpret_cast<unsigned long long *>(steps_done) + b, (unsigned long long)played);
+      }
+      WAVE_SYNC();
+    } else {
+      // byte planes in place: the whole group in one contiguous write, then the per-game outputs
+      const int nbrd = (int)((B - b_first) < nb ? (B - b_first) : nb);
+      bool any_wr = false;
+      if (lnS < nbrd) any_wr = playedv[lnS] != 0 || (flagsv[lnS] & 32u);
+      // (the per-game words are read before the emitter takes the loop area over: the meta words live outside it)
+      if (__ballot(any_wr))
+        emit_group<R, RPL, 2>(states + b_first * (int64_t)S, nbrd, N, st, PL, RS, inv_r, flagsv, lds + Lds5<R>::kGrpBits,
+                              reinterpret_cast<uint2 *>(lds + Lds5<R>::kGrpLut), lnS);
+      if (lnS < nbrd) {
+        const int sb = lnS;
+        const int64_t b = b_first + sb;
+        const int played = playedv[sb];
+        rng[b] = (((uint64_t)rngv[2 * sb + 1] << 32) | rngv[2 * sb]) + (uint64_t)(uint32_t)played * 0x9E3779B97F4A7C15ull;
+        if (last_actions) last_actions[b] = lastv[sb];
+        if (steps_done && played) atomicAdd(reinterpret_cast<unsigned long long *>(steps_done) + b, (unsigned long long)played);
+      }
+      WAVE_SYNC();
+    }
+    GG_PROF(7);   // write-back
+    GG_PROF_FLUSH;
+  }
+}
+
+}  // namespace gg
