@@ -12,7 +12,6 @@
 #include "gg_common.h"
 #include "gg_v2.h"
 #include "gg_v4.h"
-#include "gg_v5.h"
 #include "gg_ws.h"   // (defines the weighted-draw helpers k_rollout4 names in its WTS branch, dead here)
 
 namespace gg {
@@ -36,13 +35,6 @@ void launch_rollout4(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, 
   else GG_ROLLOUT4(2);
 }
 #undef GG_ROLLOUT4
-
-// the thirty-two-board kernel (gg_v5.h): full-size 19x19 boards, byte planes (io 0) or tracked boards (io 2)
-void launch_rollout5(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, uint32_t inv,
-                     int plies, int auto_reset, int nb, int grid, hipStream_t s) {
-  if (io == 0) k_rollout5<19, 0><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, inv, plies, auto_reset, nb);
-  else k_rollout5<19, 2><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, inv, plies, auto_reset, nb);
-}
 
 }  // namespace gg
 

@@ -335,14 +335,18 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         WAVE_SYNC();
         // the new stone goes into the mover's plane right away, and - as the group G it forms on its own - into the board's
         // G block (a job floods over it when q has a friendly neighbour)
-        if (place) {
-          const int turn = reset ? 0 : (int)(fl & 1u);
-          st[turn * PL + s4 * RS + rabs] |= 1u << pos;
-          uint32_t *gb = gblk + s4 * RS;
+        // (the even lane of EVERY board clears the G block - a board that passes or idles leaves it empty, phase 3 reads it
+        // unmasked -, then the lane that holds the point writes the stone: DS instructions of a wave execute in order)
+        uint32_t *gb = gblk + s4 * RS;
+        if (t5 == 0) {
           uint4 *pz = reinterpret_cast<uint4 *>(gb);
 #pragma unroll
           for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
-          asm volatile("" ::: "memory");
+        }
+        asm volatile("" ::: "memory");
+        if (place) {
+          const int turn = reset ? 0 : (int)(fl & 1u);
+          st[turn * PL + s4 * RS + rabs] |= 1u << pos;
           gb[rabs] = 1u << pos;
         }
       }
@@ -439,7 +443,11 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
             {
               const int srw = sr & (int)(0u - ex);
               asm volatile("" ::: "memory");
+#ifdef GG_AB_R5_DUAL
+              blk[srw] = ex << ((uint32_t)scol & 31u);
+#else
               blk[srw] = ex << (((uint32_t)scol ^ (0u - ((uint32_t)sr & 1u))) & 31u);   // odd rows: bit 31 - scol
+#endif
               asm volatile("" ::: "memory");
               const uint4 *pf = reinterpret_cast<const uint4 *>(blk);
 #pragma unroll
@@ -457,7 +465,11 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
               f[r] = ft[r];
             }
             GG_PROF(1);
+#ifdef GG_AB_R5_DUAL
+            flood2_dual<R>(m, mrev, f, out);
+#else
             flood2_serial<R, true, true, false>(m, mrev, f, out);
+#endif
             GG_PROF(2);
           }
           uint32_t gt[RV * 4], ot[RV * 4];
@@ -511,27 +523,26 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         }
         const bool moves_now = a >= 0;
         const bool is_pass = a == P;
-        const uint32_t stone_m = (moves_now && !is_pass) ? ~0u : 0u;
         int ar, ac;
         split_action(a, N, inv, ar, ac);                       // (garbage for a pass / an idle board: masked below)
         const uint32_t km0 = (uint32_t)__builtin_amdgcn_sbfe((int)cA0, 5, 1), km1 = (uint32_t)__builtin_amdgcn_sbfe((int)cA1, 5, 1),
                        km2 = (uint32_t)__builtin_amdgcn_sbfe((int)cB0, 5, 1), km3 = (uint32_t)__builtin_amdgcn_sbfe((int)cB1, 5, 1);
         const uint32_t capt_m = km0 | km1 | km2 | km3;
-        uint32_t g0[RPL], gch[RPL], cap[RPL], Mm_fix[RPL];
+        // The opponent blocks hold groups with NO liberty left (captured: q was their only liberty, so they were never in M)
+        // or with exactly ONE (they had q and one more: they were in M) - a group that keeps >= 2 zeroed its block.  So the
+        // union of the four blocks splits by M alone: captured = all4 & ~M, leaving M = all4 & M.
+        uint32_t g0[RPL], all4[RPL], cap[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-          g0[r] = bg[r] & stone_m;   // the G block: the flood of G, or the stone alone as phase 1 left it there
-          gch[r] = B3(b0[r], b1[r], b2[r], T_OR3) | b3[r];   // the opponent groups whose class changes
-          cap[r] = B3(b3[r], km3, B3(b2[r], km2, B3(b1[r], km1, b0[r] & km0, T_ANDOR), T_ANDOR), T_ANDOR);
-          Mm_fix[r] = 0u;
+          g0[r] = bg[r];   // the G block: the flood of G, the stone alone as phase 1 left it there, or nothing (pass / idle board)
+          all4[r] = B3(b0[r], b1[r], b2[r], T_OR3) | b3[r];
+          cap[r] = B3(all4[r], M[r], M[r], TA & ~TB & 0xFF);
         }
         // liberties of G among the empty points (saturated at 2): G's own count, or the empty neighbours of q when the
         // stone stands alone
         const uint32_t ne = qs & 7u, ne2 = ne < 2u ? ne : 2u;
         uint32_t libsG = ((qs >> 11) & 1u) ? (cG & 3u) : ne2;
-        uint32_t kor[RPL];   // the ko point as rows of this lane (almost always none)
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) kor[r] = 0u;
+        uint32_t ko_oh = 0, ko_bit = 0;   // the ko point: one-hot row of this lane / column bit (almost always none)
         if (__ballot(capt_m != 0u)) {   // a capture on some board of the wave
           const uint32_t ncapn = 0u - (km0 + km1 + km2 + km3);    // masks are 0 / -1
           if (__ballot(ncapn == 1u && libsG == 0u)) {
@@ -552,13 +563,10 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
           // the one captured stone is q's neighbour in the direction of its job: up / down are lane 0's directions, left / right lane 1's
           const uint32_t kmU = t5 ? km2 : km0, kmD = t5 ? km3 : km1, kmL = t5 ? km0 : km2, kmR = t5 ? km1 : km3;
           const uint32_t kr = (uint32_t)ar + kmU - kmD - (uint32_t)r0;
-          const uint32_t ko_oh = (ko && kr < (uint32_t)RPL) ? (1u << (kr & 31)) : 0u;
-          if (__ballot(ko_oh != 0u)) {
-            const uint32_t ko_bit = 1u << (((uint32_t)ac + kmL - kmR) & 31u);
-#pragma unroll
-            for (int r = 0; r < RPL; ++r) kor[r] = (uint32_t)__builtin_amdgcn_sbfe((int)ko_oh, r, 1) & ko_bit;
-          }
-          // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties
+          ko_oh = (ko && kr < (uint32_t)RPL) ? (1u << (kr & 31)) : 0u;
+          ko_bit = 1u << (((uint32_t)ac + kmL - kmR) & 31u);
+          // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties: they join M
+          // before the classes are patched
           uint32_t atari[RPL], f[RPL];
           uint32_t anya = 0;
 #pragma unroll
@@ -583,17 +591,17 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
               if (__ballot(chg != 0) == 0) break;
             }
 #pragma unroll
-            for (int r = 0; r < RPL; ++r) Mm_fix[r] = f[r];
+            for (int r = 0; r < RPL; ++r) M[r] |= f[r];
           }
         }
         const uint32_t gsel = libsG >= 2u ? ~0u : 0u;
         uint32_t Mo2[RPL], opp1[RPL], Mm2[RPL], e[RPL], x[RPL], nbr[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-          Mo2[r] = B3(M[r], opp0[r], gch[r], TA & TB & ~TC & 0xFF);         // (a captured group was in atari: never in M)
-          opp1[r] = opp0[r] & ~cap[r];
+          Mo2[r] = B3(M[r], opp0[r], all4[r], TA & TB & ~TC & 0xFF);        // (a captured group was never in M)
+          opp1[r] = B3(opp0[r], cap[r], cap[r], TA & ~TB & 0xFF);
           const uint32_t Mm = B3(M[r], mine1[r], g0[r], TA & TB & ~TC & 0xFF);
-          Mm2[r] = B3(gsel, g0[r], Mm, T_ANDOR) | Mm_fix[r];               // (M & mine & ~g0) | (gsel & g0)
+          Mm2[r] = B3(gsel, g0[r], Mm, T_ANDOR);                           // (M & mine & ~g0) | (gsel & g0)
           e[r] = B3(full[r], opp1[r], mine1[r], TA & ~(TB | TC) & 0xFF);
           x[r] = B3(mine1[r], Mm2[r], e[r], (TA & ~TB & 0xFF) | TC) | Mo2[r];
         }
@@ -601,9 +609,13 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         const uint32_t mv_m = moves_now ? ~0u : 0u;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-          const uint32_t invalid = B3(e[r], nbr[r], full[r], ~(TA & TB) & TC & 0xFF) | kor[r];
+          const uint32_t invalid = B3(e[r], nbr[r], full[r], ~(TA & TB) & TC & 0xFF);
           inv_r[r] = B3(mv_m, invalid, inv_r[r], T_SEL);
           M[r] = Mm2[r] | Mo2[r];
+        }
+        if (__ballot(ko_oh != 0u)) {   // (only a board that moved has a ko point)
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) inv_r[r] |= (uint32_t)__builtin_amdgcn_sbfe((int)ko_oh, r, 1) & ko_bit;
         }
         if (capt_m) {
 #pragma unroll

@@ -10,6 +10,7 @@ L = ctypes.CDLL(_lib.LIB_PATH)
 L.gg_ab_prof_read = L.gg_ab_prof_read_rollout
 L.gg_ab_prof_read.argtypes = [ctypes.c_void_p]; L.gg_ab_prof_read.restype = ctypes.c_int32
 N, F, B = 19, 256, int(os.environ.get('B', '65536'))
+BPW = int(os.environ.get('BPW', '16'))   # boards per wave of the kernel that serves the launch (32: k_rollout5)
 st = gogame.batch_init_state(B, N, device='cuda'); rng = gogame.rng_seed(B, 20260927)
 ch = B // 16
 for g in range(1, 16):
@@ -25,6 +26,6 @@ L.gg_ab_prof_read(buf)
 v = list(buf)[:8]; tot = sum(v)
 names = ['phase1 sampling', 'phase2 roles+setup', 'phase2 flood', 'phase2 liberties+cls', 'phase3 class patch', '-', 'load', 'write-back']
 print('B %d: %.3f ms per launch (instrumented)' % (B, a.elapsed_time(b) / 4))
-wave_plies = ((B + 15) // 16) * 4 * F
+wave_plies = ((B + BPW - 1) // BPW) * 4 * F
 for n, x in zip(names, v):
     print('  %-22s %5.1f %%  %8.1f cycles per wave-ply' % (n, 100.0 * x / tot, x / wave_plies))

@@ -4,6 +4,7 @@ rest: v_bfrev, v_bcnt, v_cndmask, v_cmp, v_lshlrev, three-operand ops, DPP moves
 
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -mllvm -enable-post-misched=false -S --cuda-device-only -o /tmp/gg.s gymgo_amd/csrc/gg_rollout.hip
     python tools/isa_mix.py /tmp/gg.s > profiles/rNN_isa_mix.txt
+    python tools/isa_mix.py /tmp/gg.s _ZN2gg10k_rollout5ILi19ELi0E 32      (another kernel of the family, boards per wave)
 
 The ply loop is the longest stretch between two consecutive `v_mbcnt_lo` markers of k_rollout4<19, 0, false, true, false, false> (the kernel reads
 its lane id afresh at the top of every ply and once more before the write-back).  Inner loops are weighted by the trip
@@ -18,7 +19,7 @@ FAST = {'v_xor_b32', 'v_and_b32', 'v_or_b32', 'v_add_u32', 'v_sub_u32', 'v_subre
 KERNEL = '_ZN2gg10k_rollout4ILi19ELi0ELb0ELb1ELb0ELb0E'
 
 
-def main(path):
+def main(path, KERNEL=KERNEL, NB=16):
     text = open(path).read().split('\n')
     start = next(i for i, l in enumerate(text) if l.startswith(KERNEL))
     end = next(i for i in range(start, len(text)) if 's_endpgm' in text[i])
@@ -53,9 +54,17 @@ def main(path):
     weights = [1.0] * len(loop)
     names = ['auto-reset clear (rare)', 'flood', 'atari re-flood after a capture']
     trip = [0.02, None, 0.3]
-    for k, (a, b) in enumerate(runs[:3]):
-        for i in range(a, b + 1):
-            weights[i] = trip[k] if trip[k] is not None else 3.07 / 2.0   # the flood loop body holds two sweeps (down, up)
+    if any(d >= 4 for d in blocks):
+        # k_rollout5: the flood (depth 4) sits inside the job-batch loop (depth 3, one trip unless a ply posts > 64 jobs)
+        names[1] = 'job batch + flood'
+        for k, (a, b) in enumerate(runs[:3]):
+            inner = any(blocks[i] >= 4 for i in range(a, b + 1))
+            for i in range(a, b + 1):
+                weights[i] = (3.07 / 2.0 if blocks[i] >= 4 else 1.0) if inner else trip[0 if k == 0 else 2]
+    else:
+        for k, (a, b) in enumerate(runs[:3]):
+            for i in range(a, b + 1):
+                weights[i] = trip[k] if trip[k] is not None else 3.07 / 2.0   # the flood loop body holds two sweeps (down, up)
     tot, cyc = collections.Counter(), 0.0
     slow = collections.Counter()
     for l, w in zip(loop, weights):
@@ -78,7 +87,7 @@ def main(path):
             tot['other'] += w
     print('ply loop of %s...: %d static lines; depth-3 runs: %s' % (KERNEL, len(loop), [(names[k], b - a + 1) for k, (a, b) in enumerate(runs[:3])]))
     for k in sorted(tot):
-        print('  %-22s %8.1f per wave-ply  (%.1f per env step at 16 boards per wave)' % (k, tot[k], tot[k] / 16))
+        print('  %-22s %8.1f per wave-ply  (%.1f per env step at %d boards per wave)' % (k, tot[k], tot[k] / NB, NB))
     valu = tot['valu fast (2 cycles)'] + tot['valu slow (4 cycles)']
     print('  VALU issue cycles per wave-ply: %.0f  (%.2f cycles per VALU instruction on average)' % (cyc, cyc / valu))
     print('  slow ops: ' + ', '.join('%s %.0f' % (k, v) for k, v in slow.most_common(12)))
@@ -86,4 +95,4 @@ def main(path):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1])
+    main(sys.argv[1], *([sys.argv[2]] if len(sys.argv) > 2 else []), **({'NB': int(sys.argv[3])} if len(sys.argv) > 3 else {}))

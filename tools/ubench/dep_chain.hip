@@ -1,0 +1,60 @@
+// dep_chain.hip - what a DEPENDENT chain of VALU instructions costs per instruction with 1, 2, 3, 4, 8 waves on a SIMD
+// (tools/ubench/valu_rate2.hip measures independent streams: the issue rate).  Chains: v_add (2-cycle op), v_bfrev (4-cycle op),
+// the flood's visit (bitop3, add, bitop3, bfrev, add, bitop3: gg_common.h FLOOD_VISIT), and the visit as TWO interleaved chains.
+//   hipcc -O3 --offload-arch=gfx950 -o dep_chain dep_chain.hip && ./dep_chain
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#define B3(a, b, c, t) __builtin_amdgcn_bitop3_b32((a), (b), (c), (t))
+constexpr int kIters = 2048;
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k(uint32_t *out, uint32_t seed) {
+  uint32_t x = seed + threadIdx.x, y = seed * 3u + 1u, m = ~seed, mr = seed ^ 0x55u, x2 = x ^ 77u;
+#pragma unroll 1
+  for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (MODE == 0) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(y)); }
+      if (MODE == 1) { asm volatile("v_bfrev_b32 %0, %0" : "+v"(x)); }
+      if (MODE == 2 || MODE == 3) {
+        uint32_t s = B3(y, m, x, 0xEA), t = m + s, uu = B3(t, s, m, 0xCA), v = __brev(uu), t2 = mr + v;
+        x = B3(t2, v, mr, 0xCA);
+        asm volatile("" : "+v"(x));
+        if (MODE == 3) {
+          uint32_t s_ = B3(y, m, x2, 0xEA), t_ = m + s_, u_ = B3(t_, s_, m, 0xCA), v_ = __brev(u_), t2_ = mr + v_;
+          x2 = B3(t2_, v_, mr, 0xCA);
+          asm volatile("" : "+v"(x2));
+        }
+      }
+    }
+  }
+  if (x == 0x12345u && x2 == 7u) out[0] = x;
+}
+
+template <int MODE>
+void run(const char *name, int instr_per_iter) {
+  uint32_t *out;
+  (void)hipMalloc(&out, 4);
+  hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
+  const int simds = p.multiProcessorCount * 4;
+  for (int w : {1, 2, 3, 4, 8}) {
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    k<MODE><<<simds * w, 64>>>(out, 12345u);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(a);
+    for (int r = 0; r < 4; ++r) k<MODE><<<simds * w, 64>>>(out, 12345u);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    const double ns = ms * 1e6 / 4.0 / ((double)kIters * 8 * instr_per_iter);
+    printf("%-28s %d waves per SIMD: %.2f ns per instruction of a wave, %.2f ns per instruction of the SIMD\n", name, w, ns, ns / w);
+  }
+}
+
+int main() {
+  run<0>("v_add_u32 chain", 1);
+  run<1>("v_bfrev_b32 chain", 1);
+  run<2>("flood visit, one chain", 6);
+  run<3>("flood visit, two chains", 12);
+  return 0;
+}
