@@ -436,6 +436,8 @@ def rollout_kernel_name(n, games, plies, cus, auto_reset=True):
     lat_per_cu, lat_plies = {9: (128, 3), 13: (80, 3 if games >= 16 * cus else 4), 19: (31, 8)}[rcap]
     if plies >= lat_plies and games <= lat_per_cu * cus:
         return 'k_rollout_lat<%d, %s, %s, 0>' % (rcap, full, 'true' if auto_reset else 'false')
+    if n == 19 and plies >= 8 and games >= 256 * cus:
+        return 'k_rollout5<19, 0>'                              # a full machine: 32 boards per wave, flood jobs (gg_v5.h)
     if plies >= 2 and games >= 32 * cus:
         return 'k_rollout4<%d, 0, false, %s, false, false>' % (rcap, full)
     if plies == 1 and n in (9, 13, 19):
@@ -522,13 +524,16 @@ def _mask_pc_relative(code):
 
 
 def rollout_symbol_prefix(kernel):
-    """Mangled-name prefix of a rollout kernel instantiation given as rollout_kernel_name writes it (k_rollout4<R, IO, MOVES,
+    """Mangled-name prefix of a rollout kernel instantiation given as rollout_kernel_name writes it (k_rollout5<R, IO>, k_rollout4<R, IO, MOVES,
     FULLN, ENV, WTS>, k_rollout_lat<R, FULLN, AUTO, IO>, k_rollout2<R, PERPLY, PACKED, FULLN>)."""
     import re
     b = lambda x: 'Lb1E' if x == 'true' else 'Lb0E'
     m = re.match(r'k_rollout4<(\d+), (\d+), (\w+), (\w+), (\w+), (\w+)>', kernel)
     if m:
         return '_ZN2gg10k_rollout4ILi%sELi%sE%s%s%s%sEE' % (m.group(1), m.group(2), b(m.group(3)), b(m.group(4)), b(m.group(5)), b(m.group(6)))
+    m = re.match(r'k_rollout5<(\d+), (\d+)>', kernel)
+    if m:
+        return '_ZN2gg10k_rollout5ILi%sELi%sEEE' % (m.group(1), m.group(2))
     m = re.match(r'k_rollout_lat<(\d+), (\w+), (\w+), (\d+)>', kernel)
     if m:
         return '_ZN2gg13k_rollout_latILi%sE%s%sLi%sELb0EEE' % (m.group(1), b(m.group(2)), b(m.group(3)), m.group(4))      # (+ SHORT = false)

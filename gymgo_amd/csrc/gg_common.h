@@ -454,6 +454,22 @@ struct FairShare {
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc0 sc1" ::"s"(mates_lds), "v"(src) : "memory", "m0");
     }
   }
+  // the same exchange without the priority: returns how many mates are >= lag units behind (wave-uniform); the caller sets
+  // its priority itself (k_rollout5 combines it with the phase of the ply it is in)
+  __device__ __forceinline__ uint32_t behind(uint32_t progress, uint32_t lag) {
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t mate = ln < 16 ? mates[ln] : 0u;
+    const uint32_t n = (uint32_t)__popcll(__ballot(mate != 0u && mate != 0xFFFFFFFFu && mate + lag <= progress + 1u));
+    if (ln == 0) __hip_atomic_store(row + slot, progress + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (ln < 16) {
+      const unsigned int *src = row + ln;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc0 sc1" ::"s"(mates_lds), "v"(src) : "memory", "m0");
+    }
+    return n;
+  }
   __device__ __forceinline__ void release() {
     int ln;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));

@@ -67,8 +67,44 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
 }
 constexpr int QP_L0 = 0xA0;   // quad_perm [0,0,2,2]: the even lane of each pair
 
-// job descriptor: bits 0-4 board, 5-9 seed row, 10-14 seed column, 15 the colour flooded, 16 the job floods G, 17 the seed
-// is a one-stone group (ko needs it), 18 the job exists
+// kth_set_bit (gg_v4.h) for TEN rows per lane: the row is found by a search tree over the prefix counts (5 | 2 + 3 | 1 + 1 (+ 1):
+// 31 instructions) instead of nine select steps in a row (45); the bit search inside the row is the same.
+__device__ __forceinline__ void kth_set_bit10(const uint32_t (&v)[10], const uint32_t (&p)[10], uint32_t tt, int &rr, uint32_t &pos) {
+  uint32_t ntt = ~tt;
+  // c + ~tt = c - tt - 1 is negative iff tt >= c: the target lies beyond the rows counted by c
+  const uint32_t g5 = (uint32_t)((int32_t)(p[4] + ntt) >> 31);
+  uint32_t a[5], t[4];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) a[i] = B3(g5, v[5 + i], v[i], T_SEL);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = B3(g5, p[5 + i], p[i], T_SEL);
+  uint32_t base = g5 & p[4], row = g5 & 5u;
+  const uint32_t g2 = (uint32_t)((int32_t)(t[1] + ntt) >> 31);            // rows 2 .. 4 of the half
+  const uint32_t b0 = B3(g2, a[2], a[0], T_SEL), b1 = B3(g2, a[3], a[1], T_SEL), u0 = B3(g2, t[2], t[0], T_SEL);
+  base = B3(g2, t[1], base, T_SEL);
+  row = B3(g2, 2u, row, T_ANDOR);                                          // (0 or 5) + 2: no carry
+  const uint32_t g1 = (uint32_t)((int32_t)(u0 + ntt) >> 31);
+  uint32_t vr = B3(g1, b1, b0, T_SEL);
+  base = B3(g1, u0, base, T_SEL);
+  row -= g1;
+  const uint32_t g1b = B3(g2, g1, (uint32_t)((int32_t)(t[3] + ntt) >> 31), TA & TB & TC);   // the last row of the three-row group
+  vr = B3(g1b, a[4], vr, T_SEL);
+  base = B3(g1b, t[3], base, T_SEL);
+  row -= g1b;
+  ntt += base;                                                          // ~(tt - base)
+  uint32_t ps = 0;
+#pragma unroll
+  for (int sh = 16; sh >= 1; sh >>= 1) {
+    const uint32_t e = (uint32_t)__popc((vr >> ps) & ((1u << sh) - 1u)) + ntt;
+    const uint32_t ge = (uint32_t)((int32_t)e >> 31);
+    ntt = B3(ge, e, ntt, T_SEL);
+    ps = B3((uint32_t)sh, ge, ps, T_ANDOR);
+  }
+  rr = (int)row;
+  pos = ps;
+}
+
+// job descriptor: bits 0-4 board, 5-9 seed row, 10-14 seed column, 15 the colour flooded, 16 the job floods G, 18 the job exists
 template <int R, int IO>
 __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                        int32_t *__restrict__ last_actions, int64_t *__restrict__ steps_done,
@@ -261,12 +297,19 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
     GG_PROF(6);   // load
     FairShare fair(lds + Lds5<R>::kFair);
     const uint32_t fair_lag = plies >= 192 ? 24u : (plies >= 16 ? (uint32_t)plies >> 3 : 2u);
+    bool lead = false;   // this wave is >= fair_lag plies ahead of its SIMD-mate
     uint32_t uq = 0;   // this lane's pre-mixed draw: lane j of a pair holds the one of ply (t & ~1) + j, swapped every ply
 #pragma unroll 1
     for (int t = 0; t < plies; ++t) {
+      // Fair share of the SIMD (gg_common.h) every fourth ply - without it the older of a SIMD's two waves runs ahead and the
+      // launch ends on one wave per SIMD: 1.51 -> 1.66 ms - combined with the PHASE of the ply: the flood of phase 2b is one
+      // dependent chain per lane that needs the issue port every fifth cycle or so, the other phases have ten independent
+      // rows per lane.  A wave in the flood therefore yields (priority 0 / 1: leader / straggler) and a wave in any other phase
+      // issues first (2 / 3): 1.509 -> 1.488 ms per launch of 65 536 games x 256 plies; the other way round 1.561.
       if ((t & 3) == 0 && plies >= 8) {
         const uint32_t left = (uint32_t)(plies - t);
-        fair.update((uint32_t)t, left < fair_lag ? (left > 2u ? left : 2u) : fair_lag);
+        lead = fair.behind((uint32_t)t, left < fair_lag ? (left > 2u ? left : 2u) : fair_lag) != 0u;
+        if (lead) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
       }
       int ln;
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
@@ -309,7 +352,8 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         const bool hit = k >= Pb && k < Pb + T;       // this lane holds the k-th valid point
         int rr;
         uint32_t pos;
-        kth_set_bit<RPL>(v, p, (k - Pb) & 0x3FFu, rr, pos);
+        if constexpr (RPL == 10) kth_set_bit10(v, p, (k - Pb) & 0x3FFu, rr, pos);
+        else kth_set_bit<RPL>(v, p, (k - Pb) & 0x3FFu, rr, pos);
         const int rabs = r0 + rr;
         const int a = !live ? -1 : (k < n ? rabs * N + (int)pos : P);
         const bool wr_act = bl && (live && k < n ? hit : t5 == 0);
@@ -366,24 +410,21 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         int ar, ac;
         split_action(mv1 ? a : 0, N, inv, ar, ac);
         const uint32_t *pm = st + turn * PL + s4 * RS, *po = st + (1u - turn) * PL + s4 * RS;
-        uint32_t obit[2], single[2], packed = 0;
+        uint32_t obit[2], packed = 0;
         int nrv[2], ncv[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int sg = 2 * j - 1;
           const int dr = t5 ? 0 : sg, dc = t5 ? sg : 0;
           const int nr = ar + dr, nc = ac + dc;   // row -1 .. N, column -1 .. N
-          // (row -1 / -2 of a board is a zero row of the board before it or the pad, row N a zero row, row N + 1 - read for
-          // an off-board neighbour only - whatever follows: masked by obit)
-          const uint32_t rowm = pm[nr], rowo = po[nr], oup = po[nr - 1], odn = po[nr + 1];
+          // (row -1 of a board is a zero row of the board before it or the pad, row N a zero row)
+          const uint32_t rowm = pm[nr], rowo = po[nr];
           const uint32_t ncs = (uint32_t)nc & 31u;   // column -1 reads bit 31, column N bit N: never set in a row
           const uint32_t mbit = (rowm >> ncs) & mv1, ob = (rowo >> ncs) & mv1;
           const uint32_t onb = ((uint32_t)nr < (uint32_t)N && (uint32_t)nc < (uint32_t)N) ? mv1 : 0u;
           const uint32_t ex = mbit | ob;
           packed += (onb & ~ex) | (mbit << 8) | ((onb & ~ob) << 16);
-          const uint32_t onbr = B3(oup, odn, rowo >> 1, T_OR3) | shl1(rowo);
           obit[j] = ob;
-          single[j] = ob & ~(onbr >> ncs);
           nrv[j] = nr; ncv[j] = nc;
         }
         qs = packed + dpp0<QP_X1>(packed) + 0x70700u;
@@ -397,8 +438,8 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         const uint32_t common = (uint32_t)s4 | (1u << 18);
         const uint32_t oc = (turn ^ 1u) << 15;
         jobv[gf ? sG : (uint32_t)DUMP] = common | ((uint32_t)ar << 5) | ((uint32_t)ac << 10) | (turn << 15) | (1u << 16);
-        jobv[obit[0] ? s0 : (uint32_t)DUMP] = common | (((uint32_t)nrv[0] & 31u) << 5) | (((uint32_t)ncv[0] & 31u) << 10) | oc | (single[0] << 17);
-        jobv[obit[1] ? s1 : (uint32_t)DUMP] = common | (((uint32_t)nrv[1] & 31u) << 5) | (((uint32_t)ncv[1] & 31u) << 10) | oc | (single[1] << 17);
+        jobv[obit[0] ? s0 : (uint32_t)DUMP] = common | (((uint32_t)nrv[0] & 31u) << 5) | (((uint32_t)ncv[0] & 31u) << 10) | oc;
+        jobv[obit[1] ? s1 : (uint32_t)DUMP] = common | (((uint32_t)nrv[1] & 31u) << 5) | (((uint32_t)ncv[1] & 31u) << 10) | oc;
         slA0 = obit[0] ? (int)s0 : ZERO;
         slA1 = obit[1] ? (int)s1 : ZERO;
         slG = (int)dpp0<QP_L0>(gf ? sG : (uint32_t)ZERO);
@@ -406,9 +447,10 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
       WAVE_SYNC();
 
       // phase 2b - lane L runs job L: the flood (seed staged through the job's cleared block), then the liberties of the
-      // group (dilate & empty, saturated at 2), all rows in registers; the class word: bits 0-1 liberties, 2 the group is
-      // one stone, 5 an opponent group without a liberty (captured).  An opponent group that keeps >= 2 liberties zeroes
+      // group (dilate & empty, saturated at 2), all rows in registers; the class word: bits 0-1 liberties, 5 an opponent group
+      // without a liberty (captured).  An opponent group that keeps >= 2 liberties zeroes
       // its block: phase 3 never sees it.
+      if (plies >= 8) { if (lead) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
 #pragma unroll 1
       for (int jb = 0; jb < njobs; jb += kWave) {
         const int j = jb + ln;
@@ -418,7 +460,6 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         const int sj = (int)(d & 31u), sr = (int)((d >> 5) & 31u), scol = (int)((d >> 10) & 31u);
         const uint32_t ownc = (d >> 15) & 1u;
         const uint32_t isG = have ? (d >> 16) & 1u : 0u;
-        const uint32_t single = have ? (d >> 17) & 1u : 0u;
         uint32_t *blk = sc + (have ? j : DUMP) * RS;
         {
           uint4 *pz = reinterpret_cast<uint4 *>(blk);
@@ -443,11 +484,7 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
             {
               const int srw = sr & (int)(0u - ex);
               asm volatile("" ::: "memory");
-#ifdef GG_AB_R5_DUAL
-              blk[srw] = ex << ((uint32_t)scol & 31u);
-#else
               blk[srw] = ex << (((uint32_t)scol ^ (0u - ((uint32_t)sr & 1u))) & 31u);   // odd rows: bit 31 - scol
-#endif
               asm volatile("" ::: "memory");
               const uint4 *pf = reinterpret_cast<const uint4 *>(blk);
 #pragma unroll
@@ -465,14 +502,11 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
               f[r] = ft[r];
             }
             GG_PROF(1);
-#ifdef GG_AB_R5_DUAL
-            flood2_dual<R>(m, mrev, f, out);
-#else
+            // (the two-chain flood2_dual: 1.758 against 1.579 ms per launch - one more sweep-equivalent, as in k_rollout4)
             flood2_serial<R, true, true, false>(m, mrev, f, out);
-#endif
             GG_PROF(2);
           }
-          uint32_t gt[RV * 4], ot[RV * 4];
+          uint32_t gt[RV * 4], ot[RV * 4], cnt3[3] = {0u, 0u, 0u};
           const uint4 *pg = reinterpret_cast<const uint4 *>(out);
 #pragma unroll
           for (int i = 0; i < RV; ++i) {
@@ -486,18 +520,20 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
             const uint32_t up = r > 0 ? gt[r - 1] : 0u, dn = r + 1 < R ? gt[r + 1] : 0u;
             const uint32_t dd = B3(shl1(gt[r]), gt[r] >> 1, up, T_OR3);
             const uint32_t l = B3(dd, dn, e, (TA | TB) & TC);
-            cnt += (uint32_t)__popc(l);
+            cnt3[r % 3] += (uint32_t)__popc(l);   // (three accumulating chains, not one of nineteen v_bcnt)
           }
+          cnt = cnt3[0] + cnt3[1] + cnt3[2];
         }
         const uint32_t lib2 = cnt < 2u ? cnt : 2u;
         const uint32_t dead = (cnt == 0u && have && !isG) ? CL_CAPT : 0u;
-        clsv[have ? j : DUMP] = lib2 | (single << 2) | dead;
+        clsv[have ? j : DUMP] = lib2 | dead;
         if (!isG && cnt >= 2u) {
           uint4 *pz = reinterpret_cast<uint4 *>(blk);
 #pragma unroll
           for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
         }
       }
+      if (plies >= 8) { if (lead) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
       WAVE_SYNC();
       GG_PROF(3);
 
@@ -557,41 +593,47 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
           } else {
             libsG += ncapn;
           }
-          // gogame.py:72-75: ko iff exactly one stone died and the new stone is boxed in
-          const uint32_t ncap1 = ((cA0 >> 2) & km0 & 1u) + ((cA1 >> 2) & km1 & 1u) + ((cB0 >> 2) & km2 & 1u) + ((cB1 >> 2) & km3 & 1u);
-          const bool ko = !(qs & CL_OPEN) && ncapn == 1u && ncap1 == 1u;
-          // the one captured stone is q's neighbour in the direction of its job: up / down are lane 0's directions, left / right lane 1's
-          const uint32_t kmU = t5 ? km2 : km0, kmD = t5 ? km3 : km1, kmL = t5 ? km0 : km2, kmR = t5 ? km1 : km3;
-          const uint32_t kr = (uint32_t)ar + kmU - kmD - (uint32_t)r0;
-          ko_oh = (ko && kr < (uint32_t)RPL) ? (1u << (kr & 31)) : 0u;
-          ko_bit = 1u << (((uint32_t)ac + kmL - kmR) & 31u);
+          // gogame.py:72-75: ko iff exactly one stone died and the new stone is boxed in (one captured NEIGHBOUR and a boxed-in
+          // stone first: rare enough to keep the rest off the usual path)
+          const bool ko1 = ncapn == 1u && !(qs & CL_OPEN);
+          if (__ballot(ko1)) {
+            uint32_t died = 0;   // captured stones on this lane's rows (one captured neighbour: exactly one stone died iff its group is that stone)
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) died += (uint32_t)__popc(cap[r]);
+            const bool ko = ko1 && died + dpp0<QP_X1>(died) == 1u;
+            // the one captured stone is q's neighbour in the direction of its job: up / down are lane 0's directions, left / right lane 1's
+            const uint32_t kmU = t5 ? km2 : km0, kmD = t5 ? km3 : km1, kmL = t5 ? km0 : km2, kmR = t5 ? km1 : km3;
+            const uint32_t kr = (uint32_t)ar + kmU - kmD - (uint32_t)r0;
+            ko_oh = (ko && kr < (uint32_t)RPL) ? (1u << (kr & 31)) : 0u;
+            ko_bit = 1u << (((uint32_t)ac + kmL - kmR) & 31u);
+          }
           // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties: they join M
           // before the classes are patched
-          uint32_t atari[RPL], f[RPL];
+          uint32_t atari[RPL];
           uint32_t anya = 0;
 #pragma unroll
-          for (int r = 0; r < RPL; ++r) { atari[r] = B3(mine1[r], M[r], g0[r], TA & ~(TB | TC) & 0xFF); f[r] = 0u; anya |= atari[r]; }
-          uint32_t anyf = 0;
+          for (int r = 0; r < RPL; ++r) { atari[r] = B3(mine1[r], M[r], g0[r], TA & ~(TB | TC) & 0xFF); anya |= atari[r]; }
           if (__ballot(anya != 0u && capt_m != 0u)) {
+            uint32_t f[RPL], anyf = 0;
             dilate_rows<RPL>(cap, f);
 #pragma unroll
             for (int r = 0; r < RPL; ++r) { f[r] &= atari[r]; anyf |= f[r]; }
-          }
-          if (__ballot(anyf != 0)) {
+            if (__ballot(anyf != 0)) {
 #pragma unroll 1
-            for (int it = 0; it < R * R; ++it) {
-              uint32_t dd[RPL], chg = 0;
-              dilate_rows<RPL>(f, dd);
+              for (int it = 0; it < R * R; ++it) {
+                uint32_t dd[RPL], chg = 0;
+                dilate_rows<RPL>(f, dd);
 #pragma unroll
-              for (int r = 0; r < RPL; ++r) {
-                const uint32_t nw = B3(dd[r], atari[r], f[r], T_ANDOR);
-                chg |= nw ^ f[r];
-                f[r] = nw;
+                for (int r = 0; r < RPL; ++r) {
+                  const uint32_t nw = B3(dd[r], atari[r], f[r], T_ANDOR);
+                  chg |= nw ^ f[r];
+                  f[r] = nw;
+                }
+                if (__ballot(chg != 0) == 0) break;
               }
-              if (__ballot(chg != 0) == 0) break;
-            }
 #pragma unroll
-            for (int r = 0; r < RPL; ++r) M[r] |= f[r];
+              for (int r = 0; r < RPL; ++r) M[r] |= f[r];
+            }
           }
         }
         const uint32_t gsel = libsG >= 2u ? ~0u : 0u;

@@ -139,7 +139,12 @@ def test_bench_argument_plumbing():
     a = bench.parse_args(['--fuse', '64'])
     assert a.plies_per_step == 64 and a.gpus == 1
     assert bench.algo_bytes_per_step(19) == 4336 and bench.fused_bytes_per_game(19) == 4348
-    assert bench.rollout_kernel_name(19, 65536, 256, 256) == 'k_rollout4<19, 0, false, true, false, false>'
+    # (round 6: full-size 19x19 launches of >= 8 plies from 256 games per CU on take the thirty-two-board kernel, gg_v5.h)
+    assert bench.rollout_kernel_name(19, 65536, 256, 256) == 'k_rollout5<19, 0>' and bench.rollout_kernel_name(19, 131072, 8, 256) == 'k_rollout5<19, 0>'
+    assert bench.rollout_kernel_name(19, 65535, 256, 256) == 'k_rollout4<19, 0, false, true, false, false>'
+    assert bench.rollout_kernel_name(19, 65536, 7, 256) == 'k_rollout4<19, 0, false, true, false, false>'
+    assert bench.rollout_kernel_name(18, 65536, 256, 256) == 'k_rollout4<19, 0, false, false, false, false>'
+    assert bench.rollout_symbol_prefix('k_rollout5<19, 0>') == '_ZN2gg10k_rollout5ILi19ELi0EEE'
     assert bench.rollout_kernel_name(9, 4096, 256, 256) == 'k_rollout_lat<9, true, true, 0>'      # config 2 (use_lat: <= 64 games per CU, >= 3 plies)
     assert bench.rollout_kernel_name(9, 4096, 2, 256) == 'k_rollout2_w4<9, true>' and bench.rollout_kernel_name(9, 8194, 1, 256) == 'k_rollout2<9, true, false, true>'
     assert bench.rollout_kernel_name(19, 4096, 1, 256) == 'k_rollout2_w4<19, true>' and bench.rollout_kernel_name(19, 4098, 1, 256) == 'k_rollout2<19, true, false, true>'
