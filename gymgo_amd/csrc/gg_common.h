@@ -152,7 +152,15 @@ __device__ __forceinline__ void flood2_dual(const uint32_t (&m)[R], const uint32
 // EARLY: the first closure test already after the second sweep (down, up).  It pays on 9x9 boards in the from-scratch
 // analysis (groups are small: config 2 fused 2.32 -> 2.38e9 steps/s, the 9x9 per-ply kernels -3 %) and nowhere else
 // (13x13: -3 % in the fused rollout; 19x19: 2.33 -> 2.43 ms; the multi-ply kernel's floods at 9x9: -1.5 %)
-template <int R, bool PREREV = false, bool OUT128 = false, bool EARLY = false>
+#ifdef GG_AB_SWEEPS
+// A/B builds only: sweeps per flood batch of the kernels that ask for it (gg_sweeps[0] sweeps, [1] batches)
+static __device__ unsigned long long gg_sweeps[2];
+#define GG_SWEEP_COUNT(n) do { if (COUNT) { int l_; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_)); \
+    if (l_ == 0) { atomicAdd(&gg_sweeps[0], (unsigned long long)(n)); atomicAdd(&gg_sweeps[1], 1ull); } } } while (0)
+#else
+#define GG_SWEEP_COUNT(n) do {} while (0)
+#endif
+template <int R, bool PREREV = false, bool OUT128 = false, bool EARLY = false, bool COUNT = false>
 __device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R],
                                               uint32_t *out) {
   if (!PREREV) {
@@ -180,7 +188,7 @@ __device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint
         above = g;
       }
       if ((R - 1) & 1) open |= pend;
-      if (__ballot(open != 0) == 0) return;
+      if (__ballot(open != 0) == 0) { GG_SWEEP_COUNT(2 * it + 1); return; }
     }
 #pragma unroll
     for (int r = R - 1; r >= 0; --r) FLOOD_VISIT(r, r + 1, ((r + 1) & 1) != 0);  // up: domain ((r+1)&1) -> (r&1)
@@ -203,7 +211,7 @@ __device__ __forceinline__ void flood2_serial(const uint32_t (&m)[R], const uint
         below = g;
       }
       if ((R - 1) & 1) open |= pend;
-      if (__ballot(open != 0) == 0) return;
+      if (__ballot(open != 0) == 0) { GG_SWEEP_COUNT(2 * it + 2); return; }
     }
   }
   // iteration bound hit (cannot happen for R <= 19): rows are in domain (r & 1)

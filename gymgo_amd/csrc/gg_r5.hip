@@ -23,6 +23,16 @@ void launch_rollout5(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, 
 
 }  // namespace gg
 
+#ifdef GG_AB_SWEEPS
+// A/B builds only: read and clear the sweep counters of k_rollout5's flood batches
+extern "C" int32_t gg_ab_sweeps_read_r5(unsigned long long *out2) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out2, HIP_SYMBOL(gg::gg_sweeps), 16) != hipSuccess) return 2;
+  unsigned long long z[2] = {0, 0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(gg::gg_sweeps), z, 16) == hipSuccess ? 0 : 3;
+}
+#endif
+
 #ifdef GG_AB_PROF
 // A/B builds only: read and clear the phase clocks of THIS translation unit's launches (gg_prof has internal linkage)
 GG_PROF_READ(gg_ab_prof_read_r5)

@@ -104,7 +104,87 @@ __device__ __forceinline__ void kth_set_bit10(const uint32_t (&v)[10], const uin
   pos = ps;
 }
 
-// job descriptor: bits 0-4 board, 5-9 seed row, 10-14 seed column, 15 the colour flooded, 16 the job floods G, 18 the job exists
+// flood2_serial (gg_common.h; seeds with their odd rows bit-reversed, the normal-order copy of the fill streamed into the
+// 16-byte aligned `out`) for a batch of JOBS of which only some need the fixed point: the sweeps go on while a lane with
+// `need` is open; `open` returns what this lane's last closure test found (0: its fill is closed).  A lane whose flood is cut
+// short holds a PART of its group - every liberty of the part is a liberty of the group.
+template <int R>
+__device__ __forceinline__ void flood_jobs(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R], uint32_t *out,
+                                           bool need, uint32_t &open) {
+  int sweeps = 0;
+#pragma unroll 1
+  for (int it = 0; it < R * R; ++it) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) FLOOD_VISIT(r, r - 1, (r & 1) != 0);       // down: domain (r&1) -> ((r+1)&1)
+    if (it > 0) {
+      uint32_t op = 0, pend = 0, above = 0;
+      uint32_t q[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int r = R - 1; r >= 0; --r) {
+        const uint32_t g = ((r + 1) & 1) ? __brev(f[r]) : f[r];
+        q[r & 3] = g;
+        if ((r & 3) == 0) *reinterpret_cast<uint4 *>(out + r) = make_uint4(q[0], q[1], q[2], q[3]);
+        if (r < R - 1) or_pairs(op, pend, (R - 2 - r) & 1, B3(above, m[r], g, T_AND_ANDN));
+        above = g;
+      }
+      if ((R - 1) & 1) op |= pend;
+      open = op;
+      if (__ballot(op != 0 && need) == 0) { sweeps = 2 * it + 1; break; }
+    }
+#pragma unroll
+    for (int r = R - 1; r >= 0; --r) FLOOD_VISIT(r, r + 1, ((r + 1) & 1) != 0);  // up: domain ((r+1)&1) -> (r&1)
+    if (it > 0) {
+      uint32_t op = 0, pend = 0, below = 0;
+      uint32_t q[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t g = (r & 1) ? __brev(f[r]) : f[r];
+        q[r & 3] = g;
+        if ((r & 3) == 3 || r == R - 1) {
+          if ((r & 3) != 3) { for (int z = (r & 3) + 1; z < 4; ++z) q[z] = 0u; }
+          *reinterpret_cast<uint4 *>(out + (r & ~3)) = make_uint4(q[0], q[1], q[2], q[3]);
+        }
+        if (r > 0) or_pairs(op, pend, (r - 1) & 1, B3(below, m[r], g, T_AND_ANDN));
+        below = g;
+      }
+      if ((R - 1) & 1) op |= pend;
+      open = op;
+      if (__ballot(op != 0 && need) == 0) { sweeps = 2 * it + 2; break; }
+    }
+  }
+#ifdef GG_AB_SWEEPS
+  { int l_; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+    if (l_ == 0) { atomicAdd(&gg_sweeps[0], (unsigned long long)sweeps); atomicAdd(&gg_sweeps[1], 1ull); } }
+#endif
+  (void)sweeps;
+}
+
+// liberties (dilate & empty, counted; only min(count, 2) is used) of the group whose rows lie at `out`, m[] = the rows of its
+// colour, pov = the other colour's rows
+template <int R>
+__device__ __forceinline__ uint32_t job_liberties(const uint32_t *out, const uint4 *pov, const uint32_t (&m)[R]) {
+  constexpr int RV = (R + 3) / 4;
+  constexpr uint32_t FULLROW = (1u << R) - 1u;
+  uint32_t gt[RV * 4], ot[RV * 4], cnt3[3] = {0u, 0u, 0u};
+  const uint4 *pg = reinterpret_cast<const uint4 *>(out);
+#pragma unroll
+  for (int i = 0; i < RV; ++i) {
+    const uint4 x = pg[i], y = pov[i];
+    gt[4 * i] = x.x; gt[4 * i + 1] = x.y; gt[4 * i + 2] = x.z; gt[4 * i + 3] = x.w;
+    ot[4 * i] = y.x; ot[4 * i + 1] = y.y; ot[4 * i + 2] = y.z; ot[4 * i + 3] = y.w;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t e = B3(ot[r], m[r], FULLROW, ~(TA | TB) & TC & 0xFF);   // empty points
+    const uint32_t up = r > 0 ? gt[r - 1] : 0u, dn = r + 1 < R ? gt[r + 1] : 0u;
+    const uint32_t dd = B3(shl1(gt[r]), gt[r] >> 1, up, T_OR3);
+    const uint32_t l = B3(dd, dn, e, (TA | TB) & TC);
+    cnt3[r % 3] += (uint32_t)__popc(l);   // (three accumulating chains, not one of nineteen v_bcnt)
+  }
+  return cnt3[0] + cnt3[1] + cnt3[2];
+}
+
+// job descriptor: bits 0-4 board, 5-13 the seed (flat point index), 15 the colour flooded, 16 the job floods G, 18 the job exists
 template <int R, int IO>
 __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                        int32_t *__restrict__ last_actions, int64_t *__restrict__ steps_done,
@@ -355,10 +435,11 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         if constexpr (RPL == 10) kth_set_bit10(v, p, (k - Pb) & 0x3FFu, rr, pos);
         else kth_set_bit<RPL>(v, p, (k - Pb) & 0x3FFu, rr, pos);
         const int rabs = r0 + rr;
-        const int a = !live ? -1 : (k < n ? rabs * N + (int)pos : P);
-        const bool wr_act = bl && (live && k < n ? hit : t5 == 0);
-        const bool place = bl && live && hit;
-        a_q = (int)(((wr_act ? (uint32_t)(a + 2) : 0u) | dpp0<QP_X1>(wr_act ? (uint32_t)(a + 2) : 0u))) - 2;
+        // (k < n: exactly one lane of the pair holds the point and hands it to the other; k, n and live are the same in both)
+        const uint32_t cand = hit ? (uint32_t)(rabs * N + (int)pos) : 0u;
+        const uint32_t pt = cand | dpp0<QP_X1>(cand);
+        a_q = !live ? -1 : (k < n ? (int)pt : P);
+        const bool place = live && hit;
         fl_q = reset ? 40u : fl;   // a board being reset: on, dirty, black to move
         uint64_t resetm = __ballot(reset && t5 == 0);
         const bool none_live = __ballot(live) == 0;
@@ -411,7 +492,6 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         split_action(mv1 ? a : 0, N, inv, ar, ac);
         const uint32_t *pm = st + turn * PL + s4 * RS, *po = st + (1u - turn) * PL + s4 * RS;
         uint32_t obit[2], packed = 0;
-        int nrv[2], ncv[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int sg = 2 * j - 1;
@@ -425,7 +505,6 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
           const uint32_t ex = mbit | ob;
           packed += (onb & ~ex) | (mbit << 8) | ((onb & ~ob) << 16);
           obit[j] = ob;
-          nrv[j] = nr; ncv[j] = nc;
         }
         qs = packed + dpp0<QP_X1>(packed) + 0x70700u;
         const uint32_t friendly = (qs >> 11) & 1u;
@@ -435,11 +514,12 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         const uint32_t base = mbcnt64(b0) + 2u * mbcnt64(b1);
         njobs = (int)__popcll(b0) + 2 * (int)__popcll(b1);
         const uint32_t sG = base, s0 = base + gf, s1 = s0 + obit[0];
-        const uint32_t common = (uint32_t)s4 | (1u << 18);
-        const uint32_t oc = (turn ^ 1u) << 15;
-        jobv[gf ? sG : (uint32_t)DUMP] = common | ((uint32_t)ar << 5) | ((uint32_t)ac << 10) | (turn << 15) | (1u << 16);
-        jobv[obit[0] ? s0 : (uint32_t)DUMP] = common | (((uint32_t)nrv[0] & 31u) << 5) | (((uint32_t)ncv[0] & 31u) << 10) | oc;
-        jobv[obit[1] ? s1 : (uint32_t)DUMP] = common | (((uint32_t)nrv[1] & 31u) << 5) | (((uint32_t)ncv[1] & 31u) << 10) | oc;
+        // (the seed travels as a flat point index: q itself for G, q -+ N / q -+ 1 for the opponent stone above / below / left / right)
+        const uint32_t common = (uint32_t)s4 | (1u << 18) | ((turn ^ 1u) << 15);
+        const int step = t5 ? 1 : N;
+        jobv[gf ? sG : (uint32_t)DUMP] = ((uint32_t)s4 | (1u << 18) | (turn << 15) | (1u << 16)) | ((uint32_t)a << 5);
+        jobv[obit[0] ? s0 : (uint32_t)DUMP] = common | ((uint32_t)(a - step) << 5);
+        jobv[obit[1] ? s1 : (uint32_t)DUMP] = common | ((uint32_t)(a + step) << 5);
         slA0 = obit[0] ? (int)s0 : ZERO;
         slA1 = obit[1] ? (int)s1 : ZERO;
         slG = (int)dpp0<QP_L0>(gf ? sG : (uint32_t)ZERO);
@@ -457,7 +537,9 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         const bool have = j < njobs;
         const uint32_t d = jobv[have ? j : DUMP];
         const uint32_t ex = have ? 1u : 0u;
-        const int sj = (int)(d & 31u), sr = (int)((d >> 5) & 31u), scol = (int)((d >> 10) & 31u);
+        const int sj = (int)(d & 31u);
+        int sr, scol;
+        split_action((int)((d >> 5) & 511u), N, inv, sr, scol);
         const uint32_t ownc = (d >> 15) & 1u;
         const uint32_t isG = have ? (d >> 16) & 1u : 0u;
         uint32_t *blk = sc + (have ? j : DUMP) * RS;
@@ -472,9 +554,8 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         uint32_t *out = isG ? gblk + sj * RS : blk;
         uint32_t cnt = 0;
         {
-          uint32_t m[R];
+          uint32_t m[R], mrev[R], f[R];
           {
-            uint32_t mrev[R], f[R];
             uint32_t mt[RV * 4], ft[RV * 4];
 #pragma unroll
             for (int i = 0; i < RV; ++i) {
@@ -501,28 +582,33 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
               mrev[r] = __brev(m[r]);
               f[r] = ft[r];
             }
-            GG_PROF(1);
-            // (the two-chain flood2_dual: 1.758 against 1.579 ms per launch - one more sweep-equivalent, as in k_rollout4)
-            flood2_serial<R, true, true, false>(m, mrev, f, out);
-            GG_PROF(2);
           }
-          uint32_t gt[RV * 4], ot[RV * 4], cnt3[3] = {0u, 0u, 0u};
-          const uint4 *pg = reinterpret_cast<const uint4 *>(out);
+          GG_PROF(1);
+          // Only the floods of G must reach their fixed point in the batch's loop: its length is the longest of 0.6 floods per
+          // board, not of 1.56 (4.21 -> ... sweeps per batch).  An OPPONENT group whose flood is cut short is settled all the
+          // same when the part found so far already has two liberties - they are liberties of the whole group, it keeps its
+          // class and phase 3 never looks at its block.  With fewer than two the group may be captured or leave M, and then
+          // its full extent matters: those lanes (rare: groups in atari or with two liberties are small) flood on to the end.
+          // (the two-chain flood2_dual: 1.758 against 1.579 ms per launch - one more sweep-equivalent, as in k_rollout4)
+          uint32_t open = 0;
+          flood_jobs<R>(m, mrev, f, out, isG != 0u, open);
+          GG_PROF(2);
+          cnt = job_liberties<R>(out, pov, m);
+          const bool unsettled = have && !isG && open != 0u && cnt < 2u;
+          if (__ballot(unsettled)) {
+            // (the sweeps resume from the fill as the last test left it in `out`: normal bit order -> odd rows reversed)
+            uint32_t gt[RV * 4];
+            const uint4 *pg = reinterpret_cast<const uint4 *>(out);
 #pragma unroll
-          for (int i = 0; i < RV; ++i) {
-            const uint4 x = pg[i], y = pov[i];
-            gt[4 * i] = x.x; gt[4 * i + 1] = x.y; gt[4 * i + 2] = x.z; gt[4 * i + 3] = x.w;
-            ot[4 * i] = y.x; ot[4 * i + 1] = y.y; ot[4 * i + 2] = y.z; ot[4 * i + 3] = y.w;
-          }
+            for (int i = 0; i < RV; ++i) {
+              const uint4 x = pg[i];
+              gt[4 * i] = x.x; gt[4 * i + 1] = x.y; gt[4 * i + 2] = x.z; gt[4 * i + 3] = x.w;
+            }
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const uint32_t e = B3(ot[r], m[r], FULLROW, ~(TA | TB) & TC & 0xFF);   // empty points
-            const uint32_t up = r > 0 ? gt[r - 1] : 0u, dn = r + 1 < R ? gt[r + 1] : 0u;
-            const uint32_t dd = B3(shl1(gt[r]), gt[r] >> 1, up, T_OR3);
-            const uint32_t l = B3(dd, dn, e, (TA | TB) & TC);
-            cnt3[r % 3] += (uint32_t)__popc(l);   // (three accumulating chains, not one of nineteen v_bcnt)
+            for (int r = 0; r < R; ++r) f[r] = (r & 1) ? __brev(gt[r]) : gt[r];
+            flood_jobs<R>(m, mrev, f, out, unsettled, open);
+            cnt = job_liberties<R>(out, pov, m);
           }
-          cnt = cnt3[0] + cnt3[1] + cnt3[2];
         }
         const uint32_t lib2 = cnt < 2u ? cnt : 2u;
         const uint32_t dead = (cnt == 0u && have && !isG) ? CL_CAPT : 0u;
