@@ -585,10 +585,10 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
           }
           GG_PROF(1);
           // Only the floods of G must reach their fixed point in the batch's loop: its length is the longest of 0.6 floods per
-          // board, not of 1.56 (4.21 -> ... sweeps per batch).  An OPPONENT group whose flood is cut short is settled all the
+          // board, not of 1.56 (4.21 -> 3.87 sweeps per batch on the stationary mix, tools/exp/r5_sweeps.py: 1.445 -> 1.415 ms per launch).  An OPPONENT group whose flood is cut short is settled all the
           // same when the part found so far already has two liberties - they are liberties of the whole group, it keeps its
           // class and phase 3 never looks at its block.  With fewer than two the group may be captured or leave M, and then
-          // its full extent matters: those lanes (rare: groups in atari or with two liberties are small) flood on to the end.
+          // its full extent matters: those lanes (0.3 % of the batches: groups in atari or with two liberties are small) flood on to the end.
           // (the two-chain flood2_dual: 1.758 against 1.579 ms per launch - one more sweep-equivalent, as in k_rollout4)
           uint32_t open = 0;
           flood_jobs<R>(m, mrev, f, out, isG != 0u, open);
