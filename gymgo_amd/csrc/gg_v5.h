@@ -105,36 +105,42 @@ __device__ __forceinline__ void kth_set_bit10(const uint32_t (&v)[10], const uin
 }
 
 // flood2_serial (gg_common.h; seeds with their odd rows bit-reversed, the normal-order copy of the fill streamed into the
-// 16-byte aligned `out`) for a batch of JOBS of which only some need the fixed point: the sweeps go on while a lane with
-// `need` is open; `open` returns what this lane's last closure test found (0: its fill is closed).  A lane whose flood is cut
-// short holds a PART of its group - every liberty of the part is a liberty of the group.
-template <int R>
+// 16-byte aligned `out`) for a batch of JOBS of which only some need a fixed point: the sweeps go on while a lane with `need`
+// is open.  WEAK: such a lane counts as open only where the fill could still grow into a stone that is NOT in `mm` (the rows
+// of M, the stones whose group had >= 2 liberties before the move); `open` returns what this lane's last FULL closure test
+// found (0: its fill is closed).  A lane whose flood is cut short holds a PART of its group - every liberty of the part is a
+// liberty of the group.
+template <int R, bool WEAK>
 __device__ __forceinline__ void flood_jobs(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R], uint32_t *out,
-                                           bool need, uint32_t &open) {
+                                           bool need, const uint32_t (&mm)[R], uint32_t &open) {
   int sweeps = 0;
 #pragma unroll 1
   for (int it = 0; it < R * R; ++it) {
 #pragma unroll
     for (int r = 0; r < R; ++r) FLOOD_VISIT(r, r - 1, (r & 1) != 0);       // down: domain (r&1) -> ((r+1)&1)
     if (it > 0) {
-      uint32_t op = 0, pend = 0, above = 0;
+      uint32_t op = 0, opw = 0, pend = 0, above = 0;
       uint32_t q[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int r = R - 1; r >= 0; --r) {
         const uint32_t g = ((r + 1) & 1) ? __brev(f[r]) : f[r];
         q[r & 3] = g;
         if ((r & 3) == 0) *reinterpret_cast<uint4 *>(out + r) = make_uint4(q[0], q[1], q[2], q[3]);
-        if (r < R - 1) or_pairs(op, pend, (R - 2 - r) & 1, B3(above, m[r], g, T_AND_ANDN));
+        if (r < R - 1) {
+          const uint32_t t = B3(above, m[r], g, T_AND_ANDN);   // a filled stone below a fillable, unfilled one
+          if (WEAK) { op |= t; opw = B3(t, mm[r], opw, (TA & ~TB & 0xFF) | TC); }
+          else or_pairs(op, pend, (R - 2 - r) & 1, t);
+        }
         above = g;
       }
-      if ((R - 1) & 1) op |= pend;
+      if (!WEAK && ((R - 1) & 1)) op |= pend;
       open = op;
-      if (__ballot(op != 0 && need) == 0) { sweeps = 2 * it + 1; break; }
+      if (__ballot((WEAK ? opw : op) != 0 && need) == 0) { sweeps = 2 * it + 1; break; }
     }
 #pragma unroll
     for (int r = R - 1; r >= 0; --r) FLOOD_VISIT(r, r + 1, ((r + 1) & 1) != 0);  // up: domain ((r+1)&1) -> (r&1)
-    if (it > 0) {
-      uint32_t op = 0, pend = 0, below = 0;
+    if (it > 0) {   // (a first test already after the second sweep: 2.23 sweeps per batch, but 27 % of the batches then have a lane to flood on: 1.351 -> 1.385 ms)
+      uint32_t op = 0, opw = 0, pend = 0, below = 0;
       uint32_t q[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -144,12 +150,16 @@ __device__ __forceinline__ void flood_jobs(const uint32_t (&m)[R], const uint32_
           if ((r & 3) != 3) { for (int z = (r & 3) + 1; z < 4; ++z) q[z] = 0u; }
           *reinterpret_cast<uint4 *>(out + (r & ~3)) = make_uint4(q[0], q[1], q[2], q[3]);
         }
-        if (r > 0) or_pairs(op, pend, (r - 1) & 1, B3(below, m[r], g, T_AND_ANDN));
+        if (r > 0) {
+          const uint32_t t = B3(below, m[r], g, T_AND_ANDN);
+          if (WEAK) { op |= t; opw = B3(t, mm[r], opw, (TA & ~TB & 0xFF) | TC); }
+          else or_pairs(op, pend, (r - 1) & 1, t);
+        }
         below = g;
       }
-      if ((R - 1) & 1) op |= pend;
+      if (!WEAK && ((R - 1) & 1)) op |= pend;
       open = op;
-      if (__ballot(op != 0 && need) == 0) { sweeps = 2 * it + 2; break; }
+      if (__ballot((WEAK ? opw : op) != 0 && need) == 0) { sweeps = 2 * it + 2; break; }
     }
   }
 #ifdef GG_AB_SWEEPS
@@ -583,18 +593,33 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
               f[r] = ft[r];
             }
           }
+          // the rows of M (the classes BEFORE this move) of the job's board, out of the registers of the two lanes that hold them
+          uint32_t mm[R];
+          {
+            const int src = 8 * sj;   // byte address of lane 2 sj for ds_bpermute
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+              mm[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M[i]);
+              if (RPL + i < R) mm[RPL + i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src + 4, (int)M[i]);
+            }
+          }
           GG_PROF(1);
-          // Only the floods of G must reach their fixed point in the batch's loop: its length is the longest of 0.6 floods per
-          // board, not of 1.56 (4.21 -> 3.87 sweeps per batch on the stationary mix, tools/exp/r5_sweeps.py: 1.445 -> 1.415 ms per launch).  An OPPONENT group whose flood is cut short is settled all the
-          // same when the part found so far already has two liberties - they are liberties of the whole group, it keeps its
-          // class and phase 3 never looks at its block.  With fewer than two the group may be captured or leave M, and then
-          // its full extent matters: those lanes (0.3 % of the batches: groups in atari or with two liberties are small) flood on to the end.
+          // Which floods must reach their fixed point inside the batch's loop?  (Its length is the longest of its floods: 4.21
+          // sweeps per batch when all 1.56 floods per board count, 3.87 when only G's 0.6 per board do, 3.00 - the minimum - with
+          // the weak closure below, tools/exp/r5_sweeps.py: 1.445 -> 1.415 -> 1.349 ms per launch of 65 536 games x 256 plies;
+          // 1.8 % of the batches have a lane that floods on afterwards.)
+          //  * An OPPONENT group never: cut short, the part found so far either has two liberties - liberties of the whole
+          //    group, which keeps its class: phase 3 never looks at the block - or fewer, and then the group may be captured or
+          //    leave M and its full extent matters: that lane floods on afterwards (below; groups with < 2 liberties are small).
+          //  * The mover's group G only as far as its stones OUTSIDE M go: with two liberties found G joins M whole, and what the
+          //    cut-short flood has not reached of it are stones of groups that were in M already (a group in atari that q
+          //    connects hangs on q itself, stone by stone outside M: the weak closure holds it whole); with fewer, as above.
           // (the two-chain flood2_dual: 1.758 against 1.579 ms per launch - one more sweep-equivalent, as in k_rollout4)
           uint32_t open = 0;
-          flood_jobs<R>(m, mrev, f, out, isG != 0u, open);
+          flood_jobs<R, true>(m, mrev, f, out, isG != 0u, mm, open);
           GG_PROF(2);
           cnt = job_liberties<R>(out, pov, m);
-          const bool unsettled = have && !isG && open != 0u && cnt < 2u;
+          const bool unsettled = have && open != 0u && cnt < 2u;
           if (__ballot(unsettled)) {
             // (the sweeps resume from the fill as the last test left it in `out`: normal bit order -> odd rows reversed)
             uint32_t gt[RV * 4];
@@ -606,7 +631,7 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) f[r] = (r & 1) ? __brev(gt[r]) : gt[r];
-            flood_jobs<R>(m, mrev, f, out, unsettled, open);
+            flood_jobs<R, false>(m, mrev, f, out, unsettled, mm, open);
             cnt = job_liberties<R>(out, pov, m);
           }
         }
