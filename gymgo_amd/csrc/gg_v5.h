@@ -10,17 +10,25 @@ namespace gg {
 // 39 % of those flood lanes carry a flood (1.56 per board and ply) - the flood batch, the liberty count and the seed set-up,
 // 54 % of a ply's instructions, cost the same whatever their lanes carry.  Here a board is a PAIR of lanes (lane t owns
 // the RPL = ceil(R / 2) adjacent rows RPL t ..), a wave holds 32 boards, and a ply is
-//   1.  sampling, as in k_rollout4 (the pair scan is one DPP swap);
+//   1.  sampling, as in k_rollout4 (the pair scan is one DPP swap, the row of the k-th point a search tree over the prefix
+//       counts);
 //   2a. the board's own lanes look at q's four neighbours (two directions each) and post the floods the ply needs as JOBS:
 //       one per opponent stone next to q, and ONE for the mover's group G when q has a friendly neighbour (k_rollout4 runs
 //       that flood in every friendly lane); the slots come from two ballots (v_mbcnt prefix), the descriptors go to LDS;
-//   2b. lane L runs job L - 32 boards x 1.56 = 50 jobs in 64 lanes (a second batch when a ply posts more than 64: < 1 %);
-//   3.  class patch, captures, ko and the next mover's mask on the pair lanes: the flood of direction d is read through the
-//       slot the board posted it in, an absent one through an all-zero block.
+//   2b. lane L runs job L - 32 boards x 1.56 = 50 jobs in 64 lanes (a second batch when a ply posts more than 64: 0.7 %) -
+//       with the fill in registers from the seed to the liberty count.  The batch's loop ends as soon as every flood of a G
+//       is closed as far as stones OUTSIDE M go (the rows of M come out of the board lanes' registers by ds_bpermute): the
+//       minimum of three sweeps on 98 % of the batches; an opponent group whose part found so far has two liberties is
+//       settled, the few lanes left with fewer flood on.  What phase 3 needs leaves the lane at the end: G as a block of its
+//       board, an opponent group that is captured or leaves M ORed into the board's collection block, a captured direction
+//       and G's liberties ORed into the board's info word;
+//   3.  class patch, captures, ko and the next mover's mask on the pair lanes, from ONE collection block per board: it
+//       splits by M alone (captured = not in M: q was the only liberty).
 // Instructions per board: the flood batch is shared by twice the boards, and so is everything in phases 1 and 3 that does not
-// scale with the rows a lane holds (the draw, the k-th-bit search, the capture / ko logic, addresses): ~44 VALU per env step
-// against 73.  65 536 games are 2 048 waves = TWO per SIMD (20 KB of LDS, up to 256 VGPRs per wave): what the SIMD loses in
-// waves to switch between it gets back as independent rows inside each wave (ten per lane in phases 1 and 3).
+// scale with the rows a lane holds (the draw, the k-th-bit search, the capture / ko logic, addresses): 47.6 VALU per env step
+// (PMC) in the first version against k_rollout4's 73.2, fewer since.  65 536 games are 2 048 waves = TWO per SIMD (19.5 KB of
+// LDS, up to 256 VGPRs per wave); a SIMD with two waves sustains one dependent VALU instruction per 1.77 ns against 1.60
+// with four (tools/ubench/dep_chain.hip), which is why the kernel pays from 256 games per CU on and not below.
 // Scope: drawn moves on full-size boards (N == R), byte planes or tracked boards - the fused rollout of big batches; every
 // other form stays on k_rollout4.
 constexpr int kNB5 = 32;
@@ -37,13 +45,15 @@ struct Lds5 {
   static constexpr int kFair = kMeta + 5 * kNB5;                 // [16]: FairShare
   static constexpr int kTmp = kFair + 16;                        // [2][2][RS]: layout change of one pair at load
   static constexpr int kUnion = kTmp + 4 * RS;
-  // ply loop: per job its class word and descriptor, per board the block of the mover's group, per job its flood block
-  static constexpr int kZero = kJobCap, kDump = kJobCap + 1;     // slot of an absent job (all zero, never written) / of a write nobody reads
-  static constexpr int kCls = kUnion;                            // [kJobCap + 4]
+  // ply loop: per job its descriptor, per board an info word (what its jobs found); per board the block of the mover's group G and the block in which the
+  // opponent groups that are captured or leave M are collected (one OR per job that has such a group); per LANE a seed block
+  // that is all zero between two uses (a job's seed is staged through it)
+  static constexpr int kZero = kJobCap, kDump = kJobCap + 1;     // slot of an absent job (its class word is zero, never written) / of a write nobody reads
+  static constexpr int kCls = kUnion;                            // [kJobCap + 4]: the first kNB5 words are the boards' info words
   static constexpr int kJob = kCls + kJobCap + 4;                // [kJobCap + 4]
-  static constexpr int kG = kJob + kJobCap + 4;                  // [kNB5][RS]
-  static constexpr int kSc = kG + kNB5 * RS;                     // [kJobCap + 2][RS]
-  static constexpr int kLoopEnd = kSc + (kJobCap + 2) * RS;
+  static constexpr int kG = kJob + kJobCap + 4;                  // [kNB5][2][RS]: G, the collected opponent groups
+  static constexpr int kSc = kG + 2 * kNB5 * RS;                 // [kWave][RS]
+  static constexpr int kLoopEnd = kSc + kWave * RS;
   // load: the v2 analysis in its compact form (region 0 only); tracked boards: the DMA landing area, the parked rows
   static constexpr int kV2 = kUnion;
   static constexpr int kIoEnd = kV2 + (Lds2<R>::kRegion0 > 768 ? Lds2<R>::kRegion0 : 768);
@@ -104,14 +114,13 @@ __device__ __forceinline__ void kth_set_bit10(const uint32_t (&v)[10], const uin
   pos = ps;
 }
 
-// flood2_serial (gg_common.h; seeds with their odd rows bit-reversed, the normal-order copy of the fill streamed into the
-// 16-byte aligned `out`) for a batch of JOBS of which only some need a fixed point: the sweeps go on while a lane with `need`
-// is open.  WEAK: such a lane counts as open only where the fill could still grow into a stone that is NOT in `mm` (the rows
-// of M, the stones whose group had >= 2 liberties before the move); `open` returns what this lane's last FULL closure test
-// found (0: its fill is closed).  A lane whose flood is cut short holds a PART of its group - every liberty of the part is a
-// liberty of the group.
+// flood2_serial (gg_common.h; seeds with their odd rows bit-reversed) for a batch of JOBS of which only some need a fixed
+// point: the sweeps go on while a lane with `need` is open.  WEAK: such a lane counts as open only where the fill could still
+// grow into a stone that is NOT in `mm` (the rows of M, the stones whose group had >= 2 liberties before the move).  res[] =
+// the fill as the last closure test saw it, normal bit order; `open` = what that test found for this lane (0: its fill is
+// closed).  A lane whose flood is cut short holds a PART of its group - every liberty of the part is a liberty of the group.
 template <int R, bool WEAK>
-__device__ __forceinline__ void flood_jobs(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R], uint32_t *out,
+__device__ __forceinline__ void flood_jobs(const uint32_t (&m)[R], const uint32_t (&mrev)[R], uint32_t (&f)[R], uint32_t (&res)[R],
                                            bool need, const uint32_t (&mm)[R], uint32_t &open) {
   int sweeps = 0;
 #pragma unroll 1
@@ -120,12 +129,10 @@ __device__ __forceinline__ void flood_jobs(const uint32_t (&m)[R], const uint32_
     for (int r = 0; r < R; ++r) FLOOD_VISIT(r, r - 1, (r & 1) != 0);       // down: domain (r&1) -> ((r+1)&1)
     if (it > 0) {
       uint32_t op = 0, opw = 0, pend = 0, above = 0;
-      uint32_t q[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int r = R - 1; r >= 0; --r) {
         const uint32_t g = ((r + 1) & 1) ? __brev(f[r]) : f[r];
-        q[r & 3] = g;
-        if ((r & 3) == 0) *reinterpret_cast<uint4 *>(out + r) = make_uint4(q[0], q[1], q[2], q[3]);
+        res[r] = g;
         if (r < R - 1) {
           const uint32_t t = B3(above, m[r], g, T_AND_ANDN);   // a filled stone below a fillable, unfilled one
           if (WEAK) { op |= t; opw = B3(t, mm[r], opw, (TA & ~TB & 0xFF) | TC); }
@@ -141,15 +148,10 @@ __device__ __forceinline__ void flood_jobs(const uint32_t (&m)[R], const uint32_
     for (int r = R - 1; r >= 0; --r) FLOOD_VISIT(r, r + 1, ((r + 1) & 1) != 0);  // up: domain ((r+1)&1) -> (r&1)
     if (it > 0) {   // (a first test already after the second sweep: 2.23 sweeps per batch, but 27 % of the batches then have a lane to flood on: 1.351 -> 1.385 ms)
       uint32_t op = 0, opw = 0, pend = 0, below = 0;
-      uint32_t q[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const uint32_t g = (r & 1) ? __brev(f[r]) : f[r];
-        q[r & 3] = g;
-        if ((r & 3) == 3 || r == R - 1) {
-          if ((r & 3) != 3) { for (int z = (r & 3) + 1; z < 4; ++z) q[z] = 0u; }
-          *reinterpret_cast<uint4 *>(out + (r & ~3)) = make_uint4(q[0], q[1], q[2], q[3]);
-        }
+        res[r] = g;
         if (r > 0) {
           const uint32_t t = B3(below, m[r], g, T_AND_ANDN);
           if (WEAK) { op |= t; opw = B3(t, mm[r], opw, (TA & ~TB & 0xFF) | TC); }
@@ -169,18 +171,16 @@ __device__ __forceinline__ void flood_jobs(const uint32_t (&m)[R], const uint32_
   (void)sweeps;
 }
 
-// liberties (dilate & empty, counted; only min(count, 2) is used) of the group whose rows lie at `out`, m[] = the rows of its
-// colour, pov = the other colour's rows
+// liberties (dilate & empty, counted; only min(count, 2) is used) of the group gt[], m[] = the rows of its colour, pov = the
+// other colour's rows
 template <int R>
-__device__ __forceinline__ uint32_t job_liberties(const uint32_t *out, const uint4 *pov, const uint32_t (&m)[R]) {
+__device__ __forceinline__ uint32_t job_liberties(const uint32_t (&gt)[R], const uint4 *pov, const uint32_t (&m)[R]) {
   constexpr int RV = (R + 3) / 4;
   constexpr uint32_t FULLROW = (1u << R) - 1u;
-  uint32_t gt[RV * 4], ot[RV * 4], cnt3[3] = {0u, 0u, 0u};
-  const uint4 *pg = reinterpret_cast<const uint4 *>(out);
+  uint32_t ot[RV * 4], cnt3[3] = {0u, 0u, 0u};
 #pragma unroll
   for (int i = 0; i < RV; ++i) {
-    const uint4 x = pg[i], y = pov[i];
-    gt[4 * i] = x.x; gt[4 * i + 1] = x.y; gt[4 * i + 2] = x.z; gt[4 * i + 3] = x.w;
+    const uint4 y = pov[i];
     ot[4 * i] = y.x; ot[4 * i + 1] = y.y; ot[4 * i + 2] = y.z; ot[4 * i + 3] = y.w;
   }
 #pragma unroll
@@ -194,7 +194,10 @@ __device__ __forceinline__ uint32_t job_liberties(const uint32_t *out, const uin
   return cnt3[0] + cnt3[1] + cnt3[2];
 }
 
-// job descriptor: bits 0-4 board, 5-13 the seed (flat point index), 15 the colour flooded, 16 the job floods G, 18 the job exists
+// job descriptor: bits 0-4 board, 5-13 the seed (flat point index), 15 the colour flooded, 16 the job floods G, 18 the job exists,
+// 19-20 the direction of q's neighbour it starts from (0 up, 1 down, 2 left, 3 right)
+// info word of a board (cleared in phase 1, ORed by its jobs): bits 0-3 the directions whose opponent group was captured, 4-5 the
+// liberties of G (saturated at 2)
 template <int R, int IO>
 __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ states, uint64_t *__restrict__ rng,
                                                        int32_t *__restrict__ last_actions, int64_t *__restrict__ steps_done,
@@ -379,8 +382,7 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
     }
     // the slot of an absent job: an all-zero block and class word (the loop area was the load's scratch)
     WAVE_SYNC();
-    if (hf.lane < RS) sc[ZERO * RS + hf.lane] = 0u;
-    if (hf.lane == 0) clsv[ZERO] = 0u;
+    for (int i = hf.lane; i < kWave * RS; i += kWave) sc[i] = 0u;   // the seed blocks: all zero between two uses
     WAVE_SYNC();
 
     // ---------------------------------------------------------------- the plies
@@ -470,11 +472,13 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         WAVE_SYNC();
         // the new stone goes into the mover's plane right away, and - as the group G it forms on its own - into the board's
         // G block (a job floods over it when q has a friendly neighbour)
-        // (the even lane of EVERY board clears the G block - a board that passes or idles leaves it empty, phase 3 reads it
-        // unmasked -, then the lane that holds the point writes the stone: DS instructions of a wave execute in order)
-        uint32_t *gb = gblk + s4 * RS;
-        if (t5 == 0) {
-          uint4 *pz = reinterpret_cast<uint4 *>(gb);
+        // (the lanes of EVERY board clear its G block and its collection block - a board that passes or idles leaves them
+        // empty, phase 3 reads them unmasked -, then the lane that holds the point writes the stone: DS instructions of a wave
+        // execute in order)
+        uint32_t *gb = gblk + 2 * s4 * RS;
+        if (t5 == 0) clsv[s4] = 0u;   // the board's info word
+        {
+          uint4 *pz = reinterpret_cast<uint4 *>(gb + t5 * RS);   // (lane 0 of the pair: the G block, lane 1: the collection block)
 #pragma unroll
           for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
         }
@@ -492,7 +496,6 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
       // to the left / right; what the board-level tests need (empty neighbours of q, is any of them friendly, is q boxed
       // in) is one packed pair sum; the floods become jobs
       uint32_t qs;                 // bits 0-2 empty neighbours of q, 11 q has a friendly neighbour, 19 q is NOT boxed in
-      int slA0, slA1, slG;         // job slots of this lane's two directions and of G (ZERO: no such job)
       int njobs;
       {
         const int a = a_q;
@@ -528,11 +531,9 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         const uint32_t common = (uint32_t)s4 | (1u << 18) | ((turn ^ 1u) << 15);
         const int step = t5 ? 1 : N;
         jobv[gf ? sG : (uint32_t)DUMP] = ((uint32_t)s4 | (1u << 18) | (turn << 15) | (1u << 16)) | ((uint32_t)a << 5);
-        jobv[obit[0] ? s0 : (uint32_t)DUMP] = common | ((uint32_t)(a - step) << 5);
-        jobv[obit[1] ? s1 : (uint32_t)DUMP] = common | ((uint32_t)(a + step) << 5);
-        slA0 = obit[0] ? (int)s0 : ZERO;
-        slA1 = obit[1] ? (int)s1 : ZERO;
-        slG = (int)dpp0<QP_L0>(gf ? sG : (uint32_t)ZERO);
+        const uint32_t dirs = (uint32_t)t5 << 20;   // bits 19-20: the direction of the job (0 up, 1 down, 2 left, 3 right)
+        jobv[obit[0] ? s0 : (uint32_t)DUMP] = common | dirs | ((uint32_t)(a - step) << 5);
+        jobv[obit[1] ? s1 : (uint32_t)DUMP] = common | dirs | (1u << 19) | ((uint32_t)(a + step) << 5);
       }
       WAVE_SYNC();
 
@@ -552,17 +553,22 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         split_action((int)((d >> 5) & 511u), N, inv, sr, scol);
         const uint32_t ownc = (d >> 15) & 1u;
         const uint32_t isG = have ? (d >> 16) & 1u : 0u;
-        uint32_t *blk = sc + (have ? j : DUMP) * RS;
-        {
-          uint4 *pz = reinterpret_cast<uint4 *>(blk);
-#pragma unroll
-          for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
+        uint32_t *blk = sc + ln * RS;   // this lane's seed block (all zero)
         const uint4 *lds4 = reinterpret_cast<const uint4 *>(lds);
         const uint4 *pmv = lds4 + (Lds5<R>::kState + (int)ownc * PL + sj * RS) / 4;
         const uint4 *pov = lds4 + (Lds5<R>::kState + (int)(ownc ^ 1u) * PL + sj * RS) / 4;
-        uint32_t *out = isG ? gblk + sj * RS : blk;
+        // the rows of M (the classes BEFORE this move) of the job's board, out of the registers of the two lanes that hold them
+        uint32_t mm[R];
+        {
+          const int src = 8 * sj;   // byte address of lane 2 sj for ds_bpermute
+#pragma unroll
+          for (int i = 0; i < RPL; ++i) {
+            mm[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M[i]);
+            if (RPL + i < R) mm[RPL + i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src + 4, (int)M[i]);
+          }
+        }
         uint32_t cnt = 0;
+        uint32_t res[R];   // the group (or the part of it that settles its class), normal bit order
         {
           uint32_t m[R], mrev[R], f[R];
           {
@@ -572,6 +578,8 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
               const uint4 x = pmv[i];
               mt[4 * i] = x.x; mt[4 * i + 1] = x.y; mt[4 * i + 2] = x.z; mt[4 * i + 3] = x.w;
             }
+            // the seed is one bit of one row: written into the lane's zero block at its (dynamic) row and read back as the
+            // flood's row set - two LDS instructions instead of a select per row (odd rows bit-reversed) -, then cleared again
             {
               const int srw = sr & (int)(0u - ex);
               asm volatile("" ::: "memory");
@@ -591,16 +599,7 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
               m[r] = mt[r];
               mrev[r] = __brev(m[r]);
               f[r] = ft[r];
-            }
-          }
-          // the rows of M (the classes BEFORE this move) of the job's board, out of the registers of the two lanes that hold them
-          uint32_t mm[R];
-          {
-            const int src = 8 * sj;   // byte address of lane 2 sj for ds_bpermute
-#pragma unroll
-            for (int i = 0; i < RPL; ++i) {
-              mm[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M[i]);
-              if (RPL + i < R) mm[RPL + i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src + 4, (int)M[i]);
+              res[r] = 0u;
             }
           }
           GG_PROF(1);
@@ -609,39 +608,39 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
           // the weak closure below, tools/exp/r5_sweeps.py: 1.445 -> 1.415 -> 1.349 ms per launch of 65 536 games x 256 plies;
           // 1.8 % of the batches have a lane that floods on afterwards.)
           //  * An OPPONENT group never: cut short, the part found so far either has two liberties - liberties of the whole
-          //    group, which keeps its class: phase 3 never looks at the block - or fewer, and then the group may be captured or
-          //    leave M and its full extent matters: that lane floods on afterwards (below; groups with < 2 liberties are small).
+          //    group, which keeps its class: phase 3 never sees it - or fewer, and then the group may be captured or leave M
+          //    and its full extent matters: that lane floods on afterwards (below; groups with < 2 liberties are small).
           //  * The mover's group G only as far as its stones OUTSIDE M go: with two liberties found G joins M whole, and what the
           //    cut-short flood has not reached of it are stones of groups that were in M already (a group in atari that q
           //    connects hangs on q itself, stone by stone outside M: the weak closure holds it whole); with fewer, as above.
           // (the two-chain flood2_dual: 1.758 against 1.579 ms per launch - one more sweep-equivalent, as in k_rollout4)
           uint32_t open = 0;
-          flood_jobs<R, true>(m, mrev, f, out, isG != 0u, mm, open);
+          flood_jobs<R, true>(m, mrev, f, res, isG != 0u, mm, open);
           GG_PROF(2);
-          cnt = job_liberties<R>(out, pov, m);
+          cnt = job_liberties<R>(res, pov, m);
           const bool unsettled = have && open != 0u && cnt < 2u;
           if (__ballot(unsettled)) {
-            // (the sweeps resume from the fill as the last test left it in `out`: normal bit order -> odd rows reversed)
-            uint32_t gt[RV * 4];
-            const uint4 *pg = reinterpret_cast<const uint4 *>(out);
+            // (the sweeps resume from the fill as the last test left it: normal bit order -> odd rows reversed)
 #pragma unroll
-            for (int i = 0; i < RV; ++i) {
-              const uint4 x = pg[i];
-              gt[4 * i] = x.x; gt[4 * i + 1] = x.y; gt[4 * i + 2] = x.z; gt[4 * i + 3] = x.w;
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) f[r] = (r & 1) ? __brev(gt[r]) : gt[r];
-            flood_jobs<R, false>(m, mrev, f, out, unsettled, mm, open);
-            cnt = job_liberties<R>(out, pov, m);
+            for (int r = 0; r < R; ++r) f[r] = (r & 1) ? __brev(res[r]) : res[r];
+            flood_jobs<R, false>(m, mrev, f, res, unsettled, mm, open);
+            cnt = job_liberties<R>(res, pov, m);
           }
         }
         const uint32_t lib2 = cnt < 2u ? cnt : 2u;
-        const uint32_t dead = (cnt == 0u && have && !isG) ? CL_CAPT : 0u;
-        clsv[have ? j : DUMP] = lib2 | dead;
-        if (!isG && cnt >= 2u) {
-          uint4 *pz = reinterpret_cast<uint4 *>(blk);
+        // G goes to its board's G block (over the stone phase 1 left there); an opponent group with no liberty left
+        // (captured) or with one (it leaves M) is ORed into the board's collection block - one that keeps >= 2 is dropped
+        uint32_t *gb = gblk + 2 * sj * RS;
+        if (isG) {
+          uint4 *pz = reinterpret_cast<uint4 *>(gb);
 #pragma unroll
-          for (int i = 0; i < RV; ++i) pz[i] = make_uint4(0u, 0u, 0u, 0u);
+          for (int i = 0; i < RV; ++i)
+            pz[i] = make_uint4(res[4 * i], 4 * i + 1 < R ? res[4 * i + 1] : 0u, 4 * i + 2 < R ? res[4 * i + 2] : 0u, 4 * i + 3 < R ? res[4 * i + 3] : 0u);
+          if (lib2) atomicOr(clsv + sj, lib2 << 4);
+        } else if (have && cnt < 2u) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) atomicOr(gb + RS + r, res[r]);
+          if (cnt == 0u) atomicOr(clsv + sj, 1u << ((d >> 19) & 3u));
         }
       }
       if (plies >= 8) { if (lead) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
@@ -653,45 +652,40 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
       {
         const int a = a_q;
         const uint32_t fl = fl_q;
-        const int slB0 = (int)dpp0<QP_X1>((uint32_t)slA0), slB1 = (int)dpp0<QP_X1>((uint32_t)slA1);
-        const uint32_t cA0 = clsv[slA0], cA1 = clsv[slA1], cB0 = clsv[slB0], cB1 = clsv[slB1], cG = clsv[slG];
+        const uint32_t info = clsv[s4];
         const int turn0 = fl & 1u;
         uint32_t *pmine = st + turn0 * PL + s4 * RS + r0;
         uint32_t *popp = st + (1 - turn0) * PL + s4 * RS + r0;
-        const uint32_t *gA0 = sc + slA0 * RS + r0, *gA1 = sc + slA1 * RS + r0, *gB0 = sc + slB0 * RS + r0, *gB1 = sc + slB1 * RS + r0;
-        const uint32_t *gG = gblk + s4 * RS + r0;
-        uint32_t mine1[RPL], opp0[RPL], b0[RPL], b1[RPL], b2[RPL], b3[RPL], bg[RPL];
+        const uint32_t *gG = gblk + 2 * s4 * RS + r0;   // the board's G block, behind it the collected opponent groups
+        uint32_t mine1[RPL], opp0[RPL], all4[RPL], bg[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
           mine1[r] = pmine[r];   // (rows >= N are zero)
           opp0[r] = popp[r];
-          b0[r] = gA0[r]; b1[r] = gA1[r]; b2[r] = gB0[r]; b3[r] = gB1[r];
           bg[r] = gG[r];
+          all4[r] = gG[RS + r];
         }
         const bool moves_now = a >= 0;
         const bool is_pass = a == P;
         int ar, ac;
         split_action(a, N, inv, ar, ac);                       // (garbage for a pass / an idle board: masked below)
-        const uint32_t km0 = (uint32_t)__builtin_amdgcn_sbfe((int)cA0, 5, 1), km1 = (uint32_t)__builtin_amdgcn_sbfe((int)cA1, 5, 1),
-                       km2 = (uint32_t)__builtin_amdgcn_sbfe((int)cB0, 5, 1), km3 = (uint32_t)__builtin_amdgcn_sbfe((int)cB1, 5, 1);
-        const uint32_t capt_m = km0 | km1 | km2 | km3;
-        // The opponent blocks hold groups with NO liberty left (captured: q was their only liberty, so they were never in M)
-        // or with exactly ONE (they had q and one more: they were in M) - a group that keeps >= 2 zeroed its block.  So the
-        // union of the four blocks splits by M alone: captured = all4 & ~M, leaving M = all4 & M.
-        uint32_t g0[RPL], all4[RPL], cap[RPL];
+        const uint32_t capt_m = info & 15u;   // the directions in which an opponent group died (never set on a board that does not move)
+        // The collection block holds the opponent groups next to q with NO liberty left (captured: q was their only liberty, so
+        // they were never in M) or with exactly ONE (they had q and one more: they were in M).  So it splits by M alone:
+        // captured = all4 & ~M, leaving M = all4 & M.
+        uint32_t g0[RPL], cap[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
           g0[r] = bg[r];   // the G block: the flood of G, the stone alone as phase 1 left it there, or nothing (pass / idle board)
-          all4[r] = B3(b0[r], b1[r], b2[r], T_OR3) | b3[r];
           cap[r] = B3(all4[r], M[r], M[r], TA & ~TB & 0xFF);
         }
         // liberties of G among the empty points (saturated at 2): G's own count, or the empty neighbours of q when the
         // stone stands alone
         const uint32_t ne = qs & 7u, ne2 = ne < 2u ? ne : 2u;
-        uint32_t libsG = ((qs >> 11) & 1u) ? (cG & 3u) : ne2;
+        uint32_t libsG = ((qs >> 11) & 1u) ? ((info >> 4) & 3u) : ne2;
         uint32_t ko_oh = 0, ko_bit = 0;   // the ko point: one-hot row of this lane / column bit (almost always none)
         if (__ballot(capt_m != 0u)) {   // a capture on some board of the wave
-          const uint32_t ncapn = 0u - (km0 + km1 + km2 + km3);    // masks are 0 / -1
+          const uint32_t ncapn = (uint32_t)__popc(capt_m);        // captured neighbours of q
           if (__ballot(ncapn == 1u && libsG == 0u)) {
             uint32_t dg[RPL];
             dilate_rows<RPL>(g0, dg);
@@ -712,11 +706,10 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
 #pragma unroll
             for (int r = 0; r < RPL; ++r) died += (uint32_t)__popc(cap[r]);
             const bool ko = ko1 && died + dpp0<QP_X1>(died) == 1u;
-            // the one captured stone is q's neighbour in the direction of its job: up / down are lane 0's directions, left / right lane 1's
-            const uint32_t kmU = t5 ? km2 : km0, kmD = t5 ? km3 : km1, kmL = t5 ? km0 : km2, kmR = t5 ? km1 : km3;
-            const uint32_t kr = (uint32_t)ar + kmU - kmD - (uint32_t)r0;
+            // the one captured stone is q's neighbour in the direction of its job (bit 0 up, 1 down, 2 left, 3 right)
+            const uint32_t kr = (uint32_t)ar - (capt_m & 1u) + ((capt_m >> 1) & 1u) - (uint32_t)r0;
             ko_oh = (ko && kr < (uint32_t)RPL) ? (1u << (kr & 31)) : 0u;
-            ko_bit = 1u << (((uint32_t)ac + kmL - kmR) & 31u);
+            ko_bit = 1u << (((uint32_t)ac - ((capt_m >> 2) & 1u) + (capt_m >> 3)) & 31u);
           }
           // the mover's groups in atari next to a captured stone (and not merged into G) now have >= 2 liberties: they join M
           // before the classes are patched

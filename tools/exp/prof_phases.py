@@ -7,7 +7,7 @@ _lib.LIB_PATH = os.path.join(ROOT, os.environ.get('LIB', 'ab_libs/libgg_prof.so'
 from gymgo_amd import gogame
 L = ctypes.CDLL(_lib.LIB_PATH)
 # (the fused launches with drawn moves live in gg_rollout.hip, whose phase clocks have their own reader)
-L.gg_ab_prof_read = L.gg_ab_prof_read_rollout
+L.gg_ab_prof_read = getattr(L, os.environ.get("PROF_READ", "gg_ab_prof_read_rollout"))
 L.gg_ab_prof_read.argtypes = [ctypes.c_void_p]; L.gg_ab_prof_read.restype = ctypes.c_int32
 N, F, B = 19, 256, int(os.environ.get('B', '65536'))
 BPW = int(os.environ.get('BPW', '16'))   # boards per wave of the kernel that serves the launch (32: k_rollout5)
