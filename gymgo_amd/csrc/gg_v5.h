@@ -385,6 +385,12 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
     for (int i = hf.lane; i < kWave * RS; i += kWave) sc[i] = 0u;   // the seed blocks: all zero between two uses
     WAVE_SYNC();
 
+    // the flag word, the generator and the played plies of this lane's board travel in REGISTERS through the plies (the same
+    // in both lanes of a pair): read back from LDS every ply they cost phase 1 a dependent round trip; LDS keeps the copies
+    // the write-back reads (stores only)
+    uint32_t flr = flagsv[s5];
+    const uint64_t x0r = ((uint64_t)rngv[2 * s5 + 1] << 32) | rngv[2 * s5];
+    int playedr = 0;
     // ---------------------------------------------------------------- the plies
     GG_PROF(6);   // load
     FairShare fair(lds + Lds5<R>::kFair);
@@ -415,7 +421,7 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
       uint32_t fl_q;
       // phase 1 - two lanes per board, RPL rows each: liveness, the draw, the k-th valid point of the mask
       {
-        const uint32_t fl = flagsv[s4];
+        const uint32_t fl = flr;
         const bool on = bl && ((fl >> 3) & 1u);
         const bool done = (fl >> 2) & 1u;
         const bool live = on && !(done && !auto_reset);
@@ -435,7 +441,7 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         // launch found; lane j of the pair mixes the draw of ply t + j every second ply, a ply takes the even lane's and
         // the pair swaps
         if ((t & 1) == 0) {
-          uint64_t xx = (((uint64_t)rngv[2 * s4 + 1] << 32) | rngv[2 * s4]) + (uint64_t)(uint32_t)(t + t5) * 0x9E3779B97F4A7C15ull;
+          uint64_t xx = x0r + (uint64_t)(uint32_t)(t + t5) * 0x9E3779B97F4A7C15ull;
           uq = (uint32_t)(splitmix_next(xx) >> 32);
         }
         const uint32_t uh = dpp0<QP_L0>(uq);
@@ -767,12 +773,18 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
 #pragma unroll
           for (int r = 0; r < RPL; ++r) popp[r] = opp1[r];
         }
-        if (moves_now && t5 == 0) {
+        // (a board being reset found fl_q = on | dirty | black to move in phase 1: the register copy follows even if it does not move)
+        flr = fl;
+        if (moves_now) {
           const uint32_t passed0 = (fl >> 1) & 1u, done0 = (fl >> 2) & 1u;
           const uint32_t passed = is_pass ? 1u : 0u, done = done0 | (passed & passed0);
-          flagsv[s4] = (uint32_t)(turn0 ^ 1) | (passed << 1) | (done << 2) | 8u | (fl & 32u);
-          lastv[s4] = a;
-          playedv[s4] += 1;
+          flr = (uint32_t)(turn0 ^ 1) | (passed << 1) | (done << 2) | 8u | (fl & 32u);
+          playedr += 1;
+          if (t5 == 0) {
+            flagsv[s4] = flr;
+            lastv[s4] = a;
+            playedv[s4] = playedr;
+          }
         }
       }
       WAVE_SYNC();
