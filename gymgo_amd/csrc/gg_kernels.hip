@@ -240,19 +240,23 @@ bool use_multi_ply(int cus, int64_t B, int plies) {
 }
 
 // The thirty-two-board multi-ply kernel (gg_v5.h: a pair of lanes per board, the floods of a ply as a compacted job list) serves
-// the fused launches of full-size 19x19 batches that give every SIMD two of its waves: 20 KB of LDS per wave = eight waves per CU.
-// Boards per wave: as many as keep the rounds of resident waves full (65 536 games on 256 CUs: 32 boards x 2 048 waves).
+// the fused launches of full-size 19x19 batches from the point on where k_rollout4 would need a THIRD wave per SIMD (more than 128
+// games per CU); 19.5 KB of LDS per wave = eight waves per CU = two per SIMD.  Boards per wave: as many as keep the rounds of
+// resident waves full (65 536 games on 256 CUs: 32 boards x 2 048 waves; 34 816: 18 boards).  Measured new / k_rollout4, ms per
+// launch of 256 plies (profiles/r06f_r5_edges.txt, r06f_r5_time.txt): 32 768 games 1.195 / 1.190, 34 816 1.208 / 1.455, 49 152
+// 1.247 / 1.490, 65 536 1.304 / 1.835, 98 304 2.47 / 3.55, 131 072 2.57 / 3.62; and per launch length at 65 536 games: 2 plies
+// 0.082 / 0.072, 4 0.093 / 0.088, 6 0.105 / 0.105, 8 0.114 / 0.122, 32 0.239 / 0.296 -> from 8 plies per launch on.
 // (A/B builds: GG_AB_R5 = 0 / 1 forces the choice, GG_AB_R5_MIN = games per CU, GG_AB_R5_PLIES, GG_AB_NB5 = boards per wave.)
 bool use_rollout5(int cus, int64_t B, int32_t N, int plies) {
-  int64_t per_cu = 8 * kNB5;
+  int64_t per_cu = 4 * kNB5;
   int min_plies = 8;
   bool ok = N == 19;
 #ifdef GG_AB
   if (const char *e = getenv("GG_AB_R5_MIN")) per_cu = atoll(e);
   if (const char *e = getenv("GG_AB_R5_PLIES")) min_plies = atoi(e);
-  if (const char *e = getenv("GG_AB_R5")) { if (atoi(e) == 0) ok = false; else { per_cu = 0; min_plies = 1; } }
+  if (const char *e = getenv("GG_AB_R5")) { if (atoi(e) == 0) ok = false; else { per_cu = -1; min_plies = 1; } }
 #endif
-  return ok && plies >= min_plies && B >= (int64_t)cus * per_cu;
+  return ok && plies >= min_plies && B > (int64_t)cus * per_cu;
 }
 int boards_per_wave5(int cus, int64_t B, int &grid) {
   const int64_t resident = (int64_t)cus * 8;

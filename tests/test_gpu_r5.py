@@ -1,10 +1,10 @@
 """-m gpu: the thirty-two-board multi-ply kernel (gymgo_amd/csrc/gg_v5.h, k_rollout5: a pair of lanes per board, the floods of a
 ply as a compacted job list) against the pinned C oracle - states, generator states, last actions, step counters.
 
-gg_batch_rollout / gg_batch_rollout_tracked hand full-size 19x19 launches of >= 8 plies to it from 256 games per CU on
-(gg_kernels.hip: use_rollout5), i.e. 65 536 games on the whole device: the BASELINE config-3 test (test_gpu_configs.py) and the
+gg_batch_rollout / gg_batch_rollout_tracked hand full-size 19x19 launches of >= 8 plies to it above 128 games per CU
+(gg_kernels.hip: use_rollout5), i.e. from 32 769 games on the whole device: the BASELINE config-3 test (test_gpu_configs.py) and the
 bench's own driver (test_gpu_deep.py) run it at that size.  Here the library is sized for FOUR compute units
-(GYMGO_AMD_CUS=4, read once per process: a process of its own), so that 1 024 games take the kernel and the oracle can replay
+(GYMGO_AMD_CUS=4, read once per process: a process of its own), so that 513 games take the kernel and the oracle can replay
 whole games: both sides of the games / plies take-over, ragged last waves (a wave of 2 .. 32 boards), frozen games, resets, and a
 crafted position whose first ply posts MORE flood jobs than a wave has lanes (a second job batch).
 Reference loop: gym_go/envs/go_env.py:49-81 over gym_go/gogame.py:34-87.
@@ -58,8 +58,8 @@ def run(states, B, launches, auto_reset, seed, tracked):
 ''' % ROOT
 
 TAKE_OVER = PRELUDE + r'''
-# 4 CUs: the kernel takes launches of >= 8 plies from 1 024 games on; 1 023 games / 7 plies stay with the other families
-for B in (1023, 1024, 1025, 1090, 2049):
+# 4 CUs: the kernel takes launches of >= 8 plies above 512 games; 512 games / 7 plies stay with the other families
+for B in (512, 513, 514, 600, 1025, 2049):
     empty = np.zeros((B, 6, N, N), np.uint8)
     for tracked in (False, True):
         run(empty, B, (7, 8, 9, 90, 300), True, 100 + B, tracked)
@@ -117,7 +117,7 @@ def test_r5_full_device_batch_same_as_chunks_on_the_other_kernels():
     enough to stay on the sixteen-board / one-row-per-lane kernels, which test_gpu_lat.py and test_gpu_configs.py hold to the oracle."""
     from gymgo_amd import gogame, _lib
     cus = int(_lib.lib().gg_device_cus())
-    B = cus * 256 + 37
+    B = cus * 256 + 37   # (two waves of 32 boards per SIMD and a ragged last wave)
     for tracked in (False, True):
         st = gogame.batch_init_state(B, 19, device='cuda')
         rng = gogame.rng_seed(B, 99, 0, 'cuda')

@@ -139,9 +139,10 @@ def test_bench_argument_plumbing():
     a = bench.parse_args(['--fuse', '64'])
     assert a.plies_per_step == 64 and a.gpus == 1
     assert bench.algo_bytes_per_step(19) == 4336 and bench.fused_bytes_per_game(19) == 4348
-    # (round 6: full-size 19x19 launches of >= 8 plies from 256 games per CU on take the thirty-two-board kernel, gg_v5.h)
+    # (round 6: full-size 19x19 launches of >= 8 plies on more than 128 games per CU take the thirty-two-board kernel, gg_v5.h)
     assert bench.rollout_kernel_name(19, 65536, 256, 256) == 'k_rollout5<19, 0>' and bench.rollout_kernel_name(19, 131072, 8, 256) == 'k_rollout5<19, 0>'
-    assert bench.rollout_kernel_name(19, 65535, 256, 256) == 'k_rollout4<19, 0, false, true, false, false>'
+    assert bench.rollout_kernel_name(19, 32769, 256, 256) == 'k_rollout5<19, 0>'
+    assert bench.rollout_kernel_name(19, 32768, 256, 256) == 'k_rollout4<19, 0, false, true, false, false>'
     assert bench.rollout_kernel_name(19, 65536, 7, 256) == 'k_rollout4<19, 0, false, true, false, false>'
     assert bench.rollout_kernel_name(18, 65536, 256, 256) == 'k_rollout4<19, 0, false, false, false, false>'
     assert bench.rollout_symbol_prefix('k_rollout5<19, 0>') == '_ZN2gg10k_rollout5ILi19ELi0EEE'
