@@ -171,18 +171,12 @@ __device__ __forceinline__ void flood_jobs(const uint32_t (&m)[R], const uint32_
   (void)sweeps;
 }
 
-// liberties (dilate & empty, counted; only min(count, 2) is used) of the group gt[], m[] = the rows of its colour, pov = the
-// other colour's rows
+// liberties (dilate & empty, counted; only min(count, 2) is used) of the group gt[], m[] = the rows of its colour, ot[] = the
+// other colour's rows (read from LDS together with m[], BEFORE the flood: read behind it they cost the lane a round trip)
 template <int R>
-__device__ __forceinline__ uint32_t job_liberties(const uint32_t (&gt)[R], const uint4 *pov, const uint32_t (&m)[R]) {
-  constexpr int RV = (R + 3) / 4;
+__device__ __forceinline__ uint32_t job_liberties(const uint32_t (&gt)[R], const uint32_t (&ot)[R], const uint32_t (&m)[R]) {
   constexpr uint32_t FULLROW = (1u << R) - 1u;
-  uint32_t ot[RV * 4], cnt3[3] = {0u, 0u, 0u};
-#pragma unroll
-  for (int i = 0; i < RV; ++i) {
-    const uint4 y = pov[i];
-    ot[4 * i] = y.x; ot[4 * i + 1] = y.y; ot[4 * i + 2] = y.z; ot[4 * i + 3] = y.w;
-  }
+  uint32_t cnt3[3] = {0u, 0u, 0u};
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const uint32_t e = B3(ot[r], m[r], FULLROW, ~(TA | TB) & TC & 0xFF);   // empty points
@@ -491,7 +485,7 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         asm volatile("" ::: "memory");
         if (place) {
           const int turn = reset ? 0 : (int)(fl & 1u);
-          st[turn * PL + s4 * RS + rabs] |= 1u << pos;
+          atomicOr(st + turn * PL + s4 * RS + rabs, 1u << pos);   // (ds_or without a return value: no round trip inside the phase)
           gb[rabs] = 1u << pos;
         }
       }
@@ -576,13 +570,17 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
         uint32_t cnt = 0;
         uint32_t res[R];   // the group (or the part of it that settles its class), normal bit order
         {
-          uint32_t m[R], mrev[R], f[R];
+          uint32_t m[R], mrev[R], f[R], ot[R];
           {
             uint32_t mt[RV * 4], ft[RV * 4];
 #pragma unroll
             for (int i = 0; i < RV; ++i) {
-              const uint4 x = pmv[i];
+              const uint4 x = pmv[i], y = pov[i];
               mt[4 * i] = x.x; mt[4 * i + 1] = x.y; mt[4 * i + 2] = x.z; mt[4 * i + 3] = x.w;
+              ot[4 * i] = y.x;
+              if (4 * i + 1 < R) ot[4 * i + 1] = y.y;
+              if (4 * i + 2 < R) ot[4 * i + 2] = y.z;
+              if (4 * i + 3 < R) ot[4 * i + 3] = y.w;
             }
             // the seed is one bit of one row: written into the lane's zero block at its (dynamic) row and read back as the
             // flood's row set - two LDS instructions instead of a select per row (odd rows bit-reversed) -, then cleared again
@@ -623,14 +621,14 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
           uint32_t open = 0;
           flood_jobs<R, true>(m, mrev, f, res, isG != 0u, mm, open);
           GG_PROF(2);
-          cnt = job_liberties<R>(res, pov, m);
+          cnt = job_liberties<R>(res, ot, m);
           const bool unsettled = have && open != 0u && cnt < 2u;
           if (__ballot(unsettled)) {
             // (the sweeps resume from the fill as the last test left it: normal bit order -> odd rows reversed)
 #pragma unroll
             for (int r = 0; r < R; ++r) f[r] = (r & 1) ? __brev(res[r]) : res[r];
             flood_jobs<R, false>(m, mrev, f, res, unsettled, mm, open);
-            cnt = job_liberties<R>(res, pov, m);
+            cnt = job_liberties<R>(res, ot, m);
           }
         }
         const uint32_t lib2 = cnt < 2u ? cnt : 2u;
