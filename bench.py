@@ -349,6 +349,9 @@ def run_rank(rank, world, backend, opts, dist=None):
                            'max': max(probe.mhz), 'power_raw': probe.record().get('power_raw')})
         elif probe is not None:
             settle['note'] = probe.record().get('note')
+    # (the played-steps counter is read BEFORE the warm-up - whose launches do not count - so that nothing but the fence sits
+    # between the last warm-up launch and the first timed one: a reduction + a host read there is an idle gap on the device)
+    before = backend.played()
     for _ in range(W):
         backend.rollout(F, count_steps=False)
 
@@ -358,7 +361,6 @@ def run_rank(rank, world, backend, opts, dist=None):
             dist.barrier()
             backend.sync()
 
-    before = backend.played()
     start, stop, elapsed_ms = backend.timer()
     fence()
     t0 = time.perf_counter()
