@@ -43,7 +43,7 @@ if [ -n "${SAN_PREBUILT:-}" ] && [ -f "$SAN_PREBUILT" ]; then
 else
   echo "[sanitize] building the $KIND build (host side only) ..."
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -I$R/include $FLAGS -fno-gpu-sanitize -shared \
-      -o $TMP/libgymgo_amd.so $R/gymgo_amd/csrc/gg_kernels.hip $R/gymgo_amd/csrc/gg_rollout.hip $R/gymgo_amd/csrc/gg_lat.hip 2> $TMP/build.log || { tail -20 $TMP/build.log; exit 1; }
+      -o $TMP/libgymgo_amd.so $R/gymgo_amd/csrc/gg_kernels.hip $R/gymgo_amd/csrc/gg_rollout.hip $R/gymgo_amd/csrc/gg_lat.hip $R/gymgo_amd/csrc/gg_r5.hip 2> $TMP/build.log || { tail -20 $TMP/build.log; exit 1; }
   [ -n "${SAN_KEEP:-}" ] && cp $TMP/libgymgo_amd.so "$SAN_KEEP"
 fi
 [ -f "$LIB" ] && cp -p "$LIB" $TMP/shipped.so
