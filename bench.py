@@ -438,8 +438,8 @@ def rollout_kernel_name(n, games, plies, cus, auto_reset=True):
     lat_per_cu, lat_plies = {9: (128, 3), 13: (80, 3 if games >= 16 * cus else 4), 19: (31, 8)}[rcap]
     if plies >= lat_plies and games <= lat_per_cu * cus:
         return 'k_rollout_lat<%d, %s, %s, 0>' % (rcap, full, 'true' if auto_reset else 'false')
-    if n == 19 and plies >= 8 and games > 128 * cus:
-        return 'k_rollout5<19, 0>'                              # a full machine: 32 boards per wave, flood jobs (gg_v5.h)
+    if n == rcap and plies >= 8 and games > (128 if n == 19 else 159) * cus:
+        return 'k_rollout5<%d, 0>' % n                          # a full machine: 32 boards per wave, flood jobs (gg_v5.h)
     if plies >= 2 and games >= 32 * cus:
         return 'k_rollout4<%d, 0, false, %s, false, false>' % (rcap, full)
     if plies == 1 and n in (9, 13, 19):

@@ -34,7 +34,7 @@ namespace gg {
 // gg_rollout.hip: the fused multi-ply launches with drawn moves, a translation unit of their own (one code-generation switch differs)
 void launch_rollout4(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N,
                      uint32_t inv, int plies, int auto_reset, int nb, int grid, hipStream_t s);
-void launch_rollout5(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, uint32_t inv,
+void launch_rollout5(int io, int N, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, uint32_t inv,
                      int plies, int auto_reset, int nb, int grid, hipStream_t s);
 void launch_rollout_lat(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, int32_t N, int plies,
                         int auto_reset, bool w4, hipStream_t s);
@@ -241,16 +241,20 @@ bool use_multi_ply(int cus, int64_t B, int plies) {
 
 // The thirty-two-board multi-ply kernel (gg_v5.h: a pair of lanes per board, the floods of a ply as a compacted job list) serves
 // the fused launches of full-size 19x19 batches from the point on where k_rollout4 would need a THIRD wave per SIMD (more than 128
-// games per CU); 19.5 KB of LDS per wave = eight waves per CU = two per SIMD.  Boards per wave: as many as keep the rounds of
+// games per CU; round 6, last session: also 9x9 and 13x13 batches, from 160 games per CU); 19.5 KB of LDS per wave = eight waves per CU = two per SIMD.  Boards per wave: as many as keep the rounds of
 // resident waves full (65 536 games on 256 CUs: 32 boards x 2 048 waves; 34 816: 18 boards).  Measured new / k_rollout4, ms per
 // launch of 256 plies (profiles/r06f_r5_edges.txt, r06f_r5_time.txt): 32 768 games 1.195 / 1.190, 34 816 1.208 / 1.455, 49 152
 // 1.247 / 1.490, 65 536 1.304 / 1.835, 98 304 2.47 / 3.55, 131 072 2.57 / 3.62; and per launch length at 65 536 games: 2 plies
 // 0.082 / 0.072, 4 0.093 / 0.088, 6 0.105 / 0.105, 8 0.114 / 0.122, 32 0.239 / 0.296 -> from 8 plies per launch on.
 // (A/B builds: GG_AB_R5 = 0 / 1 forces the choice, GG_AB_R5_MIN = games per CU, GG_AB_R5_PLIES, GG_AB_NB5 = boards per wave.)
 bool use_rollout5(int cus, int64_t B, int32_t N, int plies) {
-  int64_t per_cu = 4 * kNB5;
+  // 9x9 / 13x13 (tools/exp/r5_small.py, ms per launch of 256 plies, new / k_rollout4 or k_rollout_lat): 9x9 32 768 games 0.735 / 0.726,
+  // 40 960 0.826 / 0.854, 49 152 0.845 / 0.869, 65 536 0.874 / 1.032, 131 072 1.98 / 2.36; 13x13 32 768 0.966 / 0.894, 40 960 0.987 /
+  // 1.084, 49 152 1.009 / 1.104, 65 536 1.051 / 1.337, 131 072 2.32 / 2.64 -> from 160 games per CU on (13x13 with a row stride of
+  // 20 words: with the 16 of the other kernels the blocks of every fourth board share their LDS banks, 1.42 ms at 65 536 games)
+  int64_t per_cu = N == 19 ? 4 * kNB5 : 5 * kNB5 - 1;
   int min_plies = 8;
-  bool ok = N == 19;
+  bool ok = N == 19 || N == 13 || N == 9;
 #ifdef GG_AB
   if (const char *e = getenv("GG_AB_R5_MIN")) per_cu = atoll(e);
   if (const char *e = getenv("GG_AB_R5_PLIES")) min_plies = atoi(e);
@@ -628,7 +632,7 @@ int32_t gg_batch_rollout(uint8_t *states, uint64_t *rng, int32_t *last_actions, 
   if (use_rollout5(cus, B, N, plies)) {   // a full machine: 32 boards per wave, the floods of a ply as a job list (gg_v5.h)
     int grid;
     const int nb = boards_per_wave5(cus, B, grid);
-    launch_rollout5(0, states, rng, last_actions, steps_done, B, inv, plies, auto_reset, nb, grid, s);
+    launch_rollout5(0, N, states, rng, last_actions, steps_done, B, inv, plies, auto_reset, nb, grid, s);
     return (int32_t)hipGetLastError();
   }
   if (use_multi_ply(cus, B, plies)) {   // liberty classes carried across the plies, 16 boards per wave
@@ -974,7 +978,7 @@ int32_t gg_batch_rollout_tracked(uint32_t *tracked, uint64_t *rng, int32_t *last
   if (use_rollout5(cus, B, N, plies)) {
     int grid5;
     const int nb5 = boards_per_wave5(cus, B, grid5);
-    launch_rollout5(2, st, rng, last_actions, steps_done, B, inv, plies, auto_reset, nb5, grid5, s);
+    launch_rollout5(2, N, st, rng, last_actions, steps_done, B, inv, plies, auto_reset, nb5, grid5, s);
     return (int32_t)hipGetLastError();
   }
   int grid3;

@@ -15,10 +15,17 @@
 namespace gg {
 
 // full-size 19x19 boards, byte planes (io 0) or tracked boards (io 2)
-void launch_rollout5(int io, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, uint32_t inv,
+void launch_rollout5(int io, int N, uint8_t *st, uint64_t *rng, int32_t *last_actions, int64_t *steps_done, int64_t B, uint32_t inv,
                      int plies, int auto_reset, int nb, int grid, hipStream_t s) {
-  if (io == 0) k_rollout5<19, 0><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, inv, plies, auto_reset, nb);
-  else k_rollout5<19, 2><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, inv, plies, auto_reset, nb);
+#define GG_R5(R)                                                                                                              \
+  do {                                                                                                                        \
+    if (io == 0) k_rollout5<R, 0><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, inv, plies, auto_reset, nb);   \
+    else k_rollout5<R, 2><<<grid, kWave, 0, s>>>(st, rng, last_actions, steps_done, B, inv, plies, auto_reset, nb);           \
+  } while (0)
+  if (N == 19) GG_R5(19);
+  else if (N == 13) GG_R5(13);
+  else GG_R5(9);
+#undef GG_R5
 }
 
 }  // namespace gg

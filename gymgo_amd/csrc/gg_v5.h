@@ -36,7 +36,9 @@ constexpr int kJobCap = 128;   // jobs of one ply: <= 4 per board (four opponent
 
 template <int R>
 struct Lds5 {
-  static constexpr int RS = Cfg<R>::kRowStride;
+  // words per row block.  (13x13: 20 instead of the 16 of the other kernels - the lanes of a wave address 32 or 64 blocks at once,
+  // and a stride of 16 words puts every fourth of them on the same LDS banks: 1.42 -> ms per launch of 65 536 games x 256 plies)
+  static constexpr int RS = R == 13 ? 20 : Cfg<R>::kRowStride;
   static constexpr int RPL = (R + 1) / 2;                        // rows per lane in phases 1 and 3
   static_assert(2 * RPL <= RS, "a pair's rows must fit the row stride");
   static constexpr int kPad = 4;                                 // zero words in front of the planes: "row -1" / "row -2" of the first board

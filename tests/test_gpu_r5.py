@@ -2,7 +2,7 @@
 ply as a compacted job list) against the pinned C oracle - states, generator states, last actions, step counters.
 
 gg_batch_rollout / gg_batch_rollout_tracked hand full-size 19x19 launches of >= 8 plies to it above 128 games per CU
-(gg_kernels.hip: use_rollout5), i.e. from 32 769 games on the whole device: the BASELINE config-3 test (test_gpu_configs.py) and the
+(gg_kernels.hip: use_rollout5; 9x9 and 13x13: from 160 games per CU), i.e. from 32 769 games on the whole device: the BASELINE config-3 test (test_gpu_configs.py) and the
 bench's own driver (test_gpu_deep.py) run it at that size.  Here the library is sized for FOUR compute units
 (GYMGO_AMD_CUS=4, read once per process: a process of its own), so that 513 games take the kernel and the oracle can replay
 whole games: both sides of the games / plies take-over, ragged last waves (a wave of 2 .. 32 boards), frozen games, resets, and a
@@ -57,6 +57,20 @@ def run(states, B, launches, auto_reset, seed, tracked):
         assert int(sd.max()) <= played and int(sd.min()) > 0
 ''' % ROOT
 
+SMALL = PRELUDE + r'''
+# 9x9 / 13x13 on 4 CUs: the kernel takes launches of >= 8 plies from 640 games on (160 per CU); below that and for shorter launches
+# the one-row-per-lane and sixteen-board kernels serve the call
+for N in (9, 13):
+    for B in (639, 640, 641, 700, 1025, 2049):
+        empty = np.zeros((B, 6, N, N), np.uint8)
+        for tracked in (False, True):
+            run(empty, B, (7, 8, 9, 60, 200), True, 300 + B + N, tracked)
+    run(np.zeros((1100, 6, N, N), np.uint8), 1100, (3 * N * N + 9, 8, 150), True, 17 + N, False)      # whole games: passes, resets
+    run(np.zeros((1100, 6, N, N), np.uint8), 1100, (3 * N * N + 9, 8, 300), False, 18 + N, False)     # frozen games
+    run(np.zeros((1030, 6, N, N), np.uint8), 1030, (2 * N * N, 400, 9), False, 19 + N, True)
+print('R5 OK')
+'''
+
 TAKE_OVER = PRELUDE + r'''
 # 4 CUs: the kernel takes launches of >= 8 plies above 512 games; 512 games / 7 plies stay with the other families
 for B in (512, 513, 514, 600, 1025, 2049):
@@ -108,18 +122,23 @@ def test_r5_both_sides_of_its_take_over_ragged_waves_frozen_games():
     _run(TAKE_OVER)
 
 
+def test_r5_small_boards_both_sides_of_their_take_over():
+    _run(SMALL)
+
+
 def test_r5_second_job_batch_on_a_crafted_position():
     _run(JOBS)
 
 
-def test_r5_full_device_batch_same_as_chunks_on_the_other_kernels():
+@pytest.mark.parametrize('size', [19, 13, 9])
+def test_r5_full_device_batch_same_as_chunks_on_the_other_kernels(size):
     """65 536 games on the whole device (the kernel's own shape, two waves per SIMD) against the same games run in chunks small
     enough to stay on the sixteen-board / one-row-per-lane kernels, which test_gpu_lat.py and test_gpu_configs.py hold to the oracle."""
     from gymgo_amd import gogame, _lib
     cus = int(_lib.lib().gg_device_cus())
     B = cus * 256 + 37   # (two waves of 32 boards per SIMD and a ragged last wave)
     for tracked in (False, True):
-        st = gogame.batch_init_state(B, 19, device='cuda')
+        st = gogame.batch_init_state(B, size, device='cuda')
         rng = gogame.rng_seed(B, 99, 0, 'cuda')
         ch = B // 16
         for g in range(1, 16):      # de-synchronised games

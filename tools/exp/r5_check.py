@@ -10,7 +10,7 @@ from gymgo_amd import _lib
 if os.environ.get('LIB'):
     _lib.LIB_PATH = os.path.join(ROOT, os.environ['LIB'])
 from gymgo_amd import gogame
-N = 19
+N = int(os.environ.get('GGN', '19'))
 
 
 def dig(*ts):
