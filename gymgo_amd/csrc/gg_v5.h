@@ -813,17 +813,30 @@ __global__ __launch_bounds__(kWave, 2) void k_rollout5(uint8_t *__restrict__ sta
       const int64_t nbrd = (B - b_first) < nb ? (B - b_first) : nb;
       const int nw = (int)nbrd * W;
       uint32_t *gp = reinterpret_cast<uint32_t *>(states) + b_first * (int64_t)W;
-      for (int i = lnS; i < nw; i += kWave) {
-        const int sb = i / W, w = i - sb * W;
-        if (playedv[sb] == 0 && !(flagsv[sb] & 32u)) continue;   // untouched boards are not rewritten
-        uint32_t v;
-        if (w == 5 * N) {
-          v = flagsv[sb] & 7u;
-        } else {
-          const int pl = w / N, rw = w - pl * N;
-          v = pl < 2 ? st[pl * PL + sb * RS + rw] : park[(pl - 2) * PL + sb * RS + rw];
+      // (untouched boards are not rewritten: one bit per board, read once; four words per lane and round with their LDS reads in
+      // flight together - as k_rollout4's write-back: 48 rounds of flag read -> branch -> row read -> store were 10 us of a launch,
+      // now 7.5)
+      bool tch = false;
+      if (lnS < (int)nbrd) tch = playedv[lnS] != 0 || (flagsv[lnS] & 32u);
+      const uint64_t tmask = __ballot(tch);
+#pragma unroll 1
+      for (int i0 = lnS; i0 < nw; i0 += 4 * kWave) {
+        uint32_t v[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * kWave;
+          const int ic = i < nw ? i : 0;
+          const int sb = ic / W, w = ic - sb * W;
+          ok[k] = i < nw && ((tmask >> sb) & 1ull);
+          const int pl = w / N, rw = w - pl * N;   // (w == 5 N: pl == 5, rw == 0)
+          const uint32_t *src = pl >= 5 ? flagsv + sb : (pl < 2 ? st + pl * PL + sb * RS + rw : park + (pl - 2) * PL + sb * RS + rw);
+          const uint32_t x = *src;
+          v[k] = pl >= 5 ? (x & 7u) : x;
         }
-        gp[i] = v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (ok[k]) gp[i0 + k * kWave] = v[k];
       }
       if (lnS < nb && b_first + lnS < B) {
         const int sb = lnS;
