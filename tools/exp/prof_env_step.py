@@ -27,7 +27,13 @@ out2 = None
 def env_noobs():
     global out2
     out2 = gogame.batch_env_step_tracked(tr, None, rng, 7.5, 'real', True, out=out2)
-for label, fn, reader in (('env step + observation', env_obs, 'gg_ab_prof_read_kernels'), ('env step, no observation', env_noobs, 'gg_ab_prof_read_kernels'),
+w32 = torch.rand((B, N * N + 1), dtype=torch.float32, device='cuda'); w16 = w32.to(torch.bfloat16)
+outw = None
+def env_w(w):
+    global outw
+    outw = gogame.batch_env_step_tracked(tr, None, rng, 7.5, 'real', True, out=outw, states_out=obs, weights=w)
+for label, fn, reader in (('env step + observation, float32 weights', lambda: env_w(w32), 'gg_ab_prof_read_kernels'), ('env step + observation, bfloat16 weights', lambda: env_w(w16), 'gg_ab_prof_read_kernels'),
+                          ('env step + observation', env_obs, 'gg_ab_prof_read_kernels'), ('env step, no observation', env_noobs, 'gg_ab_prof_read_kernels'),
                           ('one-ply tracked rollout', lambda: gogame.batch_rollout_tracked(tr, rng, 1, True), 'gg_ab_prof_read_rollout')):
     rd = getattr(L, reader); rd.argtypes = [ctypes.c_void_p]; rd.restype = ctypes.c_int32
     for _ in range(10): fn()
