@@ -609,6 +609,13 @@ def roofline_record(dev, n, games, plies, launch_ms, per_ply, clocks=None):
         if rec['pmc_stale']:
             rec['pmc_stale_note'] = ('the instruction mix / traffic above were counted on ANOTHER build of this kernel (or the '
                                      'hash is missing): re-run tools/profile_round.sh')
+        if kernel.startswith('k_rollout5<19'):
+            rec['frac_note'] = ('frac prices INSTRUCTIONS against the issue port (VALU wave-instructions per env step x env steps/s / peak): '
+                                'k_rollout5 issues %.1f per env step where the kernel of rounds 3 - 5 (k_rollout4) issued 73.2 - 74.1 at '
+                                'frac 0.51 - 0.54 and 8.45 - 9.1e9 env steps/s; removing instructions lowers the fraction while the rate '
+                                'rises (DESIGN.md 6).  Two waves per SIMD: a two-wave SIMD running flood visits alone issues one VALU '
+                                'instruction per 1.47 ns (profiles/r06i_ubench_dep_chain2.txt)' % ipe['valu'])
+            rec['env_steps_per_s_vs_round5_driver_value'] = round(steps_per_s / 8.45e9, 3)
         busy = pmc.get('valu_busy')
         if busy:
             rec['valu_busy_counters'] = busy      # counter-derived (tools/summarize_profiles.py), with its formula
